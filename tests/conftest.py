@@ -1,0 +1,64 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+class Golden:
+    """npz fixture with '@key' aliases resolved (see tests/golden/make_golden.py:dedupe)."""
+
+    def __init__(self, name):
+        self.z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+        self.files = set(self.z.files)
+
+    def __contains__(self, k):
+        return k in self.files
+
+    def np(self, k):
+        v = self.z[k]
+        if v.dtype.kind == "U" and str(v).startswith("@"):
+            return self.np(str(v)[1:])
+        return v
+
+    def t(self, k):
+        return torch.from_numpy(np.ascontiguousarray(self.np(k)))
+
+    def seq(self, prefix):
+        n = int(self.z[prefix + ".len"])
+        return [self.t(f"{prefix}.{i}") for i in range(n)]
+
+    def meta(self):
+        return json.loads(str(self.z["meta"]))
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = Golden(name)
+        return cache[name]
+    return get
+
+
+def state_keys(variant):
+    with open(os.path.join(GOLDEN, f"state_keys_{variant}.json")) as f:
+        return json.load(f)
+
+
+def rel_l1(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().mean() / b.abs().mean().clamp_min(1e-30))
