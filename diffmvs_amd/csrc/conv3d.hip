@@ -1,0 +1,146 @@
+// Direct fp32 3-D convolutions of PixelViewWeight / CostRegNet_small (reference
+// models/module.py:422-463): 3x3x3, padding 1, stride 1|2, and the stride-2 transposed form
+// with output_padding 1.  One lane = one output voxel (x fastest, so a wave reads 64
+// consecutive floats of a (c,d,y) row), CO accumulators in VGPRs, tap weights wave-uniform
+// -> scalar loads.  The transposed convolution is evaluated in gather form, one output
+// parity class (od&1, oh&1, ow&1) per blockIdx.z so that the live taps stay wave-uniform:
+//   o = 2j   : k = 1 reads i = j            o = 2j+1 : k = 0 reads i = j+1, k = 2 reads i = j
+#include "dmvs_common.h"
+
+template <int CO>
+__device__ __forceinline__ void conv3d_epilogue(const dmvs_conv3d_desc& d, const float (&acc)[CO], int co0, int b,
+                                                size_t ovox) {
+    const size_t ovol = (size_t)d.Dout * d.Hout * d.Wout;
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+        const int cg = co0 + co;
+        if (cg >= d.cout) break;
+        float y = acc[co];
+        if (d.scale) y *= d.scale[cg];
+        if (d.shift) y += d.shift[cg];
+        y = dmvs_act(y, d.act);
+        const size_t oi = ((size_t)b * d.cout + cg) * ovol + ovox;
+        if (d.residual) y += d.residual[oi];
+        d.out[oi] = y;
+    }
+}
+
+template <int CO, int STRIDE>
+__global__ void __launch_bounds__(DMVS_BLOCK) conv3d_kernel(const dmvs_conv3d_desc d) {
+    const long total = (long)d.B * d.Dout * d.Hout * d.Wout;
+    const long p = (long)blockIdx.x * DMVS_BLOCK + threadIdx.x;
+    const int co0 = blockIdx.y * CO;
+    const bool live = p < total;
+    long q = live ? p : total - 1;
+    const int ox = (int)(q % d.Wout); q /= d.Wout;
+    const int oy = (int)(q % d.Hout); q /= d.Hout;
+    const int od = (int)(q % d.Dout);
+    const int b = (int)(q / d.Dout);
+
+    float acc[CO];
+#pragma unroll
+    for (int i = 0; i < CO; ++i) acc[i] = 0.0f;
+    const size_t ivol = (size_t)d.Din * d.Hin * d.Win;
+    const int id0 = od * STRIDE - 1, iy0 = oy * STRIDE - 1, ix0 = ox * STRIDE - 1;
+    for (int ci = 0; ci < d.cin; ++ci) {
+        const float* vol = d.in + ((size_t)b * d.cin + ci) * ivol;
+        const float* wrow = d.weight + (size_t)ci * 27 * d.cout_pad + co0;
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {
+            const int id = id0 + kd;
+            const bool din = id >= 0 && id < d.Din;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = iy0 + ky;
+                const bool yin = din && iy >= 0 && iy < d.Hin;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ix = ix0 + kx;
+                    float v = 0.0f;
+                    if (yin && ix >= 0 && ix < d.Win) v = vol[((size_t)id * d.Hin + iy) * d.Win + ix];
+                    const float* wt = wrow + ((kd * 3 + ky) * 3 + kx) * d.cout_pad;
+#pragma unroll
+                    for (int co = 0; co < CO; ++co) acc[co] = fmaf(v, wt[co], acc[co]);
+                }
+            }
+        }
+    }
+    if (!live) return;
+    conv3d_epilogue<CO>(d, acc, co0, b, ((size_t)od * d.Hout + oy) * d.Wout + ox);
+}
+
+template <int CO>
+__global__ void __launch_bounds__(DMVS_BLOCK) deconv3d_kernel(const dmvs_conv3d_desc d) {
+    // thread = one input-grid position j; this block's parity class gives output o = 2j + par
+    const long total = (long)d.B * d.Din * d.Hin * d.Win;
+    const long p = (long)blockIdx.x * DMVS_BLOCK + threadIdx.x;
+    const int co0 = blockIdx.y * CO;
+    const int pd = (blockIdx.z >> 2) & 1, py = (blockIdx.z >> 1) & 1, px = blockIdx.z & 1;
+    const bool live = p < total;
+    long q = live ? p : total - 1;
+    const int jx = (int)(q % d.Win); q /= d.Win;
+    const int jy = (int)(q % d.Hin); q /= d.Hin;
+    const int jd = (int)(q % d.Din);
+    const int b = (int)(q / d.Din);
+
+    float acc[CO];
+#pragma unroll
+    for (int i = 0; i < CO; ++i) acc[i] = 0.0f;
+    const size_t ivol = (size_t)d.Din * d.Hin * d.Win;
+    // per dimension: parity 0 -> taps {(k=1, +0)}; parity 1 -> taps {(k=0, +1), (k=2, +0)}
+    const int nd = pd ? 2 : 1, ny = py ? 2 : 1, nx = px ? 2 : 1;
+    for (int ci = 0; ci < d.cin; ++ci) {
+        const float* vol = d.in + ((size_t)b * d.cin + ci) * ivol;
+        const float* wrow = d.weight + (size_t)ci * 27 * d.cout_pad + co0;
+        for (int td = 0; td < nd; ++td) {
+            const int kd = pd ? (td == 0 ? 0 : 2) : 1;
+            const int id = jd + ((pd && td == 0) ? 1 : 0);
+            for (int ty = 0; ty < ny; ++ty) {
+                const int ky = py ? (ty == 0 ? 0 : 2) : 1;
+                const int iy = jy + ((py && ty == 0) ? 1 : 0);
+                for (int tx = 0; tx < nx; ++tx) {
+                    const int kx = px ? (tx == 0 ? 0 : 2) : 1;
+                    const int ix = jx + ((px && tx == 0) ? 1 : 0);
+                    float v = 0.0f;
+                    if (id < d.Din && iy < d.Hin && ix < d.Win) v = vol[((size_t)id * d.Hin + iy) * d.Win + ix];
+                    const float* wt = wrow + ((kd * 3 + ky) * 3 + kx) * d.cout_pad;
+#pragma unroll
+                    for (int co = 0; co < CO; ++co) acc[co] = fmaf(v, wt[co], acc[co]);
+                }
+            }
+        }
+    }
+    if (!live) return;
+    const int od = 2 * jd + pd, oy = 2 * jy + py, ox = 2 * jx + px;
+    conv3d_epilogue<CO>(d, acc, co0, b, ((size_t)od * d.Hout + oy) * d.Wout + ox);
+}
+
+extern "C" int dmvs_conv3d_f32(const dmvs_conv3d_desc* dp, void* stream) {
+    if (!dp) return DMVS_EINVAL;
+    const dmvs_conv3d_desc& d = *dp;
+    hipStream_t st = (hipStream_t)stream;
+    if (d.cout_pad % 8 || d.cout > d.cout_pad || !d.in || !d.weight || !d.out) return DMVS_EINVAL;
+    const int co = (d.cout_pad % 16 == 0) ? 16 : 8;
+    dim3 block(DMVS_BLOCK);
+    if (d.transposed) {
+        if (d.stride != 2 || d.Dout != 2 * d.Din || d.Hout != 2 * d.Hin || d.Wout != 2 * d.Win) return DMVS_EINVAL;
+        const long total = (long)d.B * d.Din * d.Hin * d.Win;
+        dim3 grid(dmvs_ceil_div(total, DMVS_BLOCK), d.cout_pad / co, 8);
+        if (co == 16) hipLaunchKernelGGL((deconv3d_kernel<16>), grid, block, 0, st, d);
+        else hipLaunchKernelGGL((deconv3d_kernel<8>), grid, block, 0, st, d);
+        return dmvs_launch_status();
+    }
+    if (d.stride != 1 && d.stride != 2) return DMVS_EINVAL;
+    const int ed = (d.Din - 1) / d.stride + 1, eh = (d.Hin - 1) / d.stride + 1, ew = (d.Win - 1) / d.stride + 1;
+    if (ed != d.Dout || eh != d.Hout || ew != d.Wout) return DMVS_EINVAL;
+    const long total = (long)d.B * d.Dout * d.Hout * d.Wout;
+    dim3 grid(dmvs_ceil_div(total, DMVS_BLOCK), d.cout_pad / co);
+    if (d.stride == 1) {
+        if (co == 16) hipLaunchKernelGGL((conv3d_kernel<16, 1>), grid, block, 0, st, d);
+        else hipLaunchKernelGGL((conv3d_kernel<8, 1>), grid, block, 0, st, d);
+    } else {
+        if (co == 16) hipLaunchKernelGGL((conv3d_kernel<16, 2>), grid, block, 0, st, d);
+        else hipLaunchKernelGGL((conv3d_kernel<8, 2>), grid, block, 0, st, d);
+    }
+    return dmvs_launch_status();
+}

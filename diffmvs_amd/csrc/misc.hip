@@ -1,0 +1,370 @@
+// Bandwidth-trivial pieces of the path: camera composition, view aggregation, depth
+// regression, convex upsampling, GroupNorm, refinement bookkeeping, layout helpers.
+// All are one-lane-per-pixel streaming kernels over planar fp32 tensors.
+#include "dmvs_common.h"
+
+extern "C" int dmvs_abi_version(void) { return DMVS_ABI_VERSION; }
+
+// ------------------------------------------------------------------------------------------
+// compose_proj: fp64 Gauss-Jordan inverse of the reference camera, one thread per (b, s)
+__device__ static void build_cam(const float* pm, double (&P)[4][4]) {
+    // pm: [2,4,4]; P = E with its top 3x4 replaced by K @ E[:3,:4]   (reference :520-525)
+    const float* E = pm;
+    const float* K = pm + 16;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) P[i][j] = (double)E[i * 4 + j];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double a = 0.0;
+            for (int k = 0; k < 3; ++k) a += (double)K[i * 4 + k] * (double)E[k * 4 + j];
+            P[i][j] = a;
+        }
+}
+
+__global__ void compose_proj_kernel(const float* __restrict__ proj, float* __restrict__ out, int B, int V) {
+    const int S = V - 1;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * S) return;
+    const int b = idx / S, s = idx % S;
+    double R[4][4], A[4][8];
+    build_cam(proj + ((size_t)b * V) * 32, R);
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            A[i][j] = R[i][j];
+            A[i][4 + j] = i == j ? 1.0 : 0.0;
+        }
+    for (int c = 0; c < 4; ++c) {   // partial pivoting
+        int piv = c;
+        double best = fabs(A[c][c]);
+        for (int r = c + 1; r < 4; ++r)
+            if (fabs(A[r][c]) > best) { best = fabs(A[r][c]); piv = r; }
+        if (piv != c)
+            for (int j = 0; j < 8; ++j) { double t = A[c][j]; A[c][j] = A[piv][j]; A[piv][j] = t; }
+        const double inv = 1.0 / A[c][c];
+        for (int j = 0; j < 8; ++j) A[c][j] *= inv;
+        for (int r = 0; r < 4; ++r) {
+            if (r == c) continue;
+            const double f = A[r][c];
+            for (int j = 0; j < 8; ++j) A[r][j] -= f * A[c][j];
+        }
+    }
+    double P[4][4];
+    build_cam(proj + ((size_t)b * V + s + 1) * 32, P);
+    float* o = out + (size_t)idx * 12;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 4; ++j) {
+            double a = 0.0;
+            for (int k = 0; k < 4; ++k) a += P[i][k] * A[k][4 + j];
+            if (j < 3) o[i * 3 + j] = (float)a;
+            else o[9 + i] = (float)a;
+        }
+    }
+}
+
+extern "C" int dmvs_compose_proj_f32(const float* proj, float* out, int32_t B, int32_t V, void* stream) {
+    if (!proj || !out || V < 2) return DMVS_EINVAL;
+    const int n = B * (V - 1);
+    hipLaunchKernelGGL(compose_proj_kernel, dim3(dmvs_ceil_div(n, 64)), dim3(64), 0, (hipStream_t)stream, proj, out, B, V);
+    return dmvs_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(DMVS_BLOCK)
+view_aggregate_kernel(const float* __restrict__ cor, const float* __restrict__ w, float* __restrict__ out, int B, int S,
+                      int GD, int HW) {
+    const long i = (long)blockIdx.x * DMVS_BLOCK + threadIdx.x;
+    if (i >= (long)B * HW) return;
+    const int b = (int)(i / HW), p = (int)(i % HW);
+    float wsum = 1e-8f;
+    for (int s = 0; s < S; ++s) wsum += w[((long)b * S + s) * HW + p];
+    const float inv = 1.0f / wsum;
+    for (int gd = 0; gd < GD; ++gd) {
+        float a = 0.0f;
+        for (int s = 0; s < S; ++s) a = fmaf(w[((long)b * S + s) * HW + p], cor[(((long)b * S + s) * GD + gd) * HW + p], a);
+        out[((long)b * GD + gd) * HW + p] = a * inv;
+    }
+}
+
+extern "C" int dmvs_view_aggregate_f32(const float* cor, const float* w, float* out, int32_t B, int32_t S, int32_t GD,
+                                       int32_t HW, void* stream) {
+    hipLaunchKernelGGL(view_aggregate_kernel, dim3(dmvs_ceil_div((long)B * HW, DMVS_BLOCK)), dim3(DMVS_BLOCK), 0,
+                       (hipStream_t)stream, cor, w, out, B, S, GD, HW);
+    return dmvs_launch_status();
+}
+
+__global__ void __launch_bounds__(DMVS_BLOCK)
+sigmoid_max_d_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int D, int HW) {
+    const long i = (long)blockIdx.x * DMVS_BLOCK + threadIdx.x;
+    if (i >= (long)N * HW) return;
+    const int n = (int)(i / HW), p = (int)(i % HW);
+    float m = -3.0e38f;
+    for (int d = 0; d < D; ++d) m = fmaxf(m, x[((long)n * D + d) * HW + p]);
+    out[i] = dmvs_sigmoid(m);   // sigmoid is monotone: max of sigmoids = sigmoid of max
+}
+
+extern "C" int dmvs_sigmoid_max_d_f32(const float* x, float* out, int32_t N, int32_t D, int32_t HW, void* stream) {
+    hipLaunchKernelGGL(sigmoid_max_d_kernel, dim3(dmvs_ceil_div((long)N * HW, DMVS_BLOCK)), dim3(DMVS_BLOCK), 0,
+                       (hipStream_t)stream, x, out, N, D, HW);
+    return dmvs_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(DMVS_BLOCK)
+depth_regress_kernel(const float* __restrict__ logits, const float* __restrict__ disp_min,
+                     const float* __restrict__ disp_max, float* __restrict__ norm_depth, float* __restrict__ depth,
+                     float* __restrict__ conf, int B, int D, int HW) {
+    const long i = (long)blockIdx.x * DMVS_BLOCK + threadIdx.x;
+    if (i >= (long)B * HW) return;
+    const int b = (int)(i / HW), p = (int)(i % HW);
+    const float* l = logits + (long)b * D * HW + p;
+    float m = -3.0e38f;
+    for (int d = 0; d < D; ++d) m = fmaxf(m, l[(long)d * HW]);
+    float sum = 0.0f, ex = 0.0f;
+    for (int d = 0; d < D; ++d) {
+        const float e = expf(l[(long)d * HW] - m);
+        sum += e;
+        ex = fmaf((float)d, e, ex);
+    }
+    const float inv = 1.0f / sum;
+    const float index = ex * inv;
+    const float nd = index / ((float)D - 1.0f);
+    norm_depth[i] = nd;
+    depth[i] = dmvs_disp_to_depth(nd, disp_min[b], disp_max[b]);
+    int k = (int)index;   // index >= 0: truncation == floor, as .long() in the reference
+    k = k < 0 ? 0 : (k > D - 1 ? D - 1 : k);
+    float c = 0.0f;
+    for (int d = k - 1; d <= k + 2; ++d)
+        if (d >= 0 && d < D) c += expf(l[(long)d * HW] - m) * inv;
+    conf[i] = c;
+}
+
+extern "C" int dmvs_depth_regress_f32(const float* logits, const float* disp_min, const float* disp_max,
+                                      float* norm_depth, float* depth, float* conf, int32_t B, int32_t D, int32_t HW,
+                                      void* stream) {
+    hipLaunchKernelGGL(depth_regress_kernel, dim3(dmvs_ceil_div((long)B * HW, DMVS_BLOCK)), dim3(DMVS_BLOCK), 0,
+                       (hipStream_t)stream, logits, disp_min, disp_max, norm_depth, depth, conf, B, D, HW);
+    return dmvs_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
+// convex upsampling: one lane per OUTPUT pixel
+__global__ void __launch_bounds__(DMVS_BLOCK)
+convex_upsample_kernel(const float* __restrict__ inv, const float* __restrict__ mask,
+                       const float* __restrict__ disp_min, const float* __restrict__ disp_max,
+                       float* __restrict__ out_inv, float* __restrict__ out_depth, int B, int H, int W, int r) {
+    const int Ho = H * r, Wo = W * r;
+    const long i = (long)blockIdx.x * DMVS_BLOCK + threadIdx.x;
+    if (i >= (long)B * Ho * Wo) return;
+    const int xo = (int)(i % Wo), yo = (int)((i / Wo) % Ho), b = (int)(i / ((long)Wo * Ho));
+    const int x = xo / r, jx = xo % r, y = yo / r, jy = yo % r;
+    const long hw = (long)H * W;
+    const float* mp = mask + ((long)b * 9 * r * r + jy * r + jx) * hw + (long)y * W + x;
+    const long kstride = (long)r * r * hw;
+    float m[9], mx = -3.0e38f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        m[k] = mp[k * kstride];
+        mx = fmaxf(mx, m[k]);
+    }
+    float sum = 0.0f, acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const float e = expf(m[k] - mx);
+        sum += e;
+        const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+        const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? inv[(long)b * hw + (long)yy * W + xx] : 0.0f;
+        acc = fmaf(e, v, acc);
+    }
+    const float up = acc / sum;
+    if (out_inv) out_inv[i] = up;
+    if (out_depth) out_depth[i] = dmvs_disp_to_depth(up, disp_min[b], disp_max[b]);
+}
+
+extern "C" int dmvs_convex_upsample_f32(const float* inv, const float* mask, const float* disp_min,
+                                        const float* disp_max, float* out_inv, float* out_depth, int32_t B, int32_t H,
+                                        int32_t W, int32_t ratio, void* stream) {
+    hipLaunchKernelGGL(convex_upsample_kernel, dim3(dmvs_ceil_div((long)B * H * W * ratio * ratio, DMVS_BLOCK)),
+                       dim3(DMVS_BLOCK), 0, (hipStream_t)stream, inv, mask, disp_min, disp_max, out_inv, out_depth, B, H,
+                       W, ratio);
+    return dmvs_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
+// GroupNorm: pass 1 = per-(b,group) sum / sum of squares (block tree + one fp64 atomic pair
+// per block), pass 2 = normalise + scale/shift + SiLU (+ residual), one (b,c) row per
+// blockIdx.y so the statistics are block-uniform scalars.
+__global__ void __launch_bounds__(DMVS_BLOCK)
+gn_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, long per_group, int chunk) {
+    __shared__ float red[2][DMVS_BLOCK / 64];
+    const int bg = blockIdx.y;
+    const long base = (long)bg * per_group;
+    const long lo = (long)blockIdx.x * chunk;
+    const long hi = lo + chunk < per_group ? lo + chunk : per_group;
+    float s = 0.0f, ss = 0.0f;
+    for (long i = lo + threadIdx.x; i < hi; i += DMVS_BLOCK) {
+        const float v = x[base + i];
+        s += v;
+        ss = fmaf(v, v, ss);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_down(s, o, 64);
+        ss += __shfl_down(ss, o, 64);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        red[0][wave] = s;
+        red[1][wave] = ss;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, c = 0.0;
+        for (int w = 0; w < DMVS_BLOCK / 64; ++w) {
+            a += (double)red[0][w];
+            c += (double)red[1][w];
+        }
+        atomicAdd(&stats[2 * bg], a);
+        atomicAdd(&stats[2 * bg + 1], c);
+    }
+}
+
+__global__ void __launch_bounds__(DMVS_BLOCK)
+gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                const float* __restrict__ scale_shift, const float* __restrict__ residual, float* __restrict__ y,
+                const double* __restrict__ stats, int C, int HW, int groups, float eps) {
+    const int bc = blockIdx.y;
+    const int b = bc / C, c = bc % C;
+    const int cg = C / groups;
+    const int g = c / cg;
+    const double n = (double)cg * HW;
+    const double mean = stats[2 * (b * groups + g)] / n;
+    double var = stats[2 * (b * groups + g) + 1] / n - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    // y = ((x - mean) * rstd * gamma + beta) * (scale + 1) + shift  ==  x * A + Bc
+    float A = rstd * gamma[c];
+    float Bc = beta[c] - (float)mean * A;
+    if (scale_shift) {
+        const float sc = scale_shift[(long)b * 2 * C + c] + 1.0f, sh = scale_shift[(long)b * 2 * C + C + c];
+        A *= sc;
+        Bc = Bc * sc + sh;
+    }
+    const long base = (long)bc * HW;
+    for (long i = (long)blockIdx.x * DMVS_BLOCK + threadIdx.x; i < HW; i += (long)gridDim.x * DMVS_BLOCK) {
+        float v = fmaf(x[base + i], A, Bc);
+        v = v * dmvs_sigmoid(v);
+        if (residual) v += residual[base + i];
+        y[base + i] = v;
+    }
+}
+
+extern "C" int dmvs_groupnorm_silu_f32(const float* x, const float* gamma, const float* beta, const float* scale_shift,
+                                       const float* residual, float* y, double* stats, int32_t B, int32_t C, int32_t HW,
+                                       int32_t groups, float eps, void* stream) {
+    if (!x || !y || !stats || groups <= 0 || C % groups) return DMVS_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 2 * B * groups, st);
+    if (e != hipSuccess) return (int)e;
+    const long per_group = (long)(C / groups) * HW;
+    const int chunk = 8192;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(dmvs_ceil_div(per_group, chunk), B * groups), dim3(DMVS_BLOCK), 0, st, x,
+                       stats, per_group, chunk);
+    unsigned gx = dmvs_ceil_div(HW, DMVS_BLOCK * 4);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(gx, B * C), dim3(DMVS_BLOCK), 0, st, x, gamma, beta, scale_shift, residual, y,
+                       stats, C, HW, groups, eps);
+    return dmvs_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(DMVS_BLOCK)
+delta_update_kernel(const float* __restrict__ inv, const float* __restrict__ delta_in, const float* __restrict__ update,
+                    float dscale, float* __restrict__ delta_out, float* __restrict__ new_inv,
+                    float* __restrict__ new_inv2, int cstride2, int coffset2, int B, int HW) {
+    const long i = (long)blockIdx.x * DMVS_BLOCK + threadIdx.x;
+    if (i >= (long)B * HW) return;
+    const float base = inv[i];
+    float dl = delta_in[i] * dscale;
+    if (update) dl += update[i];
+    float nv = base + dl;
+    nv = fminf(fmaxf(nv, 0.0f), 1.0f);
+    delta_out[i] = nv - base;
+    if (new_inv) new_inv[i] = nv;
+    if (new_inv2) {
+        const int b = (int)(i / HW), p = (int)(i % HW);
+        new_inv2[((long)b * cstride2 + coffset2) * HW + p] = nv;
+    }
+}
+
+extern "C" int dmvs_delta_update_f32(const float* inv, const float* delta_in, const float* update,
+                                     float delta_in_scale, float* delta_out, float* new_inv, float* new_inv2,
+                                     int32_t new2_cstride, int32_t new2_coffset, int32_t B, int32_t HW, void* stream) {
+    hipLaunchKernelGGL(delta_update_kernel, dim3(dmvs_ceil_div((long)B * HW, DMVS_BLOCK)), dim3(DMVS_BLOCK), 0,
+                       (hipStream_t)stream, inv, delta_in, update, delta_in_scale, delta_out, new_inv, new_inv2,
+                       new2_cstride, new2_coffset, B, HW);
+    return dmvs_launch_status();
+}
+
+__global__ void __launch_bounds__(DMVS_BLOCK)
+depth_convert_kernel(const float* __restrict__ in, const float* __restrict__ disp_min,
+                     const float* __restrict__ disp_max, float* __restrict__ out, int mode, int B, int HW) {
+    const long i = (long)blockIdx.x * DMVS_BLOCK + threadIdx.x;
+    if (i >= (long)B * HW) return;
+    const int b = (int)(i / HW);
+    const float lo = disp_min[b], hi = disp_max[b];
+    if (mode == DMVS_EW_DEPTH_TO_DISP) out[i] = (1.0f / in[i] - lo) / (hi - lo);   // reference :229-235
+    else out[i] = dmvs_disp_to_depth(in[i], lo, hi);
+}
+
+extern "C" int dmvs_depth_convert_f32(const float* in, const float* disp_min, const float* disp_max, float* out,
+                                      int32_t mode, int32_t B, int32_t HW, void* stream) {
+    hipLaunchKernelGGL(depth_convert_kernel, dim3(dmvs_ceil_div((long)B * HW, DMVS_BLOCK)), dim3(DMVS_BLOCK), 0,
+                       (hipStream_t)stream, in, disp_min, disp_max, out, mode, B, HW);
+    return dmvs_launch_status();
+}
+
+__global__ void __launch_bounds__(DMVS_BLOCK)
+act_slice_kernel(const float* __restrict__ in, float* __restrict__ out, int act, int B, int C, int HW, int ics, int ico,
+                 int ocs, int oco) {
+    const long i = (long)blockIdx.x * DMVS_BLOCK + threadIdx.x;
+    if (i >= (long)B * C * HW) return;
+    const int p = (int)(i % HW), c = (int)((i / HW) % C), b = (int)(i / ((long)HW * C));
+    out[((long)b * ocs + oco + c) * HW + p] = dmvs_act(in[((long)b * ics + ico + c) * HW + p], act);
+}
+
+extern "C" int dmvs_act_slice_f32(const float* in, float* out, int32_t act, int32_t B, int32_t C, int32_t HW,
+                                  int32_t in_cstride, int32_t in_coffset, int32_t out_cstride, int32_t out_coffset,
+                                  void* stream) {
+    hipLaunchKernelGGL(act_slice_kernel, dim3(dmvs_ceil_div((long)B * C * HW, DMVS_BLOCK)), dim3(DMVS_BLOCK), 0,
+                       (hipStream_t)stream, in, out, act, B, C, HW, in_cstride, in_coffset, out_cstride, out_coffset);
+    return dmvs_launch_status();
+}
+
+__global__ void __launch_bounds__(DMVS_BLOCK)
+upsample_nearest_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int H, int W, int f) {
+    const int Ho = H * f, Wo = W * f;
+    const long i = (long)blockIdx.x * DMVS_BLOCK + threadIdx.x;
+    if (i >= (long)N * Ho * Wo) return;
+    const int xo = (int)(i % Wo), yo = (int)((i / Wo) % Ho), n = (int)(i / ((long)Wo * Ho));
+    out[i] = in[((long)n * H + yo / f) * W + xo / f];
+}
+
+extern "C" int dmvs_upsample_nearest_f32(const float* in, float* out, int32_t N, int32_t H, int32_t W, int32_t factor,
+                                         void* stream) {
+    hipLaunchKernelGGL(upsample_nearest_kernel, dim3(dmvs_ceil_div((long)N * H * W * factor * factor, DMVS_BLOCK)),
+                       dim3(DMVS_BLOCK), 0, (hipStream_t)stream, in, out, N, H, W, factor);
+    return dmvs_launch_status();
+}
+
+__global__ void __launch_bounds__(DMVS_BLOCK)
+nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int HW) {
+    const long i = (long)blockIdx.x * DMVS_BLOCK + threadIdx.x;   // over output elements, c fastest
+    if (i >= (long)B * C * HW) return;
+    const int c = (int)(i % C), p = (int)((i / C) % HW), b = (int)(i / ((long)C * HW));
+    out[i] = in[((long)b * C + c) * HW + p];
+}
+
+extern "C" int dmvs_nchw_to_nhwc_f32(const float* in, float* out, int32_t B, int32_t C, int32_t HW, void* stream) {
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(dmvs_ceil_div((long)B * C * HW, DMVS_BLOCK)), dim3(DMVS_BLOCK), 0,
+                       (hipStream_t)stream, in, out, B, C, HW);
+    return dmvs_launch_status();
+}

@@ -1,0 +1,313 @@
+"""Tensor-level wrappers around the C ABI (include/dmvs.h).
+
+torch is used here for device memory and the stream handle only; every arithmetic
+operation on the hot path is a kernel of libdmvs_hip.so.  `Ops` is bound to one library and
+one device; the product constructs it with `Ops.for_device(cuda_device)` which loads the
+gfx950 library and refuses anything else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU, ACT_TANH, IN_PLAIN, IN_UNSHUFFLE2,  # noqa: F401
+                   IN_UPSAMPLE2, LAYOUT_NCHW, LAYOUT_NHWC)
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class PackedConv:
+    """Weights in kernel layout [cin][k...][cout_pad] + folded per-channel epilogue."""
+    weight: torch.Tensor
+    scale: Optional[torch.Tensor]
+    shift: Optional[torch.Tensor]
+    cin: int
+    cout: int
+    cout_pad: int
+    k: tuple
+    stride: int = 1
+    pad: tuple = (0, 0)
+    transposed: bool = False
+
+
+def _pad_cout(cout: int) -> int:
+    return 8 if cout <= 8 else _round_up(cout, 16)
+
+
+def fold_bn(bn: dict, eps: float = 1e-5):
+    """eval BatchNorm -> (scale, shift).  reference models/module.py:46,90 (torch default eps)."""
+    scale = bn["weight"] * torch.rsqrt(bn["running_var"] + eps)
+    shift = bn["bias"] - bn["running_mean"] * scale
+    return scale, shift
+
+
+def pack_conv2d(w: torch.Tensor, bias=None, bn: Optional[dict] = None, stride=1, pad=(0, 0),
+                standardize=False) -> PackedConv:
+    """w: [cout, cin, kh, kw] (torch layout).  standardize: WeightStandardizedConv2d,
+    reference models/update.py:86-94 (fp32 eps 1e-5) applied once at pack time."""
+    w = w.detach().float()
+    if standardize:
+        mean = w.mean(dim=(1, 2, 3), keepdim=True)
+        var = w.var(dim=(1, 2, 3), unbiased=False, keepdim=True)
+        w = (w - mean) * torch.rsqrt(var + 1e-5)
+    cout, cin, kh, kw = w.shape
+    cp = _pad_cout(cout)
+    wk = torch.zeros(cin, kh, kw, cp, dtype=torch.float32, device=w.device)
+    wk[..., :cout] = w.permute(1, 2, 3, 0)
+    scale = shift = None
+    if bn is not None:
+        scale, shift = fold_bn(bn)
+        if bias is not None:
+            shift = shift + bias.detach().float() * scale
+    elif bias is not None:
+        shift = bias.detach().float()
+    pad = (pad, pad) if isinstance(pad, int) else tuple(pad)
+    return PackedConv(wk.contiguous(), None if scale is None else scale.contiguous().float(),
+                      None if shift is None else shift.contiguous().float(), cin, cout, cp, (kh, kw), stride, pad)
+
+
+def pack_conv3d(w: torch.Tensor, bias=None, bn: Optional[dict] = None, stride=1, transposed=False) -> PackedConv:
+    """w: Conv3d [cout,cin,3,3,3] or ConvTranspose3d [cin,cout,3,3,3] (reference module.py:88,130)."""
+    w = w.detach().float()
+    if transposed:
+        cin, cout = w.shape[0], w.shape[1]
+        wk_src = w.permute(0, 2, 3, 4, 1)          # [cin,kd,kh,kw,cout]
+    else:
+        cout, cin = w.shape[0], w.shape[1]
+        wk_src = w.permute(1, 2, 3, 4, 0)
+    cp = _pad_cout(cout)
+    wk = torch.zeros(cin, 27, cp, dtype=torch.float32, device=w.device)
+    wk[..., :cout] = wk_src.reshape(cin, 27, cout)
+    scale = shift = None
+    if bn is not None:
+        scale, shift = fold_bn(bn)
+    elif bias is not None:
+        shift = bias.detach().float()
+    return PackedConv(wk.contiguous(), None if scale is None else scale.contiguous(),
+                      None if shift is None else shift.contiguous(), cin, cout, cp, (3, 3, 3), stride, (1, 1),
+                      transposed)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Ops:
+    def __init__(self, lib: _lib.Lib, device):
+        self.lib = lib
+        self.device = torch.device(device)
+
+    @classmethod
+    def for_device(cls, device) -> "Ops":
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise _lib.DmvsError(
+                f"diffmvs_amd runs on MI355X only (got device '{device}'); there is no CPU path. "
+                "Move the model and inputs to a HIP device.")
+        return cls(_lib.hip_lib(), device)
+
+    # ------------------------------------------------------------------ plumbing
+    def stream(self):
+        if self.device.type == "cuda":
+            return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return None
+
+    def empty(self, *shape, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    def _chk(self, *ts):
+        for t in ts:
+            if t is None:
+                continue
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
+                raise _lib.DmvsError(f"expected contiguous fp32 tensor on {self.device}, got {t.dtype} "
+                                     f"contiguous={t.is_contiguous()} on {t.device}")
+
+    # ------------------------------------------------------------------ conv2d
+    def conv2d(self, pc: PackedConv, x0, x1=None, *, mul0=None, in_mode=IN_PLAIN, act=ACT_NONE, residual=None,
+               res_mode=IN_PLAIN, res_after_act=False, post_scale=1.0, gru_z=None, gru_h=None, out=None,
+               out_layout=LAYOUT_NCHW, out_cstride=None, out_coffset=0):
+        self._chk(x0, x1, mul0, residual, gru_z, gru_h, out)
+        B = x0.shape[0]
+        if in_mode == IN_PLAIN:
+            c0, Hin, Win = x0.shape[1], x0.shape[2], x0.shape[3]
+        elif in_mode == IN_UPSAMPLE2:
+            c0, Hin, Win = x0.shape[1], x0.shape[2] * 2, x0.shape[3] * 2
+        else:
+            c0, Hin, Win = x0.shape[1] * 4, x0.shape[2] // 2, x0.shape[3] // 2
+        c1 = 0 if x1 is None else x1.shape[1]
+        assert c0 + c1 == pc.cin, (c0, c1, pc.cin)
+        kh, kw = pc.k
+        Hout = (Hin + 2 * pc.pad[0] - kh) // pc.stride + 1
+        Wout = (Win + 2 * pc.pad[1] - kw) // pc.stride + 1
+        if out_cstride is None:
+            out_cstride = pc.cout
+        if out is None:
+            shape = (B, out_cstride, Hout, Wout) if out_layout == LAYOUT_NCHW else (B, Hout, Wout, out_cstride)
+            out = self.empty(*shape)
+        d = _lib.Conv2dDesc(
+            in0=_ptr(x0), in1=_ptr(x1), mul0=_ptr(mul0), weight=_ptr(pc.weight), scale=_ptr(pc.scale),
+            shift=_ptr(pc.shift), residual=_ptr(residual), gru_z=_ptr(gru_z), gru_h=_ptr(gru_h), out=_ptr(out),
+            B=B, c0=c0, c1=c1, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, cout=pc.cout, cout_pad=pc.cout_pad,
+            kh=kh, kw=kw, stride=pc.stride, pad_h=pc.pad[0], pad_w=pc.pad[1], in_mode=in_mode, act=act,
+            res_mode=res_mode, res_after_act=int(res_after_act), out_layout=out_layout, out_cstride=out_cstride,
+            out_coffset=out_coffset, post_scale=post_scale)
+        self.lib.call("dmvs_conv2d_f32", C.byref(d), self.stream())
+        return out
+
+    # ------------------------------------------------------------------ conv3d
+    def conv3d(self, pc: PackedConv, x, *, act=ACT_NONE, residual=None, out=None):
+        self._chk(x, residual, out)
+        B, cin, Din, Hin, Win = x.shape
+        assert cin == pc.cin
+        if pc.transposed:
+            Dout, Hout, Wout = 2 * Din, 2 * Hin, 2 * Win
+        else:
+            s = pc.stride
+            Dout, Hout, Wout = (Din - 1) // s + 1, (Hin - 1) // s + 1, (Win - 1) // s + 1
+        if out is None:
+            out = self.empty(B, pc.cout, Dout, Hout, Wout)
+        d = _lib.Conv3dDesc(in_=_ptr(x), weight=_ptr(pc.weight), scale=_ptr(pc.scale), shift=_ptr(pc.shift),
+                            residual=_ptr(residual), out=_ptr(out), B=B, cin=cin, cout=pc.cout, cout_pad=pc.cout_pad,
+                            Din=Din, Hin=Hin, Win=Win, Dout=Dout, Hout=Hout, Wout=Wout, stride=pc.stride,
+                            transposed=int(pc.transposed), act=act)
+        self.lib.call("dmvs_conv3d_f32", C.byref(d), self.stream())
+        return out
+
+    # ------------------------------------------------------------------ geometry / cost volumes
+    def compose_proj(self, proj):
+        """proj [B,V,2,4,4] -> [B,S,12] (rot row-major, trans)."""
+        self._chk(proj)
+        B, V = proj.shape[0], proj.shape[1]
+        out = self.empty(B, V - 1, 12)
+        self.lib.call("dmvs_compose_proj_f32", _ptr(proj), _ptr(out), B, V, self.stream())
+        return out
+
+    def warp_corr_init(self, ref, src, rt, disp_min, disp_max, D, G=4):
+        """ref [B,H,W,C], src [S,B,Hs,Ws,C] (NHWC) -> [B,S,G,D,H,W]."""
+        self._chk(ref, src, rt, disp_min, disp_max)
+        B, H, W, Cc = ref.shape
+        S, _, Hs, Ws, _ = src.shape
+        out = self.empty(B, S, G, D, H, W)
+        self.lib.call("dmvs_warp_corr_init_f32", _ptr(ref), _ptr(src), _ptr(rt), _ptr(disp_min), _ptr(disp_max),
+                      _ptr(out), B, S, Cc, G, D, H, W, Hs, Ws, self.stream())
+        return out
+
+    def getcost(self, ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, min_radius,
+                max_radius, vw_shift, out_cost=None, cost_cstride=None, cost_coffset=0, out_samples=None,
+                samp_cstride=None, samp_coffset=0, G=4):
+        self._chk(ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, out_cost, out_samples)
+        B, H, W, Cc = ref.shape
+        S = src.shape[0]
+        if out_cost is None:
+            cost_cstride = G * n
+            out_cost = self.empty(B, G * n, H, W)
+        if out_samples is None:
+            samp_cstride = n
+            out_samples = self.empty(B, n, H, W)
+        d = _lib.GetCostDesc(ref=_ptr(ref), src=_ptr(src), rt=_ptr(rt), inv_depth=_ptr(inv_depth),
+                             confidence=_ptr(confidence), view_w=_ptr(view_w), disp_min=_ptr(disp_min),
+                             disp_max=_ptr(disp_max), out_cost=_ptr(out_cost), out_samples=_ptr(out_samples),
+                             B=B, S=S, C=Cc, G=G, n=n, H=H, W=W, vw_shift=vw_shift, cost_cstride=cost_cstride,
+                             cost_coffset=cost_coffset, samp_cstride=samp_cstride, samp_coffset=samp_coffset,
+                             interval=interval, min_radius=min_radius, max_radius=max_radius)
+        self.lib.call("dmvs_getcost_f32", C.byref(d), self.stream())
+        return out_cost, out_samples
+
+    def view_aggregate(self, cor, w):
+        """cor [B,S,G,D,H,W], w [B,S,H,W] -> [B,G,D,H,W]."""
+        self._chk(cor, w)
+        B, S, G, D, H, W = cor.shape
+        out = self.empty(B, G, D, H, W)
+        self.lib.call("dmvs_view_aggregate_f32", _ptr(cor), _ptr(w), _ptr(out), B, S, G * D, H * W, self.stream())
+        return out
+
+    def sigmoid_max_d(self, x):
+        """x [N,D,H,W] -> [N,H,W]."""
+        self._chk(x)
+        N, D, H, W = x.shape
+        out = self.empty(N, H, W)
+        self.lib.call("dmvs_sigmoid_max_d_f32", _ptr(x), _ptr(out), N, D, H * W, self.stream())
+        return out
+
+    def depth_regress(self, logits, disp_min, disp_max):
+        """logits [B,D,H,W] -> norm_depth [B,1,H,W], depth [B,H,W], conf [B,1,H,W]."""
+        self._chk(logits, disp_min, disp_max)
+        B, D, H, W = logits.shape
+        nd, depth, conf = self.empty(B, 1, H, W), self.empty(B, H, W), self.empty(B, 1, H, W)
+        self.lib.call("dmvs_depth_regress_f32", _ptr(logits), _ptr(disp_min), _ptr(disp_max), _ptr(nd), _ptr(depth),
+                      _ptr(conf), B, D, H * W, self.stream())
+        return nd, depth, conf
+
+    def convex_upsample(self, inv, mask, disp_min, disp_max, ratio, want_inv=True):
+        """inv [B,1,H,W] or [B,H,W]; mask [B,9*r*r,H,W] -> (inv_up [B,rH,rW] | None, depth_up [B,rH,rW])."""
+        self._chk(inv, mask, disp_min, disp_max)
+        B, H, W = inv.shape[0], inv.shape[-2], inv.shape[-1]
+        assert mask.shape[1] == 9 * ratio * ratio
+        out_inv = self.empty(B, H * ratio, W * ratio) if want_inv else None
+        out_depth = self.empty(B, H * ratio, W * ratio)
+        self.lib.call("dmvs_convex_upsample_f32", _ptr(inv), _ptr(mask), _ptr(disp_min), _ptr(disp_max), _ptr(out_inv),
+                      _ptr(out_depth), B, H, W, ratio, self.stream())
+        return out_inv, out_depth
+
+    def groupnorm_silu(self, x, gamma, beta, groups, scale_shift=None, residual=None, out=None, eps=1e-5):
+        self._chk(x, gamma, beta, scale_shift, residual, out)
+        B, Cc, H, W = x.shape
+        if out is None:
+            out = self.empty(B, Cc, H, W)
+        stats = torch.empty(B * groups * 2, dtype=torch.float64, device=self.device)
+        self.lib.call("dmvs_groupnorm_silu_f32", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(scale_shift), _ptr(residual),
+                      _ptr(out), _ptr(stats), B, Cc, H * W, groups, eps, self.stream())
+        return out
+
+    def delta_update(self, inv, delta_in, update, delta_in_scale=1.0, new2=None, new2_cstride=0, new2_coffset=0):
+        """-> (delta_out, new_inv), also mirrors new_inv into channel new2_coffset of new2."""
+        self._chk(inv, delta_in, update, new2)
+        B = inv.shape[0]
+        HW = inv.numel() // B
+        delta_out = torch.empty_like(inv)
+        new_inv = torch.empty_like(inv)
+        self.lib.call("dmvs_delta_update_f32", _ptr(inv), _ptr(delta_in), _ptr(update), delta_in_scale,
+                      _ptr(delta_out), _ptr(new_inv), _ptr(new2), new2_cstride, new2_coffset, B, HW, self.stream())
+        return delta_out, new_inv
+
+    def depth_convert(self, x, disp_min, disp_max, mode):
+        self._chk(x, disp_min, disp_max)
+        B = x.shape[0]
+        out = torch.empty_like(x)
+        self.lib.call("dmvs_depth_convert_f32", _ptr(x), _ptr(disp_min), _ptr(disp_max), _ptr(out), mode, B,
+                      x.numel() // B, self.stream())
+        return out
+
+    def act_slice(self, x, act, c_from, c_count, out=None, out_cstride=None, out_coffset=0):
+        self._chk(x, out)
+        B, Ct, H, W = x.shape
+        if out is None:
+            out_cstride = c_count
+            out = self.empty(B, c_count, H, W)
+        self.lib.call("dmvs_act_slice_f32", _ptr(x), _ptr(out), act, B, c_count, H * W, Ct, c_from, out_cstride,
+                      out_coffset, self.stream())
+        return out
+
+    def upsample_nearest(self, x, factor):
+        """x [..., H, W] -> [..., fH, fW]."""
+        self._chk(x)
+        H, W = x.shape[-2], x.shape[-1]
+        N = x.numel() // (H * W)
+        out = self.empty(*x.shape[:-2], H * factor, W * factor)
+        self.lib.call("dmvs_upsample_nearest_f32", _ptr(x), _ptr(out), N, H, W, factor, self.stream())
+        return out
+
+    def nchw_to_nhwc(self, x):
+        self._chk(x)
+        B, Cc, H, W = x.shape
+        out = self.empty(B, H, W, Cc)
+        self.lib.call("dmvs_nchw_to_nhwc_f32", _ptr(x), _ptr(out), B, Cc, H * W, self.stream())
+        return out

@@ -1,0 +1,223 @@
+/*
+ * dmvs.h -- C ABI of libdmvs_hip.so: the MI355X (gfx950) kernels behind the DiffMVS /
+ * CasDiffMVS depth-estimation path.
+ *
+ * The reference (cvg/diffmvs) has no native layer at all: every entry point
+ * below replaces a span of PyTorch ops inside models/module.py / models/update.py, cited
+ * per function as  <file>:<lines>  relative to the reference repository root.
+ *
+ * Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller; nothing is allocated, freed or
+ *     retained by the library; no global state  => re-entrant, graph-capturable;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing syncs;
+ *   - the return value is 0 on success, a hipError_t otherwise, or DMVS_EINVAL for a
+ *     descriptor the library cannot run (unsupported kernel size, channel tile, ...);
+ *   - activations are fp32, planar NCHW / NCDHW unless a field says NHWC;
+ *   - functions never throw.
+ */
+#ifndef DMVS_H
+#define DMVS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMVS_ABI_VERSION 1
+#define DMVS_EINVAL (-22)
+
+/* activation codes for the fused epilogues */
+enum { DMVS_ACT_NONE = 0, DMVS_ACT_RELU = 1, DMVS_ACT_SIGMOID = 2, DMVS_ACT_TANH = 3, DMVS_ACT_SILU = 4 };
+/* how the logical input of a 2-D convolution is read from memory */
+enum { DMVS_IN_PLAIN = 0, DMVS_IN_UPSAMPLE2 = 1 /* nearest x2, F.interpolate */, DMVS_IN_UNSHUFFLE2 = 2 /* einops 'b c (h p1) (w p2) -> b (c p1 p2) h w' */ };
+enum { DMVS_LAYOUT_NCHW = 0, DMVS_LAYOUT_NHWC = 1 };
+
+int dmvs_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * 2-D convolution with everything around it fused.   Replaces, depending on the fields:
+ *   module.Conv2d / ConvBnReLU / ConvBn (conv -> eval BN -> ReLU)      models/module.py:24-58, :279-301
+ *   ResidualBlock's relu(x + y)                                        models/module.py:315-319
+ *   FeatureNet's  nearest-x2(intra) + inner(conv)                      models/module.py:409-417
+ *   ConditionEncoder convs, mask heads (0.25 * conv)                   models/update.py:289-297, :335-339,:473
+ *   Unet init_conv / Downsample (pixel-unshuffle + 1x1) / Upsample     models/update.py:38-48, :186, :246
+ *   WeightStandardizedConv2d (weights are pre-standardised by caller)  models/update.py:81-94
+ *   SepConvGRU gates: z|r = sigmoid(conv[h,x]);  h' = (1-z)h + z*tanh(conv[r*h,x])
+ *                                                                      models/module.py:164-177
+ * Logical input = concat(in0 (* mul0), in1) along channels, read through `in_mode`.
+ * Weight layout: [c0+c1][kh][kw][cout_pad] (cout fastest, zero padded to cout_pad, a
+ * multiple of 8).  Epilogue, per output channel co:
+ *   y = acc * scale[co] + shift[co]         (scale NULL = 1, shift NULL = 0; folded BN / bias)
+ *   y += residual (read through res_mode)   if residual && !res_after_act
+ *   y = act(y) * post_scale
+ *   y += residual                           if residual &&  res_after_act
+ *   y = (1 - gru_z) * gru_h + gru_z * y     if gru_z           (act must be TANH)
+ * Output is written at channel offset out_coffset of a tensor with out_cstride channels
+ * (so that concatenations never have to be materialised), NCHW or NHWC.
+ */
+typedef struct dmvs_conv2d_desc {
+    const float* in0;       /* [B,c0,*,*] physical tensor                                   */
+    const float* in1;       /* [B,c1,Hin,Win] or NULL; only with DMVS_IN_PLAIN               */
+    const float* mul0;      /* [B,c0,Hin,Win] or NULL: in0 is multiplied element-wise       */
+    const float* weight;
+    const float* scale;
+    const float* shift;
+    const float* residual;  /* [B,cout,*,*] or NULL                                         */
+    const float* gru_z;     /* [B,cout,Hout,Wout] or NULL                                   */
+    const float* gru_h;
+    float* out;
+    int32_t B, c0, c1;
+    int32_t Hin, Win;       /* LOGICAL input size (after in_mode)                           */
+    int32_t Hout, Wout;
+    int32_t cout, cout_pad;
+    int32_t kh, kw, stride, pad_h, pad_w;
+    int32_t in_mode, act;
+    int32_t res_mode;       /* DMVS_IN_PLAIN or DMVS_IN_UPSAMPLE2                           */
+    int32_t res_after_act;
+    int32_t out_layout, out_cstride, out_coffset;
+    float post_scale;
+} dmvs_conv2d_desc;
+
+int dmvs_conv2d_f32(const dmvs_conv2d_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * 3-D convolution 3x3x3, padding 1 (module.Conv3d, models/module.py:66-102) and stride-2
+ * transposed convolution with output_padding 1 (module.Deconv3d, :110-144, :436-437), with
+ * eval-BN folded into scale/shift, optional ReLU and an optional post-activation residual
+ * (CostRegNet_small skip adds, models/module.py:445-446).
+ * Weight layout: [cin][27][cout_pad].  For transposed convs the caller passes the weight of
+ * the equivalent gather form: w[ci][kd][kh][kw][co] = W_torch[ci][co][kd][kh][kw].
+ */
+typedef struct dmvs_conv3d_desc {
+    const float* in;        /* [B,cin,Din,Hin,Win]                                          */
+    const float* weight;
+    const float* scale;
+    const float* shift;
+    const float* residual;  /* [B,cout,Dout,Hout,Wout] or NULL, added after the activation  */
+    float* out;             /* [B,cout,Dout,Hout,Wout]                                      */
+    int32_t B, cin, cout, cout_pad;
+    int32_t Din, Hin, Win;
+    int32_t Dout, Hout, Wout;
+    int32_t stride;         /* 1 or 2                                                       */
+    int32_t transposed;     /* 0 | 1 (stride must be 2)                                     */
+    int32_t act;
+} dmvs_conv3d_desc;
+
+int dmvs_conv3d_f32(const dmvs_conv3d_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Camera composition.  For each batch item b and source view s = 1..S:
+ *   P = (K_s E_s[:3,:4] | 0001) * inverse(K_0 E_0[:3,:4] | 0001)   models/module.py:188, :520-525
+ * proj: [B,V,2,4,4] (V = S+1; [:, :, 0] extrinsic, [:, :, 1, :3, :3] intrinsic).
+ * out:  [B,S,12]  = rot (row-major 3x3) followed by trans (3).  Computed in fp64 from the
+ * fp32 inputs and rounded once.
+ */
+int dmvs_compose_proj_f32(const float* proj, float* out, int32_t B, int32_t V, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Plane-sweep group-wise correlation volumes for depth initialisation.
+ * Fuses differentiable_warping (models/module.py:181-218) with the group-wise correlation of
+ * InitialCost.forward (:514-531) for ALL source views in one launch; the hypotheses are
+ * uniform in normalised inverse depth (models/diffusion.py:187-192), so they are generated
+ * in-kernel:  depth_d = 1 / clamp(1/dmax + (1/dmin - 1/dmax) * d/(D-1), 1e-6).
+ *   ref  [B,H,W,C]  NHWC        src  [S][B,Hs,Ws,C] NHWC, contiguous over S
+ *   rt   [B,S,12]   from dmvs_compose_proj_f32
+ *   disp_min/disp_max [B]       (= depth_values[:,0], depth_values[:,-1])
+ *   out  [B,S,G,D,H,W]          cor[g] = mean over the C/G channels of group g
+ * C in {16,32,48}, G = 4.
+ */
+int dmvs_warp_corr_init_f32(const float* ref, const float* src, const float* rt,
+                            const float* disp_min, const float* disp_max, float* out,
+                            int32_t B, int32_t S, int32_t C, int32_t G, int32_t D,
+                            int32_t H, int32_t W, int32_t Hs, int32_t Ws, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * GetCost.forward (models/module.py:583-667) in ONE kernel: hypothesis generation
+ * (get_cur_depth_range_samples :250-277 + disp_to_depth :220-227), S homography warps,
+ * group-wise correlation and view-weighted aggregation  sum_s w_s cor_s / (1e-8 + sum_s w_s).
+ *   inv_depth  [B,1,H,W] normalised inverse depth      confidence [B,H,W] or NULL
+ *   view_w     [B,S,H>>vw_shift,W>>vw_shift]  (nearest-upsampled on the fly,
+ *              models/diffusion.py:219-221)
+ *   out_cost   [B,G*n,H,W]  written at channel offset cost_coffset of a tensor with
+ *              cost_cstride channels;   out_samples [B,n,H,W] likewise
+ * n in {4,6}; interval = depth_interval * ratio (models/diffusion.py:246).
+ */
+typedef struct dmvs_getcost_desc {
+    const float* ref;       /* [B,H,W,C] NHWC */
+    const float* src;       /* [S][B,H,W,C] NHWC */
+    const float* rt;        /* [B,S,12] */
+    const float* inv_depth;
+    const float* confidence;
+    const float* view_w;
+    const float* disp_min;  /* [B] */
+    const float* disp_max;  /* [B] */
+    float* out_cost;
+    float* out_samples;
+    int32_t B, S, C, G, n, H, W;
+    int32_t vw_shift;
+    int32_t cost_cstride, cost_coffset, samp_cstride, samp_coffset;
+    float interval, min_radius, max_radius;
+} dmvs_getcost_desc;
+
+int dmvs_getcost_f32(const dmvs_getcost_desc* d, void* stream);
+
+/* view-weighted aggregation of the per-view volumes (models/module.py:539-548):
+ * out[b,g,d,p] = sum_s w[b,s,p] cor[b,s,g,d,p] / (1e-8 + sum_s w[b,s,p]) */
+int dmvs_view_aggregate_f32(const float* cor, const float* w, float* out,
+                            int32_t B, int32_t S, int32_t GD, int32_t HW, void* stream);
+
+/* PixelViewWeight tail (models/module.py:460-463): out[n,p] = max_d sigmoid(x[n,d,p]) */
+int dmvs_sigmoid_max_d_f32(const float* x, float* out, int32_t N, int32_t D, int32_t HW, void* stream);
+
+/* InitialCost epilogue (models/module.py:553-571): softmax over D, expectation index,
+ * normalised depth index/(D-1), metric depth via disp_to_depth, photometric confidence =
+ * sum of the 4 probabilities d-1..d+2 around floor(index).
+ *   logits [B,D,HW] -> norm_depth [B,HW], depth [B,HW], conf [B,HW] */
+int dmvs_depth_regress_f32(const float* logits, const float* disp_min, const float* disp_max,
+                           float* norm_depth, float* depth, float* conf,
+                           int32_t B, int32_t D, int32_t HW, void* stream);
+
+/* upsample_depth (models/module.py:237-248) fused with disp_to_depth (:220-227):
+ * convex combination of the 3x3 neighbourhood with softmax(mask) weights.
+ *   inv [B,H,W], mask [B,9*r*r,H,W] -> out_inv [B,rH,rW] (may be NULL), out_depth [B,rH,rW] */
+int dmvs_convex_upsample_f32(const float* inv, const float* mask, const float* disp_min,
+                             const float* disp_max, float* out_inv, float* out_depth,
+                             int32_t B, int32_t H, int32_t W, int32_t ratio, void* stream);
+
+/* GroupNorm statistics + fused apply of Block.forward (models/update.py:124-133):
+ *   y = silu( gn(x) * (scale+1) + shift ) [+ residual]
+ * x [B,C,HW]; gamma,beta [C]; scale_shift [B,2C] (scale then shift) or NULL; residual or NULL.
+ * stats: caller-provided scratch of B*groups*2 doubles.  In-place (y == x) is allowed. */
+int dmvs_groupnorm_silu_f32(const float* x, const float* gamma, const float* beta,
+                            const float* scale_shift, const float* residual, float* y,
+                            double* stats, int32_t B, int32_t C, int32_t HW, int32_t groups,
+                            float eps, void* stream);
+
+/* Refinement bookkeeping (models/update.py:479-483, :496-502):
+ *   new = clamp(inv + delta_in (+ update), 0, 1);  delta_out = new - inv
+ * update may be NULL (first step: delta_in = scale * noise).  `new` is written with channel
+ * stride/offset so that it can land directly inside the Unet input tensor. */
+int dmvs_delta_update_f32(const float* inv, const float* delta_in, const float* update,
+                          float delta_in_scale, float* delta_out, float* new_inv,
+                          float* new_inv2, int32_t new2_cstride, int32_t new2_coffset,
+                          int32_t B, int32_t HW, void* stream);
+
+/* element-wise helpers:  depth <-> normalised inverse depth (models/module.py:220-235),
+ * activations on a channel slice, nearest upsampling by an integer factor. */
+enum { DMVS_EW_DEPTH_TO_DISP = 0, DMVS_EW_DISP_TO_DEPTH = 1 };
+int dmvs_depth_convert_f32(const float* in, const float* disp_min, const float* disp_max,
+                           float* out, int32_t mode, int32_t B, int32_t HW, void* stream);
+/* out[b, out_coffset + c, p] = act(in[b, in_coffset + c, p]) for c < C */
+int dmvs_act_slice_f32(const float* in, float* out, int32_t act, int32_t B, int32_t C, int32_t HW,
+                       int32_t in_cstride, int32_t in_coffset, int32_t out_cstride, int32_t out_coffset,
+                       void* stream);
+int dmvs_upsample_nearest_f32(const float* in, float* out, int32_t N, int32_t H, int32_t W,
+                              int32_t factor, void* stream);
+/* NCHW -> NHWC for features that did not come out of dmvs_conv2d_f32 channel-last */
+int dmvs_nchw_to_nhwc_f32(const float* in, float* out, int32_t B, int32_t C, int32_t HW, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMVS_H */

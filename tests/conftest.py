@@ -62,3 +62,30 @@ def state_keys(variant):
 def rel_l1(a, b):
     a, b = a.double(), b.double()
     return float((a - b).abs().mean() / b.abs().mean().clamp_min(1e-30))
+
+
+# ---------------------------------------------------------------------------------------
+# backends for the kernel tests: "hip" = the product library on cuda:0 (GPU box, -m gpu);
+# "emu" = the same kernel sources compiled for the host by tests/hipemu (CPU container).
+_EMU = {}
+
+
+def emu_ops():
+    if "ops" not in _EMU:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from hipemu.build import build_emu
+        from diffmvs_amd import _lib
+        from diffmvs_amd.ops import Ops
+        _EMU["ops"] = Ops(_lib.Lib(build_emu()), "cpu")
+    return _EMU["ops"]
+
+
+def hip_ops():
+    from diffmvs_amd.ops import Ops
+    assert torch.cuda.is_available(), "gpu-marked test needs a HIP device"
+    return Ops.for_device("cuda:0")
+
+
+@pytest.fixture(params=[pytest.param("emu"), pytest.param("hip", marks=pytest.mark.gpu)])
+def ops(request):
+    return emu_ops() if request.param == "emu" else hip_ops()

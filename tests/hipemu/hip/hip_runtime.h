@@ -1,0 +1,203 @@
+// TEST-ONLY host emulation of the small slice of the HIP kernel language that
+// diffmvs_amd/csrc uses.  It lets `python -m pytest -m "not gpu"` execute the *same* kernel
+// sources on CPU threads (tests/hipemu/build.py compiles csrc/*.hip with g++ -I tests/hipemu),
+// so index arithmetic, tiling and epilogues are checked against the oracle in a container
+// that has no GPU.  It is NOT a product backend: nothing under diffmvs_amd/ or models/
+// references it, the product loader only ever opens libdmvs_hip.so (gfx950 code object).
+//
+// Model: one fiber (ucontext) per GPU thread, the fibers of a block run round-robin on one
+// OS thread; __syncthreads() and the wave shuffles are "yield until the scheduler comes
+// round again", which is a block-wide barrier as long as every live thread of the block
+// executes the same sequence of them (the same rule the hardware imposes on barriers).
+#pragma once
+#include <ucontext.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static thread_local
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 { float x, y; };
+struct float3 { float x, y, z; };
+struct alignas(16) float4 { float x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline float3 make_float3(float x, float y, float z) { return float3{x, y, z}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+enum { hipSuccess = 0 };
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+
+namespace hipemu {
+struct Fiber {
+    ucontext_t ctx;
+    bool done;
+};
+struct Worker {
+    ucontext_t main_ctx;
+    std::vector<Fiber> fibers;
+    std::vector<char> stacks;
+    std::vector<uint64_t> slots;   // shuffle exchange, one per thread of the block
+    int current = -1;
+    const std::function<void()>* body = nullptr;
+};
+inline thread_local Worker* g_worker = nullptr;
+inline thread_local dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
+constexpr size_t kStack = 256 * 1024;
+
+inline void set_tid(int t) {
+    g_threadIdx.x = t % g_blockDim.x;
+    g_threadIdx.y = (t / g_blockDim.x) % g_blockDim.y;
+    g_threadIdx.z = t / (g_blockDim.x * g_blockDim.y);
+}
+inline void trampoline() {
+    Worker* w = g_worker;
+    (*w->body)();
+    w->fibers[w->current].done = true;
+    swapcontext(&w->fibers[w->current].ctx, &w->main_ctx);
+}
+inline void yield() {
+    Worker* w = g_worker;
+    swapcontext(&w->fibers[w->current].ctx, &w->main_ctx);
+}
+inline int linear_tid() { return g_threadIdx.x + g_blockDim.x * (g_threadIdx.y + g_blockDim.y * g_threadIdx.z); }
+
+inline void run_block(Worker& w, int nthreads) {
+    for (int t = 0; t < nthreads; ++t) {
+        Fiber& f = w.fibers[t];
+        f.done = false;
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = w.stacks.data() + size_t(t) * kStack;
+        f.ctx.uc_stack.ss_size = kStack;
+        f.ctx.uc_link = nullptr;
+        makecontext(&f.ctx, (void (*)())trampoline, 0);
+    }
+    int alive = nthreads;
+    while (alive > 0) {
+        for (int t = 0; t < nthreads; ++t) {
+            if (w.fibers[t].done) continue;
+            w.current = t;
+            set_tid(t);
+            swapcontext(&w.main_ctx, &w.fibers[t].ctx);
+            if (w.fibers[t].done) --alive;
+        }
+    }
+}
+
+inline void launch(dim3 grid, dim3 block, size_t, const std::function<void()>& body) {
+    const long nblocks = long(grid.x) * grid.y * grid.z;
+    const int nthreads = int(block.x * block.y * block.z);
+    if (nblocks == 0 || nthreads == 0) return;
+    std::atomic<long> next{0};
+    auto work = [&]() {
+        Worker w;
+        w.fibers.resize(nthreads);
+        w.stacks.resize(size_t(nthreads) * kStack);
+        w.slots.resize(nthreads);
+        w.body = &body;
+        g_worker = &w;
+        g_blockDim = block;
+        g_gridDim = grid;
+        for (;;) {
+            long b = next.fetch_add(1);
+            if (b >= nblocks) break;
+            g_blockIdx.x = unsigned(b % grid.x);
+            g_blockIdx.y = unsigned((b / grid.x) % grid.y);
+            g_blockIdx.z = unsigned(b / (long(grid.x) * grid.y));
+            run_block(w, nthreads);
+        }
+        g_worker = nullptr;
+    };
+    unsigned nw = std::min<long>(std::max(1u, std::thread::hardware_concurrency()), nblocks);
+    std::vector<std::thread> pool;
+    for (unsigned i = 1; i < nw; ++i) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+}
+
+template <typename T>
+inline T shfl_from(T v, int src_lane_abs) {
+    Worker* w = g_worker;
+    uint64_t raw = 0;
+    memcpy(&raw, &v, sizeof(T));
+    w->slots[linear_tid()] = raw;
+    yield();
+    uint64_t got = w->slots[src_lane_abs];
+    yield();
+    T r;
+    memcpy(&r, &got, sizeof(T));
+    return r;
+}
+}  // namespace hipemu
+
+#define threadIdx hipemu::g_threadIdx
+#define blockIdx hipemu::g_blockIdx
+#define blockDim hipemu::g_blockDim
+#define gridDim hipemu::g_gridDim
+#define hipLaunchKernelGGL(k, g, b, sh, st, ...) \
+    hipemu::launch((g), (b), (sh), std::function<void()>([=]() { k(__VA_ARGS__); }))
+
+static inline void __syncthreads() { hipemu::yield(); }
+template <typename T>
+static inline T __shfl_down(T v, unsigned delta, int width = 64) {
+    int t = hipemu::linear_tid();
+    int lane = t & 63, base = t & ~63;
+    int src = lane + int(delta);
+    if ((lane & (width - 1)) + int(delta) >= width) src = lane;
+    return hipemu::shfl_from(v, base + src);
+}
+template <typename T>
+static inline T __shfl_xor(T v, int mask, int width = 64) {
+    int t = hipemu::linear_tid();
+    int lane = t & 63, base = t & ~63;
+    (void)width;
+    return hipemu::shfl_from(v, base + (lane ^ mask));
+}
+template <typename T>
+static inline T __shfl(T v, int src, int width = 64) {
+    int t = hipemu::linear_tid();
+    int lane = t & 63, base = t & ~63;
+    int grp = lane & ~(width - 1);
+    return hipemu::shfl_from(v, base + grp + (src & (width - 1)));
+}
+
+template <typename T>
+static inline T hipemu_atomic_add(T* addr, T val) {
+    using U = typename std::conditional<sizeof(T) == 4, uint32_t, uint64_t>::type;
+    U* p = reinterpret_cast<U*>(addr);
+    U old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    for (;;) {
+        T cur;
+        memcpy(&cur, &old, sizeof(T));
+        T nv = cur + val;
+        U nraw;
+        memcpy(&nraw, &nv, sizeof(T));
+        if (__atomic_compare_exchange_n(p, &old, nraw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return cur;
+    }
+}
+static inline float atomicAdd(float* a, float v) { return hipemu_atomic_add(a, v); }
+static inline double atomicAdd(double* a, double v) { return hipemu_atomic_add(a, v); }
+static inline int atomicAdd(int* a, int v) { return __atomic_fetch_add(a, v, __ATOMIC_RELAXED); }
+
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline float __frcp_rn(float x) { return 1.0f / x; }
+static inline float __fdividef(float a, float b) { return a / b; }

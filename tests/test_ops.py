@@ -1,0 +1,310 @@
+"""Kernel-level parity: every C-ABI entry point against the oracle / the matching ATen op.
+Runs twice: on the host emulation of the kernel sources (CPU container) and, with -m gpu,
+through libdmvs_hip.so on the MI355X."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from diffmvs_amd import ops as K
+from oracle import diffmvs_oracle as O
+
+
+def rnd(*shape, seed=0, lo=-1.0, hi=1.0):
+    rs = np.random.RandomState(seed + sum(shape))
+    return torch.from_numpy(rs.uniform(lo, hi, shape).astype(np.float32))
+
+
+def dev(ops, *ts):
+    r = [None if t is None else t.to(ops.device).contiguous() for t in ts]
+    return r if len(r) > 1 else r[0]
+
+
+def close(a, b, tol=1e-5):
+    a = a.detach().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert torch.isfinite(a).all()
+    err = float((a - b).abs().max())
+    scale = max(1.0, float(b.abs().max()))
+    assert err <= tol * scale, f"max abs err {err:.3e} (scale {scale:.3e})"
+
+
+ACTS = {K.ACT_NONE: lambda x: x, K.ACT_RELU: F.relu, K.ACT_SIGMOID: torch.sigmoid, K.ACT_TANH: torch.tanh,
+        K.ACT_SILU: F.silu}
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,act", [
+    (3, 8, (3, 3), 1, (1, 1), K.ACT_RELU),
+    (8, 16, (5, 5), 2, (2, 2), K.ACT_RELU),
+    (16, 48, (1, 1), 1, (0, 0), K.ACT_NONE),
+    (12, 31, (3, 3), 1, (1, 1), K.ACT_RELU),
+    (10, 16, (7, 7), 1, (3, 3), K.ACT_NONE),
+    (9, 20, (1, 5), 1, (0, 2), K.ACT_SIGMOID),
+    (9, 20, (5, 1), 1, (2, 0), K.ACT_TANH),
+    (6, 36, (3, 3), 2, (1, 1), K.ACT_SILU),
+    (64, 144, (1, 1), 1, (0, 0), K.ACT_NONE),
+])
+def test_conv2d_basic(ops, cin, cout, k, stride, pad, act):
+    B, H, W = 2, 13, 18
+    x = rnd(B, cin, H, W, seed=1)
+    w = rnd(cout, cin, *k, seed=2) * 0.3
+    bias = rnd(cout, seed=3)
+    bn = {"weight": rnd(cout, seed=4, lo=0.5, hi=1.5), "bias": rnd(cout, seed=5),
+          "running_mean": rnd(cout, seed=6), "running_var": rnd(cout, seed=7, lo=0.5, hi=1.5)}
+    for use_bn in (False, True):
+        ref = F.conv2d(x, w, None if use_bn else bias, stride, pad)
+        if use_bn:
+            ref = F.batch_norm(ref, bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"], False, 0.0, 1e-5)
+        ref = ACTS[act](ref)
+        pc = K.pack_conv2d(*dev(ops, w, None if use_bn else bias), bn=None if not use_bn else
+                           {k_: v.to(ops.device) for k_, v in bn.items()}, stride=stride, pad=pad)
+        out = ops.conv2d(pc, dev(ops, x), act=act)
+        close(out, ref, 2e-5)
+
+
+def test_conv2d_fusions(ops):
+    B, H, W = 2, 10, 12
+    # concat + r*h gating + GRU blend  (reference models/module.py:164-177)
+    h, x = rnd(B, 6, H, W, seed=1), rnd(B, 10, H, W, seed=2)
+    r, z = torch.sigmoid(rnd(B, 6, H, W, seed=3)), torch.sigmoid(rnd(B, 6, H, W, seed=4))
+    w, bias = rnd(6, 16, 1, 5, seed=5) * 0.3, rnd(6, seed=6)
+    q = torch.tanh(F.conv2d(torch.cat([r * h, x], 1), w, bias, 1, (0, 2)))
+    ref = (1 - z) * h + z * q
+    pc = K.pack_conv2d(*dev(ops, w, bias), pad=(0, 2))
+    out = ops.conv2d(pc, *dev(ops, h, x), mul0=dev(ops, r), act=K.ACT_TANH, gru_z=dev(ops, z), gru_h=dev(ops, h))
+    close(out, ref, 2e-5)
+    # nearest-x2 upsampled input (update.py:38-42) and pre-activation residual read through upsampling
+    xs = rnd(B, 8, H // 2, W // 2, seed=7)
+    w3, b3 = rnd(12, 8, 3, 3, seed=8) * 0.3, rnd(12, seed=9)
+    ref = F.conv2d(F.interpolate(xs, scale_factor=2, mode="nearest"), w3, b3, 1, 1)
+    out = ops.conv2d(K.pack_conv2d(*dev(ops, w3, b3), pad=1), dev(ops, xs), in_mode=K.IN_UPSAMPLE2)
+    close(out, ref, 2e-5)
+    res = rnd(B, 12, H // 2, W // 2, seed=10)
+    x8 = rnd(B, 8, H, W, seed=11)
+    w1 = rnd(12, 8, 1, 1, seed=12)
+    ref = F.interpolate(res, scale_factor=2, mode="nearest") + F.conv2d(x8, w1, b3)
+    out = ops.conv2d(K.pack_conv2d(*dev(ops, w1, b3)), dev(ops, x8), residual=dev(ops, res), res_mode=K.IN_UPSAMPLE2)
+    close(out, ref, 2e-5)
+    # pixel-unshuffle + 1x1 (update.py:44-48)
+    xu = rnd(B, 5, H, W, seed=13)
+    wu, bu = rnd(7, 20, 1, 1, seed=14), rnd(7, seed=15)
+    ref = F.conv2d(O._pixel_unshuffle(xu), wu, bu)
+    out = ops.conv2d(K.pack_conv2d(*dev(ops, wu, bu)), dev(ops, xu), in_mode=K.IN_UNSHUFFLE2)
+    close(out, ref, 2e-5)
+    # relu(x + y) residual, post-scale, channel-offset output, NHWC output
+    xr = rnd(B, 8, H, W, seed=16)
+    ref = F.relu(F.conv2d(x8, w3[:8], None, 1, 1) + xr) * 0.25
+    big = torch.full((B, 20, H, W), 7.0)
+    bigd = dev(ops, big)
+    ops.conv2d(K.pack_conv2d(dev(ops, w3[:8].contiguous()), pad=1), dev(ops, x8), residual=dev(ops, xr),
+               act=K.ACT_RELU, post_scale=0.25, out=bigd, out_cstride=20, out_coffset=5)
+    close(bigd[:, 5:13], ref, 2e-5)
+    assert float(bigd[:, :5].min()) == 7.0 and float(bigd[:, 13:].min()) == 7.0
+    out = ops.conv2d(K.pack_conv2d(dev(ops, w3[:8].contiguous()), pad=1), dev(ops, x8), out_layout=K.LAYOUT_NHWC)
+    close(out, F.conv2d(x8, w3[:8], None, 1, 1).permute(0, 2, 3, 1).contiguous(), 2e-5)
+
+
+@pytest.mark.parametrize("cin,cout,stride,transposed", [(4, 8, 1, False), (8, 16, 2, False), (16, 12, 1, False),
+                                                         (16, 8, 2, True), (8, 1, 1, False), (12, 20, 2, True)])
+def test_conv3d(ops, cin, cout, stride, transposed):
+    B, D, H, W = 2, 6, 7, 10
+    if transposed:
+        D, H, W = 3, 4, 5
+    x = rnd(B, cin, D, H, W, seed=1)
+    bn = {"weight": rnd(cout, seed=4, lo=0.5, hi=1.5), "bias": rnd(cout, seed=5),
+          "running_mean": rnd(cout, seed=6), "running_var": rnd(cout, seed=7, lo=0.5, hi=1.5)}
+    if transposed:
+        w = rnd(cin, cout, 3, 3, 3, seed=2) * 0.2
+        ref = F.conv_transpose3d(x, w, None, 2, 1, 1)
+    else:
+        w = rnd(cout, cin, 3, 3, 3, seed=2) * 0.2
+        ref = F.conv3d(x, w, None, stride, 1)
+    ref = F.relu(F.batch_norm(ref, bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"], False, 0.0, 1e-5))
+    res = rnd(*ref.shape, seed=9)
+    ref = ref + res
+    pc = K.pack_conv3d(dev(ops, w), bn={k_: v.to(ops.device) for k_, v in bn.items()}, stride=stride,
+                       transposed=transposed)
+    out = ops.conv3d(pc, dev(ops, x), act=K.ACT_RELU, residual=dev(ops, res))
+    close(out, ref, 2e-5)
+
+
+def _cams(B, V, H, W, seed):
+    rs = np.random.RandomState(seed)
+    pm = np.zeros((B, V, 2, 4, 4), np.float32)
+    for b in range(B):
+        for v in range(V):
+            a = 0.06 * v + 0.01 * b
+            R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+            E = np.eye(4)
+            E[:3, :3] = R
+            E[:3, 3] = [-25.0 * v, 3.0 * v, 2.0 * b]
+            pm[b, v, 0] = E
+            pm[b, v, 1, :3, :3] = [[1.1 * W, 0, W / 2 + rs.uniform(-1, 1)], [0, 1.1 * W, H / 2], [0, 0, 1]]
+    return torch.from_numpy(pm)
+
+
+def test_compose_proj(ops):
+    pm = _cams(3, 4, 16, 20, 0)
+    out = ops.compose_proj(dev(ops, pm)).cpu()
+    ref_proj = O.compose_proj(pm[:, 0])
+    for s in range(3):
+        m = torch.matmul(O.compose_proj(pm[:, s + 1]).double(), torch.inverse(ref_proj.double()))
+        close(out[:, s, :9].reshape(-1, 3, 3), m[:, :3, :3].float(), 1e-6)
+        assert float((out[:, s, 9:] - m[:, :3, 3].float()).abs().max()) < 1e-3 * float(m[:, :3, 3].abs().max())
+
+
+@pytest.mark.parametrize("C", [48, 32, 16])
+def test_warp_corr_init(ops, C):
+    B, S, D, H, W = 2, 3, 7, 11, 14
+    pm = _cams(B, S + 1, H, W, 1)
+    feats = [rnd(B, C, H, W, seed=10 + v) for v in range(S + 1)]
+    dv = torch.tensor([[1 / 935.0, 1 / 425.0], [1 / 800.0, 1 / 500.0]])
+    disp_min, disp_max = 1 / (1 / dv[:, 0]), 1 / (1 / dv[:, 1])
+    hyp = (torch.arange(D).view(1, -1, 1, 1) / (D - 1.0)).repeat(B, 1, H, W)
+    hyp = O.disp_to_depth(hyp, (1 / dv[:, 1]).view(-1, 1, 1, 1), (1 / dv[:, 0]).view(-1, 1, 1, 1))[1]
+    ref_proj = O.compose_proj(pm[:, 0])
+    want = torch.stack([O.group_corr(O.warp(feats[v], O.compose_proj(pm[:, v]), ref_proj, hyp), feats[0], 4)
+                        for v in range(1, S + 1)], 1)
+    rt = ops.compose_proj(dev(ops, pm))
+    ref_nhwc = dev(ops, feats[0].permute(0, 2, 3, 1))
+    src_nhwc = dev(ops, torch.stack([f.permute(0, 2, 3, 1) for f in feats[1:]]))
+    out = ops.warp_corr_init(ref_nhwc, src_nhwc, rt, dev(ops, disp_min), dev(ops, disp_max), D)
+    close(out, want, 1e-4)
+
+
+def test_warp_golden_edge_cases(ops, golden):
+    """differentiable_warping edge cases recorded from the reference (big rotations, points behind
+    the camera, z == 0, source grid != hypothesis grid), pushed through the fused kernel by using
+    an all-ones reference feature: cor[g] = mean over group of warped."""
+    g = golden("warp_edge.npz")
+    for ci in range(int(g.np("n_cases"))):
+        src, depth, want = g.t(f"c{ci}.src"), g.t(f"c{ci}.depth"), g.t(f"c{ci}.out")
+        B, Cc, Hs, Ws = src.shape
+        D, H, W = depth.shape[1:]
+        # the fused kernel generates uniform inverse-depth hypotheses itself; per-pixel depth maps go
+        # through getcost-style sampling, so here we test each depth plane d separately via D=2
+        # kernels is not possible -> use the generic C=16 path with channel padding and constant depth
+        # planes: only cases whose depth is constant per plane are comparable; others are covered by
+        # test_getcost below.  Case 4 (z==0) has constant planes.
+        if ci != 4:
+            continue
+        pad = 16 - Cc
+        srcp = torch.cat([src, torch.zeros(B, pad, Hs, Ws)], 1)
+        P = torch.matmul(g.t(f"c{ci}.src_proj"), torch.inverse(g.t(f"c{ci}.ref_proj")))
+        rt = torch.cat([P[:, :3, :3].reshape(B, 9), P[:, :3, 3]], 1).view(B, 1, 12)
+        d0, d1 = float(depth[0, 0, 0, 0]), float(depth[0, 1, 0, 0])
+        out = ops.warp_corr_init(dev(ops, torch.ones(B, H, W, 16)), dev(ops, srcp.permute(0, 2, 3, 1).unsqueeze(0)),
+                                 dev(ops, rt), dev(ops, torch.tensor([1 / d1])), dev(ops, torch.tensor([1 / d0])), 2)
+        # hypothesis 0 = disp_min -> depth d1 ; hypothesis 1 = disp_max -> depth d0
+        got = out.cpu()[:, 0, 0] * 4.0   # group 0 = channels 0..3 = the real channels, mean -> sum
+        want_g = want.sum(1)             # [B,D,H,W]
+        close(got[:, 1], want_g[:, 0], 1e-4)
+        close(got[:, 0], want_g[:, 1], 1e-4)
+
+
+@pytest.mark.parametrize("C,n,with_conf", [(32, 6, False), (32, 6, True), (16, 4, True), (48, 4, False)])
+def test_getcost(ops, C, n, with_conf):
+    B, S, H, W = 2, 3, 12, 16
+    pm = _cams(B, S + 1, H, W, 2)
+    feats = [rnd(B, C, H, W, seed=20 + v) for v in range(S + 1)]
+    inv = rnd(B, 1, H, W, seed=30, lo=-0.1, hi=1.1)      # some hypotheses get clamped
+    conf = rnd(B, H, W, seed=31, lo=0.0, hi=1.0) if with_conf else None
+    vw = rnd(B, S, H // 2, W // 2, seed=32, lo=0.0, hi=1.0)
+    dv0, dv1 = torch.tensor([1 / 935.0, 1 / 700.0]), torch.tensor([1 / 425.0, 1 / 450.0])
+    dmax, dmin = (1 / dv0).view(-1, 1, 1, 1), (1 / dv1).view(-1, 1, 1, 1)
+    interval = 2.0 / 384
+    want_cost, want_s = O.get_cost(feats, pm, inv, interval, dmax, dmin, n,
+                                   F.interpolate(vw, scale_factor=2, mode="nearest"), conf, 4, 0.25, 4.0)
+    rt = ops.compose_proj(dev(ops, pm))
+    cost, samp = ops.getcost(dev(ops, feats[0].permute(0, 2, 3, 1)),
+                             dev(ops, torch.stack([f.permute(0, 2, 3, 1) for f in feats[1:]])), rt,
+                             dev(ops, inv), dev(ops, conf), dev(ops, vw), dev(ops, 1 / (1 / dv0)), dev(ops, 1 / (1 / dv1)),
+                             n, interval, 0.25, 4.0, vw_shift=1)
+    close(samp, want_s, 1e-6)
+    close(cost, want_cost, 1e-4)
+
+
+def test_getcost_extreme_geometry(ops, golden):
+    """per-pixel depth maps + the reference's own warping edge cases (OOB, negative z)."""
+    g = golden("warp_edge.npz")
+    for ci in (1, 2):
+        src, depth, want = g.t(f"c{ci}.src"), g.t(f"c{ci}.depth"), g.t(f"c{ci}.out")
+        B, Cc, Hs, Ws = src.shape
+        D, H, W = depth.shape[1:]
+        if (Hs, Ws) != (H, W):
+            continue
+        # choose disp range so that inv=0.5 with zero radius reproduces depth plane d exactly enough
+        srcp = torch.cat([src, torch.zeros(B, 16 - Cc, Hs, Ws)], 1)
+        P = torch.matmul(g.t(f"c{ci}.src_proj"), torch.inverse(g.t(f"c{ci}.ref_proj")))
+        rt = torch.cat([P[:, :3, :3].reshape(B, 9), P[:, :3, 3]], 1).view(B, 1, 12)
+        lo, hi = torch.full((B,), 1 / 2000.0), torch.full((B,), 1 / 100.0)
+        for d in range(D):
+            inv = ((1 / depth[:, d:d + 1]) - lo.view(-1, 1, 1, 1)) / (hi - lo).view(-1, 1, 1, 1)
+            cost, samp = ops.getcost(dev(ops, torch.ones(B, H, W, 16)), dev(ops, srcp.permute(0, 2, 3, 1).unsqueeze(0)),
+                                     dev(ops, rt), dev(ops, inv.contiguous()), None, dev(ops, torch.ones(B, 1, H, W)),
+                                     dev(ops, lo), dev(ops, hi), 4, 0.0, 1.0, 1.0, vw_shift=0)
+            got = cost.cpu()[:, 0] * 4.0        # group 0, hypothesis 0 (all 4 identical: zero radius)
+            w = want[:, :, d].sum(1)
+            # inverse-depth round trip perturbs depth by ~1e-4 relative; compare loosely but everywhere
+            assert float((got - w).abs().mean()) <= 2e-3 * max(1.0, float(w.abs().mean())), (ci, d)
+
+
+def test_misc_kernels(ops):
+    B, S, G, D, H, W = 2, 3, 4, 6, 5, 7
+    cor, w = rnd(B, S, G, D, H, W, seed=1), rnd(B, S, H, W, seed=2, lo=0, hi=1)
+    want = (cor * w.view(B, S, 1, 1, H, W)).sum(1) / (1e-8 + w.sum(1)).view(B, 1, 1, H, W)
+    close(ops.view_aggregate(*dev(ops, cor, w)), want, 1e-5)
+    x = rnd(B * S, D, H, W, seed=3) * 3
+    close(ops.sigmoid_max_d(dev(ops, x)), torch.sigmoid(x).max(1)[0], 1e-6)
+    # depth regression (module.py:553-571)
+    logits = rnd(B, D, H, W, seed=4) * 4
+    lo, hi = torch.tensor([1 / 935.0, 1 / 800.0]), torch.tensor([1 / 425.0, 1 / 500.0])
+    prob = F.softmax(logits, 1)
+    index = (torch.arange(D).view(1, D, 1, 1) * prob).sum(1, keepdim=True)
+    nd = index / (D - 1.0)
+    depth = O.disp_to_depth(nd, (1 / hi).view(-1, 1, 1, 1), (1 / lo).view(-1, 1, 1, 1))[1].squeeze(1)
+    padded = F.pad(prob, (0, 0, 0, 0, 1, 2))
+    sum4 = padded[:, 0:D] + padded[:, 1:D + 1] + padded[:, 2:D + 2] + padded[:, 3:D + 3]
+    conf = torch.gather(sum4, 1, index.long().clamp(0, D - 1))
+    g_nd, g_depth, g_conf = ops.depth_regress(*dev(ops, logits, 1 / (1 / lo), 1 / (1 / hi)))
+    close(g_nd, nd, 1e-5)
+    close(g_depth, depth, 1e-5)
+    assert float(((g_conf.cpu() - conf).abs() > 1e-4).float().mean()) < 0.05
+    # convex upsampling (module.py:237-248) for both ratios
+    for r in (2, 4):
+        inv, mask = rnd(B, 1, H, W, seed=5, lo=0, hi=1), rnd(B, 9 * r * r, H, W, seed=6) * 2
+        up = O.upsample_depth(inv, mask, r)
+        g_inv, g_depth = ops.convex_upsample(*dev(ops, inv, mask, 1 / (1 / lo), 1 / (1 / hi)), r)
+        close(g_inv, up, 1e-5)
+        close(g_depth, O.disp_to_depth(up.unsqueeze(1), (1 / hi).view(-1, 1, 1, 1), (1 / lo).view(-1, 1, 1, 1))[1].squeeze(1), 1e-5)
+    # depth <-> disp
+    dep = rnd(B, 1, H, W, seed=7, lo=430, hi=900)
+    close(ops.depth_convert(*dev(ops, dep, 1 / (1 / lo), 1 / (1 / hi)), 0),
+          O.depth_to_disp(dep, (1 / hi).view(-1, 1, 1, 1), (1 / lo).view(-1, 1, 1, 1)), 1e-5)
+    # refinement bookkeeping
+    inv, dl, upd = rnd(B, 1, H, W, seed=8, lo=0, hi=1), rnd(B, 1, H, W, seed=9), rnd(B, 1, H, W, seed=10)
+    new = (inv + 0.5 * dl + upd).clamp(0, 1)
+    big = dev(ops, torch.zeros(B, 3, H, W))
+    g_delta, g_new = ops.delta_update(*dev(ops, inv, dl, upd), 0.5, new2=big, new2_cstride=3, new2_coffset=2)
+    close(g_new, new, 1e-6)
+    close(g_delta, new - inv, 1e-6)
+    close(big[:, 2:3], new, 1e-6)
+    g_delta, g_new = ops.delta_update(*dev(ops, inv, dl), None, 0.5)
+    close(g_new, (inv + 0.5 * dl).clamp(0, 1), 1e-6)
+    # slices / resampling / layout
+    x = rnd(B, 9, H, W, seed=11)
+    close(ops.act_slice(dev(ops, x), K.ACT_TANH, 2, 4), torch.tanh(x[:, 2:6]), 1e-6)
+    close(ops.upsample_nearest(dev(ops, x), 4), F.interpolate(x, scale_factor=4, mode="nearest"), 0)
+    close(ops.nchw_to_nhwc(dev(ops, x)), x.permute(0, 2, 3, 1).contiguous(), 0)
+
+
+@pytest.mark.parametrize("C,HW", [(16, (9, 13)), (32, (40, 70))])
+def test_groupnorm_silu(ops, C, HW):
+    B = 2
+    x = rnd(B, C, *HW, seed=1) * 2 + 0.3
+    gamma, beta = rnd(C, seed=2, lo=0.5, hi=1.5), rnd(C, seed=3)
+    ss, res = rnd(B, 2 * C, seed=4), rnd(B, C, *HW, seed=5)
+    y = F.group_norm(x, 4, gamma, beta, 1e-5)
+    want = F.silu(y * (ss[:, :C, None, None] + 1) + ss[:, C:, None, None]) + res
+    close(ops.groupnorm_silu(*dev(ops, x, gamma, beta), 4, scale_shift=dev(ops, ss), residual=dev(ops, res)), want, 2e-5)
+    close(ops.groupnorm_silu(*dev(ops, x, gamma, beta), 4), F.silu(y), 2e-5)
