@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Headline benchmark: depth-maps/sec of the DiffMVS depth-estimation forward
+(BASELINE.json configs[1]: DTU eval 640x512, 5 source views, numdepth_initial=48, 1 DDIM
+step, fp32) on N MI355X of one node.
+
+A step = one model() call on one batch of `--batch` reference views per GPU (inputs already
+resident in HBM), timed like reference test.py:122-127 (device sync on both sides).  Reference
+views shard across GPUs with no data-path collective (inference is embarrassingly parallel,
+SURVEY section 8e) => weak scaling; value = all ranks' depth maps / max-over-ranks time.
+
+Also reported on the same JSON line:
+  roofline      the homography-warp kernel (getcost_kernel, launched stage_iters[1]=4 times per
+                step): algorithmic bytes per launch (SURVEY section 8d formula) / mean launch
+                duration from HIP events recorded on the launch stream inside the timed region
+  cpu_baseline  oracle/diffmvs_oracle.py (CPU restatement pinned to the reference) timed on this
+                box's host cores on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from diffmvs_amd import synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 achievable)
+
+
+def getcost_algorithmic_bytes(B, C, S, n, G, H, W):
+    """4 * [C*HW (ref) + S*C*HW (src) + n*HW (hypotheses) + S*HW (view weights) + G*n*HW (out)]"""
+    return 4 * B * H * W * (C + S * C + n + S + G * n)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("DMVS_BENCH_BATCH", "8")),
+                    help="reference views per GPU per step")
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--src-views", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-forwards", type=int, default=8)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = world > 1
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if dist:
+        import torch.distributed as td
+        td.init_process_group("nccl", device_id=dev)
+
+    from models import CasDiffMVS
+    args = synth.make_args("diffmvs", numdepth_initial=48)
+    model = CasDiffMVS(args, test=True).eval()
+    sd = synth.synth_state_dict(model.state_dict(), 123)
+    model.load_state_dict(sd)
+    model = model.to(dev)
+    H, W, S, B = a.height, a.width, a.src_views, a.batch
+    imgs, proj, dv = synth.synth_inputs(H, W, S, B=B, seed=100 + rank)
+    imgs = [i.to(dev) for i in imgs]
+    proj = {k: v.to(dev) for k, v in proj.items()}
+    dv = dv.to(dev)
+    eng = model.engine()
+
+    def barrier():
+        if dist:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(a.warmup):
+            model(imgs, proj, dv)
+        eng.ops.timers = {"dmvs_getcost_f32": [], "dmvs_warp_corr_init_f32": []}
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            model(imgs, proj, dv)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    timers, eng.ops.timers = eng.ops.timers, None
+    if dist:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    maps = B * a.steps * world
+    value = maps / elapsed
+    gc_ms = [s.elapsed_time(e) for s, e in timers["dmvs_getcost_f32"]]
+    wi_ms = [s.elapsed_time(e) for s, e in timers["dmvs_warp_corr_init_f32"]]
+    gc_avg_s = sum(gc_ms) / max(1, len(gc_ms)) * 1e-3
+    h2, w2 = H // 4, W // 4
+    alg = getcost_algorithmic_bytes(B, 32, S, args.CostNum[1], 4, h2, w2)
+    achieved = alg / gc_avg_s / 1e9 if gc_avg_s > 0 else 0.0
+    h1, w1 = H // 8, W // 8
+    alg_init = 4 * B * h1 * w1 * (48 + S * 48 + S * 4 * 48)      # ref + src + per-view volumes out
+    wi_avg_s = sum(wi_ms) / max(1, len(wi_ms)) * 1e-3
+
+    result = {
+        "metric": "depth-maps/sec (640x512, 5 src views)", "value": round(value, 3), "unit": "depth-maps/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"DiffMVS DTU eval {W}x{H}, {S} src views, numdepth_initial=48, 1 DDIM step, fp32",
+                   "ref_views_per_gpu_per_step": B, "parallelism": f"ref-view sharding x{world}, no collective",
+                   "weights": "seeded random init (no checkpoint offline)"},
+        "roofline": {"kernel": "getcost_kernel<32,4,6> (homography warp + group corr + view aggregation)",
+                     "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(gc_avg_s * 1e6, 2),
+                     "launches_timed": len(gc_ms)},
+        "roofline_warp_init": {"kernel": "warp_corr_init_kernel<48,3>", "bound": "hbm",
+                               "achieved": round(alg_init / wi_avg_s / 1e9, 2) if wi_avg_s > 0 else 0.0,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(alg_init / wi_avg_s / 1e9 / HBM_PEAK_GBS, 4) if wi_avg_s > 0 else 0.0,
+                               "algorithmic_bytes_per_launch": alg_init, "avg_launch_us": round(wi_avg_s * 1e6, 2)},
+    }
+
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        from oracle import diffmvs_oracle as O
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        ci, cp, cd = synth.synth_inputs(H, W, S, B=1, seed=100)
+        src = synth.NoiseSource(0)
+        with torch.no_grad():
+            O.forward(sd, args, ci, cp, cd, noise_fn=lambda shape: src(shape, "cpu"))      # warm-up
+            t0 = time.perf_counter()
+            n = 0
+            while n < a.cpu_forwards and time.perf_counter() - t0 < 25.0:
+                O.forward(sd, args, ci, cp, cd, noise_fn=lambda shape: src(shape, "cpu"))
+                n += 1
+            ct = time.perf_counter() - t0
+        result["cpu_baseline"] = {"value": round(n / ct, 4), "unit": "depth-maps/s", "cores": cores, "kind": "port",
+                                  "sample": f"{n} forwards of the same workload at batch 1 after 1 warm-up, "
+                                            f"torch CPU backend with {cores} threads"}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist:
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

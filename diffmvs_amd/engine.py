@@ -1,0 +1,389 @@
+"""Inference engine: the DiffMVS / CasDiffMVS depth-estimation forward as a sequence of
+libdmvs_hip.so kernel launches on one HIP stream.
+
+It consumes the reference's flat checkpoint layout and the constructor
+namespace, packs the weights once into kernel layout (eval-BN folded into per-channel
+scale/shift, weight-standardised convs standardised, time-embedding scale/shift tables
+evaluated -- all parameter-only constant folding), and then `forward` issues only kernel
+launches plus torch memory plumbing (allocation, cat of the input images).  Nothing in
+here computes on the CPU and nothing falls back to ATen operators for the hot path.
+
+Reference call graph followed (models/diffusion.py:139-295):
+  FeatureNet x V, ContextNet -> InitialCost (stage 1) -> [DiffusionUpdateBlockDepth (stage 2, 3)].
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import ops as K
+from .ops import Ops, PackedConv, pack_conv2d, pack_conv3d
+
+_RATIOS = [4, 2, 1]                      # depth_interals_ratio default (diffusion.py:15)
+_MULTS = [(1,), (1, 2), (1, 2, 4)]       # unet_dim_mults (diffusion.py:33)
+
+
+def _bn(sd, p):
+    return {k: sd[f"{p}.{k}"] for k in ("weight", "bias", "running_mean", "running_var")}
+
+
+class _UpdateBlock:
+    """Packed weights of one DiffusionUpdateBlockDepth (reference models/update.py:299-391)."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], p: str, args, stage: int, up_ratio: int):
+        self.p = p
+        self.stage = stage
+        self.iters = args.stage_iters[stage]
+        self.cd = args.context_dim[stage]
+        self.hd = args.hidden_dim[stage]
+        self.n = args.CostNum[stage]
+        self.dim = args.unet_dim[stage]
+        self.mults = _MULTS[stage]
+        self.timesteps = args.timesteps[stage]
+        st = args.sampling_timesteps[stage]
+        self.sampling_timesteps = self.timesteps if st is None else st
+        self.eta = args.ddim_eta[stage]
+        self.scale = args.scale[stage]
+        self.up_ratio = up_ratio
+        c2 = lambda name, **kw: pack_conv2d(sd[f"{p}.{name}.weight"], sd.get(f"{p}.{name}.bias"), **kw)  # noqa: E731
+        self.enc = {n: c2(f"encoder.{n}", pad=1) for n in ("convc1", "convc2", "convd1", "convd2", "output")}
+        self.mask0, self.mask2 = c2("mask.0", pad=1), c2("mask.2")
+        u = p + ".unet"
+        self.init_conv = c2("unet.init_conv", pad=3)
+        L = len(self.mults)
+        self.downs = []
+        for i in range(L):
+            blk = self._resblock(sd, f"{u}.downs.{i}.0")
+            if i < L - 1:
+                ds = pack_conv2d(sd[f"{u}.downs.{i}.1.1.weight"], sd[f"{u}.downs.{i}.1.1.bias"])
+            else:
+                ds = pack_conv2d(sd[f"{u}.downs.{i}.1.weight"], sd[f"{u}.downs.{i}.1.bias"], pad=1)
+            self.downs.append((blk, ds))
+        self.gru = {}
+        for n, pad in (("1", (0, 2)), ("2", (2, 0))):
+            for gate in "zrq":
+                self.gru[gate + n] = pack_conv2d(sd[f"{u}.gru.conv{gate}{n}.weight"], sd[f"{u}.gru.conv{gate}{n}.bias"], pad=pad)
+        self.mid = self._resblock(sd, f"{u}.mid")
+        self.ups = []
+        for i in range(L):
+            blk = self._resblock(sd, f"{u}.ups.{i}.0")
+            if i < L - 1:
+                us = pack_conv2d(sd[f"{u}.ups.{i}.1.1.weight"], sd[f"{u}.ups.{i}.1.1.bias"], pad=1)
+            else:
+                us = pack_conv2d(sd[f"{u}.ups.{i}.1.weight"], sd[f"{u}.ups.{i}.1.bias"], pad=1)
+            self.ups.append((blk, us))
+        self.final = self._resblock(sd, f"{u}.final_res_block")
+        self.final_conv, self.conf = c2("unet.final_conv"), c2("unet.conf")
+        self.acp = sd[f"{p}.alphas_cumprod"].float()
+        self.sqrt_recip_acp = sd[f"{p}.sqrt_recip_alphas_cumprod"].float()
+        self.sqrt_recipm1_acp = sd[f"{p}.sqrt_recipm1_alphas_cumprod"].float()
+        # DDIM schedule (update.py:469-471) and the time-conditioned scale/shift of every ResnetBlock,
+        # evaluated once: they depend on parameters and the integer time step only.
+        times = torch.linspace(-1, self.timesteps - 1, steps=self.sampling_timesteps + 1)
+        times = list(reversed(times.int().tolist()))
+        self.time_pairs = list(zip(times[:-1], times[1:]))
+        self.ss_tables = {t: self._scale_shift_table(sd, u, t) for t, _ in self.time_pairs}
+
+    @staticmethod
+    def _resblock(sd, p):
+        rb = {
+            "p": p,
+            "c1": pack_conv2d(sd[p + ".block1.proj.weight"], sd[p + ".block1.proj.bias"], pad=1, standardize=True),
+            "c2": pack_conv2d(sd[p + ".block2.proj.weight"], sd[p + ".block2.proj.bias"], pad=1, standardize=True),
+            "g1": (sd[p + ".block1.norm.weight"].float().contiguous(), sd[p + ".block1.norm.bias"].float().contiguous()),
+            "g2": (sd[p + ".block2.norm.weight"].float().contiguous(), sd[p + ".block2.norm.bias"].float().contiguous()),
+            "res": None,
+            "has_mlp": (p + ".mlp.1.weight") in sd,
+        }
+        if (p + ".res_conv.weight") in sd:
+            rb["res"] = pack_conv2d(sd[p + ".res_conv.weight"], sd[p + ".res_conv.bias"])
+        return rb
+
+    def _scale_shift_table(self, sd, u, t: int):
+        """SinusoidalPosEmb -> Linear -> GELU -> Linear (update.py:50-62, :204-211), then each block's
+        SiLU -> Linear (update.py:138-153).  Returns {block prefix: [1, 2*dim_out]}."""
+        dev = sd[u + ".time_mlp.1.weight"].device
+        half = self.dim // 2
+        k = math.log(10000) / (half - 1)
+        freqs = torch.exp(torch.arange(half, device=dev) * -k)
+        e = torch.tensor([float(t)], device=dev)[:, None] * freqs[None, :]
+        e = torch.cat((e.sin(), e.cos()), -1)
+        e = F.gelu(F.linear(e, sd[u + ".time_mlp.1.weight"], sd[u + ".time_mlp.1.bias"]))
+        te = F.linear(e, sd[u + ".time_mlp.3.weight"], sd[u + ".time_mlp.3.bias"])
+        table = {}
+        blocks = [b for b, _ in self.downs] + [self.mid] + [b for b, _ in self.ups] + [self.final]
+        for rb in blocks:
+            if rb["has_mlp"]:
+                pp = rb["p"]
+                table[pp] = F.linear(F.silu(te), sd[pp + ".mlp.1.weight"], sd[pp + ".mlp.1.bias"]).float().contiguous()
+        return table
+
+
+class Engine:
+    def __init__(self, sd: Dict[str, torch.Tensor], args, ops: Ops):
+        self.ops = ops
+        self.args = args
+        dev = ops.device
+        sd = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sd.items()}
+        self.cas = args.stage_iters[2] != 0
+        self.up_ratio = 2 if self.cas else 4
+        self.G = args.cost_dim_stage[0]
+        self.G_cost = args.cost_dim_stage[1]
+        cw = lambda p, **kw: pack_conv2d(sd[p + ".conv.weight"], None, bn=_bn(sd, p + ".bn"), **kw)  # noqa: E731
+        # ---- FeatureNet (models/module.py:357-420)
+        f = {}
+        f["conv0.0"], f["conv0.1"] = cw("feature.conv0.0", pad=1), cw("feature.conv0.1", pad=1)
+        for i in (1, 2, 3):
+            f[f"conv{i}.0"] = cw(f"feature.conv{i}.0", stride=2, pad=2)
+            f[f"conv{i}.1"], f[f"conv{i}.2"] = cw(f"feature.conv{i}.1", pad=1), cw(f"feature.conv{i}.2", pad=1)
+        f["out1"] = pack_conv2d(sd["feature.out1.weight"])
+        f["inner1"] = pack_conv2d(sd["feature.inner1.weight"], sd["feature.inner1.bias"])
+        f["out2"] = pack_conv2d(sd["feature.out2.weight"], pad=1)
+        if self.cas:
+            f["inner2"] = pack_conv2d(sd["feature.inner2.weight"], sd["feature.inner2.bias"])
+            f["out3"] = pack_conv2d(sd["feature.out3.weight"], pad=1)
+        self.feat = f
+        # ---- ContextNet (models/module.py:321-355); output heads split into hidden | context parts
+        c = {"conv1": cw("context.conv1", pad=1)}
+        for li in (1, 2, 3):
+            for bi in (0, 1):
+                p = f"context.layer{li}.{bi}"
+                s = 2 if bi == 0 else 1
+                c[f"{li}.{bi}.conv1"] = cw(p + ".conv1", stride=s, pad=1)
+                c[f"{li}.{bi}.conv2"] = cw(p + ".conv2", pad=1)
+                if bi == 0:
+                    c[f"{li}.{bi}.down"] = cw(p + ".downsample", stride=2, pad=1)
+        self.ctx = c
+        self.ctx_out = {}
+        for s in range(3):
+            name = f"context.output{s + 1}"
+            if name + ".weight" not in sd:
+                continue
+            w, b = sd[name + ".weight"], sd[name + ".bias"]
+            hd = args.hidden_dim[s]
+            hid = pack_conv2d(w[:hd].contiguous(), b[:hd].contiguous(), pad=1) if hd > 0 else None
+            self.ctx_out[s] = (hid, pack_conv2d(w[hd:].contiguous(), b[hd:].contiguous(), pad=1))
+        # ---- InitialCost (models/module.py:465-573)
+        d = "depthnet"
+        self.pvw0 = pack_conv3d(sd[d + ".pixel_view_weight.conv.0.conv.weight"], bn=_bn(sd, d + ".pixel_view_weight.conv.0.bn"))
+        self.pvw1 = pack_conv3d(sd[d + ".pixel_view_weight.conv.1.weight"], sd[d + ".pixel_view_weight.conv.1.bias"])
+        r = d + ".cost_regularization"
+        self.reg = {}
+        for i, st in ((0, 1), (1, 1), (2, 2), (3, 1), (4, 2), (5, 1)):
+            self.reg[i] = pack_conv3d(sd[f"{r}.conv{i}.conv.weight"], bn=_bn(sd, f"{r}.conv{i}.bn"), stride=st)
+        for i in (6, 7):
+            self.reg[i] = pack_conv3d(sd[f"{r}.conv{i}.conv.weight"], bn=_bn(sd, f"{r}.conv{i}.bn"), stride=2, transposed=True)
+        self.reg["prob"] = pack_conv3d(sd[r + ".prob.weight"])
+        self.mask0 = pack_conv2d(sd[d + ".mask.0.weight"], sd[d + ".mask.0.bias"], pad=1)
+        self.mask2 = pack_conv2d(sd[d + ".mask.2.weight"], sd[d + ".mask.2.bias"])
+        # ---- hidden_init (models/diffusion.py:53-58, :91-101)
+        self.hidden_init = {}
+        self.hidden_init[1] = [cw("hidden_init.0.0", stride=2, pad=1), pack_conv2d(sd["hidden_init.0.1.weight"], pad=1)]
+        if self.cas:
+            self.hidden_init[2] = [cw("hidden_init.1.0", stride=2, pad=1), cw("hidden_init.1.1", stride=2, pad=1),
+                                   pack_conv2d(sd["hidden_init.1.2.weight"], pad=1)]
+        # ---- update blocks
+        self.ub = {1: _UpdateBlock(sd, "update_block_depth2", args, 1, self.up_ratio)}
+        if self.cas:
+            self.ub[2] = _UpdateBlock(sd, "update_block_depth3", args, 2, self.up_ratio)
+
+    # ------------------------------------------------------------------ sub-networks
+    def feature_net(self, x):
+        """x [N,3,H,W] -> {'stage1': NHWC [N,H/8,W/8,48], 'stage2': [N,H/4,W/4,32], ('stage3': [N,H/2,W/2,16])}"""
+        o, f, R = self.ops, self.feat, K.ACT_RELU
+        c0 = o.conv2d(f["conv0.1"], o.conv2d(f["conv0.0"], x, act=R), act=R)
+        c1 = o.conv2d(f["conv1.2"], o.conv2d(f["conv1.1"], o.conv2d(f["conv1.0"], c0, act=R), act=R), act=R)
+        c2 = o.conv2d(f["conv2.2"], o.conv2d(f["conv2.1"], o.conv2d(f["conv2.0"], c1, act=R), act=R), act=R)
+        c3 = o.conv2d(f["conv3.2"], o.conv2d(f["conv3.1"], o.conv2d(f["conv3.0"], c2, act=R), act=R), act=R)
+        out = {"stage1": o.conv2d(f["out1"], c3, out_layout=K.LAYOUT_NHWC)}
+        intra = o.conv2d(f["inner1"], c2, residual=c3, res_mode=K.IN_UPSAMPLE2)
+        out["stage2"] = o.conv2d(f["out2"], intra, out_layout=K.LAYOUT_NHWC)
+        if self.cas:
+            intra = o.conv2d(f["inner2"], c1, residual=intra, res_mode=K.IN_UPSAMPLE2)
+            out["stage3"] = o.conv2d(f["out3"], intra, out_layout=K.LAYOUT_NHWC)
+        return out
+
+    def context_trunk(self, x):
+        """ContextNet body -> the three pre-head feature maps (full/2, /4, /8)."""
+        o, c, R = self.ops, self.ctx, K.ACT_RELU
+        x = o.conv2d(c["conv1"], x, act=R)
+        taps = {}
+        for li in (1, 2, 3):
+            y = o.conv2d(c[f"{li}.0.conv1"], x, act=R)
+            xd = o.conv2d(c[f"{li}.0.down"], x)
+            x = o.conv2d(c[f"{li}.0.conv2"], y, residual=xd, act=R)
+            y = o.conv2d(c[f"{li}.1.conv1"], x, act=R)
+            x = o.conv2d(c[f"{li}.1.conv2"], y, residual=x, act=R)
+            taps[3 - li] = x          # layer1 -> stage3 (index 2), layer2 -> stage2, layer3 -> stage1
+        return taps
+
+    def _resblock(self, rb, x0, x1, ss, B):
+        """ResnetBlock (update.py:147-159): two WS-conv/GroupNorm/SiLU blocks + residual."""
+        o = self.ops
+        scale_shift = None
+        if ss is not None and rb["p"] in ss:
+            scale_shift = ss[rb["p"]].expand(B, -1).contiguous()
+        h = o.conv2d(rb["c1"], x0, x1)
+        h = o.groupnorm_silu(h, rb["g1"][0], rb["g1"][1], 4, scale_shift=scale_shift, out=h)
+        h2 = o.conv2d(rb["c2"], h)
+        if rb["res"] is not None:
+            res = o.conv2d(rb["res"], x0, x1)
+        else:
+            assert x1 is None
+            res = x0
+        return o.groupnorm_silu(h2, rb["g2"][0], rb["g2"][1], 4, residual=res, out=h2)
+
+    def unet(self, ub: _UpdateBlock, X, hidden, ss):
+        """Unet.forward (update.py:245-274).  X [B,2cd,H,W], hidden [B,hd,h,w]."""
+        o = self.ops
+        B = X.shape[0]
+        x = o.conv2d(ub.init_conv, X)
+        r = x
+        skips = []
+        L = len(ub.mults)
+        for i, (blk, ds) in enumerate(ub.downs):
+            x = self._resblock(blk, x, None, ss, B)
+            skips.append(x)
+            x = o.conv2d(ds, x, in_mode=(K.IN_UNSHUFFLE2 if i < L - 1 else K.IN_PLAIN))
+        h = hidden
+        for n in ("1", "2"):     # SepConvGRU: horizontal then vertical pass (module.py:164-177)
+            z = o.conv2d(ub.gru["z" + n], h, x, act=K.ACT_SIGMOID)
+            rg = o.conv2d(ub.gru["r" + n], h, x, act=K.ACT_SIGMOID)
+            h = o.conv2d(ub.gru["q" + n], h, x, mul0=rg, act=K.ACT_TANH, gru_z=z, gru_h=h)
+        hidden = h
+        x = self._resblock(ub.mid, hidden, None, None, B)
+        for i, (blk, us) in enumerate(ub.ups):
+            x = self._resblock(blk, x, skips.pop(), ss, B)
+            x = o.conv2d(us, x, in_mode=(K.IN_UPSAMPLE2 if i < L - 1 else K.IN_PLAIN))
+        x = self._resblock(ub.final, x, r, ss, B)
+        delta = o.conv2d(ub.final_conv, x)
+        conf = o.conv2d(ub.conf, x, act=K.ACT_SIGMOID)
+        return hidden, delta, conf
+
+    # ------------------------------------------------------------------ stage 1
+    def initial_cost(self, ref, src, rt, context, disp_min, disp_max, D):
+        """InitialCost.forward eval branch (module.py:487-573) on NHWC features."""
+        o = self.ops
+        B, H, W, _ = ref.shape
+        S = src.shape[0]
+        cor = o.warp_corr_init(ref, src, rt, disp_min, disp_max, D, self.G)            # [B,S,G,D,H,W]
+        x = o.conv3d(self.pvw0, cor.view(B * S, self.G, D, H, W), act=K.ACT_RELU)
+        x = o.conv3d(self.pvw1, x)                                                      # [B*S,1,D,H,W]
+        vw = o.sigmoid_max_d(x.view(B * S, D, H, W)).view(B, S, H, W)
+        agg = o.view_aggregate(cor, vw)
+        R = K.ACT_RELU
+        c1 = o.conv3d(self.reg[1], o.conv3d(self.reg[0], agg, act=R), act=R)
+        c3 = o.conv3d(self.reg[3], o.conv3d(self.reg[2], c1, act=R), act=R)
+        x = o.conv3d(self.reg[5], o.conv3d(self.reg[4], c3, act=R), act=R)
+        x = o.conv3d(self.reg[6], x, act=R, residual=c3)
+        x = o.conv3d(self.reg[7], x, act=R, residual=c1)
+        logits = o.conv3d(self.reg["prob"], x)                                          # [B,1,D,H,W]
+        nd, depth, conf = o.depth_regress(logits.view(B, D, H, W), disp_min, disp_max)
+        mask = o.conv2d(self.mask2, o.conv2d(self.mask0, context, act=R), post_scale=0.25)
+        return mask, nd, depth, vw, conf
+
+    # ------------------------------------------------------------------ stages 2, 3
+    def update_block(self, ub: _UpdateBlock, feats_ref, feats_src, rt, inv_depth, hidden, X, view_w, vw_shift,
+                     disp_min, disp_max, interval, noise_fn):
+        """DiffusionUpdateBlockDepth.forward eval branch (update.py:466-521).
+        X: Unet input buffer [B,2cd,H,W] whose first cd channels already hold relu(context)."""
+        o = self.ops
+        a = self.args
+        B, _, H, W = inv_depth.shape
+        cd, n = ub.cd, ub.n
+        context = None
+        noise = noise_fn((B, 1, H, W), o.device).float().contiguous()
+        # mask head reads relu(context) = X[:, :cd]; for B > 1 that slice is strided, so give it its own copy
+        context = o.act_slice(X, K.ACT_NONE, 0, cd)
+        mask = o.conv2d(ub.mask2, o.conv2d(ub.mask0, context, act=K.ACT_RELU), post_scale=0.25)
+        img, img_scale = noise, float(ub.scale)
+        inv_list: List[torch.Tensor] = []
+        conf_list: List[torch.Tensor] = []
+        cur_hidden = hidden
+        for time, time_next in ub.time_pairs:
+            ss = ub.ss_tables[time]
+            inv_list, conf_list = [], []
+            delta, new = o.delta_update(inv_depth, img, None, img_scale, new2=X, new2_cstride=2 * cd, new2_coffset=2 * cd - 1)
+            img, img_scale = delta, 1.0
+            cur_hidden, confidence = hidden, None
+            for _ in range(ub.iters):
+                cost, samples = o.getcost(feats_ref, feats_src, rt, new, confidence, view_w, disp_min, disp_max, n,
+                                          interval, a.min_radius, a.max_radius, vw_shift, G=self.G_cost)
+                cf = o.conv2d(ub.enc["convc2"], o.conv2d(ub.enc["convc1"], cost, act=K.ACT_RELU), act=K.ACT_RELU)
+                df = o.conv2d(ub.enc["convd2"], o.conv2d(ub.enc["convd1"], samples, act=K.ACT_RELU), act=K.ACT_RELU)
+                o.conv2d(ub.enc["output"], cf, df, act=K.ACT_RELU, out=X, out_cstride=2 * cd, out_coffset=cd)
+                cur_hidden, upd, conf = self.unet(ub, X, cur_hidden, ss)
+                confidence = conf.view(B, H, W)
+                delta, new = o.delta_update(inv_depth, delta, upd, 1.0, new2=X, new2_cstride=2 * cd, new2_coffset=2 * cd - 1)
+                conf_list.append(confidence)
+                inv_list.append(new)
+            if time_next < 0:
+                continue
+            # multi-step DDIM update (update.py:504-519); not exercised by the shipped configs
+            # (sampling_timesteps = 1), kept as plain device tensor arithmetic.
+            pred_noise = (ub.sqrt_recip_acp[time] * img - delta) / ub.sqrt_recipm1_acp[time]
+            alpha, alpha_next = ub.acp[time], ub.acp[time_next]
+            sigma = ub.eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+            c = (1 - alpha_next - sigma ** 2).sqrt()
+            fresh = (ub.scale * noise_fn((B, 1, H, W), o.device)).float()
+            img = (delta * alpha_next.sqrt() + c * pred_noise + sigma * fresh).contiguous()
+        return mask, cur_hidden, inv_list, conf_list
+
+    # ------------------------------------------------------------------ whole forward
+    @torch.no_grad()
+    def forward(self, imgs, proj_matrices, depth_values, noise_fn: Optional[Callable] = None):
+        """CasDiffMVS.forward with test=True in eval mode (models/diffusion.py:139-295)."""
+        o, a = self.ops, self.args
+        if noise_fn is None:
+            noise_fn = lambda shape, device: torch.randn(shape, device=device)  # noqa: E731
+        V = len(imgs)
+        B = imgs[0].shape[0]
+        dv = depth_values.to(o.device).float()
+        depth_max_, depth_min_ = 1.0 / dv[:, 0], 1.0 / dv[:, -1]
+        disp_min, disp_max = (1.0 / depth_max_).contiguous(), (1.0 / depth_min_).contiguous()   # module.py:222-223
+        interval = 1.0 / depth_values.size(1)
+
+        x = torch.cat([im.to(o.device).float() for im in imgs], 0).contiguous()                  # [V*B,3,H,W], view-major
+        feats = self.feature_net(x)
+        trunk = self.context_trunk(x[:B])
+        depths, confs_full = [], []
+        view_w = None
+        for s in range(3):
+            if a.stage_iters[s] == 0:
+                continue
+            name = f"stage{s + 1}"
+            fs = feats[name]
+            h, w, C = fs.shape[1], fs.shape[2], fs.shape[3]
+            ref, src = fs[:B], fs[B:].view(V - 1, B, h, w, C)
+            rt = o.compose_proj(proj_matrices[name].to(o.device).float().contiguous())
+            hid_pc, ctx_pc = self.ctx_out[s]
+            if s == 0:
+                context = o.conv2d(ctx_pc, trunk[0], act=K.ACT_RELU)
+                mask, nd, init_depth, view_w, conf = self.initial_cost(ref, src, rt, context, disp_min, disp_max,
+                                                                       a.numdepth_initial)
+                depths.append(init_depth)
+                confs_full.append(o.upsample_nearest(conf.view(B, h, w), 8))
+                _, depth_up = o.convex_upsample(nd, mask, disp_min, disp_max, 2, want_inv=False)
+                depths.append(depth_up)
+            else:
+                ub = self.ub[s]
+                cd = ub.cd
+                inv_cur = o.depth_convert(depths[-1].view(B, 1, h, w), disp_min, disp_max, K._lib.EW_DEPTH_TO_DISP)
+                hidden = o.conv2d(hid_pc, trunk[s])
+                hi = self.hidden_init[s]
+                for pc in hi[:-1]:
+                    hidden = o.conv2d(pc, hidden, act=K.ACT_RELU)
+                hidden = o.conv2d(hi[-1], hidden, act=K.ACT_TANH)
+                X = o.empty(B, 2 * cd, h, w)
+                o.conv2d(ctx_pc, trunk[s], act=K.ACT_RELU, out=X, out_cstride=2 * cd, out_coffset=0)
+                mask, hidden, inv_seq, conf_seq = self.update_block(
+                    ub, ref, src, rt, inv_cur, hidden, X, view_w, s, disp_min, disp_max,
+                    interval * _RATIOS[s], noise_fn)
+                depths.append(o.depth_convert(inv_seq[-1], disp_min, disp_max, K._lib.EW_DISP_TO_DEPTH).view(B, h, w))
+                confs_full.append(o.upsample_nearest(conf_seq[-1], 2 ** (3 - s)))
+                _, depth_up = o.convex_upsample(inv_seq[-1], mask, disp_min, disp_max, self.up_ratio, want_inv=False)
+                depths.append(depth_up)
+        return {"depth": depths, "conf": [], "photometric_confidence": confs_full}

@@ -103,6 +103,19 @@ class Ops:
     def __init__(self, lib: _lib.Lib, device):
         self.lib = lib
         self.device = torch.device(device)
+        # optional per-entry-point HIP-event timing on the launch stream (bench.py roofline leg):
+        # {"dmvs_getcost_f32": [(start_event, end_event), ...]}
+        self.timers = None
+
+    def _call(self, name, *args):
+        if self.timers is not None and name in self.timers:
+            st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            st.record()
+            self.lib.call(name, *args)
+            en.record()
+            self.timers[name].append((st, en))
+        else:
+            self.lib.call(name, *args)
 
     @classmethod
     def for_device(cls, device) -> "Ops":
@@ -159,7 +172,7 @@ class Ops:
             kh=kh, kw=kw, stride=pc.stride, pad_h=pc.pad[0], pad_w=pc.pad[1], in_mode=in_mode, act=act,
             res_mode=res_mode, res_after_act=int(res_after_act), out_layout=out_layout, out_cstride=out_cstride,
             out_coffset=out_coffset, post_scale=post_scale)
-        self.lib.call("dmvs_conv2d_f32", C.byref(d), self.stream())
+        self._call("dmvs_conv2d_f32", C.byref(d), self.stream())
         return out
 
     # ------------------------------------------------------------------ conv3d
@@ -178,7 +191,7 @@ class Ops:
                             residual=_ptr(residual), out=_ptr(out), B=B, cin=cin, cout=pc.cout, cout_pad=pc.cout_pad,
                             Din=Din, Hin=Hin, Win=Win, Dout=Dout, Hout=Hout, Wout=Wout, stride=pc.stride,
                             transposed=int(pc.transposed), act=act)
-        self.lib.call("dmvs_conv3d_f32", C.byref(d), self.stream())
+        self._call("dmvs_conv3d_f32", C.byref(d), self.stream())
         return out
 
     # ------------------------------------------------------------------ geometry / cost volumes
@@ -187,7 +200,7 @@ class Ops:
         self._chk(proj)
         B, V = proj.shape[0], proj.shape[1]
         out = self.empty(B, V - 1, 12)
-        self.lib.call("dmvs_compose_proj_f32", _ptr(proj), _ptr(out), B, V, self.stream())
+        self._call("dmvs_compose_proj_f32", _ptr(proj), _ptr(out), B, V, self.stream())
         return out
 
     def warp_corr_init(self, ref, src, rt, disp_min, disp_max, D, G=4):
@@ -196,7 +209,7 @@ class Ops:
         B, H, W, Cc = ref.shape
         S, _, Hs, Ws, _ = src.shape
         out = self.empty(B, S, G, D, H, W)
-        self.lib.call("dmvs_warp_corr_init_f32", _ptr(ref), _ptr(src), _ptr(rt), _ptr(disp_min), _ptr(disp_max),
+        self._call("dmvs_warp_corr_init_f32", _ptr(ref), _ptr(src), _ptr(rt), _ptr(disp_min), _ptr(disp_max),
                       _ptr(out), B, S, Cc, G, D, H, W, Hs, Ws, self.stream())
         return out
 
@@ -218,7 +231,7 @@ class Ops:
                              B=B, S=S, C=Cc, G=G, n=n, H=H, W=W, vw_shift=vw_shift, cost_cstride=cost_cstride,
                              cost_coffset=cost_coffset, samp_cstride=samp_cstride, samp_coffset=samp_coffset,
                              interval=interval, min_radius=min_radius, max_radius=max_radius)
-        self.lib.call("dmvs_getcost_f32", C.byref(d), self.stream())
+        self._call("dmvs_getcost_f32", C.byref(d), self.stream())
         return out_cost, out_samples
 
     def view_aggregate(self, cor, w):
@@ -226,7 +239,7 @@ class Ops:
         self._chk(cor, w)
         B, S, G, D, H, W = cor.shape
         out = self.empty(B, G, D, H, W)
-        self.lib.call("dmvs_view_aggregate_f32", _ptr(cor), _ptr(w), _ptr(out), B, S, G * D, H * W, self.stream())
+        self._call("dmvs_view_aggregate_f32", _ptr(cor), _ptr(w), _ptr(out), B, S, G * D, H * W, self.stream())
         return out
 
     def sigmoid_max_d(self, x):
@@ -234,7 +247,7 @@ class Ops:
         self._chk(x)
         N, D, H, W = x.shape
         out = self.empty(N, H, W)
-        self.lib.call("dmvs_sigmoid_max_d_f32", _ptr(x), _ptr(out), N, D, H * W, self.stream())
+        self._call("dmvs_sigmoid_max_d_f32", _ptr(x), _ptr(out), N, D, H * W, self.stream())
         return out
 
     def depth_regress(self, logits, disp_min, disp_max):
@@ -242,7 +255,7 @@ class Ops:
         self._chk(logits, disp_min, disp_max)
         B, D, H, W = logits.shape
         nd, depth, conf = self.empty(B, 1, H, W), self.empty(B, H, W), self.empty(B, 1, H, W)
-        self.lib.call("dmvs_depth_regress_f32", _ptr(logits), _ptr(disp_min), _ptr(disp_max), _ptr(nd), _ptr(depth),
+        self._call("dmvs_depth_regress_f32", _ptr(logits), _ptr(disp_min), _ptr(disp_max), _ptr(nd), _ptr(depth),
                       _ptr(conf), B, D, H * W, self.stream())
         return nd, depth, conf
 
@@ -253,7 +266,7 @@ class Ops:
         assert mask.shape[1] == 9 * ratio * ratio
         out_inv = self.empty(B, H * ratio, W * ratio) if want_inv else None
         out_depth = self.empty(B, H * ratio, W * ratio)
-        self.lib.call("dmvs_convex_upsample_f32", _ptr(inv), _ptr(mask), _ptr(disp_min), _ptr(disp_max), _ptr(out_inv),
+        self._call("dmvs_convex_upsample_f32", _ptr(inv), _ptr(mask), _ptr(disp_min), _ptr(disp_max), _ptr(out_inv),
                       _ptr(out_depth), B, H, W, ratio, self.stream())
         return out_inv, out_depth
 
@@ -263,7 +276,7 @@ class Ops:
         if out is None:
             out = self.empty(B, Cc, H, W)
         stats = torch.empty(B * groups * 2, dtype=torch.float64, device=self.device)
-        self.lib.call("dmvs_groupnorm_silu_f32", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(scale_shift), _ptr(residual),
+        self._call("dmvs_groupnorm_silu_f32", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(scale_shift), _ptr(residual),
                       _ptr(out), _ptr(stats), B, Cc, H * W, groups, eps, self.stream())
         return out
 
@@ -274,7 +287,7 @@ class Ops:
         HW = inv.numel() // B
         delta_out = torch.empty_like(inv)
         new_inv = torch.empty_like(inv)
-        self.lib.call("dmvs_delta_update_f32", _ptr(inv), _ptr(delta_in), _ptr(update), delta_in_scale,
+        self._call("dmvs_delta_update_f32", _ptr(inv), _ptr(delta_in), _ptr(update), delta_in_scale,
                       _ptr(delta_out), _ptr(new_inv), _ptr(new2), new2_cstride, new2_coffset, B, HW, self.stream())
         return delta_out, new_inv
 
@@ -282,7 +295,7 @@ class Ops:
         self._chk(x, disp_min, disp_max)
         B = x.shape[0]
         out = torch.empty_like(x)
-        self.lib.call("dmvs_depth_convert_f32", _ptr(x), _ptr(disp_min), _ptr(disp_max), _ptr(out), mode, B,
+        self._call("dmvs_depth_convert_f32", _ptr(x), _ptr(disp_min), _ptr(disp_max), _ptr(out), mode, B,
                       x.numel() // B, self.stream())
         return out
 
@@ -292,7 +305,7 @@ class Ops:
         if out is None:
             out_cstride = c_count
             out = self.empty(B, c_count, H, W)
-        self.lib.call("dmvs_act_slice_f32", _ptr(x), _ptr(out), act, B, c_count, H * W, Ct, c_from, out_cstride,
+        self._call("dmvs_act_slice_f32", _ptr(x), _ptr(out), act, B, c_count, H * W, Ct, c_from, out_cstride,
                       out_coffset, self.stream())
         return out
 
@@ -302,12 +315,12 @@ class Ops:
         H, W = x.shape[-2], x.shape[-1]
         N = x.numel() // (H * W)
         out = self.empty(*x.shape[:-2], H * factor, W * factor)
-        self.lib.call("dmvs_upsample_nearest_f32", _ptr(x), _ptr(out), N, H, W, factor, self.stream())
+        self._call("dmvs_upsample_nearest_f32", _ptr(x), _ptr(out), N, H, W, factor, self.stream())
         return out
 
     def nchw_to_nhwc(self, x):
         self._chk(x)
         B, Cc, H, W = x.shape
         out = self.empty(B, H, W, Cc)
-        self.lib.call("dmvs_nchw_to_nhwc_f32", _ptr(x), _ptr(out), B, Cc, H * W, self.stream())
+        self._call("dmvs_nchw_to_nhwc_f32", _ptr(x), _ptr(out), B, Cc, H * W, self.stream())
         return out
