@@ -36,6 +36,29 @@ def getcost_algorithmic_bytes(B, C, S, n, G, H, W):
     return 4 * B * H * W * (C + S * C + n + S + G * n)
 
 
+def cpu_baseline(a):
+    """oracle/diffmvs_oracle.py (the CPU restatement pinned to the reference) on the host cores."""
+    from oracle import diffmvs_oracle as O
+    from models import CasDiffMVS
+    cores = max(1, min(len(os.sched_getaffinity(0)), 32))
+    torch.set_num_threads(cores)
+    args = synth.make_args("diffmvs", numdepth_initial=48)
+    sd = synth.synth_state_dict(CasDiffMVS(args, test=True).state_dict(), 123)
+    ci, cp, cd = synth.synth_inputs(a.height, a.width, a.src_views, B=1, seed=100)
+    src = synth.NoiseSource(0)
+    with torch.no_grad():
+        O.forward(sd, args, ci, cp, cd, noise_fn=lambda shape: src(shape, "cpu"))      # warm-up
+        t0 = time.perf_counter()
+        n = 0
+        while n < a.cpu_forwards and time.perf_counter() - t0 < 25.0:
+            O.forward(sd, args, ci, cp, cd, noise_fn=lambda shape: src(shape, "cpu"))
+            n += 1
+        ct = time.perf_counter() - t0
+    print(json.dumps({"value": round(n / ct, 4), "unit": "depth-maps/s", "cores": cores, "kind": "port",
+                      "sample": f"{n} forwards of the same workload at batch 1 after 1 warm-up, "
+                                f"torch CPU backend with {cores} threads"}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -48,7 +71,10 @@ def main():
     ap.add_argument("--src-views", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-forwards", type=int, default=8)
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if a.cpu_baseline_only:
+        return cpu_baseline(a)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -126,22 +152,21 @@ def main():
     }
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        from oracle import diffmvs_oracle as O
-        cores = os.cpu_count() or 1
-        torch.set_num_threads(cores)
-        ci, cp, cd = synth.synth_inputs(H, W, S, B=1, seed=100)
-        src = synth.NoiseSource(0)
-        with torch.no_grad():
-            O.forward(sd, args, ci, cp, cd, noise_fn=lambda shape: src(shape, "cpu"))      # warm-up
-            t0 = time.perf_counter()
-            n = 0
-            while n < a.cpu_forwards and time.perf_counter() - t0 < 25.0:
-                O.forward(sd, args, ci, cp, cd, noise_fn=lambda shape: src(shape, "cpu"))
-                n += 1
-            ct = time.perf_counter() - t0
-        result["cpu_baseline"] = {"value": round(n / ct, 4), "unit": "depth-maps/s", "cores": cores, "kind": "port",
-                                  "sample": f"{n} forwards of the same workload at batch 1 after 1 warm-up, "
-                                            f"torch CPU backend with {cores} threads"}
+        # the CPU leg runs in a child process with a hard time limit so that an oversubscribed or slow
+        # host can never stall the GPU measurement
+        import subprocess
+        try:
+            cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only",
+                                 "--height", str(H), "--width", str(W), "--src-views", str(S),
+                                 "--cpu-forwards", str(a.cpu_forwards)],
+                                capture_output=True, text=True, timeout=150)
+            line = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+            result["cpu_baseline"] = json.loads(line[-1]) if line else {
+                "value": None, "unit": "depth-maps/s", "cores": 0, "kind": "port",
+                "sample": "cpu leg failed: " + cp.stderr[-200:]}
+        except subprocess.TimeoutExpired:
+            result["cpu_baseline"] = {"value": None, "unit": "depth-maps/s", "cores": 0, "kind": "port",
+                                      "sample": "cpu leg exceeded its 150 s limit"}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist:

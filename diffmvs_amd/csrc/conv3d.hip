@@ -1,11 +1,131 @@
-// Direct fp32 3-D convolutions of PixelViewWeight / CostRegNet_small (reference
-// models/module.py:422-463): 3x3x3, padding 1, stride 1|2, and the stride-2 transposed form
-// with output_padding 1.  One lane = one output voxel (x fastest, so a wave reads 64
-// consecutive floats of a (c,d,y) row), CO accumulators in VGPRs, tap weights wave-uniform
-// -> scalar loads.  The transposed convolution is evaluated in gather form, one output
-// parity class (od&1, oh&1, ow&1) per blockIdx.z so that the live taps stay wave-uniform:
+// fp32 3-D convolutions of PixelViewWeight / CostRegNet_small (reference
+// models/module.py:422-463): 3x3x3, padding 1.
+//
+// Stride-1 layers (all the large volumes) run as an implicit GEMM on the matrix cores,
+// the 3-D sibling of conv2d.hip:  workgroup = 16(x) x 4(y) x 4(d) output voxels x NT*16
+// channels, wave w = depth slice w (4 pixel-tiles of 16 consecutive x), K loop over chunks of
+// input channels staged in LDS as a [CK][6][6][18] halo tile + [CK][27][NT*16] weights,
+// v_mfma_f32_16x16x4_f32 with A = weights, B = voxels.
+//
+// The stride-2 and transposed layers act on 1/8 .. 1/64 of the volume and use the direct
+// form: one lane = one output voxel (x fastest), CO accumulators in VGPRs, tap weights
+// wave-uniform.  The transposed convolution is evaluated in gather form, one output parity
+// class (od&1, oh&1, ow&1) per blockIdx.z so that the live taps stay wave-uniform:
 //   o = 2j   : k = 1 reads i = j            o = 2j+1 : k = 0 reads i = j+1, k = 2 reads i = j
 #include "dmvs_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int pad16mod32_3d(int n) {
+    int m = n;
+    while (m % 32 != 16) ++m;
+    return m;
+}
+
+template <int NT>
+__global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_kernel(const dmvs_conv3d_desc d, int tiles_x, int tiles_y, int tiles_d) {
+    constexpr int TX = 16, TY = 4, TD = 4;
+    constexpr int IW = TX + 2, IH = TY + 2, ID = TD + 2;
+    constexpr int PLANE = pad16mod32_3d(ID * IH * IW);
+    constexpr int NW = NT * 16;
+    constexpr int WPAD = pad16mod32_3d(27 * NW);
+    constexpr int kCK = (8 * (PLANE + WPAD) * 4 > 49152) ? 4 : 8;
+    __shared__ float lds[kCK * PLANE + kCK * WPAD];
+    float* s_in = lds;
+    float* s_w = lds + kCK * PLANE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    int tile = blockIdx.x;
+    const int tx = tile % tiles_x; tile /= tiles_x;
+    const int ty = tile % tiles_y; tile /= tiles_y;
+    const int td = tile % tiles_d;
+    const int b = tile / tiles_d;
+    const int x0 = tx * TX, y0 = ty * TY, d0 = td * TD;
+    const int nbase = blockIdx.y * NW;
+    const size_t ivol = (size_t)d.Din * d.Hin * d.Win;
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    for (int c0 = 0; c0 < d.cin; c0 += kCK) {
+        __syncthreads();
+        for (int e = tid; e < kCK * ID * IH * IW; e += DMVS_BLOCK) {
+            const int ci = e / (ID * IH * IW), rem = e % (ID * IH * IW);
+            const int zz = rem / (IH * IW), rem2 = rem % (IH * IW);
+            const int yy = rem2 / IW, xx = rem2 % IW;
+            const int gd = d0 - 1 + zz, gy = y0 - 1 + yy, gx = x0 - 1 + xx;
+            float v = 0.0f;
+            if (c0 + ci < d.cin && gd >= 0 && gd < d.Din && gy >= 0 && gy < d.Hin && gx >= 0 && gx < d.Win)
+                v = d.in[((size_t)b * d.cin + c0 + ci) * ivol + ((size_t)gd * d.Hin + gy) * d.Win + gx];
+            s_in[ci * PLANE + rem] = v;
+        }
+        for (int e = tid; e < kCK * 27 * NW; e += DMVS_BLOCK) {
+            const int ci = e / (27 * NW), rem = e % (27 * NW);
+            const int t = rem / NW, n = rem % NW;
+            float w = 0.0f;
+            if (c0 + ci < d.cin && nbase + n < d.cout_pad) w = d.weight[((size_t)(c0 + ci) * 27 + t) * d.cout_pad + nbase + n];
+            s_w[ci * WPAD + t * NW + n] = w;
+        }
+        __syncthreads();
+        const int live_c = d.cin - c0 < kCK ? d.cin - c0 : kCK;
+        const int nc4 = (live_c + 3) >> 2;
+#pragma unroll 1
+        for (int kd = 0; kd < 3; ++kd) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+                    for (int c4 = 0; c4 < kCK / 4; ++c4) {
+                        if (c4 >= nc4) break;
+                        const int ci = c4 * 4 + kq;
+                        float av[NT];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) av[nt] = s_w[ci * WPAD + ((kd * 3 + ky) * 3 + kx) * NW + nt * 16 + m];
+                        const float* ip = s_in + ci * PLANE + ((wave + kd) * IH + ky) * IW + m + kx;
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) {
+                            const float bv = ip[mt * IW];
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[nt], bv, acc[mt][nt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    const int ox = x0 + m, od = d0 + wave;
+    if (ox >= d.Wout || od >= d.Dout) return;
+    const size_t ovol = (size_t)d.Dout * d.Hout * d.Wout;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int oy = y0 + mt;
+        if (oy >= d.Hout) continue;
+        const size_t ovox = ((size_t)od * d.Hout + oy) * d.Wout + ox;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cg = nbase + nt * 16 + kq * 4 + r;
+                if (cg >= d.cout) continue;
+                float y = acc[mt][nt][r];
+                if (d.scale) y *= d.scale[cg];
+                if (d.shift) y += d.shift[cg];
+                y = dmvs_act(y, d.act);
+                const size_t oi = ((size_t)b * d.cout + cg) * ovol + ovox;
+                if (d.residual) y += d.residual[oi];
+                d.out[oi] = y;
+            }
+        }
+    }
+}
+
 
 template <int CO>
 __device__ __forceinline__ void conv3d_epilogue(const dmvs_conv3d_desc& d, const float (&acc)[CO], int co0, int b,
@@ -136,8 +256,11 @@ extern "C" int dmvs_conv3d_f32(const dmvs_conv3d_desc* dp, void* stream) {
     const long total = (long)d.B * d.Dout * d.Hout * d.Wout;
     dim3 grid(dmvs_ceil_div(total, DMVS_BLOCK), d.cout_pad / co);
     if (d.stride == 1) {
-        if (co == 16) hipLaunchKernelGGL((conv3d_kernel<16, 1>), grid, block, 0, st, d);
-        else hipLaunchKernelGGL((conv3d_kernel<8, 1>), grid, block, 0, st, d);
+        const int tiles_x = (d.Wout + 15) / 16, tiles_y = (d.Hout + 3) / 4, tiles_d = (d.Dout + 3) / 4;
+        const int ntiles = (d.cout_pad + 15) / 16;
+        dim3 g((unsigned)(tiles_x * tiles_y * tiles_d * d.B), (unsigned)((ntiles + 1) / 2));
+        if (ntiles == 1) hipLaunchKernelGGL((conv3d_mfma_kernel<1>), g, block, 0, st, d, tiles_x, tiles_y, tiles_d);
+        else hipLaunchKernelGGL((conv3d_mfma_kernel<2>), g, block, 0, st, d, tiles_x, tiles_y, tiles_d);
     } else {
         if (co == 16) hipLaunchKernelGGL((conv3d_kernel<16, 2>), grid, block, 0, st, d);
         else hipLaunchKernelGGL((conv3d_kernel<8, 2>), grid, block, 0, st, d);

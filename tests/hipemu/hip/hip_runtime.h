@@ -57,6 +57,7 @@ struct Worker {
     std::vector<Fiber> fibers;
     std::vector<char> stacks;
     std::vector<uint64_t> slots;   // shuffle exchange, one per thread of the block
+    std::vector<float> slots_a, slots_b;   // MFMA operand exchange
     int current = -1;
     const std::function<void()>* body = nullptr;
 };
@@ -113,6 +114,8 @@ inline void launch(dim3 grid, dim3 block, size_t, const std::function<void()>& b
         w.fibers.resize(nthreads);
         w.stacks.resize(size_t(nthreads) * kStack);
         w.slots.resize(nthreads);
+        w.slots_a.resize(nthreads);
+        w.slots_b.resize(nthreads);
         w.body = &body;
         g_worker = &w;
         g_blockDim = block;
@@ -198,6 +201,27 @@ static inline float atomicAdd(float* a, float v) { return hipemu_atomic_add(a, v
 static inline double atomicAdd(double* a, double v) { return hipemu_atomic_add(a, v); }
 static inline int atomicAdd(int* a, int v) { return __atomic_fetch_add(a, v, __ATOMIC_RELAXED); }
 
+// clang's ext_vector_type spelled for g++ (kernels only use 4 x float vectors)
+#define ext_vector_type(N) vector_size((N) * 4)
+typedef float hipemu_f32x4 __attribute__((vector_size(16)));
+// v_mfma_f32_16x16x4_f32 (cdna_hip_programming.md section 3): A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
+// D[row = 4*(lane>>4) + r][col = lane&15], k-ordered fma chain.
+static inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hipemu_f32x4 c, int, int, int) {
+    hipemu::Worker* w = hipemu::g_worker;
+    const int t = hipemu::linear_tid(), lane = t & 63, base = t & ~63;
+    w->slots_a[t] = a;
+    w->slots_b[t] = b;
+    hipemu::yield();
+    const int col = lane & 15;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (lane >> 4) + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = fmaf(w->slots_a[base + k * 16 + row], w->slots_b[base + k * 16 + col], acc);
+        c[r] = acc;
+    }
+    hipemu::yield();
+    return c;
+}
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 static inline float __fdividef(float a, float b) { return a / b; }
