@@ -4,17 +4,20 @@
 //   D[cout, pixel] += W[cout, k] * X[k, pixel],   k = (ci, ky, kx)
 //
 // Work decomposition
-//   workgroup (4 waves)  = one 16x16 tile of output pixels x (NT*16) output channels
-//   wave w               = rows 4w..4w+3 of the tile: 4 pixel-tiles of 16 consecutive x
+//   workgroup (4 waves)  = a 16 x (4*MT) tile of output pixels x (NT*16) output channels
+//   wave w               = rows MT*w .. MT*w+MT-1 of the tile: MT pixel-tiles of 16 consecutive x
 //   MFMA operands        = A: weights  [cout = lane&15][k = lane>>4]
 //                          B: inputs   [k = lane>>4][pixel = lane&15]
 //                          D: 4 couts (4*(lane>>4)+r) of pixel lane&15  -> NCHW stores are 64 B
 //                             runs per cout, NHWC stores are 16 B per lane
 //   K loop               = chunks of CK=8 (or 4) input channels staged in LDS (input halo tile
 //                          [CK][TH][TW] + weight slab [CK][KH*KW][NT*16]); per (tap, 4-channel
-//                          group) every wave issues 4 ds_read_b32 (B) + NT ds_read_b32 (A)
-//                          for 4*NT MFMAs.  Channel strides in LDS are padded to 16 mod 32
-//                          words so that the four k-groups of a wave hit disjoint banks.
+//                          group) every wave issues MT ds_read (B) + NT ds_read (A) for MT*NT
+//                          MFMAs.  Channel strides in LDS are padded to 16 mod 32 words so that
+//                          the four k-groups of a wave hit disjoint banks.
+//   staging              = software-pipelined through registers: the global loads of chunk
+//                          c+1 are issued (all of them back to back, predicated, no branches)
+//                          before the MFMA sweep over chunk c and land in LDS after it.
 // Everything around the convolution is fused into staging (channel concat, nearest-x2
 // upsampling, pixel-unshuffle, r*h gating, zero padding) or into the epilogue (folded BN /
 // bias, residual adds, activations, post-scale, GRU blend, NHWC / channel-offset output);
@@ -25,46 +28,38 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int kTile = 16;   // output tile edge (pixels)
-
-
 constexpr int pad16mod32(int n) {   // smallest m >= n with m % 32 == 16
     int m = n;
     while (m % 32 != 16) ++m;
     return m;
 }
 
-// logical input element (b, ci, iy, ix) with zero padding; handles concat / upsample / unshuffle / gating
-__device__ __forceinline__ float conv_in(const dmvs_conv2d_desc& d, int b, int ci, int iy, int ix) {
-    if (ci >= d.c0 + d.c1 || iy < 0 || iy >= d.Hin || ix < 0 || ix >= d.Win) return 0.0f;
-    if (ci >= d.c0) return d.in1[(((size_t)b * d.c1 + (ci - d.c0)) * d.Hin + iy) * d.Win + ix];
-    if (d.in_mode == DMVS_IN_PLAIN) {
-        const size_t o = (((size_t)b * d.c0 + ci) * d.Hin + iy) * d.Win + ix;
-        float v = d.in0[o];
-        if (d.mul0) v *= d.mul0[o];
-        return v;
-    }
-    if (d.in_mode == DMVS_IN_UPSAMPLE2) {
-        const int pH = d.Hin >> 1, pW = d.Win >> 1;
-        return d.in0[(((size_t)b * d.c0 + ci) * pH + (iy >> 1)) * pW + (ix >> 1)];
-    }
-    // pixel-unshuffle: logical channel ci = c*4 + p1*2 + p2 reads physical (c, 2*iy+p1, 2*ix+p2)
-    const int pH = d.Hin << 1, pW = d.Win << 1;
-    return d.in0[(((size_t)b * (d.c0 >> 2) + (ci >> 2)) * pH + (iy * 2 + ((ci >> 1) & 1))) * pW + ix * 2 + (ci & 1)];
-}
+template <int KH, int KW, int S, int NT, int MT>
+struct ConvCfg {
+    static constexpr int T = KH * KW;
+    static constexpr int ROWS = 4 * MT;
+    static constexpr int TW = 15 * S + KW, TH = (ROWS - 1) * S + KH;
+    static constexpr int PLANE = pad16mod32(TH * TW);
+    static constexpr int NW = NT * 16;
+    static constexpr int WPAD = pad16mod32(T * NW);
+    // input channels per LDS chunk: 8; 4 for stride-2 shapes (their halo tile is 4x larger, and the
+    // chunk is also what each thread prefetches into registers) or when 8 would pass 48 KB of LDS
+    static constexpr int CK = (S == 2 || 8 * (PLANE + WPAD) * 4 > 49152) ? 4 : 8;
+    static constexpr int IN_ELEMS = CK * TH * TW, W_ELEMS = CK * T * NW;
+    static constexpr int IN_IT = (IN_ELEMS + DMVS_BLOCK - 1) / DMVS_BLOCK;
+    static constexpr int W_IT = (W_ELEMS + DMVS_BLOCK - 1) / DMVS_BLOCK;
+};
 
-template <int KH, int KW, int S, int NT>
-__global__ void __launch_bounds__(DMVS_BLOCK) conv2d_mfma_kernel(const dmvs_conv2d_desc d, int tiles_x, int tiles_y) {
-    constexpr int T = KH * KW;
-    constexpr int TW = (kTile - 1) * S + KW, TH = (kTile - 1) * S + KH;
-    constexpr int PLANE = pad16mod32(TH * TW);
-    constexpr int NW = NT * 16;
-    constexpr int WPAD = pad16mod32(T * NW);
-    // input channels per LDS chunk: 8, or 4 when 8 would push a workgroup past 48 KB of LDS
-    constexpr int kCK = (8 * (PLANE + WPAD) * 4 > 49152) ? 4 : 8;
-    __shared__ float lds[kCK * PLANE + kCK * WPAD];
+// second launch-bound = workgroups (one wave per SIMD each) we want co-resident per CU; it caps the
+// VGPR budget so that the scheduler does not hoist every LDS read of the unrolled tap loop
+template <int KH, int KW, int S, int NT, int MT>
+__global__ void __launch_bounds__(DMVS_BLOCK, 2) conv2d_mfma_kernel(const dmvs_conv2d_desc d, int tiles_x, int tiles_y) {
+    using Cfg = ConvCfg<KH, KW, S, NT, MT>;
+    constexpr int T = Cfg::T, TW = Cfg::TW, TH = Cfg::TH, PLANE = Cfg::PLANE, NW = Cfg::NW, WPAD = Cfg::WPAD;
+    constexpr int CK = Cfg::CK, IN_IT = Cfg::IN_IT, W_IT = Cfg::W_IT;
+    __shared__ float lds[CK * PLANE + CK * WPAD];
     float* s_in = lds;
-    float* s_w = lds + kCK * PLANE;
+    float* s_w = lds + CK * PLANE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, kq = lane >> 4;
@@ -72,49 +67,108 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_mfma_kernel(const dmvs_conv
     const int tx = tile % tiles_x; tile /= tiles_x;
     const int ty = tile % tiles_y;
     const int b = tile / tiles_y;
-    const int ox0 = tx * kTile, oy0 = ty * kTile;
+    const int ox0 = tx * 16, oy0 = ty * Cfg::ROWS;
     const int nbase = blockIdx.y * NW;
     const int cin = d.c0 + d.c1;
     const int gy0 = oy0 * S - d.pad_h, gx0 = ox0 * S - d.pad_w;
 
-    f32x4 acc[4][NT];
+    // ---- addressing of the logical input, all in 32-bit element offsets from per-batch bases
+    const int mode = d.in_mode;
+    const int pW = mode == DMVS_IN_UPSAMPLE2 ? (d.Win >> 1) : (mode == DMVS_IN_UNSHUFFLE2 ? (d.Win << 1) : d.Win);
+    const int pH = mode == DMVS_IN_UPSAMPLE2 ? (d.Hin >> 1) : (mode == DMVS_IN_UNSHUFFLE2 ? (d.Hin << 1) : d.Hin);
+    const int plane0 = pH * pW, plane1 = d.Hin * d.Win;
+    const int pc0 = mode == DMVS_IN_UNSHUFFLE2 ? (d.c0 >> 2) : d.c0;
+    const float* in0b = d.in0 + (size_t)b * pc0 * plane0;
+    const float* mul0b = d.mul0 ? d.mul0 + (size_t)b * pc0 * plane0 : nullptr;
+    const float* in1b = d.in1 ? d.in1 + (size_t)b * d.c1 * plane1 : d.in0;
+
+    float rin[IN_IT], rw[W_IT];
+
+    auto load_chunk = [&](int c0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < IN_IT; ++i) {
+            const int e = tid + i * DMVS_BLOCK;
+            const int ci = e / (TH * TW), rem = e - ci * (TH * TW);
+            const int r = rem / TW, c = rem - r * TW;
+            const int cig = c0 + ci, iy = gy0 + r, ix = gx0 + c;
+            const bool ok = e < Cfg::IN_ELEMS && cig < cin && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win;
+            const bool first = cig < d.c0;
+            int off;
+            if (mode == DMVS_IN_PLAIN) off = cig * plane0 + iy * pW + ix;
+            else if (mode == DMVS_IN_UPSAMPLE2) off = cig * plane0 + (iy >> 1) * pW + (ix >> 1);
+            else off = (cig >> 2) * plane0 + (iy * 2 + ((cig >> 1) & 1)) * pW + ix * 2 + (cig & 1);
+            // unconditional loads from clamped offsets + selects: no divergent branches, so the
+            // compiler issues the whole chunk's loads back to back
+            const bool ok0 = ok && first;
+            const int o0 = ok0 ? off : 0;
+            float v = in0b[o0];
+            v = ok0 ? v : 0.0f;
+            if (mul0b) {
+                const float g = mul0b[o0];
+                v = ok0 ? v * g : 0.0f;
+            }
+            if (d.c1 > 0) {
+                const bool ok1 = ok && !first;
+                const int o1 = ok1 ? (cig - d.c0) * plane1 + iy * d.Win + ix : 0;
+                const float v1 = in1b[o1];
+                v = ok1 ? v1 : v;
+            }
+            rin[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < W_IT; ++i) {
+            const int e = tid + i * DMVS_BLOCK;
+            const int ci = e / (T * NW), rem = e - ci * (T * NW);
+            const int t = rem / NW, n = rem - t * NW;
+            const bool ok = e < Cfg::W_ELEMS && c0 + ci < cin && nbase + n < d.cout_pad;
+            const float w = d.weight[ok ? ((c0 + ci) * T + t) * d.cout_pad + nbase + n : 0];
+            rw[i] = ok ? w : 0.0f;
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < IN_IT; ++i) {
+            const int e = tid + i * DMVS_BLOCK;
+            const int ci = e / (TH * TW), rem = e - ci * (TH * TW);
+            if (e < Cfg::IN_ELEMS) s_in[ci * PLANE + rem] = rin[i];
+        }
+#pragma unroll
+        for (int i = 0; i < W_IT; ++i) {
+            const int e = tid + i * DMVS_BLOCK;
+            const int ci = e / (T * NW), rem = e - ci * (T * NW);
+            if (e < Cfg::W_ELEMS) s_w[ci * WPAD + rem] = rw[i];
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    for (int c0 = 0; c0 < cin; c0 += kCK) {
+    load_chunk(0);
+    for (int c0 = 0; c0 < cin; c0 += CK) {
+        __syncthreads();                       // every wave is done reading the previous chunk
+        store_chunk();
         __syncthreads();
-        for (int e = tid; e < kCK * TH * TW; e += DMVS_BLOCK) {
-            const int ci = e / (TH * TW), rem = e % (TH * TW);
-            const int r = rem / TW, c = rem % TW;
-            s_in[ci * PLANE + r * TW + c] = conv_in(d, b, c0 + ci, gy0 + r, gx0 + c);
-        }
-        for (int e = tid; e < kCK * T * NW; e += DMVS_BLOCK) {
-            const int ci = e / (T * NW), rem = e % (T * NW);
-            const int t = rem / NW, n = rem % NW;
-            float w = 0.0f;
-            if (c0 + ci < cin && nbase + n < d.cout_pad) w = d.weight[((size_t)(c0 + ci) * T + t) * d.cout_pad + nbase + n];
-            s_w[ci * WPAD + t * NW + n] = w;
-        }
-        __syncthreads();
-        const int live_c = cin - c0 < kCK ? cin - c0 : kCK;
-        const int nc4 = (live_c + 3) >> 2;          // skip all-zero 4-channel groups of the last chunk
+        if (c0 + CK < cin) load_chunk(c0 + CK);   // in flight while the matrix cores chew on chunk c0
+        const int live_c = cin - c0 < CK ? cin - c0 : CK;
+        const int nc4 = (live_c + 3) >> 2;          // all-zero 4-channel groups of the last chunk are skipped
 #pragma unroll 1
-        for (int ky = 0; ky < KH; ++ky) {
+        for (int c4 = 0; c4 < nc4; ++c4) {
+            const int ci = c4 * 4 + kq;
+            const float* wp = s_w + ci * WPAD + m;
+            const float* ip = s_in + ci * PLANE + (wave * MT * S) * TW + m * S;
+#pragma unroll 1
+            for (int ky = 0; ky < KH; ++ky) {
 #pragma unroll
-            for (int kx = 0; kx < KW; ++kx) {
-#pragma unroll
-                for (int c4 = 0; c4 < kCK / 4; ++c4) {
-                    if (c4 >= nc4) break;
-                    const int ci = c4 * 4 + kq;
+                for (int kx = 0; kx < KW; ++kx) {
                     float av[NT];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) av[nt] = s_w[ci * WPAD + (ky * KW + kx) * NW + nt * 16 + m];
-                    const float* ip = s_in + ci * PLANE + (wave * 4 * S + ky) * TW + m * S + kx;
+                    for (int nt = 0; nt < NT; ++nt) av[nt] = wp[(ky * KW + kx) * NW + nt * 16];
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) {
-                        const float bv = ip[mt * S * TW];
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const float bv = ip[(mt * S + ky) * TW + kx];
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[nt], bv, acc[mt][nt], 0, 0, 0);
@@ -124,60 +178,125 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_mfma_kernel(const dmvs_conv
         }
     }
 
-    // epilogue: this lane holds couts nbase + nt*16 + 4*kq + r of pixel (oy0 + 4*wave + mt, ox0 + m)
+    // ---- epilogue: this lane holds couts nbase + nt*16 + 4*kq + r of pixels (oy0 + MT*wave + mt, ox0 + m)
     const int ox = ox0 + m;
-    if (ox >= d.Wout) return;
     const size_t oplane = (size_t)d.Hout * d.Wout;
     const bool rup = d.res_mode == DMVS_IN_UPSAMPLE2;
     const int rW = rup ? (d.Wout >> 1) : d.Wout, rH = rup ? (d.Hout >> 1) : d.Hout;
+    float sc[NT][4], sh[NT][4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int oy = oy0 + wave * 4 + mt;
-        if (oy >= d.Hout) continue;
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cg = nbase + nt * 16 + kq * 4 + r;
+            const bool okc = cg < d.cout;
+            sc[nt][r] = d.scale ? d.scale[okc ? cg : 0] : 1.0f;
+            sh[nt][r] = d.shift ? d.shift[okc ? cg : 0] : 0.0f;
+        }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int oy = oy0 + wave * MT + mt;
+        const bool okp = ox < d.Wout && oy < d.Hout;
         const size_t opix = (size_t)oy * d.Wout + ox;
         const size_t rpix = rup ? (size_t)(oy >> 1) * rW + (ox >> 1) : opix;
+        float y[NT][4];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int cg = nbase + nt * 16 + kq * 4 + r;
-                if (cg >= d.cout) continue;
-                float y = acc[mt][nt][r];
-                if (d.scale) y *= d.scale[cg];
-                if (d.shift) y += d.shift[cg];
-                float res = 0.0f;
-                if (d.residual) res = d.residual[((size_t)b * d.cout + cg) * ((size_t)rH * rW) + rpix];
-                if (d.residual && !d.res_after_act) y += res;
-                y = dmvs_act(y, d.act) * d.post_scale;
-                if (d.residual && d.res_after_act) y += res;
-                if (d.gru_z) {
-                    const size_t gi = ((size_t)b * d.cout + cg) * oplane + opix;
-                    const float z = d.gru_z[gi];
-                    y = (1.0f - z) * d.gru_h[gi] + z * y;
+            for (int r = 0; r < 4; ++r) y[nt][r] = acc[mt][nt][r] * sc[nt][r] + sh[nt][r];
+        float res[NT][4];
+        if (d.residual) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int cg = nbase + nt * 16 + kq * 4 + r;
+                    const bool okr = okp && cg < d.cout;
+                    const float rv = d.residual[okr ? ((size_t)b * d.cout + cg) * ((size_t)rH * rW) + rpix : 0];
+                    res[nt][r] = okr ? rv : 0.0f;
+                    if (!d.res_after_act) y[nt][r] += res[nt][r];
                 }
-                if (d.out_layout == DMVS_LAYOUT_NCHW)
-                    d.out[((size_t)b * d.out_cstride + d.out_coffset + cg) * oplane + opix] = y;
-                else
-                    d.out[((size_t)b * oplane + opix) * d.out_cstride + d.out_coffset + cg] = y;
-            }
+        }
+        if (d.act == DMVS_ACT_RELU) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[nt][r] = fmaxf(y[nt][r], 0.0f);
+        } else if (d.act != DMVS_ACT_NONE) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[nt][r] = dmvs_act(y[nt][r], d.act);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[nt][r] *= d.post_scale;
+        if (d.residual && d.res_after_act) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[nt][r] += res[nt][r];
+        }
+        if (d.gru_z) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int cg = nbase + nt * 16 + kq * 4 + r;
+                    const size_t gi = (okp && cg < d.cout) ? ((size_t)b * d.cout + cg) * oplane + opix : 0;
+                    const float z = d.gru_z[gi];
+                    y[nt][r] = (1.0f - z) * d.gru_h[gi] + z * y[nt][r];
+                }
+        }
+        if (d.out_layout == DMVS_LAYOUT_NCHW) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int cg = nbase + nt * 16 + kq * 4 + r;
+                    if (okp && cg < d.cout) d.out[((size_t)b * d.out_cstride + d.out_coffset + cg) * oplane + opix] = y[nt][r];
+                }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int cg = nbase + nt * 16 + kq * 4 + r;
+                    if (okp && cg < d.cout) d.out[((size_t)b * oplane + opix) * d.out_cstride + d.out_coffset + cg] = y[nt][r];
+                }
         }
     }
 }
 
-template <int KH, int KW, int S>
-int launch_conv2d(const dmvs_conv2d_desc& d, hipStream_t st) {
-    const int tiles_x = (d.Wout + kTile - 1) / kTile, tiles_y = (d.Hout + kTile - 1) / kTile;
-    const int ntiles = (d.cout_pad + 15) / 16;
-    // output channels per workgroup: up to 4 MFMA n-tiles share one staged input tile
-    int nt = ntiles <= 4 ? ntiles : (ntiles % 3 == 0 ? 3 : 4);
-    dim3 grid((unsigned)(tiles_x * tiles_y * d.B), (unsigned)((ntiles + nt - 1) / nt)), block(DMVS_BLOCK);
+template <int KH, int KW, int S, int MT>
+int launch_conv2d_mt(const dmvs_conv2d_desc& d, hipStream_t st, int nt, int ngroups) {
+    const int tiles_x = (d.Wout + 15) / 16, tiles_y = (d.Hout + 4 * MT - 1) / (4 * MT);
+    dim3 grid((unsigned)(tiles_x * tiles_y * d.B), (unsigned)ngroups), block(DMVS_BLOCK);
     switch (nt) {
-        case 1: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 1>), grid, block, 0, st, d, tiles_x, tiles_y); break;
-        case 2: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 2>), grid, block, 0, st, d, tiles_x, tiles_y); break;
-        case 3: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 3>), grid, block, 0, st, d, tiles_x, tiles_y); break;
-        default: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 4>), grid, block, 0, st, d, tiles_x, tiles_y); break;
+        case 1: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 1, MT>), grid, block, 0, st, d, tiles_x, tiles_y); break;
+        case 2: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 2, MT>), grid, block, 0, st, d, tiles_x, tiles_y); break;
+        case 3: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 3, MT>), grid, block, 0, st, d, tiles_x, tiles_y); break;
+        default: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 4, MT>), grid, block, 0, st, d, tiles_x, tiles_y); break;
     }
     return dmvs_launch_status();
+}
+
+template <int KH, int KW, int S>
+int launch_conv2d(const dmvs_conv2d_desc& d, hipStream_t st) {
+    const int ntiles = (d.cout_pad + 15) / 16;
+    // output channels per workgroup: up to 4 MFMA n-tiles share one staged input tile
+    const int nt = ntiles <= 4 ? ntiles : (ntiles % 3 == 0 ? 3 : 4);
+    const int ngroups = (ntiles + nt - 1) / nt;
+    // pixel tile = 16 x (4*MT).  Tall tiles amortise the halo and the weight slab; small images take
+    // 16x4 tiles so that the 256 CUs still see a few workgroups each; stride-2 / many-tap / wide-N
+    // shapes stop at MT=2 to keep the staging registers + accumulators inside the VGPR file.
+    constexpr bool heavy = (S == 2) || (KH * KW >= 25);
+    const long wg16 = (long)((d.Wout + 15) / 16) * ((d.Hout + 15) / 16) * d.B * ngroups;
+    if (wg16 * 4 < 1024) return launch_conv2d_mt<KH, KW, S, 1>(d, st, nt, ngroups);
+    if (heavy || nt == 4 || wg16 * 2 < 1024) return launch_conv2d_mt<KH, KW, S, 2>(d, st, nt, ngroups);
+    if constexpr (!heavy) return launch_conv2d_mt<KH, KW, S, 4>(d, st, nt, ngroups);
+    return DMVS_EINVAL;
 }
 
 }  // namespace
@@ -194,6 +313,8 @@ extern "C" int dmvs_conv2d_f32(const dmvs_conv2d_desc* dp, void* stream) {
     if (d.gru_z && (!d.gru_h || d.act != DMVS_ACT_TANH)) return DMVS_EINVAL;
     const int eh = (d.Hin + 2 * d.pad_h - d.kh) / d.stride + 1, ew = (d.Win + 2 * d.pad_w - d.kw) / d.stride + 1;
     if (eh != d.Hout || ew != d.Wout) return DMVS_EINVAL;
+    // 32-bit element offsets inside one batch item
+    if ((long)(d.c0 + d.c1) * d.Hin * d.Win * (d.in_mode == DMVS_IN_UNSHUFFLE2 ? 4 : 1) >= (1L << 31)) return DMVS_EINVAL;
     const int key = d.kh * 100 + d.kw * 10 + d.stride;
     switch (key) {
         case 111: return launch_conv2d<1, 1, 1>(d, st);

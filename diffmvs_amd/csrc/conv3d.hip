@@ -23,7 +23,7 @@ constexpr int pad16mod32_3d(int n) {
 }
 
 template <int NT>
-__global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_kernel(const dmvs_conv3d_desc d, int tiles_x, int tiles_y, int tiles_d) {
+__global__ void __launch_bounds__(DMVS_BLOCK, (NT == 1 ? 2 : 1)) conv3d_mfma_kernel(const dmvs_conv3d_desc d, int tiles_x, int tiles_y, int tiles_d) {
     constexpr int TX = 16, TY = 4, TD = 4;
     constexpr int IW = TX + 2, IH = TY + 2, ID = TD + 2;
     constexpr int PLANE = pad16mod32_3d(ID * IH * IW);
@@ -45,51 +45,80 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_kernel(const dmvs_conv
     const int nbase = blockIdx.y * NW;
     const size_t ivol = (size_t)d.Din * d.Hin * d.Win;
 
+    constexpr int IN_ELEMS = kCK * ID * IH * IW, W_ELEMS = kCK * 27 * NW;
+    constexpr int IN_IT = (IN_ELEMS + DMVS_BLOCK - 1) / DMVS_BLOCK, W_IT = (W_ELEMS + DMVS_BLOCK - 1) / DMVS_BLOCK;
+    const float* inb = d.in + (size_t)b * d.cin * ivol;
+    const int vol = (int)ivol;
+    float rin[IN_IT], rw[W_IT];
+    // branch-free predicated loads (clamped offset + select) so that a chunk's loads issue back to back
+    auto load_chunk = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < IN_IT; ++i) {
+            const int e = tid + i * DMVS_BLOCK;
+            const int ci = e / (ID * IH * IW), rem = e - ci * (ID * IH * IW);
+            const int zz = rem / (IH * IW), rem2 = rem - zz * (IH * IW);
+            const int yy = rem2 / IW, xx = rem2 - yy * IW;
+            const int gd = d0 - 1 + zz, gy = y0 - 1 + yy, gx = x0 - 1 + xx;
+            const bool ok = e < IN_ELEMS && c0 + ci < d.cin && gd >= 0 && gd < d.Din && gy >= 0 && gy < d.Hin && gx >= 0 && gx < d.Win;
+            const float v = inb[ok ? (c0 + ci) * vol + (gd * d.Hin + gy) * d.Win + gx : 0];
+            rin[i] = ok ? v : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < W_IT; ++i) {
+            const int e = tid + i * DMVS_BLOCK;
+            const int ci = e / (27 * NW), rem = e - ci * (27 * NW);
+            const int t = rem / NW, n = rem - t * NW;
+            const bool ok = e < W_ELEMS && c0 + ci < d.cin && nbase + n < d.cout_pad;
+            const float w = d.weight[ok ? ((c0 + ci) * 27 + t) * d.cout_pad + nbase + n : 0];
+            rw[i] = ok ? w : 0.0f;
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < IN_IT; ++i) {
+            const int e = tid + i * DMVS_BLOCK;
+            const int ci = e / (ID * IH * IW), rem = e - ci * (ID * IH * IW);
+            if (e < IN_ELEMS) s_in[ci * PLANE + rem] = rin[i];
+        }
+#pragma unroll
+        for (int i = 0; i < W_IT; ++i) {
+            const int e = tid + i * DMVS_BLOCK;
+            const int ci = e / (27 * NW), rem = e - ci * (27 * NW);
+            if (e < W_ELEMS) s_w[ci * WPAD + rem] = rw[i];
+        }
+    };
+
     f32x4 acc[4][NT];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
+    load_chunk(0);
     for (int c0 = 0; c0 < d.cin; c0 += kCK) {
         __syncthreads();
-        for (int e = tid; e < kCK * ID * IH * IW; e += DMVS_BLOCK) {
-            const int ci = e / (ID * IH * IW), rem = e % (ID * IH * IW);
-            const int zz = rem / (IH * IW), rem2 = rem % (IH * IW);
-            const int yy = rem2 / IW, xx = rem2 % IW;
-            const int gd = d0 - 1 + zz, gy = y0 - 1 + yy, gx = x0 - 1 + xx;
-            float v = 0.0f;
-            if (c0 + ci < d.cin && gd >= 0 && gd < d.Din && gy >= 0 && gy < d.Hin && gx >= 0 && gx < d.Win)
-                v = d.in[((size_t)b * d.cin + c0 + ci) * ivol + ((size_t)gd * d.Hin + gy) * d.Win + gx];
-            s_in[ci * PLANE + rem] = v;
-        }
-        for (int e = tid; e < kCK * 27 * NW; e += DMVS_BLOCK) {
-            const int ci = e / (27 * NW), rem = e % (27 * NW);
-            const int t = rem / NW, n = rem % NW;
-            float w = 0.0f;
-            if (c0 + ci < d.cin && nbase + n < d.cout_pad) w = d.weight[((size_t)(c0 + ci) * 27 + t) * d.cout_pad + nbase + n];
-            s_w[ci * WPAD + t * NW + n] = w;
-        }
+        store_chunk();
         __syncthreads();
+        if (c0 + kCK < d.cin) load_chunk(c0 + kCK);     // next chunk in flight during the MFMA sweep
         const int live_c = d.cin - c0 < kCK ? d.cin - c0 : kCK;
         const int nc4 = (live_c + 3) >> 2;
 #pragma unroll 1
-        for (int kd = 0; kd < 3; ++kd) {
+        for (int c4 = 0; c4 < nc4; ++c4) {
+            const int ci = c4 * 4 + kq;
+            const float* wp = s_w + ci * WPAD + m;
+            const float* ipb = s_in + ci * PLANE + wave * (IH * IW) + m;
+#pragma unroll 1
+            for (int kd = 0; kd < 3; ++kd) {
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
+                for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-#pragma unroll
-                    for (int c4 = 0; c4 < kCK / 4; ++c4) {
-                        if (c4 >= nc4) break;
-                        const int ci = c4 * 4 + kq;
+                    for (int kx = 0; kx < 3; ++kx) {
                         float av[NT];
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) av[nt] = s_w[ci * WPAD + ((kd * 3 + ky) * 3 + kx) * NW + nt * 16 + m];
-                        const float* ip = s_in + ci * PLANE + ((wave + kd) * IH + ky) * IW + m + kx;
+                        for (int nt = 0; nt < NT; ++nt) av[nt] = wp[((kd * 3 + ky) * 3 + kx) * NW + nt * 16];
 #pragma unroll
                         for (int mt = 0; mt < 4; ++mt) {
-                            const float bv = ip[mt * IW];
+                            const float bv = ipb[(kd * IH + ky + mt) * IW + kx];
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
                                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[nt], bv, acc[mt][nt], 0, 0, 0);
