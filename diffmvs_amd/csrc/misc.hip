@@ -72,22 +72,24 @@ extern "C" int dmvs_compose_proj_f32(const float* proj, float* out, int32_t B, i
 __global__ void __launch_bounds__(DMVS_BLOCK)
 view_aggregate_kernel(const float* __restrict__ cor, const float* __restrict__ w, float* __restrict__ out, int B, int S,
                       int GD, int HW) {
+    // one lane per output element (b, gd, p): S coalesced reads of cor, S (cached) reads of w
     const long i = (long)blockIdx.x * DMVS_BLOCK + threadIdx.x;
-    if (i >= (long)B * HW) return;
-    const int b = (int)(i / HW), p = (int)(i % HW);
-    float wsum = 1e-8f;
-    for (int s = 0; s < S; ++s) wsum += w[((long)b * S + s) * HW + p];
-    const float inv = 1.0f / wsum;
-    for (int gd = 0; gd < GD; ++gd) {
-        float a = 0.0f;
-        for (int s = 0; s < S; ++s) a = fmaf(w[((long)b * S + s) * HW + p], cor[(((long)b * S + s) * GD + gd) * HW + p], a);
-        out[((long)b * GD + gd) * HW + p] = a * inv;
+    if (i >= (long)B * GD * HW) return;
+    const int p = (int)(i % HW);
+    const int gd = (int)((i / HW) % GD);
+    const int b = (int)(i / ((long)HW * GD));
+    float wsum = 1e-8f, a = 0.0f;
+    for (int s = 0; s < S; ++s) {
+        const float ws = w[((long)b * S + s) * HW + p];
+        wsum += ws;
+        a = fmaf(ws, cor[(((long)b * S + s) * GD + gd) * HW + p], a);
     }
+    out[i] = a / wsum;
 }
 
 extern "C" int dmvs_view_aggregate_f32(const float* cor, const float* w, float* out, int32_t B, int32_t S, int32_t GD,
                                        int32_t HW, void* stream) {
-    hipLaunchKernelGGL(view_aggregate_kernel, dim3(dmvs_ceil_div((long)B * HW, DMVS_BLOCK)), dim3(DMVS_BLOCK), 0,
+    hipLaunchKernelGGL(view_aggregate_kernel, dim3(dmvs_ceil_div((long)B * GD * HW, DMVS_BLOCK)), dim3(DMVS_BLOCK), 0,
                        (hipStream_t)stream, cor, w, out, B, S, GD, HW);
     return dmvs_launch_status();
 }

@@ -1,58 +1,29 @@
 // Homography warp + group-wise correlation, the hot path of DiffMVS
 // (reference models/module.py:181-218 differentiable_warping, :514-548 / :630-661).
 //
-// CDNA4 mapping ("texel-coalesced"): features are channel-last (NHWC), so one bilinear tap
-// is one contiguous C-vector (192/128/64 B for C = 48/32/16).  A pixel is owned by
-// LPP = C/CPL adjacent lanes, each holding CPL = 3|4 channels, so the LPP lanes of a pixel
-// fetch one whole texel with a single coalesced request; a 64-lane wave serves 4/8/16
-// pixels.  The four texels of the current 2x2 footprint are cached in registers
-// (4*CPL VGPRs) and only re-fetched when floor(u), floor(v) move -- consecutive depth
-// hypotheses walk the epipolar line in sub-texel steps, so most hypotheses hit the cache.
-// The channel reduction of a correlation group (C/G = 12/8/4 channels = LPG = 4/2/1 lanes)
-// is a wave shuffle tree; no LDS, no atomics, outputs written once.
+// CDNA4 mapping ("texel-coalesced, batch-fetched"):
+//  * features are channel-last (NHWC): one bilinear tap is one contiguous C-vector
+//    (192/128/64 B for C = 48/32/16).  A pixel is owned by LPP = C/CPL adjacent lanes, each
+//    holding CPL = 3|4 channels, so the LPP lanes of a pixel fetch one whole texel with a
+//    single coalesced request; a 64-lane wave serves 4/8/16 pixels.
+//  * the projection of a hypothesis (p = R*(x,y,1)*depth + t, perspective divide, floor,
+//    bilinear weights) is computed ONCE per pixel, by the lane whose index in the pixel group
+//    equals the hypothesis index, and broadcast to the group with wave shuffles -- not
+//    recomputed by every channel lane.
+//  * the 4 taps of ALL hypotheses of a batch (NB <= 8) are requested back to back before the
+//    first one is consumed: one memory latency per batch instead of one per hypothesis.  The
+//    loads are branch-free (clamped offset + select); a hypothesis whose 2x2 footprint equals
+//    its predecessor's (consecutive hypotheses walk the epipolar line in sub-texel steps)
+//    degenerates to a load of the view's first texel -- one extra cache line for the whole
+//    wave -- and re-uses the predecessor's registers.
+//  * the channel reduction of a correlation group (C/G = 12/8/4 channels = LPG = 4/2/1 lanes)
+//    is a wave shuffle tree; no LDS, no atomics, every output written exactly once.
 //
 // Semantics kept from the reference: per-tap zero padding with align_corners=True pixel
 // coordinates, NO behind-camera mask, z == 0 -> z + 1e-8, non-finite coordinates sample 0.
 #include "dmvs_common.h"
 
 namespace {
-
-// one lane's CPL-channel slice of a texel: a single 16-byte (CPL=4) or 12-byte (CPL=3) load
-template <int CPL>
-__device__ __forceinline__ void load_texel(const float* p, bool ok, float (&v)[CPL]) {
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) v[j] = 0.0f;
-    if (ok) {
-        if constexpr (CPL == 4) {
-            const float4 q = *reinterpret_cast<const float4*>(p);
-            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-        } else {
-            const float3 q = *reinterpret_cast<const float3*>(p);
-            v[0] = q.x; v[1] = q.y; v[2] = q.z;
-        }
-    }
-}
-
-// register-cached 2x2 footprint of one source view for one pixel-lane
-template <int CPL>
-struct Footprint {
-    float t00[CPL], t01[CPL], t10[CPL], t11[CPL];
-    int cx, cy;
-    __device__ __forceinline__ void reset() { cx = -0x40000000; cy = -0x40000000; }
-    // view base already offset by this lane's channel slice
-    __device__ __forceinline__ void fetch(const float* view, int x0, int y0, int Hs, int Ws, int C) {
-        if (x0 == cx && y0 == cy) return;
-        cx = x0;
-        cy = y0;
-        const bool xa = x0 >= 0 && x0 < Ws, xb = x0 + 1 >= 0 && x0 + 1 < Ws;
-        const bool ya = y0 >= 0 && y0 < Hs, yb = y0 + 1 >= 0 && y0 + 1 < Hs;
-        const long base = ((long)y0 * Ws + x0) * C;
-        load_texel<CPL>(view + base, xa && ya, t00);
-        load_texel<CPL>(view + base + C, xb && ya, t01);
-        load_texel<CPL>(view + base + (long)Ws * C, xa && yb, t10);
-        load_texel<CPL>(view + base + (long)Ws * C + C, xb && yb, t11);
-    }
-};
 
 struct Ray {   // p(depth) = rot * (x, y, 1) * depth + trans   (reference :199-205)
     float rx, ry, rz, tx, ty, tz;
@@ -66,10 +37,12 @@ struct Ray {   // p(depth) = rot * (x, y, 1) * depth + trans   (reference :199-2
     }
 };
 
-// one hypothesis: project, (re)fetch the footprint, bilinear sample, dot with the reference slice
-template <int CPL>
-__device__ __forceinline__ float sample_dot(const Ray& r, float depth, const float* view, Footprint<CPL>& fp,
-                                            const float (&refv)[CPL], int Hs, int Ws, int C) {
+struct Samp {   // where a hypothesis lands in the source view
+    int x0, y0;       // top-left texel of the 2x2 footprint (far out of range if not finite)
+    float wx, wy;     // fractional parts (0 if not finite -> every tap weight is 0 or hits padding)
+};
+
+__device__ __forceinline__ Samp project(const Ray& r, float depth) {
     const float px = r.rx * depth + r.tx;
     const float py = r.ry * depth + r.ty;
     float pz = r.rz * depth + r.tz;
@@ -77,16 +50,64 @@ __device__ __forceinline__ float sample_dot(const Ray& r, float depth, const flo
     const float u = px / pz, v = py / pz;
     const bool fin = fabsf(u) < 1.0e9f && fabsf(v) < 1.0e9f;   // false for NaN / inf
     const float fx = floorf(u), fy = floorf(v);
-    const int x0 = fin ? (int)fx : -0x20000000, y0 = fin ? (int)fy : -0x20000000;
-    fp.fetch(view, x0, y0, Hs, Ws, C);
-    const float wx1 = fin ? u - fx : 0.0f, wy1 = fin ? v - fy : 0.0f;
-    const float wx0 = fin ? 1.0f - wx1 : 0.0f, wy0 = 1.0f - wy1;
+    Samp s;
+    s.x0 = fin ? (int)fx : -0x20000000;
+    s.y0 = fin ? (int)fy : -0x20000000;
+    s.wx = fin ? u - fx : 0.0f;
+    s.wy = fin ? v - fy : 0.0f;
+    return s;
+}
+
+template <int LPP>
+__device__ __forceinline__ Samp bcast(const Samp& s, int src) {
+    Samp r;
+    r.x0 = __shfl(s.x0, src, LPP);
+    r.y0 = __shfl(s.y0, src, LPP);
+    r.wx = __shfl(s.wx, src, LPP);
+    r.wy = __shfl(s.wy, src, LPP);
+    return r;
+}
+
+template <int CPL>
+struct Tex {   // this lane's CPL-channel slice of the 4 taps: [tap][channel]
+    float v[4][CPL];
+};
+
+// one lane's slice of a texel: a single 16-byte (CPL=4) or 12-byte (CPL=3) load, always issued
+template <int CPL>
+__device__ __forceinline__ void load_slice(const float* p, bool ok, float (&v)[CPL]) {
+    if constexpr (CPL == 4) {
+        const float4 q = *reinterpret_cast<const float4*>(p);
+        v[0] = ok ? q.x : 0.0f; v[1] = ok ? q.y : 0.0f; v[2] = ok ? q.z : 0.0f; v[3] = ok ? q.w : 0.0f;
+    } else {
+        const float3 q = *reinterpret_cast<const float3*>(p);
+        v[0] = ok ? q.x : 0.0f; v[1] = ok ? q.y : 0.0f; v[2] = ok ? q.z : 0.0f;
+    }
+}
+
+// branch-free fetch of the 2x2 footprint; `skip` (same footprint as the predecessor) or an
+// out-of-range tap reads the view's first texel instead and is zeroed / ignored by the caller
+template <int CPL>
+__device__ __forceinline__ void fetch4(const float* view, const Samp& s, bool skip, int Hs, int Ws, int C, Tex<CPL>& t) {
+    const bool xa = s.x0 >= 0 && s.x0 < Ws, xb = s.x0 + 1 >= 0 && s.x0 + 1 < Ws;
+    const bool ya = s.y0 >= 0 && s.y0 < Hs, yb = s.y0 + 1 >= 0 && s.y0 + 1 < Hs;
+    const int base = (int)(((unsigned)s.y0 * (unsigned)Ws + (unsigned)s.x0) * (unsigned)C);   // only used when in range
+    const bool k00 = xa && ya && !skip, k01 = xb && ya && !skip, k10 = xa && yb && !skip, k11 = xb && yb && !skip;
+    load_slice<CPL>(view + (k00 ? base : 0), k00, t.v[0]);
+    load_slice<CPL>(view + (k01 ? base + C : 0), k01, t.v[1]);
+    load_slice<CPL>(view + (k10 ? base + Ws * C : 0), k10, t.v[2]);
+    load_slice<CPL>(view + (k11 ? base + Ws * C + C : 0), k11, t.v[3]);
+}
+
+template <int CPL>
+__device__ __forceinline__ float bilinear_dot(const Tex<CPL>& t, const Samp& s, const float (&refv)[CPL]) {
+    const float wx1 = s.wx, wy1 = s.wy, wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
     const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
     float dot = 0.0f;
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
-        const float s = fp.t00[j] * w00 + fp.t01[j] * w01 + fp.t10[j] * w10 + fp.t11[j] * w11;
-        dot = fmaf(s, refv[j], dot);
+        const float smp = t.v[0][j] * w00 + t.v[1][j] * w01 + t.v[2][j] * w10 + t.v[3][j] * w11;
+        dot = fmaf(smp, refv[j], dot);
     }
     return dot;
 }
@@ -98,14 +119,44 @@ __device__ __forceinline__ float group_reduce(float v) {
     return v;
 }
 
+// Evaluate NB hypotheses of one view for this lane's pixel.  own[j] holds the projection of
+// hypothesis (sub + j*LPP) computed by this lane; results (group sums, valid on the group's
+// first lane) go to dots[0..NB).  `cur`/`prev` carry the footprint cache across batches.
+template <int CPL, int LPP, int LPG, int NB, int KPL>
+__device__ __forceinline__ void eval_batch(const float* view, const Samp (&own)[KPL], int Hs, int Ws, int C,
+                                           const float (&refv)[CPL], Tex<CPL>& cur, int& px0, int& py0,
+                                           float (&dots)[NB]) {
+    Samp sp[NB];
+    bool same[NB];
+    Tex<CPL> t[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        sp[k] = bcast<LPP>(own[k / LPP], k % LPP);
+        const int qx = k == 0 ? px0 : sp[k - 1].x0, qy = k == 0 ? py0 : sp[k - 1].y0;
+        same[k] = sp[k].x0 == qx && sp[k].y0 == qy;
+        fetch4<CPL>(view, sp[k], same[k], Hs, Ws, C, t[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+#pragma unroll
+        for (int tap = 0; tap < 4; ++tap)
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) cur.v[tap][j] = same[k] ? cur.v[tap][j] : t[k].v[tap][j];
+        dots[k] = group_reduce<LPG>(bilinear_dot<CPL>(cur, sp[k], refv));
+    }
+    px0 = sp[NB - 1].x0;
+    py0 = sp[NB - 1].y0;
+}
+
 // ------------------------------------------------------------------------------------------
-// InitialCost volumes: grid = (pixel blocks, S).  out [B,S,G,D,H,W]
-template <int C, int CPL>
+// InitialCost volumes: grid = (pixel blocks, S).  out [B,S,G,D,H,W].  D is a multiple of NB.
+template <int C, int CPL, int NB>
 __global__ void __launch_bounds__(DMVS_BLOCK)
 warp_corr_init_kernel(const float* __restrict__ ref, const float* __restrict__ src, const float* __restrict__ rt,
                       const float* __restrict__ disp_min, const float* __restrict__ disp_max,
                       float* __restrict__ out, int B, int S, int D, int H, int W, int Hs, int Ws) {
     constexpr int G = 4, LPP = C / CPL, LPG = LPP / G, PPB = DMVS_BLOCK / LPP;
+    static_assert(NB <= LPP, "one projection per lane and batch");
     const int sub = threadIdx.x % LPP, slot = threadIdx.x / LPP;
     const long npix = (long)B * H * W;
     const long pix = (long)blockIdx.x * PPB + slot;
@@ -119,23 +170,35 @@ warp_corr_init_kernel(const float* __restrict__ ref, const float* __restrict__ s
     float refv[CPL];
     const float inv_cg = 1.0f / (float)(C / G);   // mean over the channels of a group
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) refv[j] = ref[((long)pc) * C + sub * CPL + j] * inv_cg;
+    for (int j = 0; j < CPL; ++j) refv[j] = ref[pc * C + sub * CPL + j] * inv_cg;
 
     Ray ray;
     ray.init(rt + ((long)b * S + s) * 12, (float)x, (float)y);
     const float* view = src + ((long)s * B + b) * (long)Hs * Ws * C + sub * CPL;
-    Footprint<CPL> fp;
-    fp.reset();
     const float dmin = disp_min[b], dmax = disp_max[b];
-    const float inv_dm1 = (float)(D - 1);
+    const float dm1 = (float)(D - 1);
     const int g = sub / LPG;
-    float* op = out + ((((long)b * S + s) * G + g) * D) * (long)H * W + (long)y * W + x;
+    const long hw = (long)H * W;
+    float* op = out + ((((long)b * S + s) * G + g) * D) * hw + (long)y * W + x;
     const bool writer = live && (sub % LPG) == 0;
-    for (int d = 0; d < D; ++d) {
-        const float depth = dmvs_disp_to_depth((float)d / inv_dm1, dmin, dmax);
-        float dot = sample_dot<CPL>(ray, depth, view, fp, refv, Hs, Ws, C);
-        dot = group_reduce<LPG>(dot);
-        if (writer) op[(long)d * H * W] = dot;
+
+    Tex<CPL> cur;
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) cur.v[tap][j] = 0.0f;
+    int px0 = -0x40000000, py0 = -0x40000000;
+    for (int d0 = 0; d0 < D; d0 += NB) {
+        Samp own[1];
+        const int dk = d0 + (sub < NB ? sub : 0);
+        own[0] = project(ray, dmvs_disp_to_depth((float)dk / dm1, dmin, dmax));
+        float dots[NB];
+        eval_batch<CPL, LPP, LPG, NB, 1>(view, own, Hs, Ws, C, refv, cur, px0, py0, dots);
+        if (writer) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k)
+                if (d0 + k < D) op[(long)(d0 + k) * hw] = dots[k];
+        }
     }
 }
 
@@ -143,7 +206,7 @@ warp_corr_init_kernel(const float* __restrict__ ref, const float* __restrict__ s
 // GetCost: hypotheses + S warps + correlation + view-weighted aggregation in one pass.
 template <int C, int CPL, int N>
 __global__ void __launch_bounds__(DMVS_BLOCK) getcost_kernel(const dmvs_getcost_desc d) {
-    constexpr int G = 4, LPP = C / CPL, LPG = LPP / G, PPB = DMVS_BLOCK / LPP;
+    constexpr int G = 4, LPP = C / CPL, LPG = LPP / G, PPB = DMVS_BLOCK / LPP, KPL = (N + LPP - 1) / LPP;
     const int sub = threadIdx.x % LPP, slot = threadIdx.x / LPP;
     const int H = d.H, W = d.W;
     const long npix = (long)d.B * H * W;
@@ -156,23 +219,25 @@ __global__ void __launch_bounds__(DMVS_BLOCK) getcost_kernel(const dmvs_getcost_
     const long hw = (long)H * W, yx = (long)y * W + x;
 
     // hypotheses in normalised inverse depth (reference :259-276)
-    const float cur = d.inv_depth[pc];
+    const float cur_inv = d.inv_depth[pc];
     float radius = (float)(N / 2) * d.interval;
     if (d.confidence) {
         const float r0 = d.min_radius * radius, r1 = d.max_radius * radius;
         radius = r0 + (1.0f - d.confidence[pc]) * (r1 - r0);
     }
-    const float lo = cur - radius, hi = cur + radius;
+    const float lo = cur_inv - radius, hi = cur_inv + radius;
     const float step = (hi - lo) / (float)(N - 1);
     const float dmin = d.disp_min[b], dmax = d.disp_max[b];
-    float depth[N];
+    // this lane projects hypotheses sub, sub+LPP, ...: it only needs those depths
+    float own_depth[KPL];
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-        float sk = (float)k * step;
+    for (int j = 0; j < KPL; ++j) {
+        const int k = sub + j * LPP;
+        float sk = (float)(k < N ? k : 0) * step;
         sk += lo;
         sk = fminf(fmaxf(sk, 0.0f), 1.0f);
-        depth[k] = dmvs_disp_to_depth(sk, dmin, dmax);
-        if (live && sub == 0) d.out_samples[((long)b * d.samp_cstride + d.samp_coffset + k) * hw + yx] = sk;
+        own_depth[j] = dmvs_disp_to_depth(sk, dmin, dmax);
+        if (live && k < N) d.out_samples[((long)b * d.samp_cstride + d.samp_coffset + k) * hw + yx] = sk;
     }
 
     float refv[CPL];
@@ -192,14 +257,19 @@ __global__ void __launch_bounds__(DMVS_BLOCK) getcost_kernel(const dmvs_getcost_
         Ray ray;
         ray.init(d.rt + ((long)b * d.S + s) * 12, (float)x, (float)y);
         const float* view = d.src + ((long)s * d.B + b) * hw * C + sub * CPL;
-        Footprint<CPL> fp;
-        fp.reset();
+        Samp own[KPL];
 #pragma unroll
-        for (int k = 0; k < N; ++k) {
-            float dot = sample_dot<CPL>(ray, depth[k], view, fp, refv, H, W, C);
-            dot = group_reduce<LPG>(dot);
-            acc[k] = fmaf(w, dot, acc[k]);
-        }
+        for (int j = 0; j < KPL; ++j) own[j] = project(ray, own_depth[j]);
+        Tex<CPL> cur;
+#pragma unroll
+        for (int tap = 0; tap < 4; ++tap)
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) cur.v[tap][j] = 0.0f;
+        int px0 = -0x40000000, py0 = -0x40000000;
+        float dots[N];
+        eval_batch<CPL, LPP, LPG, N, KPL>(view, own, H, W, C, refv, cur, px0, py0, dots);
+#pragma unroll
+        for (int k = 0; k < N; ++k) acc[k] = fmaf(w, dots[k], acc[k]);
     }
     if (live && (sub % LPG) == 0) {
         const int g = sub / LPG;
@@ -219,31 +289,28 @@ int launch_getcost(const dmvs_getcost_desc& d, hipStream_t st) {
     return dmvs_launch_status();
 }
 
+template <int C, int CPL, int NB>
+int launch_init(const float* ref, const float* src, const float* rt, const float* disp_min, const float* disp_max,
+                float* out, int B, int S, int D, int H, int W, int Hs, int Ws, hipStream_t st) {
+    dim3 grid(dmvs_ceil_div((long)B * H * W, DMVS_BLOCK / (C / CPL)), S), block(DMVS_BLOCK);
+    hipLaunchKernelGGL((warp_corr_init_kernel<C, CPL, NB>), grid, block, 0, st, ref, src, rt, disp_min, disp_max, out, B, S,
+                       D, H, W, Hs, Ws);
+    return dmvs_launch_status();
+}
+
 }  // namespace
 
 extern "C" int dmvs_warp_corr_init_f32(const float* ref, const float* src, const float* rt, const float* disp_min,
                                        const float* disp_max, float* out, int32_t B, int32_t S, int32_t C, int32_t G,
                                        int32_t D, int32_t H, int32_t W, int32_t Hs, int32_t Ws, void* stream) {
     if (G != 4 || D < 2 || !ref || !src || !rt || !out) return DMVS_EINVAL;
+    if ((long)Hs * Ws * C >= (1L << 31)) return DMVS_EINVAL;   // 32-bit texel offsets inside one view
     hipStream_t st = (hipStream_t)stream;
-    dim3 block(DMVS_BLOCK);
-    const long npix = (long)B * H * W;
-    if (C == 48) {
-        dim3 grid(dmvs_ceil_div(npix, DMVS_BLOCK / 16), S);
-        hipLaunchKernelGGL((warp_corr_init_kernel<48, 3>), grid, block, 0, st, ref, src, rt, disp_min, disp_max, out, B, S,
-                           D, H, W, Hs, Ws);
-    } else if (C == 32) {
-        dim3 grid(dmvs_ceil_div(npix, DMVS_BLOCK / 8), S);
-        hipLaunchKernelGGL((warp_corr_init_kernel<32, 4>), grid, block, 0, st, ref, src, rt, disp_min, disp_max, out, B, S,
-                           D, H, W, Hs, Ws);
-    } else if (C == 16) {
-        dim3 grid(dmvs_ceil_div(npix, DMVS_BLOCK / 4), S);
-        hipLaunchKernelGGL((warp_corr_init_kernel<16, 4>), grid, block, 0, st, ref, src, rt, disp_min, disp_max, out, B, S,
-                           D, H, W, Hs, Ws);
-    } else {
-        return DMVS_EINVAL;
-    }
-    return dmvs_launch_status();
+    // hypotheses per fetch batch: 8 texel sets in flight per lane (4 for the 4-lane C=16 pixel group)
+    if (C == 48) return launch_init<48, 3, 8>(ref, src, rt, disp_min, disp_max, out, B, S, D, H, W, Hs, Ws, st);
+    if (C == 32) return launch_init<32, 4, 8>(ref, src, rt, disp_min, disp_max, out, B, S, D, H, W, Hs, Ws, st);
+    if (C == 16) return launch_init<16, 4, 4>(ref, src, rt, disp_min, disp_max, out, B, S, D, H, W, Hs, Ws, st);
+    return DMVS_EINVAL;
 }
 
 extern "C" int dmvs_getcost_f32(const dmvs_getcost_desc* dp, void* stream) {
@@ -251,6 +318,7 @@ extern "C" int dmvs_getcost_f32(const dmvs_getcost_desc* dp, void* stream) {
     const dmvs_getcost_desc& d = *dp;
     if (d.G != 4 || !d.ref || !d.src || !d.rt || !d.inv_depth || !d.view_w || !d.out_cost || !d.out_samples)
         return DMVS_EINVAL;
+    if ((long)d.H * d.W * d.C >= (1L << 31)) return DMVS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (d.C == 48) return launch_getcost<48, 3>(d, st);
     if (d.C == 32) return launch_getcost<32, 4>(d, st);
