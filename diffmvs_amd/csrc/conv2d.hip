@@ -15,9 +15,9 @@
 //                          group) every wave issues MT ds_read (B) + NT ds_read (A) for MT*NT
 //                          MFMAs.  Channel strides in LDS are padded to 16 mod 32 words so that
 //                          the four k-groups of a wave hit disjoint banks.
-//   staging              = software-pipelined through registers: the global loads of chunk
-//                          c+1 are issued (all of them back to back, predicated, no branches)
-//                          before the MFMA sweep over chunk c and land in LDS after it.
+//   staging              = LDS-DMA (global_load_lds): chunk c+1 streams from HBM/L2 straight into the
+//                          other half of a double-buffered LDS image while the matrix cores sweep
+//                          chunk c -- no VGPR round trip, one barrier per chunk.
 // Everything around the convolution is fused into staging (channel concat, nearest-x2
 // upsampling, pixel-unshuffle, r*h gating, zero padding) or into the epilogue (folded BN /
 // bias, residual adds, activations, post-scale, GRU blend, NHWC / channel-offset output);
@@ -34,6 +34,11 @@ constexpr int pad16mod32(int n) {   // smallest m >= n with m % 32 == 16
     return m;
 }
 
+// all-zero source for LDS-DMA lanes that stage padding (an LDS-DMA lane cannot write a literal)
+__device__ __attribute__((aligned(16))) const float dmvs_zero16[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+
+#define DMVS_LDS(p) ((__attribute__((address_space(3))) void*)(p))
+
 template <int KH, int KW, int S, int NT, int MT>
 struct ConvCfg {
     static constexpr int T = KH * KW;
@@ -42,24 +47,19 @@ struct ConvCfg {
     static constexpr int PLANE = pad16mod32(TH * TW);
     static constexpr int NW = NT * 16;
     static constexpr int WPAD = pad16mod32(T * NW);
-    // input channels per LDS chunk: 8; 4 for stride-2 shapes (their halo tile is 4x larger, and the
-    // chunk is also what each thread prefetches into registers) or when 8 would pass 48 KB of LDS
-    static constexpr int CK = (S == 2 || 8 * (PLANE + WPAD) * 4 > 49152) ? 4 : 8;
-    static constexpr int IN_ELEMS = CK * TH * TW, W_ELEMS = CK * T * NW;
-    static constexpr int IN_IT = (IN_ELEMS + DMVS_BLOCK - 1) / DMVS_BLOCK;
-    static constexpr int W_IT = (W_ELEMS + DMVS_BLOCK - 1) / DMVS_BLOCK;
+    // input channels per LDS chunk: 8 when the double-buffered chunk stays within 40 KB, else 4
+    static constexpr int CK = (2 * 8 * (PLANE + WPAD) * 4 > 40960) ? 4 : 8;
+    static constexpr int BUF = CK * (PLANE + WPAD);            // floats per pipeline stage
+    static constexpr int IN_IT = (CK * PLANE + DMVS_BLOCK - 1) / DMVS_BLOCK;           // 4-byte DMA pieces per thread
+    static constexpr int W_IT = (CK * WPAD / 4 + DMVS_BLOCK - 1) / DMVS_BLOCK;         // 16-byte DMA pieces per thread
 };
 
-// second launch-bound = workgroups (one wave per SIMD each) we want co-resident per CU; it caps the
-// VGPR budget so that the scheduler does not hoist every LDS read of the unrolled tap loop
 template <int KH, int KW, int S, int NT, int MT>
-__global__ void __launch_bounds__(DMVS_BLOCK, 2) conv2d_mfma_kernel(const dmvs_conv2d_desc d, int tiles_x, int tiles_y) {
+__global__ void __launch_bounds__(DMVS_BLOCK) conv2d_mfma_kernel(const dmvs_conv2d_desc d, int tiles_x, int tiles_y) {
     using Cfg = ConvCfg<KH, KW, S, NT, MT>;
     constexpr int T = Cfg::T, TW = Cfg::TW, TH = Cfg::TH, PLANE = Cfg::PLANE, NW = Cfg::NW, WPAD = Cfg::WPAD;
-    constexpr int CK = Cfg::CK, IN_IT = Cfg::IN_IT, W_IT = Cfg::W_IT;
-    __shared__ float lds[CK * PLANE + CK * WPAD];
-    float* s_in = lds;
-    float* s_w = lds + CK * PLANE;
+    constexpr int CK = Cfg::CK, BUF = Cfg::BUF, IN_IT = Cfg::IN_IT, W_IT = Cfg::W_IT;
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, kq = lane >> 4;
@@ -82,61 +82,46 @@ __global__ void __launch_bounds__(DMVS_BLOCK, 2) conv2d_mfma_kernel(const dmvs_c
     const float* mul0b = d.mul0 ? d.mul0 + (size_t)b * pc0 * plane0 : nullptr;
     const float* in1b = d.in1 ? d.in1 + (size_t)b * d.c1 * plane1 : d.in0;
 
-    float rin[IN_IT], rw[W_IT];
-
-    auto load_chunk = [&](int c0) {
-#pragma unroll
-        for (int i = 0; i < IN_IT; ++i) {
-            const int e = tid + i * DMVS_BLOCK;
-            const int ci = e / (TH * TW), rem = e - ci * (TH * TW);
-            const int r = rem / TW, c = rem - r * TW;
-            const int cig = c0 + ci, iy = gy0 + r, ix = gx0 + c;
-            const bool ok = e < Cfg::IN_ELEMS && cig < cin && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win;
-            const bool first = cig < d.c0;
-            int off;
-            if (mode == DMVS_IN_PLAIN) off = cig * plane0 + iy * pW + ix;
-            else if (mode == DMVS_IN_UPSAMPLE2) off = cig * plane0 + (iy >> 1) * pW + (ix >> 1);
-            else off = (cig >> 2) * plane0 + (iy * 2 + ((cig >> 1) & 1)) * pW + ix * 2 + (cig & 1);
-            // unconditional loads from clamped offsets + selects: no divergent branches, so the
-            // compiler issues the whole chunk's loads back to back
-            const bool ok0 = ok && first;
-            const int o0 = ok0 ? off : 0;
-            float v = in0b[o0];
-            v = ok0 ? v : 0.0f;
-            if (mul0b) {
-                const float g = mul0b[o0];
-                v = ok0 ? v * g : 0.0f;
-            }
-            if (d.c1 > 0) {
-                const bool ok1 = ok && !first;
-                const int o1 = ok1 ? (cig - d.c0) * plane1 + iy * d.Win + ix : 0;
-                const float v1 = in1b[o1];
-                v = ok1 ? v1 : v;
-            }
-            rin[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < W_IT; ++i) {
-            const int e = tid + i * DMVS_BLOCK;
-            const int ci = e / (T * NW), rem = e - ci * (T * NW);
-            const int t = rem / NW, n = rem - t * NW;
-            const bool ok = e < Cfg::W_ELEMS && c0 + ci < cin && nbase + n < d.cout_pad;
-            const float w = d.weight[ok ? ((c0 + ci) * T + t) * d.cout_pad + nbase + n : 0];
-            rw[i] = ok ? w : 0.0f;
-        }
+    // element e of the padded LDS input image of chunk c0 -> global source (or nullptr for padding)
+    auto in_src = [&](int c0, int e, int& off_out) -> const float* {
+        const int ci = e / PLANE, rem = e - ci * PLANE;
+        const int r = rem / TW, c = rem - r * TW;
+        const int cig = c0 + ci, iy = gy0 + r, ix = gx0 + c;
+        const bool ok = rem < TH * TW && cig < cin && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win;
+        int off;
+        if (mode == DMVS_IN_PLAIN) off = cig * plane0 + iy * pW + ix;
+        else if (mode == DMVS_IN_UPSAMPLE2) off = cig * plane0 + (iy >> 1) * pW + (ix >> 1);
+        else off = (cig >> 2) * plane0 + (iy * 2 + ((cig >> 1) & 1)) * pW + ix * 2 + (cig & 1);
+        off_out = (ok && cig < d.c0) ? off : -1;
+        if (!ok) return nullptr;
+        return cig < d.c0 ? in0b + off : in1b + ((cig - d.c0) * plane1 + iy * d.Win + ix);
     };
-    auto store_chunk = [&]() {
-#pragma unroll
+
+    // Stage chunk c0 into `buf` with LDS-DMA (global_load_lds): no VGPR round trip, fully asynchronous.
+    // A wave-instruction fills 64 consecutive LDS words (4-byte form, input halo tile -- its rows are
+    // not 16-byte multiples) or 64 consecutive 16-byte slots (weight slab) from per-lane sources.
+    auto stage = [&](int c0, float* buf) {
+#pragma unroll 2
         for (int i = 0; i < IN_IT; ++i) {
-            const int e = tid + i * DMVS_BLOCK;
-            const int ci = e / (TH * TW), rem = e - ci * (TH * TW);
-            if (e < Cfg::IN_ELEMS) s_in[ci * PLANE + rem] = rin[i];
+            const int e = i * DMVS_BLOCK + tid;
+            if (e < CK * PLANE) {
+                int off;
+                const float* src = in_src(c0, e, off);
+                if (!src) src = dmvs_zero16;
+                __builtin_amdgcn_global_load_lds(src, DMVS_LDS(buf + i * DMVS_BLOCK + wave * 64), 4, 0, 0);
+            }
         }
-#pragma unroll
+        float* wbuf = buf + CK * PLANE;
+#pragma unroll 2
         for (int i = 0; i < W_IT; ++i) {
-            const int e = tid + i * DMVS_BLOCK;
-            const int ci = e / (T * NW), rem = e - ci * (T * NW);
-            if (e < Cfg::W_ELEMS) s_w[ci * WPAD + rem] = rw[i];
+            const int e4 = i * DMVS_BLOCK + tid;
+            if (e4 < CK * WPAD / 4) {
+                const int ci = e4 / (WPAD / 4), rem4 = e4 - ci * (WPAD / 4);
+                const int t = rem4 / (NW / 4), n4 = rem4 - t * (NW / 4);
+                const bool ok = rem4 < T * NW / 4 && c0 + ci < cin && nbase + n4 * 4 < d.cout_pad;
+                const float* src = ok ? d.weight + (((c0 + ci) * T + t) * d.cout_pad + nbase + n4 * 4) : dmvs_zero16;
+                __builtin_amdgcn_global_load_lds(src, DMVS_LDS(wbuf + (i * DMVS_BLOCK + wave * 64) * 4), 16, 0, 0);
+            }
         }
     };
 
@@ -146,12 +131,26 @@ __global__ void __launch_bounds__(DMVS_BLOCK, 2) conv2d_mfma_kernel(const dmvs_c
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    load_chunk(0);
-    for (int c0 = 0; c0 < cin; c0 += CK) {
-        __syncthreads();                       // every wave is done reading the previous chunk
-        store_chunk();
+    stage(0, lds);
+    int cur = 0;
+    for (int c0 = 0; c0 < cin; c0 += CK, cur ^= 1) {
+        float* s_in = lds + cur * BUF;
+        float* s_w = s_in + CK * PLANE;
+        // __syncthreads() drains this wave's LDS-DMA (vmcnt) and orders it against everyone's ds_reads:
+        // after it, chunk c0 is complete in `cur` and the other buffer is free for the next chunk
         __syncthreads();
-        if (c0 + CK < cin) load_chunk(c0 + CK);   // in flight while the matrix cores chew on chunk c0
+        if (mul0b) {   // r*h gating of the GRU candidate conv: scale the staged in0 channels in place
+            for (int i = 0; i < IN_IT; ++i) {
+                const int e = i * DMVS_BLOCK + tid;
+                if (e < CK * PLANE) {
+                    int off;
+                    in_src(c0, e, off);
+                    if (off >= 0) s_in[e] *= mul0b[off];
+                }
+            }
+            __syncthreads();
+        }
+        if (c0 + CK < cin) stage(c0 + CK, lds + (cur ^ 1) * BUF);   // lands while the matrix cores chew on chunk c0
         const int live_c = cin - c0 < CK ? cin - c0 : CK;
         const int nc4 = (live_c + 3) >> 2;          // all-zero 4-channel groups of the last chunk are skipped
 #pragma unroll 1

@@ -222,6 +222,12 @@ static inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b
     hipemu::yield();
     return c;
 }
+// LDS-DMA (global_load_lds_dword / _dwordx4): per-lane global source, LDS destination =
+// wave-uniform base + lane * size.  Synchronous here; the kernels' barriers make that equivalent.
+static inline void __builtin_amdgcn_global_load_lds(const void* g, void* lds_base, unsigned size, int offset, int) {
+    const int lane = hipemu::linear_tid() & 63;
+    memcpy(static_cast<char*>(lds_base) + offset + size_t(lane) * size, g, size);
+}
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 static inline float __fdividef(float a, float b) { return a / b; }
