@@ -22,17 +22,22 @@ constexpr int pad16mod32_3d(int n) {
     return m;
 }
 
+// all-zero source for LDS-DMA lanes that stage padding
+__device__ __attribute__((aligned(16))) const float dmvs_zero16_3d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#define DMVS_LDS(p) ((__attribute__((address_space(3))) void*)(p))
+
 template <int NT>
-__global__ void __launch_bounds__(DMVS_BLOCK, (NT == 1 ? 2 : 1)) conv3d_mfma_kernel(const dmvs_conv3d_desc d, int tiles_x, int tiles_y, int tiles_d) {
+__global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_kernel(const dmvs_conv3d_desc d, int tiles_x, int tiles_y, int tiles_d) {
     constexpr int TX = 16, TY = 4, TD = 4;
     constexpr int IW = TX + 2, IH = TY + 2, ID = TD + 2;
     constexpr int PLANE = pad16mod32_3d(ID * IH * IW);
     constexpr int NW = NT * 16;
     constexpr int WPAD = pad16mod32_3d(27 * NW);
-    constexpr int kCK = (8 * (PLANE + WPAD) * 4 > 49152) ? 4 : 8;
-    __shared__ float lds[kCK * PLANE + kCK * WPAD];
-    float* s_in = lds;
-    float* s_w = lds + kCK * PLANE;
+    // input channels per LDS chunk (double buffered): 8 if that stays within 48 KB, else 4
+    constexpr int kCK = (2 * 8 * (PLANE + WPAD) * 4 > 49152) ? 4 : 8;
+    constexpr int BUF = kCK * (PLANE + WPAD);
+    constexpr int IN_IT = (kCK * PLANE + DMVS_BLOCK - 1) / DMVS_BLOCK, W_IT = (kCK * WPAD / 4 + DMVS_BLOCK - 1) / DMVS_BLOCK;
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, kq = lane >> 4;
@@ -44,47 +49,36 @@ __global__ void __launch_bounds__(DMVS_BLOCK, (NT == 1 ? 2 : 1)) conv3d_mfma_ker
     const int x0 = tx * TX, y0 = ty * TY, d0 = td * TD;
     const int nbase = blockIdx.y * NW;
     const size_t ivol = (size_t)d.Din * d.Hin * d.Win;
-
-    constexpr int IN_ELEMS = kCK * ID * IH * IW, W_ELEMS = kCK * 27 * NW;
-    constexpr int IN_IT = (IN_ELEMS + DMVS_BLOCK - 1) / DMVS_BLOCK, W_IT = (W_ELEMS + DMVS_BLOCK - 1) / DMVS_BLOCK;
     const float* inb = d.in + (size_t)b * d.cin * ivol;
     const int vol = (int)ivol;
-    float rin[IN_IT], rw[W_IT];
-    // branch-free predicated loads (clamped offset + select) so that a chunk's loads issue back to back
-    auto load_chunk = [&](int c0) {
-#pragma unroll
+
+    // LDS-DMA staging (global_load_lds): halo tile 4 bytes per lane, weight slab 16 bytes per lane
+    auto stage = [&](int c0, float* buf) {
+#pragma unroll 2
         for (int i = 0; i < IN_IT; ++i) {
-            const int e = tid + i * DMVS_BLOCK;
-            const int ci = e / (ID * IH * IW), rem = e - ci * (ID * IH * IW);
-            const int zz = rem / (IH * IW), rem2 = rem - zz * (IH * IW);
-            const int yy = rem2 / IW, xx = rem2 - yy * IW;
-            const int gd = d0 - 1 + zz, gy = y0 - 1 + yy, gx = x0 - 1 + xx;
-            const bool ok = e < IN_ELEMS && c0 + ci < d.cin && gd >= 0 && gd < d.Din && gy >= 0 && gy < d.Hin && gx >= 0 && gx < d.Win;
-            const float v = inb[ok ? (c0 + ci) * vol + (gd * d.Hin + gy) * d.Win + gx : 0];
-            rin[i] = ok ? v : 0.0f;
+            const int e = i * DMVS_BLOCK + tid;
+            if (e < kCK * PLANE) {
+                const int ci = e / PLANE, rem = e - ci * PLANE;
+                const int zz = rem / (IH * IW), rem2 = rem - zz * (IH * IW);
+                const int yy = rem2 / IW, xx = rem2 - yy * IW;
+                const int gd = d0 - 1 + zz, gy = y0 - 1 + yy, gx = x0 - 1 + xx;
+                const bool ok = rem < ID * IH * IW && c0 + ci < d.cin && gd >= 0 && gd < d.Din && gy >= 0 && gy < d.Hin &&
+                                gx >= 0 && gx < d.Win;
+                const float* src = ok ? inb + ((c0 + ci) * vol + (gd * d.Hin + gy) * d.Win + gx) : dmvs_zero16_3d;
+                __builtin_amdgcn_global_load_lds(src, DMVS_LDS(buf + i * DMVS_BLOCK + wave * 64), 4, 0, 0);
+            }
         }
-#pragma unroll
+        float* wbuf = buf + kCK * PLANE;
+#pragma unroll 2
         for (int i = 0; i < W_IT; ++i) {
-            const int e = tid + i * DMVS_BLOCK;
-            const int ci = e / (27 * NW), rem = e - ci * (27 * NW);
-            const int t = rem / NW, n = rem - t * NW;
-            const bool ok = e < W_ELEMS && c0 + ci < d.cin && nbase + n < d.cout_pad;
-            const float w = d.weight[ok ? ((c0 + ci) * 27 + t) * d.cout_pad + nbase + n : 0];
-            rw[i] = ok ? w : 0.0f;
-        }
-    };
-    auto store_chunk = [&]() {
-#pragma unroll
-        for (int i = 0; i < IN_IT; ++i) {
-            const int e = tid + i * DMVS_BLOCK;
-            const int ci = e / (ID * IH * IW), rem = e - ci * (ID * IH * IW);
-            if (e < IN_ELEMS) s_in[ci * PLANE + rem] = rin[i];
-        }
-#pragma unroll
-        for (int i = 0; i < W_IT; ++i) {
-            const int e = tid + i * DMVS_BLOCK;
-            const int ci = e / (27 * NW), rem = e - ci * (27 * NW);
-            if (e < W_ELEMS) s_w[ci * WPAD + rem] = rw[i];
+            const int e4 = i * DMVS_BLOCK + tid;
+            if (e4 < kCK * WPAD / 4) {
+                const int ci = e4 / (WPAD / 4), rem4 = e4 - ci * (WPAD / 4);
+                const int t = rem4 / (NW / 4), n4 = rem4 - t * (NW / 4);
+                const bool ok = rem4 < 27 * NW / 4 && c0 + ci < d.cin && nbase + n4 * 4 < d.cout_pad;
+                const float* src = ok ? d.weight + (((c0 + ci) * 27 + t) * d.cout_pad + nbase + n4 * 4) : dmvs_zero16_3d;
+                __builtin_amdgcn_global_load_lds(src, DMVS_LDS(wbuf + (i * DMVS_BLOCK + wave * 64) * 4), 16, 0, 0);
+            }
         }
     };
 
@@ -94,12 +88,13 @@ __global__ void __launch_bounds__(DMVS_BLOCK, (NT == 1 ? 2 : 1)) conv3d_mfma_ker
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    load_chunk(0);
-    for (int c0 = 0; c0 < d.cin; c0 += kCK) {
-        __syncthreads();
-        store_chunk();
-        __syncthreads();
-        if (c0 + kCK < d.cin) load_chunk(c0 + kCK);     // next chunk in flight during the MFMA sweep
+    stage(0, lds);
+    int cur = 0;
+    for (int c0 = 0; c0 < d.cin; c0 += kCK, cur ^= 1) {
+        const float* s_in = lds + cur * BUF;
+        const float* s_w = s_in + kCK * PLANE;
+        __syncthreads();     // drains this wave's LDS-DMA; chunk c0 complete, other buffer free
+        if (c0 + kCK < d.cin) stage(c0 + kCK, lds + (cur ^ 1) * BUF);
         const int live_c = d.cin - c0 < kCK ? d.cin - c0 : kCK;
         const int nc4 = (live_c + 3) >> 2;
 #pragma unroll 1
@@ -152,6 +147,87 @@ __global__ void __launch_bounds__(DMVS_BLOCK, (NT == 1 ? 2 : 1)) conv3d_mfma_ker
                 d.out[oi] = y;
             }
         }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// cout == 1 (PixelViewWeight's second conv, CostRegNet's prob head, reference :439,:456): a
+// 16-wide MFMA N-tile would be 94 % padding, so this is a direct form.  Workgroup = 32(x) x 8(y)
+// x 4(d) voxels, one lane = 4 consecutive x of one (y, d): per (ci, kd, ky) it reads a 6-float row
+// from the LDS halo tile (3 x ds_read_b64) and slides the 3 x-taps over it -- 12 FMAs per row.
+// The 27*cin weights sit in LDS and are read as wave-wide broadcasts.
+template <int CK1>
+__global__ void __launch_bounds__(DMVS_BLOCK) conv3d_c1_kernel(const dmvs_conv3d_desc d, int tiles_x, int tiles_y, int tiles_d) {
+    constexpr int TX = 32, TY = 8, TD = 4;
+    constexpr int IW = TX + 4, IH = TY + 2, ID = TD + 2;      // row pitch 36: x halo 1 left, 3 right (8-byte aligned rows)
+    constexpr int PLANE = ID * IH * IW;
+    __shared__ __attribute__((aligned(16))) float s_in[CK1 * PLANE];
+    __shared__ float s_w[CK1 * 27];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    int tile = blockIdx.x;
+    const int tx = tile % tiles_x; tile /= tiles_x;
+    const int ty = tile % tiles_y; tile /= tiles_y;
+    const int td = tile % tiles_d;
+    const int b = tile / tiles_d;
+    const int x0 = tx * TX, y0 = ty * TY, d0 = td * TD;
+    const size_t ivol = (size_t)d.Din * d.Hin * d.Win;
+    const float* inb = d.in + (size_t)b * d.cin * ivol;
+    const int vol = (int)ivol;
+    const int lx = (tid & 7) * 4, ly = (tid >> 3) & 7, ld = tid >> 6;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    constexpr int IN_IT = (CK1 * PLANE + DMVS_BLOCK - 1) / DMVS_BLOCK;
+    for (int c0 = 0; c0 < d.cin; c0 += CK1) {
+        __syncthreads();
+#pragma unroll 2
+        for (int i = 0; i < IN_IT; ++i) {
+            const int e = i * DMVS_BLOCK + tid;
+            if (e < CK1 * PLANE) {
+                const int ci = e / PLANE, rem = e - ci * PLANE;
+                const int zz = rem / (IH * IW), rem2 = rem - zz * (IH * IW);
+                const int yy = rem2 / IW, xx = rem2 - yy * IW;
+                const int gd = d0 - 1 + zz, gy = y0 - 1 + yy, gx = x0 - 1 + xx;
+                const bool ok = c0 + ci < d.cin && gd >= 0 && gd < d.Din && gy >= 0 && gy < d.Hin && gx >= 0 && gx < d.Win;
+                const float* src = ok ? inb + ((c0 + ci) * vol + (gd * d.Hin + gy) * d.Win + gx) : dmvs_zero16_3d;
+                __builtin_amdgcn_global_load_lds(src, DMVS_LDS(s_in + i * DMVS_BLOCK + wave * 64), 4, 0, 0);
+            }
+        }
+        if (tid < CK1 * 27) {
+            const int ci = tid / 27, t = tid - ci * 27;
+            s_w[tid] = c0 + ci < d.cin ? d.weight[((c0 + ci) * 27 + t) * d.cout_pad] : 0.0f;
+        }
+        __syncthreads();
+        const int live_c = d.cin - c0 < CK1 ? d.cin - c0 : CK1;
+        for (int ci = 0; ci < live_c; ++ci) {
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const float* row = s_in + ci * PLANE + ((ld + kd) * IH + ly + ky) * IW + lx;
+                    const float2 r01 = *reinterpret_cast<const float2*>(row);
+                    const float2 r23 = *reinterpret_cast<const float2*>(row + 2);
+                    const float2 r45 = *reinterpret_cast<const float2*>(row + 4);
+                    const float in6[6] = {r01.x, r01.y, r23.x, r23.y, r45.x, r45.y};
+                    const float* wr = s_w + ci * 27 + (kd * 3 + ky) * 3;
+                    const float w0 = wr[0], w1 = wr[1], w2 = wr[2];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = fmaf(in6[j], w0, fmaf(in6[j + 1], w1, fmaf(in6[j + 2], w2, acc[j])));
+                }
+            }
+        }
+    }
+    const int od = d0 + ld, oy = y0 + ly;
+    if (od >= d.Dout || oy >= d.Hout) return;
+    const size_t ovol = (size_t)d.Dout * d.Hout * d.Wout;
+    const float sc = d.scale ? d.scale[0] : 1.0f, sh = d.shift ? d.shift[0] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ox = x0 + lx + j;
+        if (ox >= d.Wout) continue;
+        const size_t oi = (size_t)b * ovol + ((size_t)od * d.Hout + oy) * d.Wout + ox;
+        float y = dmvs_act(acc[j] * sc + sh, d.act);
+        if (d.residual) y += d.residual[oi];
+        d.out[oi] = y;
     }
 }
 
@@ -284,6 +360,12 @@ extern "C" int dmvs_conv3d_f32(const dmvs_conv3d_desc* dp, void* stream) {
     if (ed != d.Dout || eh != d.Hout || ew != d.Wout) return DMVS_EINVAL;
     const long total = (long)d.B * d.Dout * d.Hout * d.Wout;
     dim3 grid(dmvs_ceil_div(total, DMVS_BLOCK), d.cout_pad / co);
+    if (d.stride == 1 && d.cout == 1) {
+        const int tiles_x = (d.Wout + 31) / 32, tiles_y = (d.Hout + 7) / 8, tiles_d = (d.Dout + 3) / 4;
+        dim3 g((unsigned)(tiles_x * tiles_y * tiles_d * d.B));
+        hipLaunchKernelGGL((conv3d_c1_kernel<4>), g, block, 0, st, d, tiles_x, tiles_y, tiles_d);
+        return dmvs_launch_status();
+    }
     if (d.stride == 1) {
         const int tiles_x = (d.Wout + 15) / 16, tiles_y = (d.Hout + 3) / 4, tiles_d = (d.Dout + 3) / 4;
         const int ntiles = (d.cout_pad + 15) / 16;
