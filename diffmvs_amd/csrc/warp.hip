@@ -37,24 +37,32 @@ struct Ray {   // p(depth) = rot * (x, y, 1) * depth + trans   (reference :199-2
     }
 };
 
-struct Samp {   // where a hypothesis lands in the source view
-    int x0, y0;       // top-left texel of the 2x2 footprint (far out of range if not finite)
-    float wx, wy;     // fractional parts (0 if not finite -> every tap weight is 0 or hits padding)
+struct Samp {   // where a hypothesis lands in the source view, as broadcast to the pixel's lanes
+    int x0, y0;                  // top-left texel of the 2x2 footprint (0,0 with zero weights if not finite)
+    float w00, w01, w10, w11;    // bilinear tap weights, already zeroed for taps that fall outside (zero padding)
 };
 
-__device__ __forceinline__ Samp project(const Ray& r, float depth) {
+// projection + perspective divide + bilinear weights, done by ONE lane per (pixel, hypothesis)
+__device__ __forceinline__ Samp project(const Ray& r, float depth, int Hs, int Ws) {
     const float px = r.rx * depth + r.tx;
     const float py = r.ry * depth + r.ty;
     float pz = r.rz * depth + r.tz;
     if (pz == 0.0f) pz += 1e-8f;
     const float u = px / pz, v = py / pz;
-    const bool fin = fabsf(u) < 1.0e9f && fabsf(v) < 1.0e9f;   // false for NaN / inf
+    // |u|,|v| < 1e9 is false for NaN / inf; beyond +-2 texels of the image every tap is padding anyway
+    const bool fin = fabsf(u) < 1.0e9f && fabsf(v) < 1.0e9f;
     const float fx = floorf(u), fy = floorf(v);
+    const int x0 = fin ? (int)fx : -4, y0 = fin ? (int)fy : -4;
+    const float wx1 = u - fx, wy1 = v - fy, wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+    const bool xa = x0 >= 0 && x0 < Ws, xb = x0 + 1 >= 0 && x0 + 1 < Ws;
+    const bool ya = y0 >= 0 && y0 < Hs, yb = y0 + 1 >= 0 && y0 + 1 < Hs;
     Samp s;
-    s.x0 = fin ? (int)fx : -0x20000000;
-    s.y0 = fin ? (int)fy : -0x20000000;
-    s.wx = fin ? u - fx : 0.0f;
-    s.wy = fin ? v - fy : 0.0f;
+    s.x0 = x0;
+    s.y0 = y0;
+    s.w00 = (fin && xa && ya) ? wx0 * wy0 : 0.0f;
+    s.w01 = (fin && xb && ya) ? wx1 * wy0 : 0.0f;
+    s.w10 = (fin && xa && yb) ? wx0 * wy1 : 0.0f;
+    s.w11 = (fin && xb && yb) ? wx1 * wy1 : 0.0f;
     return s;
 }
 
@@ -63,8 +71,10 @@ __device__ __forceinline__ Samp bcast(const Samp& s, int src) {
     Samp r;
     r.x0 = __shfl(s.x0, src, LPP);
     r.y0 = __shfl(s.y0, src, LPP);
-    r.wx = __shfl(s.wx, src, LPP);
-    r.wy = __shfl(s.wy, src, LPP);
+    r.w00 = __shfl(s.w00, src, LPP);
+    r.w01 = __shfl(s.w01, src, LPP);
+    r.w10 = __shfl(s.w10, src, LPP);
+    r.w11 = __shfl(s.w11, src, LPP);
     return r;
 }
 
@@ -73,40 +83,40 @@ struct Tex {   // this lane's CPL-channel slice of the 4 taps: [tap][channel]
     float v[4][CPL];
 };
 
-// one lane's slice of a texel: a single 16-byte (CPL=4) or 12-byte (CPL=3) load, always issued
+// one lane's slice of a texel: a single 16-byte (CPL=4) or 12-byte (CPL=3) load.  `base` is the
+// wave-uniform tensor base (SGPR pair), `byte_off` a 32-bit per-lane offset -> saddr + voffset form.
 template <int CPL>
-__device__ __forceinline__ void load_slice(const float* p, bool ok, float (&v)[CPL]) {
+__device__ __forceinline__ void load_slice(const char* base, unsigned byte_off, float (&v)[CPL]) {
     if constexpr (CPL == 4) {
-        const float4 q = *reinterpret_cast<const float4*>(p);
-        v[0] = ok ? q.x : 0.0f; v[1] = ok ? q.y : 0.0f; v[2] = ok ? q.z : 0.0f; v[3] = ok ? q.w : 0.0f;
+        const float4 q = *reinterpret_cast<const float4*>(base + byte_off);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
     } else {
-        const float3 q = *reinterpret_cast<const float3*>(p);
-        v[0] = ok ? q.x : 0.0f; v[1] = ok ? q.y : 0.0f; v[2] = ok ? q.z : 0.0f;
+        const float3 q = *reinterpret_cast<const float3*>(base + byte_off);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z;
     }
 }
 
-// branch-free fetch of the 2x2 footprint; `skip` (same footprint as the predecessor) or an
-// out-of-range tap reads the view's first texel instead and is zeroed / ignored by the caller
+// fetch of the 2x2 footprint: taps are clamped into the image (their weights are already zero when
+// they were outside), so every address is valid and no value needs masking
 template <int CPL>
-__device__ __forceinline__ void fetch4(const float* view, const Samp& s, bool skip, int Hs, int Ws, int C, Tex<CPL>& t) {
-    const bool xa = s.x0 >= 0 && s.x0 < Ws, xb = s.x0 + 1 >= 0 && s.x0 + 1 < Ws;
-    const bool ya = s.y0 >= 0 && s.y0 < Hs, yb = s.y0 + 1 >= 0 && s.y0 + 1 < Hs;
-    const int base = (int)(((unsigned)s.y0 * (unsigned)Ws + (unsigned)s.x0) * (unsigned)C);   // only used when in range
-    const bool k00 = xa && ya && !skip, k01 = xb && ya && !skip, k10 = xa && yb && !skip, k11 = xb && yb && !skip;
-    load_slice<CPL>(view + (k00 ? base : 0), k00, t.v[0]);
-    load_slice<CPL>(view + (k01 ? base + C : 0), k01, t.v[1]);
-    load_slice<CPL>(view + (k10 ? base + Ws * C : 0), k10, t.v[2]);
-    load_slice<CPL>(view + (k11 ? base + Ws * C + C : 0), k11, t.v[3]);
+__device__ __forceinline__ void fetch4(const char* base, unsigned view_off, const Samp& s, int Hs, int Ws, int C,
+                                       Tex<CPL>& t) {
+    const int xa = min(max(s.x0, 0), Ws - 1), xb = min(max(s.x0 + 1, 0), Ws - 1);
+    const int ya = min(max(s.y0, 0), Hs - 1), yb = min(max(s.y0 + 1, 0), Hs - 1);
+    const unsigned ra = view_off + (unsigned)(ya * Ws) * (unsigned)(C * 4), rb = view_off + (unsigned)(yb * Ws) * (unsigned)(C * 4);
+    const unsigned ca = (unsigned)xa * (unsigned)(C * 4), cb = (unsigned)xb * (unsigned)(C * 4);
+    load_slice<CPL>(base, ra + ca, t.v[0]);
+    load_slice<CPL>(base, ra + cb, t.v[1]);
+    load_slice<CPL>(base, rb + ca, t.v[2]);
+    load_slice<CPL>(base, rb + cb, t.v[3]);
 }
 
 template <int CPL>
 __device__ __forceinline__ float bilinear_dot(const Tex<CPL>& t, const Samp& s, const float (&refv)[CPL]) {
-    const float wx1 = s.wx, wy1 = s.wy, wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
-    const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
     float dot = 0.0f;
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
-        const float smp = t.v[0][j] * w00 + t.v[1][j] * w01 + t.v[2][j] * w10 + t.v[3][j] * w11;
+        const float smp = t.v[0][j] * s.w00 + t.v[1][j] * s.w01 + t.v[2][j] * s.w10 + t.v[3][j] * s.w11;
         dot = fmaf(smp, refv[j], dot);
     }
     return dot;
@@ -121,27 +131,26 @@ __device__ __forceinline__ float group_reduce(float v) {
 
 // Evaluate NB hypotheses of one view for this lane's pixel.  own[j] holds the projection of
 // hypothesis (sub + j*LPP) computed by this lane; results (group sums, valid on the group's
-// first lane) go to dots[0..NB).  `cur`/`prev` carry the footprint cache across batches.
+// first lane) go to dots[0..NB).  cur / (px0,py0) carry the footprint cache across batches.
+// A hypothesis whose footprint equals its predecessor's issues no loads at all (exec-masked), so the
+// texture path only sees distinct footprints; all fetches of the batch are in flight together.
 template <int CPL, int LPP, int LPG, int NB, int KPL>
-__device__ __forceinline__ void eval_batch(const float* view, const Samp (&own)[KPL], int Hs, int Ws, int C,
-                                           const float (&refv)[CPL], Tex<CPL>& cur, int& px0, int& py0,
+__device__ __forceinline__ void eval_batch(const char* base, unsigned view_off, const Samp (&own)[KPL], int Hs, int Ws,
+                                           int C, const float (&refv)[CPL], Tex<CPL>& cur, int& px0, int& py0,
                                            float (&dots)[NB]) {
     Samp sp[NB];
-    bool same[NB];
+    bool fresh[NB];
     Tex<CPL> t[NB];
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
         sp[k] = bcast<LPP>(own[k / LPP], k % LPP);
         const int qx = k == 0 ? px0 : sp[k - 1].x0, qy = k == 0 ? py0 : sp[k - 1].y0;
-        same[k] = sp[k].x0 == qx && sp[k].y0 == qy;
-        fetch4<CPL>(view, sp[k], same[k], Hs, Ws, C, t[k]);
+        fresh[k] = sp[k].x0 != qx || sp[k].y0 != qy;
+        if (fresh[k]) fetch4<CPL>(base, view_off, sp[k], Hs, Ws, C, t[k]);
     }
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
-#pragma unroll
-        for (int tap = 0; tap < 4; ++tap)
-#pragma unroll
-            for (int j = 0; j < CPL; ++j) cur.v[tap][j] = same[k] ? cur.v[tap][j] : t[k].v[tap][j];
+        if (fresh[k]) cur = t[k];
         dots[k] = group_reduce<LPG>(bilinear_dot<CPL>(cur, sp[k], refv));
     }
     px0 = sp[NB - 1].x0;
@@ -174,7 +183,8 @@ warp_corr_init_kernel(const float* __restrict__ ref, const float* __restrict__ s
 
     Ray ray;
     ray.init(rt + ((long)b * S + s) * 12, (float)x, (float)y);
-    const float* view = src + ((long)s * B + b) * (long)Hs * Ws * C + sub * CPL;
+    const char* base = reinterpret_cast<const char*>(src);
+    const unsigned view_off = (unsigned)((((long)s * B + b) * (long)Hs * Ws * C + sub * CPL) * 4);
     const float dmin = disp_min[b], dmax = disp_max[b];
     const float dm1 = (float)(D - 1);
     const int g = sub / LPG;
@@ -191,9 +201,9 @@ warp_corr_init_kernel(const float* __restrict__ ref, const float* __restrict__ s
     for (int d0 = 0; d0 < D; d0 += NB) {
         Samp own[1];
         const int dk = d0 + (sub < NB ? sub : 0);
-        own[0] = project(ray, dmvs_disp_to_depth((float)dk / dm1, dmin, dmax));
+        own[0] = project(ray, dmvs_disp_to_depth((float)dk / dm1, dmin, dmax), Hs, Ws);
         float dots[NB];
-        eval_batch<CPL, LPP, LPG, NB, 1>(view, own, Hs, Ws, C, refv, cur, px0, py0, dots);
+        eval_batch<CPL, LPP, LPG, NB, 1>(base, view_off, own, Hs, Ws, C, refv, cur, px0, py0, dots);
         if (writer) {
 #pragma unroll
             for (int k = 0; k < NB; ++k)
@@ -256,10 +266,10 @@ __global__ void __launch_bounds__(DMVS_BLOCK) getcost_kernel(const dmvs_getcost_
         wsum += w;
         Ray ray;
         ray.init(d.rt + ((long)b * d.S + s) * 12, (float)x, (float)y);
-        const float* view = d.src + ((long)s * d.B + b) * hw * C + sub * CPL;
+        const unsigned view_off = (unsigned)((((long)s * d.B + b) * hw * C + sub * CPL) * 4);
         Samp own[KPL];
 #pragma unroll
-        for (int j = 0; j < KPL; ++j) own[j] = project(ray, own_depth[j]);
+        for (int j = 0; j < KPL; ++j) own[j] = project(ray, own_depth[j], H, W);
         Tex<CPL> cur;
 #pragma unroll
         for (int tap = 0; tap < 4; ++tap)
@@ -267,7 +277,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) getcost_kernel(const dmvs_getcost_
             for (int j = 0; j < CPL; ++j) cur.v[tap][j] = 0.0f;
         int px0 = -0x40000000, py0 = -0x40000000;
         float dots[N];
-        eval_batch<CPL, LPP, LPG, N, KPL>(view, own, H, W, C, refv, cur, px0, py0, dots);
+        eval_batch<CPL, LPP, LPG, N, KPL>(reinterpret_cast<const char*>(d.src), view_off, own, H, W, C, refv, cur, px0, py0, dots);
 #pragma unroll
         for (int k = 0; k < N; ++k) acc[k] = fmaf(w, dots[k], acc[k]);
     }
@@ -304,7 +314,7 @@ extern "C" int dmvs_warp_corr_init_f32(const float* ref, const float* src, const
                                        const float* disp_max, float* out, int32_t B, int32_t S, int32_t C, int32_t G,
                                        int32_t D, int32_t H, int32_t W, int32_t Hs, int32_t Ws, void* stream) {
     if (G != 4 || D < 2 || !ref || !src || !rt || !out) return DMVS_EINVAL;
-    if ((long)Hs * Ws * C >= (1L << 31)) return DMVS_EINVAL;   // 32-bit texel offsets inside one view
+    if ((long)S * B * Hs * Ws * C * 4 >= (1L << 32)) return DMVS_EINVAL;   // 32-bit byte offsets over the source stack
     hipStream_t st = (hipStream_t)stream;
     // hypotheses per fetch batch: 8 texel sets in flight per lane (4 for the 4-lane C=16 pixel group)
     if (C == 48) return launch_init<48, 3, 8>(ref, src, rt, disp_min, disp_max, out, B, S, D, H, W, Hs, Ws, st);
@@ -318,7 +328,7 @@ extern "C" int dmvs_getcost_f32(const dmvs_getcost_desc* dp, void* stream) {
     const dmvs_getcost_desc& d = *dp;
     if (d.G != 4 || !d.ref || !d.src || !d.rt || !d.inv_depth || !d.view_w || !d.out_cost || !d.out_samples)
         return DMVS_EINVAL;
-    if ((long)d.H * d.W * d.C >= (1L << 31)) return DMVS_EINVAL;
+    if ((long)d.S * d.B * d.H * d.W * d.C * 4 >= (1L << 32)) return DMVS_EINVAL;   // 32-bit byte offsets over the source stack
     hipStream_t st = (hipStream_t)stream;
     if (d.C == 48) return launch_getcost<48, 3>(d, st);
     if (d.C == 32) return launch_getcost<32, 4>(d, st);

@@ -228,6 +228,9 @@ static inline void __builtin_amdgcn_global_load_lds(const void* g, void* lds_bas
     const int lane = hipemu::linear_tid() & 63;
     memcpy(static_cast<char*>(lds_base) + offset + size_t(lane) * size, g, size);
 }
+// HIP's global integer min / max
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 static inline float __fdividef(float a, float b) { return a / b; }
