@@ -25,6 +25,15 @@
 
 namespace {
 
+// Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, each with a private
+// 4 MiB L2).  Remap so that every XCD walks one contiguous eighth of the pixels: neighbouring pixels
+// sample neighbouring source texels, so the epipolar bands they touch stay resident in that XCD's L2
+// instead of being re-fetched by all eight.  Bijective for any grid size (cdna_hip_programming.md T1).
+__device__ __forceinline__ unsigned xcd_contiguous_block(unsigned bid, unsigned nblk) {
+    const unsigned q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 struct Ray {   // p(depth) = rot * (x, y, 1) * depth + trans   (reference :199-205)
     float rx, ry, rz, tx, ty, tz;
     __device__ __forceinline__ void init(const float* m, float x, float y) {
@@ -66,18 +75,6 @@ __device__ __forceinline__ Samp project(const Ray& r, float depth, int Hs, int W
     return s;
 }
 
-template <int LPP>
-__device__ __forceinline__ Samp bcast(const Samp& s, int src) {
-    Samp r;
-    r.x0 = __shfl(s.x0, src, LPP);
-    r.y0 = __shfl(s.y0, src, LPP);
-    r.w00 = __shfl(s.w00, src, LPP);
-    r.w01 = __shfl(s.w01, src, LPP);
-    r.w10 = __shfl(s.w10, src, LPP);
-    r.w11 = __shfl(s.w11, src, LPP);
-    return r;
-}
-
 template <int CPL>
 struct Tex {   // this lane's CPL-channel slice of the 4 taps: [tap][channel]
     float v[4][CPL];
@@ -99,10 +96,10 @@ __device__ __forceinline__ void load_slice(const char* base, unsigned byte_off, 
 // fetch of the 2x2 footprint: taps are clamped into the image (their weights are already zero when
 // they were outside), so every address is valid and no value needs masking
 template <int CPL>
-__device__ __forceinline__ void fetch4(const char* base, unsigned view_off, const Samp& s, int Hs, int Ws, int C,
+__device__ __forceinline__ void fetch4(const char* base, unsigned view_off, int x0, int y0, int Hs, int Ws, int C,
                                        Tex<CPL>& t) {
-    const int xa = min(max(s.x0, 0), Ws - 1), xb = min(max(s.x0 + 1, 0), Ws - 1);
-    const int ya = min(max(s.y0, 0), Hs - 1), yb = min(max(s.y0 + 1, 0), Hs - 1);
+    const int xa = min(max(x0, 0), Ws - 1), xb = min(max(x0 + 1, 0), Ws - 1);
+    const int ya = min(max(y0, 0), Hs - 1), yb = min(max(y0 + 1, 0), Hs - 1);
     const unsigned ra = view_off + (unsigned)(ya * Ws) * (unsigned)(C * 4), rb = view_off + (unsigned)(yb * Ws) * (unsigned)(C * 4);
     const unsigned ca = (unsigned)xa * (unsigned)(C * 4), cb = (unsigned)xb * (unsigned)(C * 4);
     load_slice<CPL>(base, ra + ca, t.v[0]);
@@ -112,11 +109,12 @@ __device__ __forceinline__ void fetch4(const char* base, unsigned view_off, cons
 }
 
 template <int CPL>
-__device__ __forceinline__ float bilinear_dot(const Tex<CPL>& t, const Samp& s, const float (&refv)[CPL]) {
+__device__ __forceinline__ float bilinear_dot(const Tex<CPL>& t, float w00, float w01, float w10, float w11,
+                                              const float (&refv)[CPL]) {
     float dot = 0.0f;
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
-        const float smp = t.v[0][j] * s.w00 + t.v[1][j] * s.w01 + t.v[2][j] * s.w10 + t.v[3][j] * s.w11;
+        const float smp = t.v[0][j] * w00 + t.v[1][j] * w01 + t.v[2][j] * w10 + t.v[3][j] * w11;
         dot = fmaf(smp, refv[j], dot);
     }
     return dot;
@@ -138,23 +136,29 @@ template <int CPL, int LPP, int LPG, int NB, int KPL>
 __device__ __forceinline__ void eval_batch(const char* base, unsigned view_off, const Samp (&own)[KPL], int Hs, int Ws,
                                            int C, const float (&refv)[CPL], Tex<CPL>& cur, int& px0, int& py0,
                                            float (&dots)[NB]) {
-    Samp sp[NB];
+    int sx[NB], sy[NB];
     bool fresh[NB];
     Tex<CPL> t[NB];
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
-        sp[k] = bcast<LPP>(own[k / LPP], k % LPP);
-        const int qx = k == 0 ? px0 : sp[k - 1].x0, qy = k == 0 ? py0 : sp[k - 1].y0;
-        fresh[k] = sp[k].x0 != qx || sp[k].y0 != qy;
-        if (fresh[k]) fetch4<CPL>(base, view_off, sp[k], Hs, Ws, C, t[k]);
+        sx[k] = __shfl(own[k / LPP].x0, k % LPP, LPP);
+        sy[k] = __shfl(own[k / LPP].y0, k % LPP, LPP);
+        const int qx = k == 0 ? px0 : sx[k - 1], qy = k == 0 ? py0 : sy[k - 1];
+        fresh[k] = sx[k] != qx || sy[k] != qy;
+        if (fresh[k]) fetch4<CPL>(base, view_off, sx[k], sy[k], Hs, Ws, C, t[k]);
     }
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
+        // the tap weights are broadcast only now, while the fetches are in flight: 4 fewer live
+        // registers per hypothesis during the fetch phase
+        const Samp& o = own[k / LPP];
+        const float w00 = __shfl(o.w00, k % LPP, LPP), w01 = __shfl(o.w01, k % LPP, LPP);
+        const float w10 = __shfl(o.w10, k % LPP, LPP), w11 = __shfl(o.w11, k % LPP, LPP);
         if (fresh[k]) cur = t[k];
-        dots[k] = group_reduce<LPG>(bilinear_dot<CPL>(cur, sp[k], refv));
+        dots[k] = group_reduce<LPG>(bilinear_dot<CPL>(cur, w00, w01, w10, w11, refv));
     }
-    px0 = sp[NB - 1].x0;
-    py0 = sp[NB - 1].y0;
+    px0 = sx[NB - 1];
+    py0 = sy[NB - 1];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -168,7 +172,7 @@ warp_corr_init_kernel(const float* __restrict__ ref, const float* __restrict__ s
     static_assert(NB <= LPP, "one projection per lane and batch");
     const int sub = threadIdx.x % LPP, slot = threadIdx.x / LPP;
     const long npix = (long)B * H * W;
-    const long pix = (long)blockIdx.x * PPB + slot;
+    const long pix = (long)xcd_contiguous_block(blockIdx.x, gridDim.x) * PPB + slot;
     const bool live = pix < npix;
     const long pc = live ? pix : npix - 1;
     const int x = (int)(pc % W);
@@ -215,12 +219,12 @@ warp_corr_init_kernel(const float* __restrict__ ref, const float* __restrict__ s
 // ------------------------------------------------------------------------------------------
 // GetCost: hypotheses + S warps + correlation + view-weighted aggregation in one pass.
 template <int C, int CPL, int N>
-__global__ void __launch_bounds__(DMVS_BLOCK) getcost_kernel(const dmvs_getcost_desc d) {
+__global__ void __launch_bounds__(DMVS_BLOCK, 4) getcost_kernel(const dmvs_getcost_desc d) {
     constexpr int G = 4, LPP = C / CPL, LPG = LPP / G, PPB = DMVS_BLOCK / LPP, KPL = (N + LPP - 1) / LPP;
     const int sub = threadIdx.x % LPP, slot = threadIdx.x / LPP;
     const int H = d.H, W = d.W;
     const long npix = (long)d.B * H * W;
-    const long pix = (long)blockIdx.x * PPB + slot;
+    const long pix = (long)xcd_contiguous_block(blockIdx.x, gridDim.x) * PPB + slot;
     const bool live = pix < npix;
     const long pc = live ? pix : npix - 1;
     const int x = (int)(pc % W);
