@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("DMVS_BENCH_BATCH", "8")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("DMVS_BENCH_BATCH", "16")),
                     help="reference views per GPU per step")
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=640)
@@ -76,15 +76,13 @@ def main():
     if a.cpu_baseline_only:
         return cpu_baseline(a)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from diffmvs_amd import shard
+    rank, world, local = shard.env_rank_world()
     dist = world > 1
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if dist:
-        import torch.distributed as td
-        td.init_process_group("nccl", device_id=dev)
+        td = shard.init_distributed("nccl", dev)       # RCCL: rendezvous, barrier and one 8-byte max-reduce only
 
     from models import CasDiffMVS
     args = synth.make_args("diffmvs", numdepth_initial=48)
@@ -115,10 +113,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
     timers, eng.ops.timers = eng.ops.timers, None
-    if dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shard.barrier_and_max(elapsed, dev)      # whole-job time = slowest rank
 
     maps = B * a.steps * world
     value = maps / elapsed

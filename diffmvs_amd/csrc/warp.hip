@@ -132,7 +132,7 @@ __device__ __forceinline__ float group_reduce(float v) {
 // first lane) go to dots[0..NB).  cur / (px0,py0) carry the footprint cache across batches.
 // A hypothesis whose footprint equals its predecessor's issues no loads at all (exec-masked), so the
 // texture path only sees distinct footprints; all fetches of the batch are in flight together.
-template <int CPL, int LPP, int LPG, int NB, int KPL>
+template <int CPL, int LPP, int LPG, int NB, int KPL, int K0 = 0>
 __device__ __forceinline__ void eval_batch(const char* base, unsigned view_off, const Samp (&own)[KPL], int Hs, int Ws,
                                            int C, const float (&refv)[CPL], Tex<CPL>& cur, int& px0, int& py0,
                                            float (&dots)[NB]) {
@@ -141,8 +141,8 @@ __device__ __forceinline__ void eval_batch(const char* base, unsigned view_off, 
     Tex<CPL> t[NB];
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
-        sx[k] = __shfl(own[k / LPP].x0, k % LPP, LPP);
-        sy[k] = __shfl(own[k / LPP].y0, k % LPP, LPP);
+        sx[k] = __shfl(own[(K0 + k) / LPP].x0, (K0 + k) % LPP, LPP);
+        sy[k] = __shfl(own[(K0 + k) / LPP].y0, (K0 + k) % LPP, LPP);
         const int qx = k == 0 ? px0 : sx[k - 1], qy = k == 0 ? py0 : sy[k - 1];
         fresh[k] = sx[k] != qx || sy[k] != qy;
         if (fresh[k]) fetch4<CPL>(base, view_off, sx[k], sy[k], Hs, Ws, C, t[k]);
@@ -151,9 +151,9 @@ __device__ __forceinline__ void eval_batch(const char* base, unsigned view_off, 
     for (int k = 0; k < NB; ++k) {
         // the tap weights are broadcast only now, while the fetches are in flight: 4 fewer live
         // registers per hypothesis during the fetch phase
-        const Samp& o = own[k / LPP];
-        const float w00 = __shfl(o.w00, k % LPP, LPP), w01 = __shfl(o.w01, k % LPP, LPP);
-        const float w10 = __shfl(o.w10, k % LPP, LPP), w11 = __shfl(o.w11, k % LPP, LPP);
+        const Samp& o = own[(K0 + k) / LPP];
+        const float w00 = __shfl(o.w00, (K0 + k) % LPP, LPP), w01 = __shfl(o.w01, (K0 + k) % LPP, LPP);
+        const float w10 = __shfl(o.w10, (K0 + k) % LPP, LPP), w11 = __shfl(o.w11, (K0 + k) % LPP, LPP);
         if (fresh[k]) cur = t[k];
         dots[k] = group_reduce<LPG>(bilinear_dot<CPL>(cur, w00, w01, w10, w11, refv));
     }
@@ -219,7 +219,7 @@ warp_corr_init_kernel(const float* __restrict__ ref, const float* __restrict__ s
 // ------------------------------------------------------------------------------------------
 // GetCost: hypotheses + S warps + correlation + view-weighted aggregation in one pass.
 template <int C, int CPL, int N>
-__global__ void __launch_bounds__(DMVS_BLOCK, 4) getcost_kernel(const dmvs_getcost_desc d) {
+__global__ void __launch_bounds__(DMVS_BLOCK) getcost_kernel(const dmvs_getcost_desc d) {
     constexpr int G = 4, LPP = C / CPL, LPG = LPP / G, PPB = DMVS_BLOCK / LPP, KPL = (N + LPP - 1) / LPP;
     const int sub = threadIdx.x % LPP, slot = threadIdx.x / LPP;
     const int H = d.H, W = d.W;
@@ -280,10 +280,15 @@ __global__ void __launch_bounds__(DMVS_BLOCK, 4) getcost_kernel(const dmvs_getco
 #pragma unroll
             for (int j = 0; j < CPL; ++j) cur.v[tap][j] = 0.0f;
         int px0 = -0x40000000, py0 = -0x40000000;
-        float dots[N];
-        eval_batch<CPL, LPP, LPG, N, KPL>(reinterpret_cast<const char*>(d.src), view_off, own, H, W, C, refv, cur, px0, py0, dots);
+        // two fetch batches of N/2 hypotheses: half the texel registers in flight -> one more wave per SIMD
+        constexpr int NH = N / 2;
+        float dots[NH];
+        eval_batch<CPL, LPP, LPG, NH, KPL, 0>(reinterpret_cast<const char*>(d.src), view_off, own, H, W, C, refv, cur, px0, py0, dots);
 #pragma unroll
-        for (int k = 0; k < N; ++k) acc[k] = fmaf(w, dots[k], acc[k]);
+        for (int k = 0; k < NH; ++k) acc[k] = fmaf(w, dots[k], acc[k]);
+        eval_batch<CPL, LPP, LPG, NH, KPL, NH>(reinterpret_cast<const char*>(d.src), view_off, own, H, W, C, refv, cur, px0, py0, dots);
+#pragma unroll
+        for (int k = 0; k < NH; ++k) acc[NH + k] = fmaf(w, dots[k], acc[NH + k]);
     }
     if (live && (sub % LPG) == 0) {
         const int g = sub / LPG;
