@@ -25,11 +25,11 @@ _F = C.c_float
 class Conv2dDesc(C.Structure):
     _fields_ = [
         ("in0", _P), ("in1", _P), ("mul0", _P), ("weight", _P), ("scale", _P), ("shift", _P),
-        ("residual", _P), ("gru_z", _P), ("gru_h", _P), ("out", _P),
+        ("residual", _P), ("gru_z", _P), ("gru_h", _P), ("out", _P), ("gn_stats", _P),
         ("B", _I), ("c0", _I), ("c1", _I), ("Hin", _I), ("Win", _I), ("Hout", _I), ("Wout", _I),
         ("cout", _I), ("cout_pad", _I), ("kh", _I), ("kw", _I), ("stride", _I), ("pad_h", _I), ("pad_w", _I),
         ("in_mode", _I), ("act", _I), ("res_mode", _I), ("res_after_act", _I),
-        ("out_layout", _I), ("out_cstride", _I), ("out_coffset", _I), ("post_scale", _F),
+        ("out_layout", _I), ("out_cstride", _I), ("out_coffset", _I), ("gn_groups", _I), ("post_scale", _F),
     ]
 
 
@@ -66,6 +66,7 @@ SIGNATURES = {
     "dmvs_depth_regress_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "dmvs_convex_upsample_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dmvs_groupnorm_silu_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "dmvs_groupnorm_apply_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "dmvs_delta_update_f32": [_P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _P],
     "dmvs_depth_convert_f32": [_P, _P, _P, _P, _I, _I, _I, _P],
     "dmvs_act_slice_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],

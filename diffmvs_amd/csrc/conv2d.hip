@@ -192,6 +192,9 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_mfma_kernel(const dmvs_conv
             sc[nt][r] = d.scale ? d.scale[okc ? cg : 0] : 1.0f;
             sh[nt][r] = d.shift ? d.shift[okc ? cg : 0] : 0.0f;
         }
+    // GroupNorm statistics of the pre-activation output (4 groups), reduced lane -> wave -> workgroup
+    float gs[4] = {0.0f, 0.0f, 0.0f, 0.0f}, gq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int gn_cg = d.gn_stats ? d.cout / d.gn_groups : 1;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int oy = oy0 + wave * MT + mt;
@@ -203,6 +206,21 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_mfma_kernel(const dmvs_conv
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) y[nt][r] = acc[mt][nt][r] * sc[nt][r] + sh[nt][r];
+        if (d.gn_stats) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int cg = nbase + nt * 16 + kq * 4 + r;
+                    const float v = (okp && cg < d.cout) ? y[nt][r] : 0.0f;
+                    const int g = cg / gn_cg;
+#pragma unroll
+                    for (int gi = 0; gi < 4; ++gi) {
+                        gs[gi] += g == gi ? v : 0.0f;
+                        gq[gi] += g == gi ? v * v : 0.0f;
+                    }
+                }
+        }
         float res[NT][4];
         if (d.residual) {
 #pragma unroll
@@ -266,6 +284,30 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_mfma_kernel(const dmvs_conv
                 }
         }
     }
+    if (d.gn_stats) {
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                gs[gi] += __shfl_down(gs[gi], o, 64);
+                gq[gi] += __shfl_down(gq[gi], o, 64);
+            }
+        }
+        __syncthreads();                  // every wave is done with the LDS tiles: reuse them as scratch
+        if (lane == 0) {
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) {
+                lds[wave * 8 + gi] = gs[gi];
+                lds[wave * 8 + 4 + gi] = gq[gi];
+            }
+        }
+        __syncthreads();
+        if (tid < 8) {
+            const float tot = lds[tid] + lds[8 + tid] + lds[16 + tid] + lds[24 + tid];
+            const int gi = tid & 3, which = tid >> 2;
+            if (tot != 0.0f) atomicAdd(&d.gn_stats[((size_t)b * 4 + gi) * 2 + which], (double)tot);
+        }
+    }
 }
 
 template <int KH, int KW, int S, int MT>
@@ -310,6 +352,7 @@ extern "C" int dmvs_conv2d_f32(const dmvs_conv2d_desc* dp, void* stream) {
     if (d.in_mode == DMVS_IN_UNSHUFFLE2 && (d.c0 % 4)) return DMVS_EINVAL;
     if (d.in_mode == DMVS_IN_UPSAMPLE2 && ((d.Hin | d.Win) & 1)) return DMVS_EINVAL;
     if (d.gru_z && (!d.gru_h || d.act != DMVS_ACT_TANH)) return DMVS_EINVAL;
+    if (d.gn_stats && (d.gn_groups != 4 || d.cout % 4)) return DMVS_EINVAL;
     const int eh = (d.Hin + 2 * d.pad_h - d.kh) / d.stride + 1, ew = (d.Win + 2 * d.pad_w - d.kw) / d.stride + 1;
     if (eh != d.Hout || ew != d.Wout) return DMVS_EINVAL;
     // 32-bit element offsets inside one batch item

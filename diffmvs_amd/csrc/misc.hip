@@ -277,6 +277,16 @@ extern "C" int dmvs_groupnorm_silu_f32(const float* x, const float* gamma, const
     return dmvs_launch_status();
 }
 
+extern "C" int dmvs_groupnorm_apply_f32(const float* x, const float* gamma, const float* beta, const float* scale_shift,
+                                        const float* residual, float* y, const double* stats, int32_t B, int32_t C,
+                                        int32_t HW, int32_t groups, float eps, void* stream) {
+    if (!x || !y || !stats || groups <= 0 || C % groups) return DMVS_EINVAL;
+    unsigned gx = dmvs_ceil_div(HW, DMVS_BLOCK * 4);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(gx, B * C), dim3(DMVS_BLOCK), 0, (hipStream_t)stream, x, gamma, beta,
+                       scale_shift, residual, y, stats, C, HW, groups, eps);
+    return dmvs_launch_status();
+}
+
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(DMVS_BLOCK)
 delta_update_kernel(const float* __restrict__ inv, const float* __restrict__ delta_in, const float* __restrict__ update,

@@ -123,8 +123,12 @@ class _UpdateBlock:
 
 
 class Engine:
+    _GN_SLOTS = 256
+
     def __init__(self, sd: Dict[str, torch.Tensor], args, ops: Ops):
         self.ops = ops
+        self._ss_cache = {}
+        self._gn_arena = None
         self.args = args
         dev = ops.device
         sd = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sd.items()}
@@ -220,21 +224,45 @@ class Engine:
             taps[3 - li] = x          # layer1 -> stage3 (index 2), layer2 -> stage2, layer3 -> stage1
         return taps
 
+    # GroupNorm statistics come out of the producing conv's epilogue; the per-forward arena of
+    # [slot][B*4*2] doubles is zeroed with a single memset at the start of forward()
+    def _gn_reset(self, B):
+        need = (self._GN_SLOTS, B * 8)
+        if getattr(self, "_gn_arena", None) is None or tuple(self._gn_arena.shape) != need:
+            self._gn_arena = torch.zeros(*need, dtype=torch.float64, device=self.ops.device)
+        else:
+            self._gn_arena.zero_()
+        self._gn_next = 0
+
+    def _gn_slot(self):
+        if self._gn_next >= self._GN_SLOTS:
+            raise RuntimeError("GroupNorm statistics arena exhausted")
+        s = self._gn_arena[self._gn_next]
+        self._gn_next += 1
+        return s
+
+    def _scale_shift(self, rb, ss, B):
+        if ss is None or rb["p"] not in ss:
+            return None
+        key = (id(ss), rb["p"], B)
+        cache = self._ss_cache
+        if key not in cache:
+            cache[key] = ss[rb["p"]].expand(B, -1).contiguous()
+        return cache[key]
+
     def _resblock(self, rb, x0, x1, ss, B):
         """ResnetBlock (update.py:147-159): two WS-conv/GroupNorm/SiLU blocks + residual."""
         o = self.ops
-        scale_shift = None
-        if ss is not None and rb["p"] in ss:
-            scale_shift = ss[rb["p"]].expand(B, -1).contiguous()
-        h = o.conv2d(rb["c1"], x0, x1)
-        h = o.groupnorm_silu(h, rb["g1"][0], rb["g1"][1], 4, scale_shift=scale_shift, out=h)
-        h2 = o.conv2d(rb["c2"], h)
+        st1, st2 = self._gn_slot(), self._gn_slot()
+        h = o.conv2d(rb["c1"], x0, x1, gn_stats=st1)
+        h = o.groupnorm_apply(h, rb["g1"][0], rb["g1"][1], 4, st1, scale_shift=self._scale_shift(rb, ss, B), out=h)
+        h2 = o.conv2d(rb["c2"], h, gn_stats=st2)
         if rb["res"] is not None:
             res = o.conv2d(rb["res"], x0, x1)
         else:
             assert x1 is None
             res = x0
-        return o.groupnorm_silu(h2, rb["g2"][0], rb["g2"][1], 4, residual=res, out=h2)
+        return o.groupnorm_apply(h2, rb["g2"][0], rb["g2"][1], 4, st2, residual=res, out=h2)
 
     def unet(self, ub: _UpdateBlock, X, hidden, ss):
         """Unet.forward (update.py:245-274).  X [B,2cd,H,W], hidden [B,hd,h,w]."""
@@ -341,6 +369,7 @@ class Engine:
             noise_fn = lambda shape, device: torch.randn(shape, device=device)  # noqa: E731
         V = len(imgs)
         B = imgs[0].shape[0]
+        self._gn_reset(B)
         dv = depth_values.to(o.device).float()
         depth_max_, depth_min_ = 1.0 / dv[:, 0], 1.0 / dv[:, -1]
         disp_min, disp_max = (1.0 / depth_max_).contiguous(), (1.0 / depth_min_).contiguous()   # module.py:222-223

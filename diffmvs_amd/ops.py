@@ -146,8 +146,12 @@ class Ops:
     # ------------------------------------------------------------------ conv2d
     def conv2d(self, pc: PackedConv, x0, x1=None, *, mul0=None, in_mode=IN_PLAIN, act=ACT_NONE, residual=None,
                res_mode=IN_PLAIN, res_after_act=False, post_scale=1.0, gru_z=None, gru_h=None, out=None,
-               out_layout=LAYOUT_NCHW, out_cstride=None, out_coffset=0):
+               out_layout=LAYOUT_NCHW, out_cstride=None, out_coffset=0, gn_stats=None, gn_groups=4):
+        """gn_stats: zeroed float64 [B*gn_groups*2] tensor that receives the GroupNorm statistics of
+        the (pre-activation) output, for a following groupnorm_apply()."""
         self._chk(x0, x1, mul0, residual, gru_z, gru_h, out)
+        if gn_stats is not None and (gn_stats.dtype != torch.float64 or gn_stats.numel() < x0.shape[0] * gn_groups * 2):
+            raise _lib.DmvsError("gn_stats must be float64 with B*groups*2 elements")
         B = x0.shape[0]
         if in_mode == IN_PLAIN:
             c0, Hin, Win = x0.shape[1], x0.shape[2], x0.shape[3]
@@ -168,7 +172,7 @@ class Ops:
         d = _lib.Conv2dDesc(
             in0=_ptr(x0), in1=_ptr(x1), mul0=_ptr(mul0), weight=_ptr(pc.weight), scale=_ptr(pc.scale),
             shift=_ptr(pc.shift), residual=_ptr(residual), gru_z=_ptr(gru_z), gru_h=_ptr(gru_h), out=_ptr(out),
-            B=B, c0=c0, c1=c1, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, cout=pc.cout, cout_pad=pc.cout_pad,
+            gn_stats=_ptr(gn_stats), gn_groups=(gn_groups if gn_stats is not None else 0), B=B, c0=c0, c1=c1, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, cout=pc.cout, cout_pad=pc.cout_pad,
             kh=kh, kw=kw, stride=pc.stride, pad_h=pc.pad[0], pad_w=pc.pad[1], in_mode=in_mode, act=act,
             res_mode=res_mode, res_after_act=int(res_after_act), out_layout=out_layout, out_cstride=out_cstride,
             out_coffset=out_coffset, post_scale=post_scale)
@@ -278,6 +282,16 @@ class Ops:
         stats = torch.empty(B * groups * 2, dtype=torch.float64, device=self.device)
         self._call("dmvs_groupnorm_silu_f32", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(scale_shift), _ptr(residual),
                       _ptr(out), _ptr(stats), B, Cc, H * W, groups, eps, self.stream())
+        return out
+
+    def groupnorm_apply(self, x, gamma, beta, groups, stats, scale_shift=None, residual=None, out=None, eps=1e-5):
+        """normalise + scale/shift + SiLU (+ residual) with statistics accumulated by conv2d(gn_stats=...)."""
+        self._chk(x, gamma, beta, scale_shift, residual, out)
+        B, Cc, H, W = x.shape
+        if out is None:
+            out = self.empty(B, Cc, H, W)
+        self._call("dmvs_groupnorm_apply_f32", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(scale_shift), _ptr(residual),
+                   _ptr(out), _ptr(stats), B, Cc, H * W, groups, eps, self.stream())
         return out
 
     def delta_update(self, inv, delta_in, update, delta_in_scale=1.0, new2=None, new2_cstride=0, new2_coffset=0):

@@ -67,6 +67,10 @@ typedef struct dmvs_conv2d_desc {
     const float* gru_z;     /* [B,cout,Hout,Wout] or NULL                                   */
     const float* gru_h;
     float* out;
+    double* gn_stats;       /* [B,gn_groups,2] or NULL: += per-(b,group) sum and sum of squares of y
+                               BEFORE the activation (GroupNorm statistics of the conv output, so
+                               that Block.forward needs no separate reduction pass; the caller
+                               zeroes the buffer).  gn_groups must be 4 and divide cout.       */
     int32_t B, c0, c1;
     int32_t Hin, Win;       /* LOGICAL input size (after in_mode)                           */
     int32_t Hout, Wout;
@@ -76,6 +80,7 @@ typedef struct dmvs_conv2d_desc {
     int32_t res_mode;       /* DMVS_IN_PLAIN or DMVS_IN_UPSAMPLE2                           */
     int32_t res_after_act;
     int32_t out_layout, out_cstride, out_coffset;
+    int32_t gn_groups;
     float post_scale;
 } dmvs_conv2d_desc;
 
@@ -193,6 +198,12 @@ int dmvs_groupnorm_silu_f32(const float* x, const float* gamma, const float* bet
                             const float* scale_shift, const float* residual, float* y,
                             double* stats, int32_t B, int32_t C, int32_t HW, int32_t groups,
                             float eps, void* stream);
+
+/* The apply half alone, for statistics that were accumulated by dmvs_conv2d_f32 (gn_stats). */
+int dmvs_groupnorm_apply_f32(const float* x, const float* gamma, const float* beta,
+                             const float* scale_shift, const float* residual, float* y,
+                             const double* stats, int32_t B, int32_t C, int32_t HW, int32_t groups,
+                             float eps, void* stream);
 
 /* Refinement bookkeeping (models/update.py:479-483, :496-502):
  *   new = clamp(inv + delta_in (+ update), 0, 1);  delta_out = new - inv

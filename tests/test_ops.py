@@ -308,3 +308,26 @@ def test_groupnorm_silu(ops, C, HW):
     want = F.silu(y * (ss[:, :C, None, None] + 1) + ss[:, C:, None, None]) + res
     close(ops.groupnorm_silu(*dev(ops, x, gamma, beta), 4, scale_shift=dev(ops, ss), residual=dev(ops, res)), want, 2e-5)
     close(ops.groupnorm_silu(*dev(ops, x, gamma, beta), 4), F.silu(y), 2e-5)
+
+
+@pytest.mark.parametrize("cin,cout,HW", [(16, 16, (21, 37)), (48, 32, (16, 16)), (8, 8, (9, 50))])
+def test_conv_fused_groupnorm_stats(ops, cin, cout, HW):
+    """WS-conv -> GroupNorm(4) -> scale/shift -> SiLU with the statistics taken in the conv epilogue
+    (reference models/update.py:124-133)."""
+    B = 2
+    x = rnd(B, cin, *HW, seed=1)
+    w, bias = rnd(cout, cin, 3, 3, seed=2) * 0.3, rnd(cout, seed=3)
+    gamma, beta, ss = rnd(cout, seed=4, lo=0.5, hi=1.5), rnd(cout, seed=5), rnd(B, 2 * cout, seed=6)
+    y = F.conv2d(x, w, bias, 1, 1)
+    want = F.silu(F.group_norm(y, 4, gamma, beta, 1e-5) * (ss[:, :cout, None, None] + 1) + ss[:, cout:, None, None])
+    stats = torch.zeros(B * 8, dtype=torch.float64, device=ops.device)
+    pc = K.pack_conv2d(*dev(ops, w, bias), pad=1)
+    h = ops.conv2d(pc, dev(ops, x), gn_stats=stats)
+    close(h, y, 2e-5)
+    n = (cout // 4) * HW[0] * HW[1]
+    st = stats.cpu().view(B, 4, 2)
+    yg = y.view(B, 4, -1).double()
+    assert torch.allclose(st[..., 0] / n, yg.mean(-1), atol=1e-5)
+    assert torch.allclose(st[..., 1] / n, (yg * yg).mean(-1), rtol=1e-5, atol=1e-6)
+    out = ops.groupnorm_apply(h, *dev(ops, gamma, beta), 4, stats, scale_shift=dev(ops, ss), out=h)
+    close(out, want, 3e-5)
