@@ -60,6 +60,7 @@ SIGNATURES = {
     "dmvs_conv3d_f32": [C.POINTER(Conv3dDesc), _P],
     "dmvs_compose_proj_f32": [_P, _P, _I, _I, _P],
     "dmvs_warp_corr_init_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "dmvs_warp_volume_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dmvs_getcost_f32": [C.POINTER(GetCostDesc), _P],
     "dmvs_view_aggregate_f32": [_P, _P, _P, _I, _I, _I, _I, _P],
     "dmvs_sigmoid_max_d_f32": [_P, _P, _I, _I, _I, _P],

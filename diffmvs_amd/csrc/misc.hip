@@ -380,3 +380,53 @@ extern "C" int dmvs_nchw_to_nhwc_f32(const float* in, float* out, int32_t B, int
                        (hipStream_t)stream, in, out, B, C, HW);
     return dmvs_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------
+// Stand-alone differentiable_warping (reference models/module.py:181-218) with the reference's own
+// tensor layouts: src [B,C,Hs,Ws] NCHW, depth [B,D,H,W] metric, out [B,C,D,H,W].  The model never
+// calls this (its fused kernels do not materialise the warped volume); it backs the function of the
+// same name in the drop-in package and pins the warp semantics on the reference's edge cases.
+__global__ void __launch_bounds__(DMVS_BLOCK)
+warp_volume_kernel(const float* __restrict__ src, const float* __restrict__ rt, const float* __restrict__ depth,
+                   float* __restrict__ out, int B, int C, int D, int H, int W, int Hs, int Ws) {
+    const long i = (long)blockIdx.x * DMVS_BLOCK + threadIdx.x;
+    const long hw = (long)H * W;
+    if (i >= (long)B * D * hw) return;
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const int d = (int)((i / hw) % D), b = (int)(i / (hw * D));
+    const float* m = rt + (long)b * 12;
+    const float dep = depth[i];
+    const float fx = (float)x, fy = (float)y;
+    const float px = (m[0] * fx + m[1] * fy + m[2]) * dep + m[9];
+    const float py = (m[3] * fx + m[4] * fy + m[5]) * dep + m[10];
+    float pz = (m[6] * fx + m[7] * fy + m[8]) * dep + m[11];
+    if (pz == 0.0f) pz += 1e-8f;
+    const float u = px / pz, v = py / pz;
+    const bool fin = fabsf(u) < 1.0e9f && fabsf(v) < 1.0e9f;
+    const float flx = floorf(u), fly = floorf(v);
+    const int x0 = fin ? (int)flx : -4, y0 = fin ? (int)fly : -4;
+    const float wx1 = u - flx, wy1 = v - fly, wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+    const bool xa = x0 >= 0 && x0 < Ws, xb = x0 + 1 >= 0 && x0 + 1 < Ws;
+    const bool ya = y0 >= 0 && y0 < Hs, yb = y0 + 1 >= 0 && y0 + 1 < Hs;
+    const float w00 = (fin && xa && ya) ? wx0 * wy0 : 0.0f, w01 = (fin && xb && ya) ? wx1 * wy0 : 0.0f;
+    const float w10 = (fin && xa && yb) ? wx0 * wy1 : 0.0f, w11 = (fin && xb && yb) ? wx1 * wy1 : 0.0f;
+    const int cxa = min(max(x0, 0), Ws - 1), cxb = min(max(x0 + 1, 0), Ws - 1);
+    const int cya = min(max(y0, 0), Hs - 1), cyb = min(max(y0 + 1, 0), Hs - 1);
+    const long shw = (long)Hs * Ws;
+    const float* sp = src + (long)b * C * shw;
+    float* op = out + ((long)b * C * D + d) * hw + (long)y * W + x;
+    for (int c = 0; c < C; ++c) {
+        const float* pl = sp + c * shw;
+        const float val = pl[(long)cya * Ws + cxa] * w00 + pl[(long)cya * Ws + cxb] * w01 + pl[(long)cyb * Ws + cxa] * w10 +
+                          pl[(long)cyb * Ws + cxb] * w11;
+        op[(long)c * D * hw] = val;
+    }
+}
+
+extern "C" int dmvs_warp_volume_f32(const float* src, const float* rt, const float* depth, float* out, int32_t B,
+                                    int32_t C, int32_t D, int32_t H, int32_t W, int32_t Hs, int32_t Ws, void* stream) {
+    if (!src || !rt || !depth || !out) return DMVS_EINVAL;
+    hipLaunchKernelGGL(warp_volume_kernel, dim3(dmvs_ceil_div((long)B * D * H * W, DMVS_BLOCK)), dim3(DMVS_BLOCK), 0,
+                       (hipStream_t)stream, src, rt, depth, out, B, C, D, H, W, Hs, Ws);
+    return dmvs_launch_status();
+}

@@ -30,6 +30,205 @@ def _bn(sd, p):
     return {k: sd[f"{p}.{k}"] for k in ("weight", "bias", "running_mean", "running_var")}
 
 
+def _cw(sd, p, **kw):
+    """module.Conv2d / ConvBnReLU / ConvBn wrapper -> packed conv with eval-BN folded (module.py:24-58, :279-301)."""
+    return pack_conv2d(sd[p + ".conv.weight"], sd.get(p + ".conv.bias"),
+                       bn=_bn(sd, p + ".bn") if (p + ".bn.weight") in sd else None, **kw)
+
+
+def pack_feature(sd, p="feature"):
+    """FeatureNet weights (models/module.py:357-420)."""
+    f = {"conv0.0": _cw(sd, p + ".conv0.0", pad=1), "conv0.1": _cw(sd, p + ".conv0.1", pad=1)}
+    for i in (1, 2, 3):
+        f[f"conv{i}.0"] = _cw(sd, f"{p}.conv{i}.0", stride=2, pad=2)
+        f[f"conv{i}.1"], f[f"conv{i}.2"] = _cw(sd, f"{p}.conv{i}.1", pad=1), _cw(sd, f"{p}.conv{i}.2", pad=1)
+    f["out1"] = pack_conv2d(sd[p + ".out1.weight"])
+    f["inner1"] = pack_conv2d(sd[p + ".inner1.weight"], sd[p + ".inner1.bias"])
+    f["out2"] = pack_conv2d(sd[p + ".out2.weight"], pad=1)
+    if (p + ".out3.weight") in sd:
+        f["inner2"] = pack_conv2d(sd[p + ".inner2.weight"], sd[p + ".inner2.bias"])
+        f["out3"] = pack_conv2d(sd[p + ".out3.weight"], pad=1)
+    return f
+
+
+def run_feature(o: Ops, f, x, layout=K.LAYOUT_NHWC):
+    """x [N,3,H,W] -> {'stage1': [N,H/8,W/8,48], 'stage2': [N,H/4,W/4,32], ('stage3': [N,H/2,W/2,16])} (NHWC by
+    default: the layout the warp kernels read)."""
+    R = K.ACT_RELU
+    c0 = o.conv2d(f["conv0.1"], o.conv2d(f["conv0.0"], x, act=R), act=R)
+    c1 = o.conv2d(f["conv1.2"], o.conv2d(f["conv1.1"], o.conv2d(f["conv1.0"], c0, act=R), act=R), act=R)
+    c2 = o.conv2d(f["conv2.2"], o.conv2d(f["conv2.1"], o.conv2d(f["conv2.0"], c1, act=R), act=R), act=R)
+    c3 = o.conv2d(f["conv3.2"], o.conv2d(f["conv3.1"], o.conv2d(f["conv3.0"], c2, act=R), act=R), act=R)
+    out = {"stage1": o.conv2d(f["out1"], c3, out_layout=layout)}
+    intra = o.conv2d(f["inner1"], c2, residual=c3, res_mode=K.IN_UPSAMPLE2)
+    out["stage2"] = o.conv2d(f["out2"], intra, out_layout=layout)
+    if "out3" in f:
+        intra = o.conv2d(f["inner2"], c1, residual=intra, res_mode=K.IN_UPSAMPLE2)
+        out["stage3"] = o.conv2d(f["out3"], intra, out_layout=layout)
+    return out
+
+
+def pack_context_trunk(sd, p="context"):
+    """ContextNet body (models/module.py:321-343)."""
+    c = {"conv1": _cw(sd, p + ".conv1", pad=1)}
+    for li in (1, 2, 3):
+        for bi in (0, 1):
+            q = f"{p}.layer{li}.{bi}"
+            c[f"{li}.{bi}.conv1"] = _cw(sd, q + ".conv1", stride=(2 if bi == 0 else 1), pad=1)
+            c[f"{li}.{bi}.conv2"] = _cw(sd, q + ".conv2", pad=1)
+            if bi == 0:
+                c[f"{li}.{bi}.down"] = _cw(sd, q + ".downsample", stride=2, pad=1)
+    return c
+
+
+def run_context_trunk(o: Ops, c, x):
+    """-> {0: 1/8-resolution map (48 ch), 1: 1/4 (32 ch), 2: 1/2 (16 ch)}: the inputs of output1/2/3."""
+    R = K.ACT_RELU
+    x = o.conv2d(c["conv1"], x, act=R)
+    taps = {}
+    for li in (1, 2, 3):
+        y = o.conv2d(c[f"{li}.0.conv1"], x, act=R)
+        xd = o.conv2d(c[f"{li}.0.down"], x)
+        x = o.conv2d(c[f"{li}.0.conv2"], y, residual=xd, act=R)       # relu(x + y), module.py:315-319
+        y = o.conv2d(c[f"{li}.1.conv1"], x, act=R)
+        x = o.conv2d(c[f"{li}.1.conv2"], y, residual=x, act=R)
+        taps[3 - li] = x
+    return taps
+
+
+def pack_pvw(sd, p):
+    """PixelViewWeight (models/module.py:450-463)."""
+    return (pack_conv3d(sd[p + ".conv.0.conv.weight"], bn=_bn(sd, p + ".conv.0.bn")),
+            pack_conv3d(sd[p + ".conv.1.weight"], sd[p + ".conv.1.bias"]))
+
+
+def run_pvw(o: Ops, pk, cor):
+    """cor [N,G,D,H,W] -> [N,H,W] = max_d sigmoid(conv1(relu(bn(conv0))))."""
+    N, _, D, H, W = cor.shape
+    x = o.conv3d(pk[1], o.conv3d(pk[0], cor, act=K.ACT_RELU))
+    return o.sigmoid_max_d(x.view(N, D, H, W))
+
+
+def pack_costreg(sd, p):
+    """CostRegNet_small (models/module.py:422-448)."""
+    reg = {}
+    for i, st in ((0, 1), (1, 1), (2, 2), (3, 1), (4, 2), (5, 1)):
+        reg[i] = pack_conv3d(sd[f"{p}.conv{i}.conv.weight"], bn=_bn(sd, f"{p}.conv{i}.bn"), stride=st)
+    for i in (6, 7):
+        reg[i] = pack_conv3d(sd[f"{p}.conv{i}.conv.weight"], bn=_bn(sd, f"{p}.conv{i}.bn"), stride=2, transposed=True)
+    reg["prob"] = pack_conv3d(sd[p + ".prob.weight"])
+    return reg
+
+
+def run_costreg(o: Ops, reg, x):
+    R = K.ACT_RELU
+    c1 = o.conv3d(reg[1], o.conv3d(reg[0], x, act=R), act=R)
+    c3 = o.conv3d(reg[3], o.conv3d(reg[2], c1, act=R), act=R)
+    x = o.conv3d(reg[5], o.conv3d(reg[4], c3, act=R), act=R)
+    x = o.conv3d(reg[6], x, act=R, residual=c3)
+    x = o.conv3d(reg[7], x, act=R, residual=c1)
+    return o.conv3d(reg["prob"], x)
+
+
+def pack_mask(sd, p):
+    """mask head: Conv3x3 -> ReLU -> Conv1x1 (module.py:481-485, update.py:335-339)."""
+    return (pack_conv2d(sd[p + ".0.weight"], sd[p + ".0.bias"], pad=1), pack_conv2d(sd[p + ".2.weight"], sd[p + ".2.bias"]))
+
+
+def run_mask(o: Ops, pk, context, post_scale=0.25):
+    return o.conv2d(pk[1], o.conv2d(pk[0], context, act=K.ACT_RELU), post_scale=post_scale)
+
+
+def pack_gru(sd, p):
+    """SepConvGRU (models/module.py:152-179)."""
+    g = {}
+    for n, pad in (("1", (0, 2)), ("2", (2, 0))):
+        for gate in "zrq":
+            g[gate + n] = pack_conv2d(sd[f"{p}.conv{gate}{n}.weight"], sd[f"{p}.conv{gate}{n}.bias"], pad=pad)
+    return g
+
+
+def run_gru(o: Ops, g, h, x):
+    for n in ("1", "2"):     # horizontal then vertical pass (module.py:164-177)
+        z = o.conv2d(g["z" + n], h, x, act=K.ACT_SIGMOID)
+        r = o.conv2d(g["r" + n], h, x, act=K.ACT_SIGMOID)
+        h = o.conv2d(g["q" + n], h, x, mul0=r, act=K.ACT_TANH, gru_z=z, gru_h=h)
+    return h
+
+
+def pack_encoder(sd, p):
+    """ConditionEncoder (models/update.py:276-297)."""
+    return {n: pack_conv2d(sd[f"{p}.{n}.weight"], sd[f"{p}.{n}.bias"], pad=1)
+            for n in ("convc1", "convc2", "convd1", "convd2", "output")}
+
+
+def run_encoder(o: Ops, enc, cost, samples, out=None, out_cstride=None, out_coffset=0):
+    """-> relu(output(cat(c_feat, d_feat))): the first out_chs-1 channels of the encoder result."""
+    R = K.ACT_RELU
+    cf = o.conv2d(enc["convc2"], o.conv2d(enc["convc1"], cost, act=R), act=R)
+    df = o.conv2d(enc["convd2"], o.conv2d(enc["convd1"], samples, act=R), act=R)
+    return o.conv2d(enc["output"], cf, df, act=R, out=out, out_cstride=out_cstride, out_coffset=out_coffset)
+
+
+class GnArena:
+    """GroupNorm statistics scratch: [slot][B*4*2] doubles, zeroed with one memset per forward; the
+    producing conv's epilogue accumulates into a slot, groupnorm_apply consumes it."""
+    SLOTS = 256
+
+    def __init__(self, ops: Ops):
+        self.ops, self.buf, self.next = ops, None, 0
+
+    def reset(self, B):
+        need = (self.SLOTS, B * 8)
+        if self.buf is None or tuple(self.buf.shape) != need:
+            self.buf = torch.zeros(*need, dtype=torch.float64, device=self.ops.device)
+        else:
+            self.buf.zero_()
+        self.next = 0
+
+    def slot(self):
+        if self.next >= self.SLOTS:
+            raise RuntimeError("GroupNorm statistics arena exhausted")
+        s = self.buf[self.next]
+        self.next += 1
+        return s
+
+
+def run_resblock(o: Ops, arena: GnArena, rb, x0, x1=None, scale_shift=None):
+    """ResnetBlock (update.py:147-159): two WS-conv/GroupNorm/SiLU blocks + residual."""
+    st1, st2 = arena.slot(), arena.slot()
+    h = o.conv2d(rb["c1"], x0, x1, gn_stats=st1)
+    h = o.groupnorm_apply(h, rb["g1"][0], rb["g1"][1], 4, st1, scale_shift=scale_shift, out=h)
+    h2 = o.conv2d(rb["c2"], h, gn_stats=st2)
+    if rb["res"] is not None:
+        res = o.conv2d(rb["res"], x0, x1)
+    else:
+        assert x1 is None
+        res = x0
+    return o.groupnorm_apply(h2, rb["g2"][0], rb["g2"][1], 4, st2, residual=res, out=h2)
+
+
+def run_unet(o: Ops, arena: GnArena, ub, X, hidden, ss_of):
+    """Unet.forward (update.py:245-274).  X [B,input_dim,H,W], hidden [B,hd,h,w]; ss_of(rb) -> [B,2*dim_out] | None."""
+    x = o.conv2d(ub.init_conv, X)
+    r = x
+    skips = []
+    L = len(ub.mults)
+    for i, (blk, ds) in enumerate(ub.downs):
+        x = run_resblock(o, arena, blk, x, None, ss_of(blk))
+        skips.append(x)
+        x = o.conv2d(ds, x, in_mode=(K.IN_UNSHUFFLE2 if i < L - 1 else K.IN_PLAIN))
+    hidden = run_gru(o, ub.gru, hidden, x)
+    x = run_resblock(o, arena, ub.mid, hidden, None, None)      # mid has no time MLP
+    for i, (blk, us) in enumerate(ub.ups):
+        x = run_resblock(o, arena, blk, x, skips.pop(), ss_of(blk))
+        x = o.conv2d(us, x, in_mode=(K.IN_UPSAMPLE2 if i < L - 1 else K.IN_PLAIN))
+    x = run_resblock(o, arena, ub.final, x, r, ss_of(ub.final))
+    delta = o.conv2d(ub.final_conv, x)
+    conf = o.conv2d(ub.conf, x, act=K.ACT_SIGMOID)
+    return hidden, delta, conf
+
+
 class _UpdateBlock:
     """Packed weights of one DiffusionUpdateBlockDepth (reference models/update.py:299-391)."""
 
@@ -49,8 +248,8 @@ class _UpdateBlock:
         self.scale = args.scale[stage]
         self.up_ratio = up_ratio
         c2 = lambda name, **kw: pack_conv2d(sd[f"{p}.{name}.weight"], sd.get(f"{p}.{name}.bias"), **kw)  # noqa: E731
-        self.enc = {n: c2(f"encoder.{n}", pad=1) for n in ("convc1", "convc2", "convd1", "convd2", "output")}
-        self.mask0, self.mask2 = c2("mask.0", pad=1), c2("mask.2")
+        self.enc = pack_encoder(sd, p + ".encoder")
+        self.mask = pack_mask(sd, p + ".mask")
         u = p + ".unet"
         self.init_conv = c2("unet.init_conv", pad=3)
         L = len(self.mults)
@@ -62,10 +261,7 @@ class _UpdateBlock:
             else:
                 ds = pack_conv2d(sd[f"{u}.downs.{i}.1.weight"], sd[f"{u}.downs.{i}.1.bias"], pad=1)
             self.downs.append((blk, ds))
-        self.gru = {}
-        for n, pad in (("1", (0, 2)), ("2", (2, 0))):
-            for gate in "zrq":
-                self.gru[gate + n] = pack_conv2d(sd[f"{u}.gru.conv{gate}{n}.weight"], sd[f"{u}.gru.conv{gate}{n}.bias"], pad=pad)
+        self.gru = pack_gru(sd, u + ".gru")
         self.mid = self._resblock(sd, f"{u}.mid")
         self.ups = []
         for i in range(L):
@@ -123,44 +319,21 @@ class _UpdateBlock:
 
 
 class Engine:
-    _GN_SLOTS = 256
-
     def __init__(self, sd: Dict[str, torch.Tensor], args, ops: Ops):
         self.ops = ops
-        self._ss_cache = {}
-        self._gn_arena = None
         self.args = args
+        self.arena = GnArena(ops)
+        self._ss_cache = {}
         dev = ops.device
         sd = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sd.items()}
         self.cas = args.stage_iters[2] != 0
         self.up_ratio = 2 if self.cas else 4
         self.G = args.cost_dim_stage[0]
         self.G_cost = args.cost_dim_stage[1]
-        cw = lambda p, **kw: pack_conv2d(sd[p + ".conv.weight"], None, bn=_bn(sd, p + ".bn"), **kw)  # noqa: E731
-        # ---- FeatureNet (models/module.py:357-420)
-        f = {}
-        f["conv0.0"], f["conv0.1"] = cw("feature.conv0.0", pad=1), cw("feature.conv0.1", pad=1)
-        for i in (1, 2, 3):
-            f[f"conv{i}.0"] = cw(f"feature.conv{i}.0", stride=2, pad=2)
-            f[f"conv{i}.1"], f[f"conv{i}.2"] = cw(f"feature.conv{i}.1", pad=1), cw(f"feature.conv{i}.2", pad=1)
-        f["out1"] = pack_conv2d(sd["feature.out1.weight"])
-        f["inner1"] = pack_conv2d(sd["feature.inner1.weight"], sd["feature.inner1.bias"])
-        f["out2"] = pack_conv2d(sd["feature.out2.weight"], pad=1)
-        if self.cas:
-            f["inner2"] = pack_conv2d(sd["feature.inner2.weight"], sd["feature.inner2.bias"])
-            f["out3"] = pack_conv2d(sd["feature.out3.weight"], pad=1)
-        self.feat = f
-        # ---- ContextNet (models/module.py:321-355); output heads split into hidden | context parts
-        c = {"conv1": cw("context.conv1", pad=1)}
-        for li in (1, 2, 3):
-            for bi in (0, 1):
-                p = f"context.layer{li}.{bi}"
-                s = 2 if bi == 0 else 1
-                c[f"{li}.{bi}.conv1"] = cw(p + ".conv1", stride=s, pad=1)
-                c[f"{li}.{bi}.conv2"] = cw(p + ".conv2", pad=1)
-                if bi == 0:
-                    c[f"{li}.{bi}.down"] = cw(p + ".downsample", stride=2, pad=1)
-        self.ctx = c
+        self.feat = pack_feature(sd, "feature")
+        self.ctx = pack_context_trunk(sd, "context")
+        # ContextNet output heads split into their hidden | context halves (diffusion.py:223-231): the
+        # context half is written straight into the Unet input buffer, the hidden half feeds hidden_init
         self.ctx_out = {}
         for s in range(3):
             name = f"context.output{s + 1}"
@@ -171,125 +344,29 @@ class Engine:
             hid = pack_conv2d(w[:hd].contiguous(), b[:hd].contiguous(), pad=1) if hd > 0 else None
             self.ctx_out[s] = (hid, pack_conv2d(w[hd:].contiguous(), b[hd:].contiguous(), pad=1))
         # ---- InitialCost (models/module.py:465-573)
-        d = "depthnet"
-        self.pvw0 = pack_conv3d(sd[d + ".pixel_view_weight.conv.0.conv.weight"], bn=_bn(sd, d + ".pixel_view_weight.conv.0.bn"))
-        self.pvw1 = pack_conv3d(sd[d + ".pixel_view_weight.conv.1.weight"], sd[d + ".pixel_view_weight.conv.1.bias"])
-        r = d + ".cost_regularization"
-        self.reg = {}
-        for i, st in ((0, 1), (1, 1), (2, 2), (3, 1), (4, 2), (5, 1)):
-            self.reg[i] = pack_conv3d(sd[f"{r}.conv{i}.conv.weight"], bn=_bn(sd, f"{r}.conv{i}.bn"), stride=st)
-        for i in (6, 7):
-            self.reg[i] = pack_conv3d(sd[f"{r}.conv{i}.conv.weight"], bn=_bn(sd, f"{r}.conv{i}.bn"), stride=2, transposed=True)
-        self.reg["prob"] = pack_conv3d(sd[r + ".prob.weight"])
-        self.mask0 = pack_conv2d(sd[d + ".mask.0.weight"], sd[d + ".mask.0.bias"], pad=1)
-        self.mask2 = pack_conv2d(sd[d + ".mask.2.weight"], sd[d + ".mask.2.bias"])
+        self.pvw = pack_pvw(sd, "depthnet.pixel_view_weight")
+        self.reg = pack_costreg(sd, "depthnet.cost_regularization")
+        self.mask = pack_mask(sd, "depthnet.mask")
         # ---- hidden_init (models/diffusion.py:53-58, :91-101)
-        self.hidden_init = {}
-        self.hidden_init[1] = [cw("hidden_init.0.0", stride=2, pad=1), pack_conv2d(sd["hidden_init.0.1.weight"], pad=1)]
+        self.hidden_init = {1: [_cw(sd, "hidden_init.0.0", stride=2, pad=1), pack_conv2d(sd["hidden_init.0.1.weight"], pad=1)]}
         if self.cas:
-            self.hidden_init[2] = [cw("hidden_init.1.0", stride=2, pad=1), cw("hidden_init.1.1", stride=2, pad=1),
+            self.hidden_init[2] = [_cw(sd, "hidden_init.1.0", stride=2, pad=1), _cw(sd, "hidden_init.1.1", stride=2, pad=1),
                                    pack_conv2d(sd["hidden_init.1.2.weight"], pad=1)]
         # ---- update blocks
         self.ub = {1: _UpdateBlock(sd, "update_block_depth2", args, 1, self.up_ratio)}
         if self.cas:
             self.ub[2] = _UpdateBlock(sd, "update_block_depth3", args, 2, self.up_ratio)
 
-    # ------------------------------------------------------------------ sub-networks
-    def feature_net(self, x):
-        """x [N,3,H,W] -> {'stage1': NHWC [N,H/8,W/8,48], 'stage2': [N,H/4,W/4,32], ('stage3': [N,H/2,W/2,16])}"""
-        o, f, R = self.ops, self.feat, K.ACT_RELU
-        c0 = o.conv2d(f["conv0.1"], o.conv2d(f["conv0.0"], x, act=R), act=R)
-        c1 = o.conv2d(f["conv1.2"], o.conv2d(f["conv1.1"], o.conv2d(f["conv1.0"], c0, act=R), act=R), act=R)
-        c2 = o.conv2d(f["conv2.2"], o.conv2d(f["conv2.1"], o.conv2d(f["conv2.0"], c1, act=R), act=R), act=R)
-        c3 = o.conv2d(f["conv3.2"], o.conv2d(f["conv3.1"], o.conv2d(f["conv3.0"], c2, act=R), act=R), act=R)
-        out = {"stage1": o.conv2d(f["out1"], c3, out_layout=K.LAYOUT_NHWC)}
-        intra = o.conv2d(f["inner1"], c2, residual=c3, res_mode=K.IN_UPSAMPLE2)
-        out["stage2"] = o.conv2d(f["out2"], intra, out_layout=K.LAYOUT_NHWC)
-        if self.cas:
-            intra = o.conv2d(f["inner2"], c1, residual=intra, res_mode=K.IN_UPSAMPLE2)
-            out["stage3"] = o.conv2d(f["out3"], intra, out_layout=K.LAYOUT_NHWC)
-        return out
-
-    def context_trunk(self, x):
-        """ContextNet body -> the three pre-head feature maps (full/2, /4, /8)."""
-        o, c, R = self.ops, self.ctx, K.ACT_RELU
-        x = o.conv2d(c["conv1"], x, act=R)
-        taps = {}
-        for li in (1, 2, 3):
-            y = o.conv2d(c[f"{li}.0.conv1"], x, act=R)
-            xd = o.conv2d(c[f"{li}.0.down"], x)
-            x = o.conv2d(c[f"{li}.0.conv2"], y, residual=xd, act=R)
-            y = o.conv2d(c[f"{li}.1.conv1"], x, act=R)
-            x = o.conv2d(c[f"{li}.1.conv2"], y, residual=x, act=R)
-            taps[3 - li] = x          # layer1 -> stage3 (index 2), layer2 -> stage2, layer3 -> stage1
-        return taps
-
-    # GroupNorm statistics come out of the producing conv's epilogue; the per-forward arena of
-    # [slot][B*4*2] doubles is zeroed with a single memset at the start of forward()
-    def _gn_reset(self, B):
-        need = (self._GN_SLOTS, B * 8)
-        if getattr(self, "_gn_arena", None) is None or tuple(self._gn_arena.shape) != need:
-            self._gn_arena = torch.zeros(*need, dtype=torch.float64, device=self.ops.device)
-        else:
-            self._gn_arena.zero_()
-        self._gn_next = 0
-
-    def _gn_slot(self):
-        if self._gn_next >= self._GN_SLOTS:
-            raise RuntimeError("GroupNorm statistics arena exhausted")
-        s = self._gn_arena[self._gn_next]
-        self._gn_next += 1
-        return s
-
-    def _scale_shift(self, rb, ss, B):
-        if ss is None or rb["p"] not in ss:
-            return None
-        key = (id(ss), rb["p"], B)
-        cache = self._ss_cache
-        if key not in cache:
-            cache[key] = ss[rb["p"]].expand(B, -1).contiguous()
-        return cache[key]
-
-    def _resblock(self, rb, x0, x1, ss, B):
-        """ResnetBlock (update.py:147-159): two WS-conv/GroupNorm/SiLU blocks + residual."""
-        o = self.ops
-        st1, st2 = self._gn_slot(), self._gn_slot()
-        h = o.conv2d(rb["c1"], x0, x1, gn_stats=st1)
-        h = o.groupnorm_apply(h, rb["g1"][0], rb["g1"][1], 4, st1, scale_shift=self._scale_shift(rb, ss, B), out=h)
-        h2 = o.conv2d(rb["c2"], h, gn_stats=st2)
-        if rb["res"] is not None:
-            res = o.conv2d(rb["res"], x0, x1)
-        else:
-            assert x1 is None
-            res = x0
-        return o.groupnorm_apply(h2, rb["g2"][0], rb["g2"][1], 4, st2, residual=res, out=h2)
-
-    def unet(self, ub: _UpdateBlock, X, hidden, ss):
-        """Unet.forward (update.py:245-274).  X [B,2cd,H,W], hidden [B,hd,h,w]."""
-        o = self.ops
-        B = X.shape[0]
-        x = o.conv2d(ub.init_conv, X)
-        r = x
-        skips = []
-        L = len(ub.mults)
-        for i, (blk, ds) in enumerate(ub.downs):
-            x = self._resblock(blk, x, None, ss, B)
-            skips.append(x)
-            x = o.conv2d(ds, x, in_mode=(K.IN_UNSHUFFLE2 if i < L - 1 else K.IN_PLAIN))
-        h = hidden
-        for n in ("1", "2"):     # SepConvGRU: horizontal then vertical pass (module.py:164-177)
-            z = o.conv2d(ub.gru["z" + n], h, x, act=K.ACT_SIGMOID)
-            rg = o.conv2d(ub.gru["r" + n], h, x, act=K.ACT_SIGMOID)
-            h = o.conv2d(ub.gru["q" + n], h, x, mul0=rg, act=K.ACT_TANH, gru_z=z, gru_h=h)
-        hidden = h
-        x = self._resblock(ub.mid, hidden, None, None, B)
-        for i, (blk, us) in enumerate(ub.ups):
-            x = self._resblock(blk, x, skips.pop(), ss, B)
-            x = o.conv2d(us, x, in_mode=(K.IN_UPSAMPLE2 if i < L - 1 else K.IN_PLAIN))
-        x = self._resblock(ub.final, x, r, ss, B)
-        delta = o.conv2d(ub.final_conv, x)
-        conf = o.conv2d(ub.conf, x, act=K.ACT_SIGMOID)
-        return hidden, delta, conf
+    def _ss_of(self, ss, B):
+        """time-conditioned scale/shift rows of one DDIM step, expanded to the batch once and cached"""
+        def get(rb):
+            if ss is None or rb["p"] not in ss:
+                return None
+            key = (id(ss), rb["p"], B)
+            if key not in self._ss_cache:
+                self._ss_cache[key] = ss[rb["p"]].expand(B, -1).contiguous()
+            return self._ss_cache[key]
+        return get
 
     # ------------------------------------------------------------------ stage 1
     def initial_cost(self, ref, src, rt, context, disp_min, disp_max, D):
@@ -298,19 +375,11 @@ class Engine:
         B, H, W, _ = ref.shape
         S = src.shape[0]
         cor = o.warp_corr_init(ref, src, rt, disp_min, disp_max, D, self.G)            # [B,S,G,D,H,W]
-        x = o.conv3d(self.pvw0, cor.view(B * S, self.G, D, H, W), act=K.ACT_RELU)
-        x = o.conv3d(self.pvw1, x)                                                      # [B*S,1,D,H,W]
-        vw = o.sigmoid_max_d(x.view(B * S, D, H, W)).view(B, S, H, W)
+        vw = run_pvw(o, self.pvw, cor.view(B * S, self.G, D, H, W)).view(B, S, H, W)
         agg = o.view_aggregate(cor, vw)
-        R = K.ACT_RELU
-        c1 = o.conv3d(self.reg[1], o.conv3d(self.reg[0], agg, act=R), act=R)
-        c3 = o.conv3d(self.reg[3], o.conv3d(self.reg[2], c1, act=R), act=R)
-        x = o.conv3d(self.reg[5], o.conv3d(self.reg[4], c3, act=R), act=R)
-        x = o.conv3d(self.reg[6], x, act=R, residual=c3)
-        x = o.conv3d(self.reg[7], x, act=R, residual=c1)
-        logits = o.conv3d(self.reg["prob"], x)                                          # [B,1,D,H,W]
+        logits = run_costreg(o, self.reg, agg)                                          # [B,1,D,H,W]
         nd, depth, conf = o.depth_regress(logits.view(B, D, H, W), disp_min, disp_max)
-        mask = o.conv2d(self.mask2, o.conv2d(self.mask0, context, act=R), post_scale=0.25)
+        mask = run_mask(o, self.mask, context)
         return mask, nd, depth, vw, conf
 
     # ------------------------------------------------------------------ stages 2, 3
@@ -322,17 +391,16 @@ class Engine:
         a = self.args
         B, _, H, W = inv_depth.shape
         cd, n = ub.cd, ub.n
-        context = None
         noise = noise_fn((B, 1, H, W), o.device).float().contiguous()
         # mask head reads relu(context) = X[:, :cd]; for B > 1 that slice is strided, so give it its own copy
         context = o.act_slice(X, K.ACT_NONE, 0, cd)
-        mask = o.conv2d(ub.mask2, o.conv2d(ub.mask0, context, act=K.ACT_RELU), post_scale=0.25)
+        mask = run_mask(o, ub.mask, context)
         img, img_scale = noise, float(ub.scale)
         inv_list: List[torch.Tensor] = []
         conf_list: List[torch.Tensor] = []
         cur_hidden = hidden
         for time, time_next in ub.time_pairs:
-            ss = ub.ss_tables[time]
+            ss_of = self._ss_of(ub.ss_tables[time], B)
             inv_list, conf_list = [], []
             delta, new = o.delta_update(inv_depth, img, None, img_scale, new2=X, new2_cstride=2 * cd, new2_coffset=2 * cd - 1)
             img, img_scale = delta, 1.0
@@ -340,10 +408,8 @@ class Engine:
             for _ in range(ub.iters):
                 cost, samples = o.getcost(feats_ref, feats_src, rt, new, confidence, view_w, disp_min, disp_max, n,
                                           interval, a.min_radius, a.max_radius, vw_shift, G=self.G_cost)
-                cf = o.conv2d(ub.enc["convc2"], o.conv2d(ub.enc["convc1"], cost, act=K.ACT_RELU), act=K.ACT_RELU)
-                df = o.conv2d(ub.enc["convd2"], o.conv2d(ub.enc["convd1"], samples, act=K.ACT_RELU), act=K.ACT_RELU)
-                o.conv2d(ub.enc["output"], cf, df, act=K.ACT_RELU, out=X, out_cstride=2 * cd, out_coffset=cd)
-                cur_hidden, upd, conf = self.unet(ub, X, cur_hidden, ss)
+                run_encoder(o, ub.enc, cost, samples, out=X, out_cstride=2 * cd, out_coffset=cd)
+                cur_hidden, upd, conf = run_unet(o, self.arena, ub, X, cur_hidden, ss_of)
                 confidence = conf.view(B, H, W)
                 delta, new = o.delta_update(inv_depth, delta, upd, 1.0, new2=X, new2_cstride=2 * cd, new2_coffset=2 * cd - 1)
                 conf_list.append(confidence)
@@ -369,15 +435,15 @@ class Engine:
             noise_fn = lambda shape, device: torch.randn(shape, device=device)  # noqa: E731
         V = len(imgs)
         B = imgs[0].shape[0]
-        self._gn_reset(B)
+        self.arena.reset(B)
         dv = depth_values.to(o.device).float()
         depth_max_, depth_min_ = 1.0 / dv[:, 0], 1.0 / dv[:, -1]
         disp_min, disp_max = (1.0 / depth_max_).contiguous(), (1.0 / depth_min_).contiguous()   # module.py:222-223
         interval = 1.0 / depth_values.size(1)
 
         x = torch.cat([im.to(o.device).float() for im in imgs], 0).contiguous()                  # [V*B,3,H,W], view-major
-        feats = self.feature_net(x)
-        trunk = self.context_trunk(x[:B])
+        feats = run_feature(o, self.feat, x)
+        trunk = run_context_trunk(o, self.ctx, x[:B])
         depths, confs_full = [], []
         view_w = None
         for s in range(3):

@@ -217,6 +217,16 @@ class Ops:
                       _ptr(out), B, S, Cc, G, D, H, W, Hs, Ws, self.stream())
         return out
 
+    def warp_volume(self, src, rt, depth):
+        """differentiable_warping: src [B,C,Hs,Ws], rt [B,12], depth [B,D,H,W] -> [B,C,D,H,W]."""
+        self._chk(src, rt, depth)
+        B, Cc, Hs, Ws = src.shape
+        D, H, W = depth.shape[1:]
+        out = self.empty(B, Cc, D, H, W)
+        self._call("dmvs_warp_volume_f32", _ptr(src), _ptr(rt), _ptr(depth), _ptr(out), B, Cc, D, H, W, Hs, Ws,
+                   self.stream())
+        return out
+
     def getcost(self, ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, min_radius,
                 max_radius, vw_shift, out_cost=None, cost_cstride=None, cost_coffset=0, out_samples=None,
                 samp_cstride=None, samp_coffset=0, G=4):

@@ -167,6 +167,13 @@ typedef struct dmvs_getcost_desc {
 
 int dmvs_getcost_f32(const dmvs_getcost_desc* d, void* stream);
 
+/* Stand-alone differentiable_warping (models/module.py:181-218) in the reference's layouts:
+ * src [B,C,Hs,Ws] NCHW, rt [B,12] (rot row-major, trans) = src_proj * inverse(ref_proj),
+ * depth [B,D,H,W] metric -> out [B,C,D,H,W].  Not used by the model's fused path. */
+int dmvs_warp_volume_f32(const float* src, const float* rt, const float* depth, float* out,
+                         int32_t B, int32_t C, int32_t D, int32_t H, int32_t W, int32_t Hs, int32_t Ws,
+                         void* stream);
+
 /* view-weighted aggregation of the per-view volumes (models/module.py:539-548):
  * out[b,g,d,p] = sum_s w[b,s,p] cor[b,s,g,d,p] / (1e-8 + sum_s w[b,s,p]) */
 int dmvs_view_aggregate_f32(const float* cor, const float* w, float* out,

@@ -9,7 +9,12 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .module import SepConvGRU, _mask_head
+from types import SimpleNamespace
+
+from diffmvs_amd import engine as E
+from diffmvs_amd import ops as K
+
+from .module import HipModule, SepConvGRU, _dev, _mask_head
 
 
 def cosine_beta_schedule(timesteps, s=0.008):
@@ -39,7 +44,7 @@ class ResnetBlock(nn.Module):                 # reference models/update.py:135-1
         self.res_conv = nn.Conv2d(dim, dim_out, 1) if dim != dim_out else nn.Identity()
 
 
-class Unet(nn.Module):                        # reference models/update.py:161-274
+class Unet(HipModule):                        # reference models/update.py:161-274
     def __init__(self, dim, hidden_dim=32, input_dim=3, out_dim=1, dim_mults=(1, 2), resnet_block_groups=4):
         super().__init__()
         self.out_dim = out_dim
@@ -66,9 +71,54 @@ class Unet(nn.Module):                        # reference models/update.py:161-2
         self.final_res_block = ResnetBlock(dim * 2, dim, time_emb_dim=time_dim, groups=g)
         self.final_conv = nn.Conv2d(dim, 1, 1)
         self.conf = nn.Conv2d(dim, 1, 1)
+        self._dim, self._mults, self._hidden_dim = dim, tuple(dim_mults), hidden_dim
+
+    def _packed_block(self):
+        """this Unet's weights as an engine _UpdateBlock-shaped namespace (no encoder / mask / schedule)"""
+        def build(sd):
+            u = {"u." + k: v for k, v in sd.items()}
+            ub = SimpleNamespace(mults=self._mults, dim=self._dim)
+            L = len(self._mults)
+            rb = E._UpdateBlock._resblock
+            ub.init_conv = K.pack_conv2d(u["u.init_conv.weight"], u["u.init_conv.bias"], pad=3)
+            ub.downs, ub.ups = [], []
+            for i in range(L):
+                ds = (K.pack_conv2d(u[f"u.downs.{i}.1.1.weight"], u[f"u.downs.{i}.1.1.bias"]) if i < L - 1
+                      else K.pack_conv2d(u[f"u.downs.{i}.1.weight"], u[f"u.downs.{i}.1.bias"], pad=1))
+                ub.downs.append((rb(u, f"u.downs.{i}.0"), ds))
+                us = (K.pack_conv2d(u[f"u.ups.{i}.1.1.weight"], u[f"u.ups.{i}.1.1.bias"], pad=1) if i < L - 1
+                      else K.pack_conv2d(u[f"u.ups.{i}.1.weight"], u[f"u.ups.{i}.1.bias"], pad=1))
+                ub.ups.append((rb(u, f"u.ups.{i}.0"), us))
+            ub.gru = E.pack_gru(u, "u.gru")
+            ub.mid, ub.final = rb(u, "u.mid"), rb(u, "u.final_res_block")
+            ub.final_conv = K.pack_conv2d(u["u.final_conv.weight"], u["u.final_conv.bias"])
+            ub.conf = K.pack_conv2d(u["u.conf.weight"], u["u.conf.bias"])
+            ub.sd = u
+            return ub
+        return self.packed(build)
+
+    def forward(self, x, hidden, time):
+        """x [B,input_dim,H,W], hidden [B,hidden_dim,h,w], time [B] long (one value for the whole batch, as in the
+        reference's sampling loop, update.py:476) -> hidden, delta [B,1,H,W], confidence [B,1,H,W]"""
+        self._eval_only()
+        o = self.ops()
+        ub = self._packed_block()
+        t = int(time.reshape(-1)[0])
+        tables = self.__dict__.setdefault("_ss_tables", {})
+        key = (id(ub), t)
+        if key not in tables:
+            tables[key] = E._UpdateBlock._scale_shift_table(ub, ub.sd, "u", t)
+        B = x.shape[0]
+
+        def ss_of(rb):
+            row = tables[key].get(rb["p"])
+            return None if row is None else row.expand(B, -1).contiguous()
+        arena = self.__dict__.setdefault("_arena", E.GnArena(o))
+        arena.reset(B)
+        return E.run_unet(o, arena, ub, _dev(o, x), _dev(o, hidden), ss_of)
 
 
-class ConditionEncoder(nn.Module):            # reference models/update.py:276-297
+class ConditionEncoder(HipModule):            # reference models/update.py:276-297
     def __init__(self, num_sample, cost_dim, hidden_dim, out_chs):
         super().__init__()
         self.out_chs = out_chs
@@ -76,8 +126,19 @@ class ConditionEncoder(nn.Module):            # reference models/update.py:276-2
         self.convd1, self.convd2 = nn.Conv2d(num_sample, hidden_dim, 3, padding=1), nn.Conv2d(hidden_dim, hidden_dim, 3, padding=1)
         self.output = nn.Conv2d(2 * hidden_dim, out_chs - 1, 3, padding=1)
 
+    def forward(self, depth, depth_values, cost_volume):
+        """-> cat([relu(output(cat(c_feat, d_feat))), depth]) = out_chs channels (update.py:289-297)"""
+        self._eval_only()
+        o = self.ops()
+        enc = self.packed(lambda sd: E.pack_encoder({"e." + k: v for k, v in sd.items()}, "e"))
+        B, _, H, W = depth.shape
+        out = o.empty(B, self.out_chs, H, W)
+        E.run_encoder(o, enc, _dev(o, cost_volume), _dev(o, depth_values), out=out, out_cstride=self.out_chs, out_coffset=0)
+        o.act_slice(_dev(o, depth), K.ACT_NONE, 0, 1, out=out, out_cstride=self.out_chs, out_coffset=self.out_chs - 1)
+        return out
 
-class DiffusionUpdateBlockDepth(nn.Module):   # reference models/update.py:299-391
+
+class DiffusionUpdateBlockDepth(HipModule):   # reference models/update.py:299-391
     def __init__(self, args, dim=16, dim_mults=(1, 2), hidden_dim=32, num_sample=4, cost_dim=16, context_dim=32,
                  stage_idx=0, iters=3, ratio=2):
         super().__init__()
@@ -108,3 +169,43 @@ class DiffusionUpdateBlockDepth(nn.Module):   # reference models/update.py:299-3
         }
         for k, v in bufs.items():
             self.register_buffer(k, v)
+        self.noise_source = None      # callable(shape, device) -> N(0,1); None = device RNG (update.py:472)
+
+    def forward(self, depth_cost_func, inv_depth, hidden, context, gt_inv_depth=None, inv_init_depth=None):
+        """Eval branch of the reference (update.py:466-521) with the reference's calling convention:
+        depth_cost_func(inv_depth_new, confidence=...) -> (cost, inverse_depth_samples) is any callable (the
+        model passes a partial of GetCost).  -> mask, hidden, inv_depth_list, conf_list."""
+        self._eval_only()
+        o = self.ops()
+        noise_fn = self.noise_source or (lambda shape, device: torch.randn(shape, device=device))
+        B, _, H, W = inv_depth.shape
+        inv_depth, context = _dev(o, inv_depth), _dev(o, context)
+        times = torch.linspace(-1, self.timesteps - 1, steps=self.sampling_timesteps + 1)
+        times = list(reversed(times.int().tolist()))
+        img, img_scale = noise_fn((B, 1, H, W), o.device).float().contiguous(), float(self.scale)
+        mask_pk = self.packed(lambda sd: E.pack_mask(sd, "mask"))
+        mask = E.run_mask(o, mask_pk, context)
+        inv_list, conf_list, cur_hidden = [], [], hidden
+        for time, time_next in zip(times[:-1], times[1:]):
+            t = torch.full((B,), time, device=o.device, dtype=torch.long)
+            inv_list, conf_list = [], []
+            delta, new = o.delta_update(inv_depth, img, None, img_scale)
+            img, img_scale = delta, 1.0
+            cur_hidden, confidence = _dev(o, hidden), None
+            for _ in range(self.iters):
+                cost, samples = depth_cost_func(new, confidence=confidence)
+                feats = self.encoder(new, samples, cost)
+                cur_hidden, upd, conf = self.unet(torch.cat([context, feats], 1), cur_hidden, t)
+                confidence = conf.squeeze(1)
+                delta, new = o.delta_update(inv_depth, delta, upd, 1.0)
+                conf_list.append(confidence)
+                inv_list.append(new)
+            if time_next < 0:
+                continue
+            pred_noise = (self.sqrt_recip_alphas_cumprod[time] * img - delta) / self.sqrt_recipm1_alphas_cumprod[time]
+            alpha, alpha_next = self.alphas_cumprod[time], self.alphas_cumprod[time_next]
+            sigma = self.ddim_sampling_eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+            c = (1 - alpha_next - sigma ** 2).sqrt()
+            fresh = (self.scale * noise_fn((B, 1, H, W), o.device)).float()
+            img = (delta * alpha_next.sqrt() + c * pred_noise + sigma * fresh).contiguous()
+        return mask, cur_hidden, inv_list, conf_list
