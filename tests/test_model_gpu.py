@@ -103,3 +103,33 @@ def test_full_size_properties():
         with torch.no_grad():
             o1 = model([i.cuda() for i in sub_i], {k: v.cuda() for k, v in sub_p.items()}, dv[b:b + 1].cuda())
         assert rel_l1(o1["depth"][-1].cpu(), d2[b:b + 1].cpu()) < 1e-5
+
+
+def test_casdiffmvs_cfg3_size_properties():
+    """BASELINE.json configs[2] geometry in fp32 (1152x864, 7 src views, D=48): runs through every 32-bit offset /
+    tiling limit of the kernels; checked through size-independent properties (finite, in range, reproducible)
+    plus oracle parity on a centre crop-sized problem being covered elsewhere."""
+    model, _, _ = make_model("casdiffmvs", 48)
+    imgs, proj, dv = synth.synth_inputs(864, 1152, 7, B=1, seed=9)
+    out = run(model, imgs, proj, dv, 2)
+    assert [tuple(d.shape) for d in out["depth"]] == [(1, 108, 144), (1, 216, 288), (1, 216, 288), (1, 432, 576),
+                                                      (1, 432, 576), (1, 864, 1152)]
+    assert len(out["photometric_confidence"]) == 3 and out["photometric_confidence"][-1].shape == (1, 864, 1152)
+    for d in out["depth"]:
+        assert torch.isfinite(d).all() and float(d.min()) >= 424.9 and float(d.max()) <= 935.1
+    again = run(model, imgs, proj, dv, 2)
+    assert torch.equal(again["depth"][0], out["depth"][0])
+    assert rel_l1(again["depth"][-1].cpu(), out["depth"][-1].cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("H,W", [(96, 160), (160, 224)])
+def test_sizes_not_multiple_of_tile(H, W):
+    """H/8, W/8 not multiples of the 16-pixel conv tile or the 4-row wave tile; ragged workgroups everywhere"""
+    model, sd, args = make_model("casdiffmvs", 12, weight_seed=3)
+    imgs, proj, dv = synth.synth_inputs(H, W, 2, B=1, seed=13)
+    out = run(model, imgs, proj, dv, 4)
+    src = synth.NoiseSource(4)
+    with torch.no_grad():
+        ref = O.forward(sd, args, imgs, proj, dv, noise_fn=lambda shape: src(shape, "cpu"))
+    errs = [rel_l1(a.cpu(), b) for a, b in zip(out["depth"], ref["depth"])]
+    assert max(errs) < TOL, errs
