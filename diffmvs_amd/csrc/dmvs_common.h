@@ -32,3 +32,12 @@ __device__ __forceinline__ float dmvs_disp_to_depth(float nd, float disp_min, fl
     scaled = fmaxf(scaled, 1e-6f);
     return 1.0f / scaled;
 }
+
+// Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, each with a private
+// 4 MiB L2).  Remap so that every XCD walks one contiguous eighth of the logical blocks: neighbouring
+// tiles share halo rows / epipolar bands, which then stay resident in that XCD's L2 instead of being
+// re-fetched by all eight.  Bijective for any grid size (cdna_hip_programming.md T1).
+__device__ __forceinline__ unsigned dmvs_xcd_contiguous_block(unsigned bid, unsigned nblk) {
+    const unsigned q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}

@@ -25,15 +25,6 @@
 
 namespace {
 
-// Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, each with a private
-// 4 MiB L2).  Remap so that every XCD walks one contiguous eighth of the pixels: neighbouring pixels
-// sample neighbouring source texels, so the epipolar bands they touch stay resident in that XCD's L2
-// instead of being re-fetched by all eight.  Bijective for any grid size (cdna_hip_programming.md T1).
-__device__ __forceinline__ unsigned xcd_contiguous_block(unsigned bid, unsigned nblk) {
-    const unsigned q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u, idx = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
-
 struct Ray {   // p(depth) = rot * (x, y, 1) * depth + trans   (reference :199-205)
     float rx, ry, rz, tx, ty, tz;
     __device__ __forceinline__ void init(const float* m, float x, float y) {
@@ -172,7 +163,7 @@ warp_corr_init_kernel(const float* __restrict__ ref, const float* __restrict__ s
     static_assert(NB <= LPP, "one projection per lane and batch");
     const int sub = threadIdx.x % LPP, slot = threadIdx.x / LPP;
     const long npix = (long)B * H * W;
-    const long pix = (long)xcd_contiguous_block(blockIdx.x, gridDim.x) * PPB + slot;
+    const long pix = (long)dmvs_xcd_contiguous_block(blockIdx.x, gridDim.x) * PPB + slot;
     const bool live = pix < npix;
     const long pc = live ? pix : npix - 1;
     const int x = (int)(pc % W);
@@ -224,7 +215,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) getcost_kernel(const dmvs_getcost_
     const int sub = threadIdx.x % LPP, slot = threadIdx.x / LPP;
     const int H = d.H, W = d.W;
     const long npix = (long)d.B * H * W;
-    const long pix = (long)xcd_contiguous_block(blockIdx.x, gridDim.x) * PPB + slot;
+    const long pix = (long)dmvs_xcd_contiguous_block(blockIdx.x, gridDim.x) * PPB + slot;
     const bool live = pix < npix;
     const long pc = live ? pix : npix - 1;
     const int x = (int)(pc % W);
