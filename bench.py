@@ -127,6 +127,16 @@ def main():
     alg_init = 4 * B * h1 * w1 * (48 + S * 48 + S * 4 * 48)      # ref + src + per-view volumes out
     wi_avg_s = sum(wi_ms) / max(1, len(wi_ms)) * 1e-3
 
+    # HBM traffic per getcost launch from the PMC passes (rocprofv3 cannot run inside the timed process); only
+    # quoted when the committed measurement was taken at this batch size
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "r1_getcost_traffic.json")
+    if os.path.exists(tj):
+        with open(tj) as f:
+            tinfo = json.load(f)
+        if tinfo.get("batch") == B and (H, W, S) == (512, 640, 5):
+            traffic = tinfo["traffic_bytes_per_launch"]
+
     result = {
         "metric": "depth-maps/sec (640x512, 5 src views)", "value": round(value, 3), "unit": "depth-maps/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4),
@@ -136,7 +146,7 @@ def main():
                    "weights": "seeded random init (no checkpoint offline)"},
         "roofline": {"kernel": "getcost_kernel<32,4,6> (homography warp + group corr + view aggregation)",
                      "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(gc_avg_s * 1e6, 2),
                      "launches_timed": len(gc_ms)},
         "roofline_warp_init": {"kernel": "warp_corr_init_kernel<48,3>", "bound": "hbm",
