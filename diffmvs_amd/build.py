@@ -15,7 +15,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libdmvs_hip.so")
-SOURCES = ["conv2d.hip", "conv3d.hip", "warp.hip", "misc.hip"]
+SOURCES = ["conv2d.hip", "conv3d.hip", "warp.hip", "warp_bwd.hip", "misc.hip"]
 
 
 def _stale() -> bool:
@@ -32,6 +32,7 @@ def build_hip(force: bool = False, save_temps: bool = False, verbose: bool = Tru
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+           "-munsafe-fp-atomics",          # hardware global_atomic_add_f32/f64 (gradient scatter, GroupNorm stats)
            "-Wall", "-Wno-unused-function"]
     if save_temps:
         tmp = os.path.join(ROOT, "build", "temps")

@@ -248,6 +248,44 @@ class Ops:
         self._call("dmvs_getcost_f32", C.byref(d), self.stream())
         return out_cost, out_samples
 
+    # ------------------------------------------------------------------ backward (training step)
+    def warp_corr_init_bwd(self, ref, src, rt, disp_min, disp_max, gcor, gsrc=None):
+        """-> gref [B,H,W,C], gsrc [S,B,Hs,Ws,C] (accumulated into `gsrc` if given)."""
+        self._chk(ref, src, rt, disp_min, disp_max, gcor, gsrc)
+        B, H, W, Cc = ref.shape
+        S, _, Hs, Ws, _ = src.shape
+        G, D = gcor.shape[2], gcor.shape[3]
+        gref = torch.empty_like(ref)
+        if gsrc is None:
+            gsrc = torch.zeros_like(src)
+        self._call("dmvs_warp_corr_init_bwd_f32", _ptr(ref), _ptr(src), _ptr(rt), _ptr(disp_min), _ptr(disp_max), _ptr(gcor),
+                   _ptr(gref), _ptr(gsrc), B, S, Cc, G, D, H, W, Hs, Ws, self.stream())
+        return gref, gsrc
+
+    def getcost_bwd(self, ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, min_radius,
+                    max_radius, vw_shift, gcost, gsrc=None, G=4):
+        self._chk(ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, gcost, gsrc)
+        B, H, W, Cc = ref.shape
+        S = src.shape[0]
+        gref = torch.empty_like(ref)
+        if gsrc is None:
+            gsrc = torch.zeros_like(src)
+        d = _lib.GetCostDesc(ref=_ptr(ref), src=_ptr(src), rt=_ptr(rt), inv_depth=_ptr(inv_depth),
+                             confidence=_ptr(confidence), view_w=_ptr(view_w), disp_min=_ptr(disp_min),
+                             disp_max=_ptr(disp_max), out_cost=None, out_samples=None, B=B, S=S, C=Cc, G=G, n=n, H=H, W=W,
+                             vw_shift=vw_shift, cost_cstride=G * n, cost_coffset=0, samp_cstride=n, samp_coffset=0,
+                             interval=interval, min_radius=min_radius, max_radius=max_radius)
+        self._call("dmvs_getcost_bwd_f32", C.byref(d), _ptr(gcost), _ptr(gref), _ptr(gsrc), self.stream())
+        return gref, gsrc
+
+    def view_aggregate_bwd(self, cor, w, out, gout):
+        self._chk(cor, w, out, gout)
+        B, S, G, D, H, W = cor.shape
+        gcor, gw = torch.empty_like(cor), torch.empty_like(w)
+        self._call("dmvs_view_aggregate_bwd_f32", _ptr(cor), _ptr(w), _ptr(out), _ptr(gout), _ptr(gcor), _ptr(gw), B, S,
+                   G * D, H * W, self.stream())
+        return gcor, gw
+
     def view_aggregate(self, cor, w):
         """cor [B,S,G,D,H,W], w [B,S,H,W] -> [B,G,D,H,W]."""
         self._chk(cor, w)

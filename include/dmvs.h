@@ -174,6 +174,25 @@ int dmvs_warp_volume_f32(const float* src, const float* rt, const float* depth, 
                          int32_t B, int32_t C, int32_t D, int32_t H, int32_t W, int32_t Hs, int32_t Ws,
                          void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Training step: backward of the fused warp / correlation kernels w.r.t. the image features (the
+ * reference builds the sampling grid under no_grad and detaches hypotheses and GetCost's view
+ * weights: models/module.py:187, :573, models/update.py:442-445).
+ *   gref [B,H,W,C] is WRITTEN; gsrc [S][B,Hs,Ws,C] is ACCUMULATED with fp32 atomics (caller zeroes it,
+ *   or passes the running gradient of the source features).
+ */
+int dmvs_warp_corr_init_bwd_f32(const float* ref, const float* src, const float* rt,
+                                const float* disp_min, const float* disp_max, const float* gcor,
+                                float* gref, float* gsrc, int32_t B, int32_t S, int32_t C, int32_t G,
+                                int32_t D, int32_t H, int32_t W, int32_t Hs, int32_t Ws, void* stream);
+/* gcost [B,G*n,H,W] contiguous; d->out_cost / out_samples are ignored */
+int dmvs_getcost_bwd_f32(const dmvs_getcost_desc* d, const float* gcost, float* gref, float* gsrc, void* stream);
+/* backward of dmvs_view_aggregate_f32 (InitialCost, where the view weights DO require grad, :539-548):
+ * gcor [B,S,GD,HW], gw [B,S,HW] are written */
+int dmvs_view_aggregate_bwd_f32(const float* cor, const float* w, const float* out, const float* gout,
+                                float* gcor, float* gw, int32_t B, int32_t S, int32_t GD, int32_t HW,
+                                void* stream);
+
 /* view-weighted aggregation of the per-view volumes (models/module.py:539-548):
  * out[b,g,d,p] = sum_s w[b,s,p] cor[b,s,g,d,p] / (1e-8 + sum_s w[b,s,p]) */
 int dmvs_view_aggregate_f32(const float* cor, const float* w, float* out,

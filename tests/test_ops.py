@@ -331,3 +331,70 @@ def test_conv_fused_groupnorm_stats(ops, cin, cout, HW):
     assert torch.allclose(st[..., 1] / n, (yg * yg).mean(-1), rtol=1e-5, atol=1e-6)
     out = ops.groupnorm_apply(h, *dev(ops, gamma, beta), 4, stats, scale_shift=dev(ops, ss), out=h)
     close(out, want, 3e-5)
+
+
+# ------------------------------------------------------------------ backward kernels (training step)
+def _oracle_init_cor(feats, pm, dv, D):
+    B, _, H, W = feats[0].shape
+    hyp = (torch.arange(D).view(1, -1, 1, 1) / (D - 1.0)).repeat(B, 1, H, W)
+    hyp = O.disp_to_depth(hyp, (1 / dv[:, 1]).view(-1, 1, 1, 1), (1 / dv[:, 0]).view(-1, 1, 1, 1))[1]
+    ref_proj = O.compose_proj(pm[:, 0])
+    return torch.stack([O.group_corr(O.warp(feats[v], O.compose_proj(pm[:, v]), ref_proj, hyp), feats[0], 4)
+                        for v in range(1, len(feats))], 1)
+
+
+@pytest.mark.parametrize("C", [48, 32, 16])
+def test_warp_corr_init_backward(ops, C):
+    """grad w.r.t. reference and source features against autograd through the oracle
+    (grid_sample backward, reference module.py:212-218; the grid itself is built under no_grad :187)"""
+    B, S, D, H, W = 2, 2, 5, 9, 12
+    pm = _cams(B, S + 1, H, W, 4)
+    feats = [rnd(B, C, H, W, seed=40 + v).requires_grad_(True) for v in range(S + 1)]
+    dv = torch.tensor([[1 / 935.0, 1 / 425.0], [1 / 800.0, 1 / 500.0]])
+    cor = _oracle_init_cor(feats, pm, dv, D)
+    gcor = rnd(*cor.shape, seed=50)
+    cor.backward(gcor)
+    rt = ops.compose_proj(dev(ops, pm))
+    ref_nhwc = dev(ops, feats[0].detach().permute(0, 2, 3, 1))
+    src_nhwc = dev(ops, torch.stack([f.detach().permute(0, 2, 3, 1) for f in feats[1:]]))
+    gref, gsrc = ops.warp_corr_init_bwd(ref_nhwc, src_nhwc, rt, dev(ops, 1 / (1 / dv[:, 0])), dev(ops, 1 / (1 / dv[:, 1])),
+                                        dev(ops, gcor))
+    close(gref.permute(0, 3, 1, 2), feats[0].grad, 1e-4)
+    for v in range(S):
+        close(gsrc[v].permute(0, 3, 1, 2), feats[v + 1].grad, 1e-4)
+
+
+@pytest.mark.parametrize("C,n,with_conf", [(32, 6, True), (16, 4, False)])
+def test_getcost_backward(ops, C, n, with_conf):
+    B, S, H, W = 2, 3, 10, 12
+    pm = _cams(B, S + 1, H, W, 5)
+    feats = [rnd(B, C, H, W, seed=60 + v).requires_grad_(True) for v in range(S + 1)]
+    inv = rnd(B, 1, H, W, seed=70, lo=-0.1, hi=1.1)
+    conf = rnd(B, H, W, seed=71, lo=0.0, hi=1.0) if with_conf else None
+    vw = rnd(B, S, H // 2, W // 2, seed=72, lo=0.0, hi=1.0)
+    dv0, dv1 = torch.tensor([1 / 935.0, 1 / 700.0]), torch.tensor([1 / 425.0, 1 / 450.0])
+    dmax, dmin = (1 / dv0).view(-1, 1, 1, 1), (1 / dv1).view(-1, 1, 1, 1)
+    cost, _ = O.get_cost(feats, pm, inv, 2.0 / 384, dmax, dmin, n, F.interpolate(vw, scale_factor=2, mode="nearest"),
+                         conf, 4, 0.25, 4.0)
+    gcost = rnd(*cost.shape, seed=73)
+    cost.backward(gcost)
+    rt = ops.compose_proj(dev(ops, pm))
+    gref, gsrc = ops.getcost_bwd(dev(ops, feats[0].detach().permute(0, 2, 3, 1)),
+                                 dev(ops, torch.stack([f.detach().permute(0, 2, 3, 1) for f in feats[1:]])), rt,
+                                 dev(ops, inv), dev(ops, conf), dev(ops, vw), dev(ops, 1 / (1 / dv0)), dev(ops, 1 / (1 / dv1)),
+                                 n, 2.0 / 384, 0.25, 4.0, 1, dev(ops, gcost))
+    close(gref.permute(0, 3, 1, 2), feats[0].grad, 1e-4)
+    for v in range(S):
+        close(gsrc[v].permute(0, 3, 1, 2), feats[v + 1].grad, 1e-4)
+
+
+def test_view_aggregate_backward(ops):
+    B, S, G, D, H, W = 2, 3, 4, 5, 4, 6
+    cor = rnd(B, S, G, D, H, W, seed=1).requires_grad_(True)
+    w = rnd(B, S, H, W, seed=2, lo=0.05, hi=1).requires_grad_(True)
+    out = (cor * w.view(B, S, 1, 1, H, W)).sum(1) / (1e-8 + w.sum(1)).view(B, 1, 1, H, W)
+    gout = rnd(*out.shape, seed=3)
+    out.backward(gout)
+    gcor, gw = ops.view_aggregate_bwd(*dev(ops, cor.detach(), w.detach(), out.detach(), gout))
+    close(gcor, cor.grad, 1e-5)
+    close(gw, w.grad, 1e-5)
