@@ -13,7 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(PKG, "libdmvs_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_SILU = range(5)
-IN_PLAIN, IN_UPSAMPLE2, IN_UNSHUFFLE2 = range(3)
+IN_PLAIN, IN_UPSAMPLE2, IN_UNSHUFFLE2, IN_ZEROINSERT2 = range(4)
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 EW_DEPTH_TO_DISP, EW_DISP_TO_DEPTH = 0, 1
 
@@ -57,7 +57,9 @@ class GetCostDesc(C.Structure):
 SIGNATURES = {
     "dmvs_abi_version": [],
     "dmvs_conv2d_f32": [C.POINTER(Conv2dDesc), _P],
+    "dmvs_conv2d_wgrad_f32": [C.POINTER(Conv2dDesc), _P, _P, _P],
     "dmvs_conv3d_f32": [C.POINTER(Conv3dDesc), _P],
+    "dmvs_conv3d_wgrad_f32": [C.POINTER(Conv3dDesc), _P, _P, _P],
     "dmvs_compose_proj_f32": [_P, _P, _I, _I, _P],
     "dmvs_warp_corr_init_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "dmvs_warp_volume_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -1,0 +1,154 @@
+"""Training-step plumbing: torch.autograd Functions whose forward AND backward are libdmvs_hip.so kernels.
+
+Status (round 1): convolution (forward, input gradient = the forward kernel on flipped weights, weight
+gradient = MFMA reduction over pixels) and the fused warp / correlation / aggregation kernels.  The
+normalisation layers and element-wise glue of the training graph still go through ATen; the train branch of
+the update block and the DDP harness are the next round's work."""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import ops as K
+from .ops import Ops, PackedConv, pack_conv2d, pack_conv3d
+
+
+class _Conv2dFn(torch.autograd.Function):
+    """conv2d(x, weight, bias) with stride 1|2 and the fused input modes of the forward kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, ops: Ops, stride, pad, in_mode):
+        pc = pack_conv2d(weight, bias, stride=stride, pad=pad)
+        out = ops.conv2d(pc, x, in_mode=in_mode)
+        ctx.save_for_backward(x, weight)
+        ctx.ops, ctx.pc, ctx.in_mode, ctx.has_bias = ops, pc, in_mode, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        ops, pc, in_mode = ctx.ops, ctx.pc, ctx.in_mode
+        g = g.contiguous()
+        kh, kw = pc.k
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            # dX = conv(dY (zero-inserted for stride 2), W flipped and cin<->cout transposed), pad' = k-1-pad
+            wb = weight.detach().flip(2, 3).permute(1, 0, 2, 3).contiguous()
+            pcb = pack_conv2d(wb, None, stride=1, pad=(kh - 1 - pc.pad[0], kw - 1 - pc.pad[1]))
+            gl = ops.conv2d(pcb, g, in_mode=(K.IN_ZEROINSERT2 if pc.stride == 2 else K.IN_PLAIN))
+            if in_mode == K.IN_UPSAMPLE2:
+                gx = F.avg_pool2d(gl, 2) * 4.0          # adjoint of nearest x2
+            elif in_mode == K.IN_UNSHUFFLE2:
+                gx = F.pixel_shuffle(gl, 2)             # adjoint of 'b c (h p1) (w p2) -> b (c p1 p2) h w'
+            else:
+                gx = gl
+        if ctx.needs_input_grad[1]:
+            gw = ops.conv2d_wgrad(pc, x, g, in_mode=in_mode)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum((0, 2, 3))
+        return gx, gw, gb, None, None, None, None
+
+
+def conv2d(ops: Ops, x, weight, bias=None, stride=1, pad=0, in_mode=K.IN_PLAIN):
+    pad = (pad, pad) if isinstance(pad, int) else tuple(pad)
+    return _Conv2dFn.apply(x.contiguous(), weight, bias, ops, stride, pad, in_mode)
+
+
+class _Conv3dFn(torch.autograd.Function):
+    """3x3x3 conv (stride 1|2, padding 1) or stride-2 transposed conv (padding 1, output_padding 1), optional bias."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, ops: Ops, stride, transposed):
+        pc = pack_conv3d(weight, bias, stride=stride, transposed=transposed)
+        ctx.save_for_backward(x, weight)
+        ctx.ops, ctx.stride, ctx.transposed, ctx.has_bias = ops, stride, transposed, bias is not None
+        return ops.conv3d(pc, x)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        ops, stride, transposed = ctx.ops, ctx.stride, ctx.transposed
+        g = g.contiguous()
+        w = weight.detach()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            if transposed:      # adjoint of the transposed conv = the stride-2 conv with the same weight tensor
+                gx = ops.conv3d(pack_conv3d(w, stride=2), g)
+            elif stride == 2:   # adjoint of the stride-2 conv = the transposed conv with the same weight tensor
+                gx = ops.conv3d(pack_conv3d(w, stride=2, transposed=True), g)
+            else:
+                gx = ops.conv3d(pack_conv3d(w.flip(2, 3, 4).permute(1, 0, 2, 3, 4).contiguous()), g)
+        if ctx.needs_input_grad[1]:
+            if transposed:      # roles swapped: "input" = grad_out, "output gradient" = x; result is [cin_t, cout_t, 3,3,3]
+                gw = ops.conv3d_wgrad(g, x, cout=x.shape[1], stride=2)
+            else:
+                gw = ops.conv3d_wgrad(x, g, cout=g.shape[1], stride=stride)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum((0, 2, 3, 4))
+        return gx, gw, gb, None, None, None
+
+
+def conv3d(ops: Ops, x, weight, bias=None, stride=1, transposed=False):
+    return _Conv3dFn.apply(x.contiguous(), weight, bias, ops, stride, transposed)
+
+
+class _WarpCorrInitFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ref, src, rt, disp_min, disp_max, ops: Ops, D):
+        ctx.save_for_backward(ref, src, rt, disp_min, disp_max)
+        ctx.ops = ops
+        return ops.warp_corr_init(ref, src, rt, disp_min, disp_max, D)
+
+    @staticmethod
+    def backward(ctx, g):
+        ref, src, rt, disp_min, disp_max = ctx.saved_tensors
+        gref, gsrc = ctx.ops.warp_corr_init_bwd(ref, src, rt, disp_min, disp_max, g.contiguous())
+        return gref, gsrc, None, None, None, None, None
+
+
+def warp_corr_init(ops: Ops, ref, src, rt, disp_min, disp_max, D):
+    """ref [B,H,W,C], src [S,B,Hs,Ws,C] (NHWC, both may require grad) -> cor [B,S,G,D,H,W]"""
+    return _WarpCorrInitFn.apply(ref.contiguous(), src.contiguous(), rt, disp_min, disp_max, ops, D)
+
+
+class _GetCostFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, ops: Ops, n, interval, rmin, rmax, shift):
+        cost, samples = ops.getcost(ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, rmin, rmax, shift)
+        ctx.save_for_backward(ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max)
+        ctx.ops, ctx.meta = ops, (n, interval, rmin, rmax, shift)
+        ctx.mark_non_differentiable(samples)
+        return cost, samples
+
+    @staticmethod
+    def backward(ctx, g, _gs):
+        ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max = ctx.saved_tensors
+        n, interval, rmin, rmax, shift = ctx.meta
+        gref, gsrc = ctx.ops.getcost_bwd(ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, rmin,
+                                         rmax, shift, g.contiguous())
+        return (gref, gsrc) + (None,) * 12
+
+
+def getcost(ops: Ops, ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, rmin, rmax, vw_shift):
+    """GetCost with gradients to the image features only (hypotheses / view weights are detached in the reference)."""
+    return _GetCostFn.apply(ref.contiguous(), src.contiguous(), rt, inv_depth, confidence, view_w, disp_min, disp_max, ops, n,
+                            interval, rmin, rmax, vw_shift)
+
+
+class _ViewAggregateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cor, w, ops: Ops):
+        out = ops.view_aggregate(cor, w)
+        ctx.save_for_backward(cor, w, out)
+        ctx.ops = ops
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        cor, w, out = ctx.saved_tensors
+        gcor, gw = ctx.ops.view_aggregate_bwd(cor, w, out, g.contiguous())
+        return gcor, gw, None
+
+
+def view_aggregate(ops: Ops, cor, w):
+    return _ViewAggregateFn.apply(cor.contiguous(), w.contiguous(), ops)

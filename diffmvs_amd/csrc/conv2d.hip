@@ -74,8 +74,9 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_mfma_kernel(const dmvs_conv
 
     // ---- addressing of the logical input, all in 32-bit element offsets from per-batch bases
     const int mode = d.in_mode;
-    const int pW = mode == DMVS_IN_UPSAMPLE2 ? (d.Win >> 1) : (mode == DMVS_IN_UNSHUFFLE2 ? (d.Win << 1) : d.Win);
-    const int pH = mode == DMVS_IN_UPSAMPLE2 ? (d.Hin >> 1) : (mode == DMVS_IN_UNSHUFFLE2 ? (d.Hin << 1) : d.Hin);
+    const bool halfres = mode == DMVS_IN_UPSAMPLE2 || mode == DMVS_IN_ZEROINSERT2;
+    const int pW = halfres ? (d.Win >> 1) : (mode == DMVS_IN_UNSHUFFLE2 ? (d.Win << 1) : d.Win);
+    const int pH = halfres ? (d.Hin >> 1) : (mode == DMVS_IN_UNSHUFFLE2 ? (d.Hin << 1) : d.Hin);
     const int plane0 = pH * pW, plane1 = d.Hin * d.Win;
     const int pc0 = mode == DMVS_IN_UNSHUFFLE2 ? (d.c0 >> 2) : d.c0;
     const float* in0b = d.in0 + (size_t)b * pc0 * plane0;
@@ -87,10 +88,11 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_mfma_kernel(const dmvs_conv
         const int ci = e / PLANE, rem = e - ci * PLANE;
         const int r = rem / TW, c = rem - r * TW;
         const int cig = c0 + ci, iy = gy0 + r, ix = gx0 + c;
-        const bool ok = rem < TH * TW && cig < cin && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win;
+        const bool ok = rem < TH * TW && cig < cin && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win &&
+                        !(mode == DMVS_IN_ZEROINSERT2 && ((iy | ix) & 1));
         int off;
         if (mode == DMVS_IN_PLAIN) off = cig * plane0 + iy * pW + ix;
-        else if (mode == DMVS_IN_UPSAMPLE2) off = cig * plane0 + (iy >> 1) * pW + (ix >> 1);
+        else if (halfres) off = cig * plane0 + (iy >> 1) * pW + (ix >> 1);
         else off = (cig >> 2) * plane0 + (iy * 2 + ((cig >> 1) & 1)) * pW + ix * 2 + (cig & 1);
         off_out = (ok && cig < d.c0) ? off : -1;
         if (!ok) return nullptr;
@@ -340,6 +342,147 @@ int launch_conv2d(const dmvs_conv2d_desc& d, hipStream_t st) {
     return DMVS_EINVAL;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient:  gw[ci][t][co] += sum_pixels dY[co][p] * X[ci][p (+) tap t]   as an MFMA GEMM with the
+// reduction over pixels:  A = dY [co = lane&15][k = pixel], B = X [k = pixel][j = (ci,t) = lane&15].
+// Workgroup = (8 input channels) x (16 output channels), sweeping 16x16 pixel tiles in a grid-stride loop;
+// wave w reduces rows 4w..4w+3 of each tile into its own accumulators, which are added to gw with hardware
+// fp32 atomics once at the end.  Same LDS-DMA staged halo tile as the forward.
+template <int KH, int KW, int S>
+__global__ void __launch_bounds__(DMVS_BLOCK) conv2d_wgrad_kernel(const dmvs_conv2d_desc d, const float* __restrict__ gout,
+                                                                  float* __restrict__ gw, int tiles_x, int tiles_y) {
+    constexpr int T = KH * KW, CK = 8;
+    constexpr int TW = 15 * S + KW, TH = 15 * S + KH;
+    constexpr int PLANE = pad16mod32(TH * TW);
+    constexpr int GROW = 257;                         // dY tile row pitch: 256 pixels + 1 (bank spread)
+    constexpr int NTN = (CK * T + 15) / 16;           // MFMA n-tiles over the (ci, tap) pairs of the chunk
+    constexpr int IN_IT = (CK * PLANE + DMVS_BLOCK - 1) / DMVS_BLOCK, G_IT = (16 * GROW + DMVS_BLOCK - 1) / DMVS_BLOCK;
+    __shared__ float lds[CK * PLANE + 16 * GROW];
+    float* s_in = lds;
+    float* s_g = lds + CK * PLANE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int c0 = blockIdx.y * CK, cobase = blockIdx.z * 16;
+    const int cin = d.c0 + d.c1;
+    const int mode = d.in_mode;
+    const bool halfres = mode == DMVS_IN_UPSAMPLE2 || mode == DMVS_IN_ZEROINSERT2;
+    const int pW = halfres ? (d.Win >> 1) : (mode == DMVS_IN_UNSHUFFLE2 ? (d.Win << 1) : d.Win);
+    const int pH = halfres ? (d.Hin >> 1) : (mode == DMVS_IN_UNSHUFFLE2 ? (d.Hin << 1) : d.Hin);
+    const int plane0 = pH * pW, plane1 = d.Hin * d.Win;
+    const int pc0 = mode == DMVS_IN_UNSHUFFLE2 ? (d.c0 >> 2) : d.c0;
+    const size_t oplane = (size_t)d.Hout * d.Wout;
+
+    // this lane's (ci, tap) column of every n-tile -> fixed LDS offset inside the halo tile
+    int boff[NTN];
+#pragma unroll
+    for (int nt = 0; nt < NTN; ++nt) {
+        const int jj = nt * 16 + m;
+        const int ci = jj / T, t = jj - ci * T;
+        boff[nt] = jj < CK * T ? ci * PLANE + (t / KW) * TW + (t % KW) : 0;
+    }
+    f32x4 acc[NTN];
+#pragma unroll
+    for (int nt = 0; nt < NTN; ++nt) acc[nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const int ntiles = tiles_x * tiles_y * d.B;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int tq = tile;
+        const int tx = tq % tiles_x; tq /= tiles_x;
+        const int ty = tq % tiles_y;
+        const int b = tq / tiles_y;
+        const int ox0 = tx * 16, oy0 = ty * 16;
+        const int gy0 = oy0 * S - d.pad_h, gx0 = ox0 * S - d.pad_w;
+        const float* in0b = d.in0 + (size_t)b * pc0 * plane0;
+        const float* mul0b = d.mul0 ? d.mul0 + (size_t)b * pc0 * plane0 : nullptr;
+        const float* in1b = d.in1 ? d.in1 + (size_t)b * d.c1 * plane1 : d.in0;
+        const float* gb = gout + (size_t)b * d.cout * oplane;
+        __syncthreads();                              // previous tile fully consumed
+#pragma unroll 2
+        for (int i = 0; i < IN_IT; ++i) {
+            const int e = i * DMVS_BLOCK + tid;
+            if (e < CK * PLANE) {
+                const int ci = e / PLANE, rem = e - ci * PLANE;
+                const int r = rem / TW, c = rem - r * TW;
+                const int cig = c0 + ci, iy = gy0 + r, ix = gx0 + c;
+                const bool ok = rem < TH * TW && cig < cin && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win &&
+                                !(mode == DMVS_IN_ZEROINSERT2 && ((iy | ix) & 1));
+                int off;
+                if (mode == DMVS_IN_PLAIN) off = cig * plane0 + iy * pW + ix;
+                else if (halfres) off = cig * plane0 + (iy >> 1) * pW + (ix >> 1);
+                else off = (cig >> 2) * plane0 + (iy * 2 + ((cig >> 1) & 1)) * pW + ix * 2 + (cig & 1);
+                const float* src = !ok ? dmvs_zero16 : (cig < d.c0 ? in0b + off : in1b + ((cig - d.c0) * plane1 + iy * d.Win + ix));
+                __builtin_amdgcn_global_load_lds(src, DMVS_LDS(s_in + i * DMVS_BLOCK + wave * 64), 4, 0, 0);
+            }
+        }
+#pragma unroll 2
+        for (int i = 0; i < G_IT; ++i) {
+            const int e = i * DMVS_BLOCK + tid;
+            if (e < 16 * GROW) {
+                const int co = e / GROW, p = e - co * GROW;
+                const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
+                const bool ok = p < 256 && cobase + co < d.cout && oy < d.Hout && ox < d.Wout;
+                const float* src = ok ? gb + ((size_t)(cobase + co) * oplane + (size_t)oy * d.Wout + ox) : dmvs_zero16;
+                __builtin_amdgcn_global_load_lds(src, DMVS_LDS(s_g + i * DMVS_BLOCK + wave * 64), 4, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (mul0b) {                                   // r*h gating (GRU candidate conv): X = in0 * mul0 on the in0 channels
+            for (int i = 0; i < IN_IT; ++i) {
+                const int e = i * DMVS_BLOCK + tid;
+                if (e < CK * PLANE) {
+                    const int ci = e / PLANE, rem = e - ci * PLANE;
+                    const int r = rem / TW, c = rem - r * TW;
+                    const int cig = c0 + ci, iy = gy0 + r, ix = gx0 + c;
+                    if (rem < TH * TW && cig < d.c0 && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win)
+                        s_in[e] *= mul0b[cig * plane0 + iy * pW + ix];
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll 1
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = wave * 4 + rr;
+#pragma unroll
+            for (int xg = 0; xg < 4; ++xg) {
+                const float av = s_g[m * GROW + row * 16 + xg * 4 + kq];
+                const float* ip = s_in + (row * S) * TW + (xg * 4 + kq) * S;
+#pragma unroll
+                for (int nt = 0; nt < NTN; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, ip[boff[nt]], acc[nt], 0, 0, 0);
+            }
+        }
+    }
+    // D[co = 4*kq + r][j = m]: one fp32 atomic per (co, ci, tap) and wave
+#pragma unroll
+    for (int nt = 0; nt < NTN; ++nt) {
+        const int jj = nt * 16 + m;
+        const int ci = jj / T, t = jj - ci * T;
+        if (jj >= CK * T || c0 + ci >= cin) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = cobase + kq * 4 + r;
+            const float v = acc[nt][r];
+            if (co < d.cout && v != 0.0f) atomicAdd(gw + ((size_t)(c0 + ci) * T + t) * d.cout_pad + co, v);
+        }
+    }
+}
+
+template <int KH, int KW, int S>
+int launch_wgrad(const dmvs_conv2d_desc& d, const float* gout, float* gw, hipStream_t st) {
+    const int tiles_x = (d.Wout + 15) / 16, tiles_y = (d.Hout + 15) / 16;
+    const int ntiles = tiles_x * tiles_y * d.B;
+    const int cin = d.c0 + d.c1;
+    const int gy = (cin + 7) / 8, gz = (d.cout + 15) / 16;
+    // enough workgroups to fill the chip, few enough that the final atomics stay cheap
+    int gx = (2048 + gy * gz - 1) / (gy * gz);
+    if (gx > ntiles) gx = ntiles;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL((conv2d_wgrad_kernel<KH, KW, S>), dim3(gx, gy, gz), dim3(DMVS_BLOCK), 0, st, d, gout, gw, tiles_x, tiles_y);
+    return dmvs_launch_status();
+}
+
 }  // namespace
 
 extern "C" int dmvs_conv2d_f32(const dmvs_conv2d_desc* dp, void* stream) {
@@ -350,7 +493,7 @@ extern "C" int dmvs_conv2d_f32(const dmvs_conv2d_desc* dp, void* stream) {
     if (d.c1 > 0 && (!d.in1 || d.in_mode != DMVS_IN_PLAIN)) return DMVS_EINVAL;
     if (d.mul0 && d.in_mode != DMVS_IN_PLAIN) return DMVS_EINVAL;
     if (d.in_mode == DMVS_IN_UNSHUFFLE2 && (d.c0 % 4)) return DMVS_EINVAL;
-    if (d.in_mode == DMVS_IN_UPSAMPLE2 && ((d.Hin | d.Win) & 1)) return DMVS_EINVAL;
+    if ((d.in_mode == DMVS_IN_UPSAMPLE2 || d.in_mode == DMVS_IN_ZEROINSERT2) && ((d.Hin | d.Win) & 1)) return DMVS_EINVAL;
     if (d.gru_z && (!d.gru_h || d.act != DMVS_ACT_TANH)) return DMVS_EINVAL;
     if (d.gn_stats && (d.gn_groups != 4 || d.cout % 4)) return DMVS_EINVAL;
     const int eh = (d.Hin + 2 * d.pad_h - d.kh) / d.stride + 1, ew = (d.Win + 2 * d.pad_w - d.kw) / d.stride + 1;
@@ -363,9 +506,32 @@ extern "C" int dmvs_conv2d_f32(const dmvs_conv2d_desc* dp, void* stream) {
         case 331: return launch_conv2d<3, 3, 1>(d, st);
         case 332: return launch_conv2d<3, 3, 2>(d, st);
         case 552: return launch_conv2d<5, 5, 2>(d, st);
+        case 551: return launch_conv2d<5, 5, 1>(d, st);   // input gradient of the 5x5 stride-2 layers
         case 771: return launch_conv2d<7, 7, 1>(d, st);
         case 151: return launch_conv2d<1, 5, 1>(d, st);
         case 511: return launch_conv2d<5, 1, 1>(d, st);
+        default: return DMVS_EINVAL;
+    }
+}
+
+extern "C" int dmvs_conv2d_wgrad_f32(const dmvs_conv2d_desc* dp, const float* grad_out, float* gw, void* stream) {
+    if (!dp || !grad_out || !gw) return DMVS_EINVAL;
+    const dmvs_conv2d_desc& d = *dp;
+    hipStream_t st = (hipStream_t)stream;
+    if (d.cout_pad % 8 || d.cout > d.cout_pad || d.B <= 0 || !d.in0) return DMVS_EINVAL;
+    if (d.c1 > 0 && (!d.in1 || d.in_mode != DMVS_IN_PLAIN)) return DMVS_EINVAL;
+    if (d.mul0 && d.in_mode != DMVS_IN_PLAIN) return DMVS_EINVAL;
+    const int eh = (d.Hin + 2 * d.pad_h - d.kh) / d.stride + 1, ew = (d.Win + 2 * d.pad_w - d.kw) / d.stride + 1;
+    if (eh != d.Hout || ew != d.Wout) return DMVS_EINVAL;
+    const int key = d.kh * 100 + d.kw * 10 + d.stride;
+    switch (key) {
+        case 111: return launch_wgrad<1, 1, 1>(d, grad_out, gw, st);
+        case 331: return launch_wgrad<3, 3, 1>(d, grad_out, gw, st);
+        case 332: return launch_wgrad<3, 3, 2>(d, grad_out, gw, st);
+        case 552: return launch_wgrad<5, 5, 2>(d, grad_out, gw, st);
+        case 771: return launch_wgrad<7, 7, 1>(d, grad_out, gw, st);
+        case 151: return launch_wgrad<1, 5, 1>(d, grad_out, gw, st);
+        case 511: return launch_wgrad<5, 1, 1>(d, grad_out, gw, st);
         default: return DMVS_EINVAL;
     }
 }

@@ -378,3 +378,119 @@ extern "C" int dmvs_conv3d_f32(const dmvs_conv3d_desc* dp, void* stream) {
     }
     return dmvs_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient of the 3x3x3 convolutions (stride 1|2), the 3-D sibling of conv2d_wgrad_kernel:
+//   gw[ci][t][co] += sum_voxels dY[co][v] * X[ci][v*S - 1 + tap t]
+// MFMA GEMM with the reduction over voxels: A = dY [co = lane&15][k = voxel], B = X [k][j = (ci,t) = lane&15].
+// Workgroup = CK input channels x 16 output channels, grid-stride over 16(x) x 4(y) x 4(d) voxel tiles; wave w
+// reduces depth slice w.  The transposed layers' weight gradient is the same reduction with the roles of
+// input and output gradient swapped (caller-side).
+template <int S>
+__global__ void __launch_bounds__(DMVS_BLOCK) conv3d_wgrad_kernel(const dmvs_conv3d_desc d, const float* __restrict__ gout,
+                                                                  float* __restrict__ gw, int tiles_x, int tiles_y, int tiles_d) {
+    constexpr int CK = S == 1 ? 8 : 2;
+    constexpr int IW = 15 * S + 3, IH = 3 * S + 3, ID = 3 * S + 3;
+    constexpr int PLANE = pad16mod32_3d(ID * IH * IW);
+    constexpr int GROW = 257;
+    constexpr int NTN = (CK * 27 + 15) / 16;
+    constexpr int IN_IT = (CK * PLANE + DMVS_BLOCK - 1) / DMVS_BLOCK, G_IT = (16 * GROW + DMVS_BLOCK - 1) / DMVS_BLOCK;
+    __shared__ float lds[CK * PLANE + 16 * GROW];
+    float* s_in = lds;
+    float* s_g = lds + CK * PLANE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int c0 = blockIdx.y * CK, cobase = blockIdx.z * 16;
+    const size_t ivol = (size_t)d.Din * d.Hin * d.Win, ovol = (size_t)d.Dout * d.Hout * d.Wout;
+    const int vol = (int)ivol;
+    int boff[NTN];
+#pragma unroll
+    for (int nt = 0; nt < NTN; ++nt) {
+        const int jj = nt * 16 + m;
+        const int ci = jj / 27, t = jj - ci * 27;
+        boff[nt] = jj < CK * 27 ? ci * PLANE + ((t / 9) * IH + (t / 3) % 3) * IW + t % 3 : 0;
+    }
+    f32x4 acc[NTN];
+#pragma unroll
+    for (int nt = 0; nt < NTN; ++nt) acc[nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const int ntiles = tiles_x * tiles_y * tiles_d * d.B;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int tq = tile;
+        const int tx = tq % tiles_x; tq /= tiles_x;
+        const int ty = tq % tiles_y; tq /= tiles_y;
+        const int td = tq % tiles_d;
+        const int b = tq / tiles_d;
+        const int x0 = tx * 16, y0 = ty * 4, d0 = td * 4;
+        const float* inb = d.in + (size_t)b * d.cin * ivol;
+        const float* gb = gout + (size_t)b * d.cout * ovol;
+        __syncthreads();
+#pragma unroll 2
+        for (int i = 0; i < IN_IT; ++i) {
+            const int e = i * DMVS_BLOCK + tid;
+            if (e < CK * PLANE) {
+                const int ci = e / PLANE, rem = e - ci * PLANE;
+                const int zz = rem / (IH * IW), rem2 = rem - zz * (IH * IW);
+                const int yy = rem2 / IW, xx = rem2 - yy * IW;
+                const int gd = d0 * S - 1 + zz, gy = y0 * S - 1 + yy, gx = x0 * S - 1 + xx;
+                const bool ok = rem < ID * IH * IW && c0 + ci < d.cin && gd >= 0 && gd < d.Din && gy >= 0 && gy < d.Hin &&
+                                gx >= 0 && gx < d.Win;
+                const float* src = ok ? inb + ((c0 + ci) * vol + (gd * d.Hin + gy) * d.Win + gx) : dmvs_zero16_3d;
+                __builtin_amdgcn_global_load_lds(src, DMVS_LDS(s_in + i * DMVS_BLOCK + wave * 64), 4, 0, 0);
+            }
+        }
+#pragma unroll 2
+        for (int i = 0; i < G_IT; ++i) {
+            const int e = i * DMVS_BLOCK + tid;
+            if (e < 16 * GROW) {
+                const int co = e / GROW, p = e - co * GROW;
+                const int od = d0 + (p >> 6), oy = y0 + ((p >> 4) & 3), ox = x0 + (p & 15);
+                const bool ok = p < 256 && cobase + co < d.cout && od < d.Dout && oy < d.Hout && ox < d.Wout;
+                const float* src = ok ? gb + ((size_t)(cobase + co) * ovol + ((size_t)od * d.Hout + oy) * d.Wout + ox) : dmvs_zero16_3d;
+                __builtin_amdgcn_global_load_lds(src, DMVS_LDS(s_g + i * DMVS_BLOCK + wave * 64), 4, 0, 0);
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int yy = 0; yy < 4; ++yy) {
+#pragma unroll
+            for (int xg = 0; xg < 4; ++xg) {
+                const float av = s_g[m * GROW + wave * 64 + yy * 16 + xg * 4 + kq];
+                const float* ip = s_in + ((wave * S) * IH + yy * S) * IW + (xg * 4 + kq) * S;
+#pragma unroll
+                for (int nt = 0; nt < NTN; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, ip[boff[nt]], acc[nt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NTN; ++nt) {
+        const int jj = nt * 16 + m;
+        const int ci = jj / 27, t = jj - ci * 27;
+        if (jj >= CK * 27 || c0 + ci >= d.cin) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = cobase + kq * 4 + r;
+            const float v = acc[nt][r];
+            if (co < d.cout && v != 0.0f) atomicAdd(gw + ((size_t)(c0 + ci) * 27 + t) * d.cout_pad + co, v);
+        }
+    }
+}
+
+extern "C" int dmvs_conv3d_wgrad_f32(const dmvs_conv3d_desc* dp, const float* grad_out, float* gw, void* stream) {
+    if (!dp || !grad_out || !gw) return DMVS_EINVAL;
+    const dmvs_conv3d_desc& d = *dp;
+    if (d.transposed || (d.stride != 1 && d.stride != 2) || !d.in || d.cout > d.cout_pad) return DMVS_EINVAL;
+    const int ed = (d.Din - 1) / d.stride + 1, eh = (d.Hin - 1) / d.stride + 1, ew = (d.Win - 1) / d.stride + 1;
+    if (ed != d.Dout || eh != d.Hout || ew != d.Wout) return DMVS_EINVAL;
+    const int tiles_x = (d.Wout + 15) / 16, tiles_y = (d.Hout + 3) / 4, tiles_d = (d.Dout + 3) / 4;
+    const int ntiles = tiles_x * tiles_y * tiles_d * d.B;
+    const int ck = d.stride == 1 ? 8 : 2;
+    const int gy = (d.cin + ck - 1) / ck, gz = (d.cout + 15) / 16;
+    int gx = (2048 + gy * gz - 1) / (gy * gz);
+    if (gx > ntiles) gx = ntiles;
+    if (gx < 1) gx = 1;
+    dim3 grid(gx, gy, gz), block(DMVS_BLOCK);
+    if (d.stride == 1) hipLaunchKernelGGL((conv3d_wgrad_kernel<1>), grid, block, 0, (hipStream_t)stream, d, grad_out, gw, tiles_x, tiles_y, tiles_d);
+    else hipLaunchKernelGGL((conv3d_wgrad_kernel<2>), grid, block, 0, (hipStream_t)stream, d, grad_out, gw, tiles_x, tiles_y, tiles_d);
+    return dmvs_launch_status();
+}

@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU, ACT_TANH, IN_PLAIN, IN_UNSHUFFLE2,  # noqa: F401
-                   IN_UPSAMPLE2, LAYOUT_NCHW, LAYOUT_NHWC)
+                   IN_UPSAMPLE2, IN_ZEROINSERT2, LAYOUT_NCHW, LAYOUT_NHWC)
 
 
 def _round_up(x: int, m: int) -> int:
@@ -155,7 +155,7 @@ class Ops:
         B = x0.shape[0]
         if in_mode == IN_PLAIN:
             c0, Hin, Win = x0.shape[1], x0.shape[2], x0.shape[3]
-        elif in_mode == IN_UPSAMPLE2:
+        elif in_mode in (IN_UPSAMPLE2, IN_ZEROINSERT2):
             c0, Hin, Win = x0.shape[1], x0.shape[2] * 2, x0.shape[3] * 2
         else:
             c0, Hin, Win = x0.shape[1] * 4, x0.shape[2] // 2, x0.shape[3] // 2
@@ -179,6 +179,29 @@ class Ops:
         self._call("dmvs_conv2d_f32", C.byref(d), self.stream())
         return out
 
+    def conv2d_wgrad(self, pc: PackedConv, x0, grad_out, x1=None, *, mul0=None, in_mode=IN_PLAIN):
+        """Weight gradient of conv2d(pc, x0, x1, mul0=..., in_mode=...) in torch layout [cout, cin, kh, kw]."""
+        self._chk(x0, x1, mul0, grad_out)
+        B = x0.shape[0]
+        if in_mode == IN_PLAIN:
+            c0, Hin, Win = x0.shape[1], x0.shape[2], x0.shape[3]
+        elif in_mode in (IN_UPSAMPLE2, IN_ZEROINSERT2):
+            c0, Hin, Win = x0.shape[1], x0.shape[2] * 2, x0.shape[3] * 2
+        else:
+            c0, Hin, Win = x0.shape[1] * 4, x0.shape[2] // 2, x0.shape[3] // 2
+        c1 = 0 if x1 is None else x1.shape[1]
+        kh, kw = pc.k
+        Hout, Wout = grad_out.shape[2], grad_out.shape[3]
+        gw = torch.zeros(pc.cin, kh, kw, pc.cout_pad, dtype=torch.float32, device=self.device)
+        d = _lib.Conv2dDesc(
+            in0=_ptr(x0), in1=_ptr(x1), mul0=_ptr(mul0), weight=None, scale=None, shift=None, residual=None, gru_z=None,
+            gru_h=None, out=None, gn_stats=None, gn_groups=0, B=B, c0=c0, c1=c1, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout,
+            cout=pc.cout, cout_pad=pc.cout_pad, kh=kh, kw=kw, stride=pc.stride, pad_h=pc.pad[0], pad_w=pc.pad[1],
+            in_mode=in_mode, act=ACT_NONE, res_mode=IN_PLAIN, res_after_act=0, out_layout=LAYOUT_NCHW,
+            out_cstride=pc.cout, out_coffset=0, post_scale=1.0)
+        self._call("dmvs_conv2d_wgrad_f32", C.byref(d), _ptr(grad_out), _ptr(gw), self.stream())
+        return gw[..., :pc.cout].permute(3, 0, 1, 2).contiguous()
+
     # ------------------------------------------------------------------ conv3d
     def conv3d(self, pc: PackedConv, x, *, act=ACT_NONE, residual=None, out=None):
         self._chk(x, residual, out)
@@ -197,6 +220,19 @@ class Ops:
                             transposed=int(pc.transposed), act=act)
         self._call("dmvs_conv3d_f32", C.byref(d), self.stream())
         return out
+
+    def conv3d_wgrad(self, x, grad_out, cout, stride):
+        """gw of a (non-transposed) 3x3x3 conv: x [B,cin,D,H,W], grad_out [B,cout,Do,Ho,Wo] -> [cout,cin,3,3,3]"""
+        self._chk(x, grad_out)
+        B, cin, Din, Hin, Win = x.shape
+        Dout, Hout, Wout = grad_out.shape[2:]
+        cp = _pad_cout(cout)
+        gw = torch.zeros(cin, 27, cp, dtype=torch.float32, device=self.device)
+        d = _lib.Conv3dDesc(in_=_ptr(x), weight=None, scale=None, shift=None, residual=None, out=None, B=B, cin=cin,
+                            cout=cout, cout_pad=cp, Din=Din, Hin=Hin, Win=Win, Dout=Dout, Hout=Hout, Wout=Wout,
+                            stride=stride, transposed=0, act=ACT_NONE)
+        self._call("dmvs_conv3d_wgrad_f32", C.byref(d), _ptr(grad_out), _ptr(gw), self.stream())
+        return gw[..., :cout].permute(2, 0, 1).reshape(cout, cin, 3, 3, 3).contiguous()
 
     # ------------------------------------------------------------------ geometry / cost volumes
     def compose_proj(self, proj):

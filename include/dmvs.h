@@ -30,7 +30,8 @@ extern "C" {
 /* activation codes for the fused epilogues */
 enum { DMVS_ACT_NONE = 0, DMVS_ACT_RELU = 1, DMVS_ACT_SIGMOID = 2, DMVS_ACT_TANH = 3, DMVS_ACT_SILU = 4 };
 /* how the logical input of a 2-D convolution is read from memory */
-enum { DMVS_IN_PLAIN = 0, DMVS_IN_UPSAMPLE2 = 1 /* nearest x2, F.interpolate */, DMVS_IN_UNSHUFFLE2 = 2 /* einops 'b c (h p1) (w p2) -> b (c p1 p2) h w' */ };
+enum { DMVS_IN_PLAIN = 0, DMVS_IN_UPSAMPLE2 = 1 /* nearest x2, F.interpolate */, DMVS_IN_UNSHUFFLE2 = 2 /* einops 'b c (h p1) (w p2) -> b (c p1 p2) h w' */,
+       DMVS_IN_ZEROINSERT2 = 3 /* logical (2y,2x) = physical (y,x), zero elsewhere: the input-gradient of a stride-2 conv as a stride-1 conv */ };
 enum { DMVS_LAYOUT_NCHW = 0, DMVS_LAYOUT_NHWC = 1 };
 
 int dmvs_abi_version(void);
@@ -86,6 +87,15 @@ typedef struct dmvs_conv2d_desc {
 
 int dmvs_conv2d_f32(const dmvs_conv2d_desc* d, void* stream);
 
+/* Weight gradient of the convolution described by `d` (its input side: in0 / in1 / mul0 / in_mode / kh / kw /
+ * stride / pad / cout / cout_pad / B / Hin / Win / Hout / Wout; epilogue fields are ignored):
+ *   gw[ci][kh][kw][co] += sum_{b,y,x} grad_out[b,co,y,x] * X[b,ci,y*stride+ky-pad,x*stride+kx-pad]
+ * grad_out [B,cout,Hout,Wout] NCHW; gw in the kernel weight layout [c0+c1][kh][kw][cout_pad], accumulated with
+ * fp32 atomics (the caller zeroes it).  The input gradient needs no entry point of its own: it is
+ * dmvs_conv2d_f32 on grad_out with the spatially flipped, cin<->cout transposed weights (DMVS_IN_ZEROINSERT2 for
+ * stride 2). */
+int dmvs_conv2d_wgrad_f32(const dmvs_conv2d_desc* d, const float* grad_out, float* gw, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * 3-D convolution 3x3x3, padding 1 (module.Conv3d, models/module.py:66-102) and stride-2
  * transposed convolution with output_padding 1 (module.Deconv3d, :110-144, :436-437), with
@@ -110,6 +120,12 @@ typedef struct dmvs_conv3d_desc {
 } dmvs_conv3d_desc;
 
 int dmvs_conv3d_f32(const dmvs_conv3d_desc* d, void* stream);
+
+/* Weight gradient of the (non-transposed, stride 1|2) 3x3x3 convolution described by `d`:
+ *   gw[ci][27][co] += sum_{b,voxel} grad_out[b,co,voxel] * in[b,ci,voxel*stride - 1 + tap]     (fp32 atomics; caller zeroes gw)
+ * The transposed layers use the same entry point with the roles of `in` and `grad_out` swapped.  Input gradients
+ * need no entry point: stride 1 = dmvs_conv3d_f32 on flipped/transposed weights, stride 2 <-> transposed. */
+int dmvs_conv3d_wgrad_f32(const dmvs_conv3d_desc* d, const float* grad_out, float* gw, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Camera composition.  For each batch item b and source view s = 1..S:

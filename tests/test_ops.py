@@ -398,3 +398,60 @@ def test_view_aggregate_backward(ops):
     gcor, gw = ops.view_aggregate_bwd(*dev(ops, cor.detach(), w.detach(), out.detach(), gout))
     close(gcor, cor.grad, 1e-5)
     close(gw, w.grad, 1e-5)
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,in_mode", [
+    (8, 16, 3, 1, 1, "plain"), (6, 10, 5, 2, 2, "plain"), (16, 8, 3, 2, 1, "plain"), (12, 20, 1, 1, 0, "plain"),
+    (5, 16, 7, 1, 3, "plain"), (8, 8, 3, 1, 1, "upsample"), (4, 12, 1, 1, 0, "unshuffle"), (9, 7, (1, 5), 1, (0, 2), "plain"),
+])
+def test_conv2d_autograd(ops, cin, cout, k, stride, pad, in_mode):
+    """forward / input gradient / weight gradient / bias gradient of the training conv against F.conv2d's autograd"""
+    from diffmvs_amd import autograd as A
+    B, H, W = 2, 12, 20
+    ks = (k, k) if isinstance(k, int) else k
+    x = rnd(B, cin, H, W, seed=1).requires_grad_(True)
+    w = (rnd(cout, cin * (4 if in_mode == "unshuffle" else 1), *ks, seed=2) * 0.3).requires_grad_(True)
+    b = rnd(cout, seed=3).requires_grad_(True)
+    if in_mode == "upsample":
+        xin = F.interpolate(x, scale_factor=2, mode="nearest")
+    elif in_mode == "unshuffle":
+        xin = O._pixel_unshuffle(x)
+    else:
+        xin = x
+    ref = F.conv2d(xin, w, b, stride, pad)
+    g = rnd(*ref.shape, seed=4)
+    ref.backward(g)
+    xd, wd, bd = [t.detach().to(ops.device).requires_grad_(True) for t in (x, w, b)]
+    mode = {"plain": K.IN_PLAIN, "upsample": K.IN_UPSAMPLE2, "unshuffle": K.IN_UNSHUFFLE2}[in_mode]
+    out = A.conv2d(ops, xd, wd, bd, stride=stride, pad=pad, in_mode=mode)
+    close(out, ref.detach(), 3e-5)
+    out.backward(dev(ops, g))
+    close(xd.grad, x.grad, 1e-4)
+    close(wd.grad, w.grad, 1e-4)
+    close(bd.grad, b.grad, 1e-4)
+
+
+@pytest.mark.parametrize("cin,cout,stride,transposed", [(4, 8, 1, False), (8, 16, 2, False), (16, 8, 2, True), (8, 1, 1, False),
+                                                         (20, 12, 1, False)])
+def test_conv3d_autograd(ops, cin, cout, stride, transposed):
+    from diffmvs_amd import autograd as A
+    B, D, H, W = 2, 6, 8, 10
+    if transposed:
+        D, H, W = 3, 4, 5
+    x = rnd(B, cin, D, H, W, seed=1).requires_grad_(True)
+    b = rnd(cout, seed=3).requires_grad_(True)
+    if transposed:
+        w = (rnd(cin, cout, 3, 3, 3, seed=2) * 0.2).requires_grad_(True)
+        ref = F.conv_transpose3d(x, w, b, 2, 1, 1)
+    else:
+        w = (rnd(cout, cin, 3, 3, 3, seed=2) * 0.2).requires_grad_(True)
+        ref = F.conv3d(x, w, b, stride, 1)
+    g = rnd(*ref.shape, seed=4)
+    ref.backward(g)
+    xd, wd, bd = [t.detach().to(ops.device).requires_grad_(True) for t in (x, w, b)]
+    out = A.conv3d(ops, xd, wd, bd, stride=stride, transposed=transposed)
+    close(out, ref.detach(), 3e-5)
+    out.backward(dev(ops, g))
+    close(xd.grad, x.grad, 1e-4)
+    close(wd.grad, w.grad, 1e-4)
+    close(bd.grad, b.grad, 1e-4)
