@@ -65,7 +65,7 @@ def _texture(xw: np.ndarray, yw: np.ndarray, rs: np.random.RandomState) -> np.nd
 
 
 def synth_inputs(H: int, W: int, n_src: int, B: int = 1, seed: int = 0, numdepth: int = 384,
-                 depth_min: float = 425.0, depth_max: float = 935.0, device="cpu"):
+                 depth_min: float = 425.0, depth_max: float = 935.0, device="cpu", with_gt: bool = False):
     """One batch of B reference views, each with n_src source views.
 
     Geometry follows SURVEY section 8d: K = [[1.2W,0,W/2],[0,1.2W,H/2],[0,0,1]], view v rotated
@@ -112,7 +112,28 @@ def synth_inputs(H: int, W: int, n_src: int, B: int = 1, seed: int = 0, numdepth
     depth_values = np.tile(dv[None], (B, 1))
     imgs_t = [torch.from_numpy(imgs[v]).to(device) for v in range(V)]
     proj_t = {k: torch.from_numpy(p).to(device) for k, p in proj.items()}
-    return imgs_t, proj_t, torch.from_numpy(depth_values).to(device)
+    if not with_gt:
+        return imgs_t, proj_t, torch.from_numpy(depth_values).to(device)
+    # ground-truth depth of the reference view (camera 0 = world frame) on the scene plane, per stage, with a
+    # band of invalid (0) pixels, plus the validity masks (contract: reference datasets/dtu.py, train.py:183-188)
+    gt, mask = {}, {}
+    for sname, sc in scales.items():
+        h, w = int(H * sc), int(W * sc)
+        Ks = K.copy()
+        Ks[:2, :] *= sc
+        yy, xx = np.meshgrid(np.arange(h, dtype=np.float64), np.arange(w, dtype=np.float64), indexing="ij")
+        rays = np.linalg.inv(Ks) @ np.stack([xx.ravel(), yy.ravel(), np.ones(h * w)])
+        g = np.zeros((B, h, w), np.float32)
+        for b in range(B):
+            rs = np.random.RandomState(1000003 * seed + 7919 * b + 17)
+            d0 = rs.uniform(560.0, 760.0)
+            a, c = rs.uniform(-0.25, 0.25, 2)
+            n = np.array([-a, -c, 1.0])
+            g[b] = (d0 / (n @ rays)).reshape(h, w).astype(np.float32)
+            g[b, : max(1, h // 8)] = 0.0
+        gt[sname] = torch.from_numpy(g).to(device)
+        mask[sname] = torch.from_numpy(((g > depth_min) & (g < depth_max)).astype(np.float32)).to(device)
+    return imgs_t, proj_t, torch.from_numpy(depth_values).to(device), gt, mask
 
 
 # --------------------------------------------------------------------------- weights
@@ -153,7 +174,7 @@ def synth_state_dict(template: dict, seed: int = 123) -> dict:
             val = rs.uniform(-0.2, 0.2, shape)
         elif leaf == "bias":
             val = rs.uniform(-0.1, 0.1, shape)
-            if key.endswith("unet.final_conv.bias"):
+            if key.endswith("unet.final_conv.bias") or key.endswith("unet.conf.bias"):
                 val = val * 0.1
         elif len(shape) <= 1:                      # norm scales (BN / GroupNorm weight)
             val = rs.uniform(0.5, 1.5, shape)
@@ -163,6 +184,8 @@ def synth_state_dict(template: dict, seed: int = 123) -> dict:
             val = rs.uniform(-bound, bound, shape)
             if key.endswith("unet.final_conv.weight"):
                 val = val * 0.005                  # keep the refinement delta well inside [0,1]
+            if key.endswith("unet.conf.weight"):
+                val = val * 0.02                   # confidences around 0.5: keeps 1/(1-conf) in the loss well conditioned
             if key.endswith("cost_regularization.prob.weight"):
                 val = val * 4.0                    # make the softmax over depth peaky enough to matter
         out[key] = torch.from_numpy(np.asarray(val)).to(ref.dtype)

@@ -66,6 +66,8 @@ class CasDiffMVS(nn.Module):
         # the HIP device), the counterpart of torch.randn_like at reference update.py:472.  Parity tests
         # inject the oracle's noise stream here.
         self.noise_source = None
+        self.t_source = None          # train mode: callable (B, timesteps, device) -> int64 [B]; None = torch.randint
+        self._train_ops = None        # tests pin the host-emulated library here
         self._engine = None
         self._engine_key = None
 
@@ -87,7 +89,13 @@ class CasDiffMVS(nn.Module):
 
     def forward(self, imgs, proj_matrices, depth_values, depth_gt_ms=None):
         if self.training:
-            raise NotImplementedError(
-                "CasDiffMVS training branch (reference update.py:423-464) is not built yet in this "
-                "MI355X implementation; call .eval() for depth estimation.")
+            # train branch (reference diffusion.py:167-172, update.py:423-464): an autograd graph whose convolution /
+            # warp / cost-volume nodes are libdmvs_hip.so kernels in both directions (diffmvs_amd/train.py)
+            if depth_gt_ms is None:
+                raise ValueError("CasDiffMVS in train mode needs depth_gt_ms (reference diffusion.py:169)")
+            from diffmvs_amd.train import forward_train
+            ops = self._train_ops
+            if ops is None:
+                ops = Ops.for_device(next(self.parameters()).device)
+            return forward_train(self, imgs, proj_matrices, depth_values, depth_gt_ms, ops)
         return self.engine().forward(imgs, proj_matrices, depth_values, noise_fn=self.noise_source)

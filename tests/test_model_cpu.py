@@ -38,8 +38,11 @@ def test_no_cpu_path():
     with pytest.raises(DmvsError):
         model(imgs, proj, dv)
     model.train()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):            # train mode needs the ground truth (reference diffusion.py:169)
         model(imgs, proj, dv)
+    imgs, proj, dv, gt, _ = synth.synth_inputs(32, 32, 1, B=1, seed=0, with_gt=True)
+    with pytest.raises(DmvsError):
+        model(imgs, proj, dv, gt)
 
 
 @pytest.mark.parametrize("variant", ["diffmvs", "casdiffmvs"])
