@@ -422,3 +422,17 @@ class Ops:
         out = self.empty(B, H, W, Cc)
         self._call("dmvs_nchw_to_nhwc_f32", _ptr(x), _ptr(out), B, Cc, H * W, self.stream())
         return out
+
+    # ------------------------------------------------------------------ training-step tail
+    def sumsq(self, g, out=None):
+        """sum of squares of a flat fp32 tensor -> device double scalar"""
+        self._chk(g)
+        if out is None:
+            out = self.empty(1, dtype=torch.float64)
+        self._call("dmvs_sumsq_f32", _ptr(g), g.numel(), _ptr(out), self.stream())
+        return out
+
+    def adamw_step(self, p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, sumsq=None, max_norm=0.0):
+        self._chk(p, g, m, v)
+        self._call("dmvs_adamw_step_f32", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, wd, step,
+                   grad_scale, _ptr(sumsq), max_norm, self.stream())

@@ -267,6 +267,17 @@ int dmvs_act_slice_f32(const float* in, float* out, int32_t act, int32_t B, int3
                        void* stream);
 int dmvs_upsample_nearest_f32(const float* in, float* out, int32_t N, int32_t H, int32_t W,
                               int32_t factor, void* stream);
+/* ---------------------------------------------------------------------------------------
+ * Training-step tail on one flat fp32 parameter bucket (the buffer RCCL all-reduces).  Replaces
+ * torch.nn.utils.clip_grad_norm_(model.parameters(), 2.0) + AdamW.step()   train.py:200-203, :321-326.
+ * dmvs_sumsq_f32: *out (a device double) = sum g[i]^2;  `g` must be 16-byte aligned.
+ * dmvs_adamw_step_f32: g' = g * grad_scale (1/world_size of the data-parallel average), further scaled by
+ *   min(1, max_norm / (grad_scale*sqrt(*sumsq) + 1e-6)) when sumsq != NULL; decoupled weight decay,
+ *   bias correction with `step` (1-based), as torch.optim.AdamW(amsgrad=False). */
+int dmvs_sumsq_f32(const float* g, int64_t n, double* out, void* stream);
+int dmvs_adamw_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                        float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale,
+                        const double* sumsq, float max_norm, void* stream);
 /* NCHW -> NHWC for features that did not come out of dmvs_conv2d_f32 channel-last */
 int dmvs_nchw_to_nhwc_f32(const float* in, float* out, int32_t B, int32_t C, int32_t HW, void* stream);
 

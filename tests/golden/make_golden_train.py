@@ -80,7 +80,17 @@ def main():
         named = dict(model.named_parameters())
         for k in FULL_GRADS:
             if k in named and named[k].grad is not None:
-                res["grad." + k] = named[k].grad.numpy()
+                res["grad." + k] = named[k].grad.numpy().copy()
+        # optimisation step of train.py:200-203 with the optimizer of train.py:321-326 (constant lr: first step)
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-3, eps=1e-8)
+        before = {k: named[k].detach().clone() for k in FULL_GRADS if k in named}
+        total_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), 2.0)
+        opt.step()
+        res["total_grad_norm"] = np.array(float(total_norm))
+        for k, b in before.items():
+            res["post." + k] = named[k].detach().numpy()
+        res["post_sum"] = np.array(sum(float(p.detach().double().sum()) for p in model.parameters()))
+        res["post_abs"] = np.array(sum(float(p.detach().double().abs().sum()) for p in model.parameters()))
         sd = model.state_dict()
         for k in ("feature.conv0.0.bn.running_mean", "feature.conv0.0.bn.running_var", "context.conv1.bn.running_mean",
                   "depthnet.pixel_view_weight.conv.0.bn.running_var", "depthnet.cost_regularization.conv5.bn.running_mean",

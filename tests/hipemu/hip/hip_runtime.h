@@ -5,13 +5,11 @@
 // that has no GPU.  It is NOT a product backend: nothing under diffmvs_amd/ or models/
 // references it, the product loader only ever opens libdmvs_hip.so (gfx950 code object).
 //
-// Model: one fiber (ucontext) per GPU thread, the fibers of a block run round-robin on one
+// Model: one fiber (own stack + hand-rolled context switch) per GPU thread, the fibers of a block run round-robin on one
 // OS thread; __syncthreads() and the wave shuffles are "yield until the scheduler comes
 // round again", which is a block-wide barrier as long as every live thread of the block
 // executes the same sequence of them (the same rule the hardware imposes on barriers).
 #pragma once
-#include <ucontext.h>
-
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -47,15 +45,79 @@ enum { hipSuccess = 0 };
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 
+// Context switch: six callee-saved registers + the stack pointer (x86-64 SysV).  swapcontext() would cost two
+// sigprocmask system calls per switch, and a block of 256 fibers switches ~10^5 times per kernel.
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.weak hipemu_switch
+.hidden hipemu_switch
+.type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size hipemu_switch, .-hipemu_switch
+)");
+
+#include <sys/mman.h>
+
+#include <mutex>
+
 namespace hipemu {
 struct Fiber {
-    ucontext_t ctx;
+    void* sp;
     bool done;
 };
+constexpr size_t kStack = 256 * 1024;
+constexpr int kMaxThreads = 1024;
+
+// fiber stacks: one lazily-committed slab per concurrently running worker, recycled across launches
+struct StackPool {
+    std::mutex mu;
+    std::vector<char*> free_;
+    char* get() {
+        {
+            std::lock_guard<std::mutex> l(mu);
+            if (!free_.empty()) {
+                char* p = free_.back();
+                free_.pop_back();
+                return p;
+            }
+        }
+        void* p = mmap(nullptr, kStack * kMaxThreads, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (p == MAP_FAILED) {
+            perror("hipemu: mmap");
+            abort();
+        }
+        return (char*)p;
+    }
+    void put(char* p) {
+        std::lock_guard<std::mutex> l(mu);
+        free_.push_back(p);
+    }
+};
+inline StackPool& stack_pool() {
+    static StackPool* p = new StackPool;
+    return *p;
+}
+
 struct Worker {
-    ucontext_t main_ctx;
+    void* main_sp = nullptr;
     std::vector<Fiber> fibers;
-    std::vector<char> stacks;
+    char* stacks = nullptr;
     std::vector<uint64_t> slots;   // shuffle exchange, one per thread of the block
     std::vector<float> slots_a, slots_b;   // MFMA operand exchange
     int current = -1;
@@ -63,22 +125,23 @@ struct Worker {
 };
 inline thread_local Worker* g_worker = nullptr;
 inline thread_local dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
-constexpr size_t kStack = 256 * 1024;
 
 inline void set_tid(int t) {
     g_threadIdx.x = t % g_blockDim.x;
     g_threadIdx.y = (t / g_blockDim.x) % g_blockDim.y;
     g_threadIdx.z = t / (g_blockDim.x * g_blockDim.y);
 }
-inline void trampoline() {
-    Worker* w = g_worker;
-    (*w->body)();
-    w->fibers[w->current].done = true;
-    swapcontext(&w->fibers[w->current].ctx, &w->main_ctx);
-}
 inline void yield() {
     Worker* w = g_worker;
-    swapcontext(&w->fibers[w->current].ctx, &w->main_ctx);
+    hipemu_switch(&w->fibers[w->current].sp, w->main_sp);
+}
+__attribute__((noinline)) inline void trampoline() {
+    Worker* w = g_worker;
+    (*w->body)();
+    w = g_worker;
+    w->fibers[w->current].done = true;
+    yield();
+    abort();   // a finished fiber is never resumed
 }
 inline int linear_tid() { return g_threadIdx.x + g_blockDim.x * (g_threadIdx.y + g_blockDim.y * g_threadIdx.z); }
 
@@ -86,11 +149,14 @@ inline void run_block(Worker& w, int nthreads) {
     for (int t = 0; t < nthreads; ++t) {
         Fiber& f = w.fibers[t];
         f.done = false;
-        getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = w.stacks.data() + size_t(t) * kStack;
-        f.ctx.uc_stack.ss_size = kStack;
-        f.ctx.uc_link = nullptr;
-        makecontext(&f.ctx, (void (*)())trampoline, 0);
+        // initial frame: six zeroed callee-saved registers, then `ret` into trampoline with rsp % 16 == 8 as at a call
+        uintptr_t top = (uintptr_t)(w.stacks + size_t(t + 1) * kStack) & ~uintptr_t(15);
+        void** slot = (void**)(top - 16);
+        slot[0] = (void*)&trampoline;
+        slot[1] = nullptr;
+        void** sp = slot - 6;
+        for (int i = 0; i < 6; ++i) sp[i] = nullptr;
+        f.sp = sp;
     }
     int alive = nthreads;
     while (alive > 0) {
@@ -98,7 +164,7 @@ inline void run_block(Worker& w, int nthreads) {
             if (w.fibers[t].done) continue;
             w.current = t;
             set_tid(t);
-            swapcontext(&w.main_ctx, &w.fibers[t].ctx);
+            hipemu_switch(&w.main_sp, w.fibers[t].sp);
             if (w.fibers[t].done) --alive;
         }
     }
@@ -108,11 +174,12 @@ inline void launch(dim3 grid, dim3 block, size_t, const std::function<void()>& b
     const long nblocks = long(grid.x) * grid.y * grid.z;
     const int nthreads = int(block.x * block.y * block.z);
     if (nblocks == 0 || nthreads == 0) return;
+    if (nthreads > kMaxThreads) abort();
     std::atomic<long> next{0};
     auto work = [&]() {
         Worker w;
         w.fibers.resize(nthreads);
-        w.stacks.resize(size_t(nthreads) * kStack);
+        w.stacks = stack_pool().get();
         w.slots.resize(nthreads);
         w.slots_a.resize(nthreads);
         w.slots_b.resize(nthreads);
@@ -129,6 +196,7 @@ inline void launch(dim3 grid, dim3 block, size_t, const std::function<void()>& b
             run_block(w, nthreads);
         }
         g_worker = nullptr;
+        stack_pool().put(w.stacks);
     };
     unsigned nw = std::min<long>(std::max(1u, std::thread::hardware_concurrency()), nblocks);
     std::vector<std::thread> pool;

@@ -44,8 +44,6 @@ def _run_step(variant, g, ops):
 
 @pytest.mark.parametrize("variant", ["diffmvs", "casdiffmvs"])
 def test_training_step_matches_reference(golden, ops, variant):
-    if variant == "casdiffmvs" and ops.device.type == "cpu":
-        pytest.skip("the emulated CasDiffMVS step takes >2 min; it runs on the GPU (-m gpu)")
     g = golden(f"train_{variant}.npz")
     model, out, loss = _run_step(variant, g, ops)
     assert len(out["depth"]) == int(g.np("n_depth")) and len(out["conf"]) == int(g.np("n_conf"))
@@ -63,9 +61,18 @@ def test_training_step_matches_reference(golden, ops, variant):
             p = named[name]
             assert p.grad is not None, name
             got = float(p.grad.double().norm())
-            if abs(got - want) > 2e-3 * want + 1e-7:
+            # per-tensor: sums with heavy cancellation (BN biases at full resolution) carry fp32 ordering noise of a few 1e-3
+            if abs(got - want) > 1e-2 * want + 1e-7:
                 bad.append((name, got, want))
     assert not bad, bad[:8]
+    pre = {}
+    seen_p = set()
+    for name, p in model.named_parameters():
+        if p.grad is not None and id(p) not in seen_p:
+            seen_p.add(id(p))
+            pre[name.split(".")[0]] = pre.get(name.split(".")[0], 0.0) + float(p.grad.double().pow(2).sum())
+    for k, want in json.loads(str(g.np("prefix_norms"))).items():
+        assert abs(pre[k] ** 0.5 - want) < 2e-3 * want, (k, pre[k] ** 0.5, want)
     for k in g.files:
         if k.startswith("grad."):
             got, want = named[k[5:]].grad.cpu(), g.t(k)
