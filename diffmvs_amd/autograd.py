@@ -42,9 +42,12 @@ class _Conv2dFn(torch.autograd.Function):
                 gx = F.pixel_shuffle(gl, 2)             # adjoint of 'b c (h p1) (w p2) -> b (c p1 p2) h w'
             else:
                 gx = gl
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            gw = ops.conv2d_wgrad(pc, x, g, in_mode=in_mode)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gw = ops.conv2d_wgrad(pc, x, g, in_mode=in_mode, want_bias=want_b)   # bias gradient rides in a spare MFMA column
+            if want_b:
+                gw, gb = gw
+        elif want_b:
             gb = g.sum((0, 2, 3))
         return gx, gw, gb, None, None, None, None
 
@@ -78,12 +81,15 @@ class _Conv3dFn(torch.autograd.Function):
                 gx = ops.conv3d(pack_conv3d(w, stride=2, transposed=True), g)
             else:
                 gx = ops.conv3d(pack_conv3d(w.flip(2, 3, 4).permute(1, 0, 2, 3, 4).contiguous()), g)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if transposed:      # roles swapped: "input" = grad_out, "output gradient" = x; result is [cin_t, cout_t, 3,3,3]
                 gw = ops.conv3d_wgrad(g, x, cout=x.shape[1], stride=2)
             else:
-                gw = ops.conv3d_wgrad(x, g, cout=g.shape[1], stride=stride)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+                gw = ops.conv3d_wgrad(x, g, cout=g.shape[1], stride=stride, want_bias=want_b)
+                if want_b:
+                    gw, gb = gw
+        if want_b and gb is None:
             gb = g.sum((0, 2, 3, 4))
         return gx, gw, gb, None, None, None
 

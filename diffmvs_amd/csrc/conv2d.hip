@@ -351,12 +351,12 @@ int launch_conv2d(const dmvs_conv2d_desc& d, hipStream_t st) {
 // fp32 atomics once at the end.  Same LDS-DMA staged halo tile as the forward.
 template <int KH, int KW, int S>
 __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_wgrad_kernel(const dmvs_conv2d_desc d, const float* __restrict__ gout,
-                                                                  float* __restrict__ gw, int tiles_x, int tiles_y) {
+                                                                  float* __restrict__ ws, int want_bias, int tiles_x, int tiles_y) {
     constexpr int T = KH * KW, CK = 8;
     constexpr int TW = 15 * S + KW, TH = 15 * S + KH;
     constexpr int PLANE = pad16mod32(TH * TW);
     constexpr int GROW = 257;                         // dY tile row pitch: 256 pixels + 1 (bank spread)
-    constexpr int NTN = (CK * T + 15) / 16;           // MFMA n-tiles over the (ci, tap) pairs of the chunk
+    constexpr int NTN = (CK * T + 1 + 15) / 16;       // MFMA n-tiles over the (ci, tap) pairs of the chunk + the bias column
     constexpr int IN_IT = (CK * PLANE + DMVS_BLOCK - 1) / DMVS_BLOCK, G_IT = (16 * GROW + DMVS_BLOCK - 1) / DMVS_BLOCK;
     __shared__ float lds[CK * PLANE + 16 * GROW];
     float* s_in = lds;
@@ -385,6 +385,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_wgrad_kernel(const dmvs_con
     f32x4 acc[NTN];
 #pragma unroll
     for (int nt = 0; nt < NTN; ++nt) acc[nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const float bias_one = (want_bias && blockIdx.y == 0) ? 1.0f : 0.0f;
 
     const int ntiles = tiles_x * tiles_y * d.B;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -449,37 +450,100 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_wgrad_kernel(const dmvs_con
                 const float av = s_g[m * GROW + row * 16 + xg * 4 + kq];
                 const float* ip = s_in + (row * S) * TW + (xg * 4 + kq) * S;
 #pragma unroll
-                for (int nt = 0; nt < NTN; ++nt)
-                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, ip[boff[nt]], acc[nt], 0, 0, 0);
+                for (int nt = 0; nt < NTN; ++nt) {
+                    float bv = ip[boff[nt]];
+                    if (nt == (CK * T) / 16) bv = m == (CK * T) % 16 ? bias_one : bv;   // column of ones: sum(dY) = bias gradient
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[nt], 0, 0, 0);
+                }
             }
         }
     }
-    // D[co = 4*kq + r][j = m]: one fp32 atomic per (co, ci, tap) and wave
+    // D[co = 4*kq + r][j = m].  Deterministic block total: the four waves add their accumulators into LDS one after
+    // the other, then the block stores ONE partial [NTN*16 (ci,tap)][16 co] into its workspace slot; a second kernel
+    // sums the slots (same-address global atomics from ~10^3 workgroups serialise at ~0.1 us each).
+    __syncthreads();
+    float* red = lds;
+    static_assert(NTN * 256 <= CK * PLANE + 16 * GROW, "block partial must fit the tile buffers");
+#pragma unroll 1
+    for (int w = 0; w < DMVS_BLOCK / 64; ++w) {
+        if (wave == w) {
 #pragma unroll
-    for (int nt = 0; nt < NTN; ++nt) {
-        const int jj = nt * 16 + m;
-        const int ci = jj / T, t = jj - ci * T;
-        if (jj >= CK * T || c0 + ci >= cin) continue;
+            for (int nt = 0; nt < NTN; ++nt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = cobase + kq * 4 + r;
-            const float v = acc[nt][r];
-            if (co < d.cout && v != 0.0f) atomicAdd(gw + ((size_t)(c0 + ci) * T + t) * d.cout_pad + co, v);
+                for (int r = 0; r < 4; ++r) {
+                    float* q = red + (nt * 16 + m) * 16 + kq * 4 + r;
+                    *q = w == 0 ? acc[nt][r] : *q + acc[nt][r];
+                }
+        }
+        __syncthreads();
+    }
+    float* slot = ws + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (NTN * 256);
+    for (int e = tid; e < NTN * 256; e += DMVS_BLOCK) slot[e] = red[e];
+}
+
+// gw[co][ci][tap] (torch layout) = sum over the gx workspace slots of one (cin chunk, cout tile); the spare MFMA
+// column CK*T of cin chunk 0 carries sum(dY) = the bias gradient.
+template <int T>
+__global__ void __launch_bounds__(DMVS_BLOCK) conv2d_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ gw,
+                                                                         float* __restrict__ gb, int gx, int gy, int cin,
+                                                                         int cout) {
+    constexpr int CK = 8, NTN = (CK * T + 1 + 15) / 16, PER = NTN * 256, SL = 16;
+    __shared__ float red[SL][17];
+    const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;                // element of the [NTN*16][16] partial
+    const int by = blockIdx.y, bz = blockIdx.z;
+    const float* base = ws + (size_t)(bz * gy + by) * gx * PER + e;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int x = sl;
+    for (; x + 3 * SL < gx; x += 4 * SL) {
+        a0 += base[(size_t)x * PER];
+        a1 += base[(size_t)(x + SL) * PER];
+        a2 += base[(size_t)(x + 2 * SL) * PER];
+        a3 += base[(size_t)(x + 3 * SL) * PER];
+    }
+    for (; x < gx; x += SL) a0 += base[(size_t)x * PER];
+    red[sl][el] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (sl == 0) {
+        float t = 0.0f;
+#pragma unroll
+        for (int i = 0; i < SL; ++i) t += red[i][el];
+        const int jj = e >> 4, co = bz * 16 + (e & 15);
+        const int ci = jj / T, tap = jj - ci * T;
+        if (co < cout) {
+            if (jj < CK * T && by * CK + ci < cin) gw[((size_t)co * cin + by * CK + ci) * T + tap] = t;
+            else if (jj == CK * T && by == 0 && gb) gb[co] = t;
         }
     }
 }
 
-template <int KH, int KW, int S>
-int launch_wgrad(const dmvs_conv2d_desc& d, const float* gout, float* gw, hipStream_t st) {
+struct WgradGrid {
+    int gx, gy, gz, ntn;
+    long floats;
+};
+static WgradGrid wgrad_grid(const dmvs_conv2d_desc& d) {
     const int tiles_x = (d.Wout + 15) / 16, tiles_y = (d.Hout + 15) / 16;
-    const int ntiles = tiles_x * tiles_y * d.B;
-    const int cin = d.c0 + d.c1;
-    const int gy = (cin + 7) / 8, gz = (d.cout + 15) / 16;
-    // enough workgroups to fill the chip, few enough that the final atomics stay cheap
-    int gx = (2048 + gy * gz - 1) / (gy * gz);
+    const long ntiles = (long)tiles_x * tiles_y * d.B;
+    WgradGrid g;
+    g.gy = (d.c0 + d.c1 + 7) / 8;
+    g.gz = (d.cout + 15) / 16;
+    // ~4 workgroups per CU so that tile loads of one overlap the MFMA phase of another; each adds a workspace slot
+    long gx = (1024 + g.gy * g.gz - 1) / (g.gy * g.gz);
     if (gx > ntiles) gx = ntiles;
-    if (gx < 1) gx = 1;
-    hipLaunchKernelGGL((conv2d_wgrad_kernel<KH, KW, S>), dim3(gx, gy, gz), dim3(DMVS_BLOCK), 0, st, d, gout, gw, tiles_x, tiles_y);
+    g.gx = gx < 1 ? 1 : (int)gx;
+    g.ntn = (8 * d.kh * d.kw + 1 + 15) / 16;
+    g.floats = (long)g.gx * g.gy * g.gz * g.ntn * 256;
+    return g;
+}
+
+template <int KH, int KW, int S>
+int launch_wgrad(const dmvs_conv2d_desc& d, const float* gout, float* gw, float* gb, float* ws, hipStream_t st) {
+    const int tiles_x = (d.Wout + 15) / 16, tiles_y = (d.Hout + 15) / 16;
+    const WgradGrid g = wgrad_grid(d);
+    hipLaunchKernelGGL((conv2d_wgrad_kernel<KH, KW, S>), dim3(g.gx, g.gy, g.gz), dim3(DMVS_BLOCK), 0, st, d, gout, ws,
+                       gb ? 1 : 0, tiles_x, tiles_y);
+    hipLaunchKernelGGL((conv2d_wgrad_reduce_kernel<KH * KW>), dim3(g.ntn * 16, g.gy, g.gz), dim3(DMVS_BLOCK), 0, st, ws, gw, gb,
+                       g.gx, g.gy, d.c0 + d.c1, d.cout);
     return dmvs_launch_status();
 }
 
@@ -514,24 +578,38 @@ extern "C" int dmvs_conv2d_f32(const dmvs_conv2d_desc* dp, void* stream) {
     }
 }
 
-extern "C" int dmvs_conv2d_wgrad_f32(const dmvs_conv2d_desc* dp, const float* grad_out, float* gw, void* stream) {
-    if (!dp || !grad_out || !gw) return DMVS_EINVAL;
-    const dmvs_conv2d_desc& d = *dp;
-    hipStream_t st = (hipStream_t)stream;
+static int wgrad_check(const dmvs_conv2d_desc& d) {
     if (d.cout_pad % 8 || d.cout > d.cout_pad || d.B <= 0 || !d.in0) return DMVS_EINVAL;
     if (d.c1 > 0 && (!d.in1 || d.in_mode != DMVS_IN_PLAIN)) return DMVS_EINVAL;
     if (d.mul0 && d.in_mode != DMVS_IN_PLAIN) return DMVS_EINVAL;
     const int eh = (d.Hin + 2 * d.pad_h - d.kh) / d.stride + 1, ew = (d.Win + 2 * d.pad_w - d.kw) / d.stride + 1;
     if (eh != d.Hout || ew != d.Wout) return DMVS_EINVAL;
+    return 0;
+}
+
+extern "C" int dmvs_conv2d_wgrad_workspace_f32(const dmvs_conv2d_desc* dp, int64_t* bytes) {
+    if (!dp || !bytes) return DMVS_EINVAL;
+    if (int rc = wgrad_check(*dp)) return rc;
+    *bytes = (int64_t)wgrad_grid(*dp).floats * 4;
+    return 0;
+}
+
+extern "C" int dmvs_conv2d_wgrad_f32(const dmvs_conv2d_desc* dp, const float* grad_out, float* gw, float* gb, float* workspace,
+                                     int64_t workspace_bytes, void* stream) {
+    if (!dp || !grad_out || !gw || !workspace) return DMVS_EINVAL;
+    const dmvs_conv2d_desc& d = *dp;
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = wgrad_check(d)) return rc;
+    if (workspace_bytes < (int64_t)wgrad_grid(d).floats * 4) return DMVS_EINVAL;
     const int key = d.kh * 100 + d.kw * 10 + d.stride;
     switch (key) {
-        case 111: return launch_wgrad<1, 1, 1>(d, grad_out, gw, st);
-        case 331: return launch_wgrad<3, 3, 1>(d, grad_out, gw, st);
-        case 332: return launch_wgrad<3, 3, 2>(d, grad_out, gw, st);
-        case 552: return launch_wgrad<5, 5, 2>(d, grad_out, gw, st);
-        case 771: return launch_wgrad<7, 7, 1>(d, grad_out, gw, st);
-        case 151: return launch_wgrad<1, 5, 1>(d, grad_out, gw, st);
-        case 511: return launch_wgrad<5, 1, 1>(d, grad_out, gw, st);
+        case 111: return launch_wgrad<1, 1, 1>(d, grad_out, gw, gb, workspace, st);
+        case 331: return launch_wgrad<3, 3, 1>(d, grad_out, gw, gb, workspace, st);
+        case 332: return launch_wgrad<3, 3, 2>(d, grad_out, gw, gb, workspace, st);
+        case 552: return launch_wgrad<5, 5, 2>(d, grad_out, gw, gb, workspace, st);
+        case 771: return launch_wgrad<7, 7, 1>(d, grad_out, gw, gb, workspace, st);
+        case 151: return launch_wgrad<1, 5, 1>(d, grad_out, gw, gb, workspace, st);
+        case 511: return launch_wgrad<5, 1, 1>(d, grad_out, gw, gb, workspace, st);
         default: return DMVS_EINVAL;
     }
 }

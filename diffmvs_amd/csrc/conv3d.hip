@@ -388,12 +388,13 @@ extern "C" int dmvs_conv3d_f32(const dmvs_conv3d_desc* dp, void* stream) {
 // input and output gradient swapped (caller-side).
 template <int S>
 __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_wgrad_kernel(const dmvs_conv3d_desc d, const float* __restrict__ gout,
-                                                                  float* __restrict__ gw, int tiles_x, int tiles_y, int tiles_d) {
+                                                                  float* __restrict__ ws, int want_bias, int tiles_x, int tiles_y,
+                                                                  int tiles_d) {
     constexpr int CK = S == 1 ? 8 : 2;
     constexpr int IW = 15 * S + 3, IH = 3 * S + 3, ID = 3 * S + 3;
     constexpr int PLANE = pad16mod32_3d(ID * IH * IW);
     constexpr int GROW = 257;
-    constexpr int NTN = (CK * 27 + 15) / 16;
+    constexpr int NTN = (CK * 27 + 1 + 15) / 16;     // (ci, tap) columns of the chunk + the bias column of ones
     constexpr int IN_IT = (CK * PLANE + DMVS_BLOCK - 1) / DMVS_BLOCK, G_IT = (16 * GROW + DMVS_BLOCK - 1) / DMVS_BLOCK;
     __shared__ float lds[CK * PLANE + 16 * GROW];
     float* s_in = lds;
@@ -413,6 +414,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_wgrad_kernel(const dmvs_con
     f32x4 acc[NTN];
 #pragma unroll
     for (int nt = 0; nt < NTN; ++nt) acc[nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const float bias_one = (want_bias && blockIdx.y == 0) ? 1.0f : 0.0f;
     const int ntiles = tiles_x * tiles_y * tiles_d * d.B;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int tq = tile;
@@ -457,40 +459,116 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_wgrad_kernel(const dmvs_con
                 const float av = s_g[m * GROW + wave * 64 + yy * 16 + xg * 4 + kq];
                 const float* ip = s_in + ((wave * S) * IH + yy * S) * IW + (xg * 4 + kq) * S;
 #pragma unroll
-                for (int nt = 0; nt < NTN; ++nt)
-                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, ip[boff[nt]], acc[nt], 0, 0, 0);
+                for (int nt = 0; nt < NTN; ++nt) {
+                    float bv = ip[boff[nt]];
+                    if (nt == (CK * 27) / 16) bv = m == (CK * 27) % 16 ? bias_one : bv;
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[nt], 0, 0, 0);
+                }
             }
         }
     }
+    // deterministic block total -> one workspace slot per workgroup (see conv2d_wgrad_kernel)
+    __syncthreads();
+    float* red = lds;
+    static_assert(NTN * 256 <= CK * PLANE + 16 * GROW, "block partial must fit the tile buffers");
+#pragma unroll 1
+    for (int w = 0; w < DMVS_BLOCK / 64; ++w) {
+        if (wave == w) {
 #pragma unroll
-    for (int nt = 0; nt < NTN; ++nt) {
-        const int jj = nt * 16 + m;
-        const int ci = jj / 27, t = jj - ci * 27;
-        if (jj >= CK * 27 || c0 + ci >= d.cin) continue;
+            for (int nt = 0; nt < NTN; ++nt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = cobase + kq * 4 + r;
-            const float v = acc[nt][r];
-            if (co < d.cout && v != 0.0f) atomicAdd(gw + ((size_t)(c0 + ci) * 27 + t) * d.cout_pad + co, v);
+                for (int r = 0; r < 4; ++r) {
+                    float* q = red + (nt * 16 + m) * 16 + kq * 4 + r;
+                    *q = w == 0 ? acc[nt][r] : *q + acc[nt][r];
+                }
+        }
+        __syncthreads();
+    }
+    float* slot = ws + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (NTN * 256);
+    for (int e = tid; e < NTN * 256; e += DMVS_BLOCK) slot[e] = red[e];
+}
+
+template <int CK>
+__global__ void __launch_bounds__(DMVS_BLOCK) conv3d_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ gw,
+                                                                         float* __restrict__ gb, int gx, int gy, int cin,
+                                                                         int cout) {
+    constexpr int T = 27, NTN = (CK * T + 1 + 15) / 16, PER = NTN * 256, SL = 16;
+    __shared__ float red[SL][17];
+    const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;
+    const int by = blockIdx.y, bz = blockIdx.z;
+    const float* base = ws + (size_t)(bz * gy + by) * gx * PER + e;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int x = sl;
+    for (; x + 3 * SL < gx; x += 4 * SL) {
+        a0 += base[(size_t)x * PER];
+        a1 += base[(size_t)(x + SL) * PER];
+        a2 += base[(size_t)(x + 2 * SL) * PER];
+        a3 += base[(size_t)(x + 3 * SL) * PER];
+    }
+    for (; x < gx; x += SL) a0 += base[(size_t)x * PER];
+    red[sl][el] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (sl == 0) {
+        float t = 0.0f;
+#pragma unroll
+        for (int i = 0; i < SL; ++i) t += red[i][el];
+        const int jj = e >> 4, co = bz * 16 + (e & 15);
+        const int ci = jj / T, tap = jj - ci * T;
+        if (co < cout) {
+            if (jj < CK * T && by * CK + ci < cin) gw[((size_t)co * cin + by * CK + ci) * T + tap] = t;
+            else if (jj == CK * T && by == 0 && gb) gb[co] = t;
         }
     }
 }
 
-extern "C" int dmvs_conv3d_wgrad_f32(const dmvs_conv3d_desc* dp, const float* grad_out, float* gw, void* stream) {
-    if (!dp || !grad_out || !gw) return DMVS_EINVAL;
-    const dmvs_conv3d_desc& d = *dp;
-    if (d.transposed || (d.stride != 1 && d.stride != 2) || !d.in || d.cout > d.cout_pad) return DMVS_EINVAL;
+struct Wgrad3dGrid {
+    int gx, gy, gz, ntn, tiles_x, tiles_y, tiles_d;
+    long floats;
+};
+static Wgrad3dGrid wgrad3d_grid(const dmvs_conv3d_desc& d) {
+    Wgrad3dGrid g;
+    g.tiles_x = (d.Wout + 15) / 16, g.tiles_y = (d.Hout + 3) / 4, g.tiles_d = (d.Dout + 3) / 4;
+    const long ntiles = (long)g.tiles_x * g.tiles_y * g.tiles_d * d.B;
+    const int ck = d.stride == 1 ? 8 : 2;
+    g.gy = (d.cin + ck - 1) / ck;
+    g.gz = (d.cout + 15) / 16;
+    long gx = (1024 + g.gy * g.gz - 1) / (g.gy * g.gz);
+    if (gx > ntiles) gx = ntiles;
+    g.gx = gx < 1 ? 1 : (int)gx;
+    g.ntn = (ck * 27 + 1 + 15) / 16;
+    g.floats = (long)g.gx * g.gy * g.gz * g.ntn * 256;
+    return g;
+}
+static int wgrad3d_check(const dmvs_conv3d_desc& d) {
+    if (d.transposed || (d.stride != 1 && d.stride != 2) || !d.in || d.cout > d.cout_pad || d.B <= 0) return DMVS_EINVAL;
     const int ed = (d.Din - 1) / d.stride + 1, eh = (d.Hin - 1) / d.stride + 1, ew = (d.Win - 1) / d.stride + 1;
     if (ed != d.Dout || eh != d.Hout || ew != d.Wout) return DMVS_EINVAL;
-    const int tiles_x = (d.Wout + 15) / 16, tiles_y = (d.Hout + 3) / 4, tiles_d = (d.Dout + 3) / 4;
-    const int ntiles = tiles_x * tiles_y * tiles_d * d.B;
-    const int ck = d.stride == 1 ? 8 : 2;
-    const int gy = (d.cin + ck - 1) / ck, gz = (d.cout + 15) / 16;
-    int gx = (2048 + gy * gz - 1) / (gy * gz);
-    if (gx > ntiles) gx = ntiles;
-    if (gx < 1) gx = 1;
-    dim3 grid(gx, gy, gz), block(DMVS_BLOCK);
-    if (d.stride == 1) hipLaunchKernelGGL((conv3d_wgrad_kernel<1>), grid, block, 0, (hipStream_t)stream, d, grad_out, gw, tiles_x, tiles_y, tiles_d);
-    else hipLaunchKernelGGL((conv3d_wgrad_kernel<2>), grid, block, 0, (hipStream_t)stream, d, grad_out, gw, tiles_x, tiles_y, tiles_d);
+    return 0;
+}
+
+extern "C" int dmvs_conv3d_wgrad_workspace_f32(const dmvs_conv3d_desc* dp, int64_t* bytes) {
+    if (!dp || !bytes) return DMVS_EINVAL;
+    if (int rc = wgrad3d_check(*dp)) return rc;
+    *bytes = (int64_t)wgrad3d_grid(*dp).floats * 4;
+    return 0;
+}
+
+extern "C" int dmvs_conv3d_wgrad_f32(const dmvs_conv3d_desc* dp, const float* grad_out, float* gw, float* gb, float* workspace,
+                                     int64_t workspace_bytes, void* stream) {
+    if (!dp || !grad_out || !gw || !workspace) return DMVS_EINVAL;
+    const dmvs_conv3d_desc& d = *dp;
+    if (int rc = wgrad3d_check(d)) return rc;
+    const Wgrad3dGrid g = wgrad3d_grid(d);
+    if (workspace_bytes < (int64_t)g.floats * 4) return DMVS_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(g.gx, g.gy, g.gz), block(DMVS_BLOCK), rgrid(g.ntn * 16, g.gy, g.gz);
+    if (d.stride == 1) {
+        hipLaunchKernelGGL((conv3d_wgrad_kernel<1>), grid, block, 0, st, d, grad_out, workspace, gb ? 1 : 0, g.tiles_x, g.tiles_y, g.tiles_d);
+        hipLaunchKernelGGL((conv3d_wgrad_reduce_kernel<8>), rgrid, block, 0, st, workspace, gw, gb, g.gx, g.gy, d.cin, d.cout);
+    } else {
+        hipLaunchKernelGGL((conv3d_wgrad_kernel<2>), grid, block, 0, st, d, grad_out, workspace, gb ? 1 : 0, g.tiles_x, g.tiles_y, g.tiles_d);
+        hipLaunchKernelGGL((conv3d_wgrad_reduce_kernel<2>), rgrid, block, 0, st, workspace, gw, gb, g.gx, g.gy, d.cin, d.cout);
+    }
     return dmvs_launch_status();
 }

@@ -179,8 +179,9 @@ class Ops:
         self._call("dmvs_conv2d_f32", C.byref(d), self.stream())
         return out
 
-    def conv2d_wgrad(self, pc: PackedConv, x0, grad_out, x1=None, *, mul0=None, in_mode=IN_PLAIN):
-        """Weight gradient of conv2d(pc, x0, x1, mul0=..., in_mode=...) in torch layout [cout, cin, kh, kw]."""
+    def conv2d_wgrad(self, pc: PackedConv, x0, grad_out, x1=None, *, mul0=None, in_mode=IN_PLAIN, want_bias=False):
+        """Weight gradient of conv2d(pc, x0, x1, mul0=..., in_mode=...) in torch layout [cout, cin, kh, kw]
+        (and the bias gradient [cout] when want_bias) -> gw | (gw, gb)."""
         self._chk(x0, x1, mul0, grad_out)
         B = x0.shape[0]
         if in_mode == IN_PLAIN:
@@ -192,15 +193,19 @@ class Ops:
         c1 = 0 if x1 is None else x1.shape[1]
         kh, kw = pc.k
         Hout, Wout = grad_out.shape[2], grad_out.shape[3]
-        gw = torch.zeros(pc.cin, kh, kw, pc.cout_pad, dtype=torch.float32, device=self.device)
+        gw = self.empty(pc.cout, pc.cin, kh, kw)
+        gb = self.empty(pc.cout) if want_bias else None
         d = _lib.Conv2dDesc(
             in0=_ptr(x0), in1=_ptr(x1), mul0=_ptr(mul0), weight=None, scale=None, shift=None, residual=None, gru_z=None,
             gru_h=None, out=None, gn_stats=None, gn_groups=0, B=B, c0=c0, c1=c1, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout,
             cout=pc.cout, cout_pad=pc.cout_pad, kh=kh, kw=kw, stride=pc.stride, pad_h=pc.pad[0], pad_w=pc.pad[1],
             in_mode=in_mode, act=ACT_NONE, res_mode=IN_PLAIN, res_after_act=0, out_layout=LAYOUT_NCHW,
             out_cstride=pc.cout, out_coffset=0, post_scale=1.0)
-        self._call("dmvs_conv2d_wgrad_f32", C.byref(d), _ptr(grad_out), _ptr(gw), self.stream())
-        return gw[..., :pc.cout].permute(3, 0, 1, 2).contiguous()
+        nbytes = C.c_int64(0)
+        self._call("dmvs_conv2d_wgrad_workspace_f32", C.byref(d), C.byref(nbytes))
+        ws = self.empty(nbytes.value // 4)
+        self._call("dmvs_conv2d_wgrad_f32", C.byref(d), _ptr(grad_out), _ptr(gw), _ptr(gb), _ptr(ws), nbytes.value, self.stream())
+        return (gw, gb) if want_bias else gw
 
     # ------------------------------------------------------------------ conv3d
     def conv3d(self, pc: PackedConv, x, *, act=ACT_NONE, residual=None, out=None):
@@ -221,18 +226,21 @@ class Ops:
         self._call("dmvs_conv3d_f32", C.byref(d), self.stream())
         return out
 
-    def conv3d_wgrad(self, x, grad_out, cout, stride):
-        """gw of a (non-transposed) 3x3x3 conv: x [B,cin,D,H,W], grad_out [B,cout,Do,Ho,Wo] -> [cout,cin,3,3,3]"""
+    def conv3d_wgrad(self, x, grad_out, cout, stride, want_bias=False):
+        """gw of a (non-transposed) 3x3x3 conv: x [B,cin,D,H,W], grad_out [B,cout,Do,Ho,Wo] -> [cout,cin,3,3,3] (, gb [cout])"""
         self._chk(x, grad_out)
         B, cin, Din, Hin, Win = x.shape
         Dout, Hout, Wout = grad_out.shape[2:]
-        cp = _pad_cout(cout)
-        gw = torch.zeros(cin, 27, cp, dtype=torch.float32, device=self.device)
+        gw = self.empty(cout, cin, 3, 3, 3)
+        gb = self.empty(cout) if want_bias else None
         d = _lib.Conv3dDesc(in_=_ptr(x), weight=None, scale=None, shift=None, residual=None, out=None, B=B, cin=cin,
-                            cout=cout, cout_pad=cp, Din=Din, Hin=Hin, Win=Win, Dout=Dout, Hout=Hout, Wout=Wout,
+                            cout=cout, cout_pad=_pad_cout(cout), Din=Din, Hin=Hin, Win=Win, Dout=Dout, Hout=Hout, Wout=Wout,
                             stride=stride, transposed=0, act=ACT_NONE)
-        self._call("dmvs_conv3d_wgrad_f32", C.byref(d), _ptr(grad_out), _ptr(gw), self.stream())
-        return gw[..., :cout].permute(2, 0, 1).reshape(cout, cin, 3, 3, 3).contiguous()
+        nbytes = C.c_int64(0)
+        self._call("dmvs_conv3d_wgrad_workspace_f32", C.byref(d), C.byref(nbytes))
+        ws = self.empty(nbytes.value // 4)
+        self._call("dmvs_conv3d_wgrad_f32", C.byref(d), _ptr(grad_out), _ptr(gw), _ptr(gb), _ptr(ws), nbytes.value, self.stream())
+        return (gw, gb) if want_bias else gw
 
     # ------------------------------------------------------------------ geometry / cost volumes
     def compose_proj(self, proj):

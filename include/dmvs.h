@@ -87,14 +87,18 @@ typedef struct dmvs_conv2d_desc {
 
 int dmvs_conv2d_f32(const dmvs_conv2d_desc* d, void* stream);
 
-/* Weight gradient of the convolution described by `d` (its input side: in0 / in1 / mul0 / in_mode / kh / kw /
- * stride / pad / cout / cout_pad / B / Hin / Win / Hout / Wout; epilogue fields are ignored):
- *   gw[ci][kh][kw][co] += sum_{b,y,x} grad_out[b,co,y,x] * X[b,ci,y*stride+ky-pad,x*stride+kx-pad]
- * grad_out [B,cout,Hout,Wout] NCHW; gw in the kernel weight layout [c0+c1][kh][kw][cout_pad], accumulated with
- * fp32 atomics (the caller zeroes it).  The input gradient needs no entry point of its own: it is
- * dmvs_conv2d_f32 on grad_out with the spatially flipped, cin<->cout transposed weights (DMVS_IN_ZEROINSERT2 for
- * stride 2). */
-int dmvs_conv2d_wgrad_f32(const dmvs_conv2d_desc* d, const float* grad_out, float* gw, void* stream);
+/* Weight (and bias) gradient of the convolution described by `d` (its input side: in0 / in1 / mul0 / in_mode / kh /
+ * kw / stride / pad / cout / cout_pad / B / Hin / Win / Hout / Wout; epilogue fields are ignored):
+ *   gw[co][ci][ky][kx] = sum_{b,y,x} grad_out[b,co,y,x] * X[b,ci,y*stride+ky-pad,x*stride+kx-pad]     (torch layout)
+ *   gb[co]             = sum_{b,y,x} grad_out[b,co,y,x]                                               (gb may be NULL)
+ * grad_out [B,cout,Hout,Wout] NCHW.  Every element of gw / gb is written exactly once (no pre-zeroing) and the
+ * summation order is fixed: workgroups store per-slot partial sums into `workspace` (caller-owned scratch of at
+ * least dmvs_conv2d_wgrad_workspace_f32() bytes) and a second kernel folds the slots -- run-to-run reproducible
+ * gradients.  The input gradient needs no entry point of its own: it is dmvs_conv2d_f32 on grad_out with the
+ * spatially flipped, cin<->cout transposed weights (DMVS_IN_ZEROINSERT2 for stride 2). */
+int dmvs_conv2d_wgrad_workspace_f32(const dmvs_conv2d_desc* d, int64_t* bytes);
+int dmvs_conv2d_wgrad_f32(const dmvs_conv2d_desc* d, const float* grad_out, float* gw, float* gb, float* workspace,
+                          int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * 3-D convolution 3x3x3, padding 1 (module.Conv3d, models/module.py:66-102) and stride-2
@@ -121,11 +125,15 @@ typedef struct dmvs_conv3d_desc {
 
 int dmvs_conv3d_f32(const dmvs_conv3d_desc* d, void* stream);
 
-/* Weight gradient of the (non-transposed, stride 1|2) 3x3x3 convolution described by `d`:
- *   gw[ci][27][co] += sum_{b,voxel} grad_out[b,co,voxel] * in[b,ci,voxel*stride - 1 + tap]     (fp32 atomics; caller zeroes gw)
+/* Weight (and bias) gradient of the (non-transposed, stride 1|2) 3x3x3 convolution described by `d`:
+ *   gw[co][ci][27] = sum_{b,voxel} grad_out[b,co,voxel] * in[b,ci,voxel*stride - 1 + tap]      (torch layout)
+ *   gb[co]         = sum_{b,voxel} grad_out[b,co,voxel]                                          (gb may be NULL)
+ * Written once, fixed summation order, via caller-owned `workspace` as for dmvs_conv2d_wgrad_f32.
  * The transposed layers use the same entry point with the roles of `in` and `grad_out` swapped.  Input gradients
  * need no entry point: stride 1 = dmvs_conv3d_f32 on flipped/transposed weights, stride 2 <-> transposed. */
-int dmvs_conv3d_wgrad_f32(const dmvs_conv3d_desc* d, const float* grad_out, float* gw, void* stream);
+int dmvs_conv3d_wgrad_workspace_f32(const dmvs_conv3d_desc* d, int64_t* bytes);
+int dmvs_conv3d_wgrad_f32(const dmvs_conv3d_desc* d, const float* grad_out, float* gw, float* gb, float* workspace,
+                          int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Camera composition.  For each batch item b and source view s = 1..S:
