@@ -158,3 +158,25 @@ class _ViewAggregateFn(torch.autograd.Function):
 
 def view_aggregate(ops: Ops, cor, w):
     return _ViewAggregateFn.apply(cor.contiguous(), w.contiguous(), ops)
+
+
+class _BatchNormActFn(torch.autograd.Function):
+    """BatchNorm in training mode (batch statistics, running stats updated in place) with the ReLU fused."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, ops: Ops, momentum, eps, relu):
+        act = K.ACT_RELU if relu else K.ACT_NONE
+        y, mean, rstd = ops.batchnorm_train_fwd(x, gamma.detach(), beta.detach(), running_mean, running_var, momentum, eps, act)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)     # x only: the ReLU mask is recomputed from it
+        ctx.ops, ctx.act = ops, act
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        dx, dgamma, dbeta = ctx.ops.batchnorm_train_bwd(x, g.contiguous(), gamma.detach(), beta.detach(), mean, rstd, ctx.act)
+        return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+def batchnorm_act(ops: Ops, x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, relu=True):
+    return _BatchNormActFn.apply(x.contiguous(), gamma, beta, running_mean, running_var, ops, momentum, eps, relu)

@@ -1,0 +1,243 @@
+// Training-mode BatchNorm (+ optional ReLU) over [B, C, S] fp32 tensors, S = H*W or D*H*W: forward with batch statistics
+// and running-stat update, and backward.  Replaces nn.BatchNorm2d/3d inside module.Conv2d / Conv3d / ConvBnReLU / ConvBn
+// in train mode (reference models/module.py:24-58, :60-96, :279-301).  HBM-bound: forward reads x twice and writes y,
+// backward reads (x, dy) twice and writes dx.  No atomics: per-chunk partial sums go through caller-owned scratch
+// and are folded in double precision by one workgroup per channel => run-to-run reproducible statistics/gradients.
+#include "dmvs_common.h"
+
+namespace {
+constexpr int BN_CHUNK = 16384;            // elements of one (b, c) row per partial-sum workgroup
+
+__device__ __forceinline__ float2 block_sum2(float a, float b, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_down(a, o, 64);
+        b += __shfl_down(b, o, 64);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        red[wave * 2] = a;
+        red[wave * 2 + 1] = b;
+    }
+    __syncthreads();
+    float2 r = make_float2(0.0f, 0.0f);
+    if (threadIdx.x == 0) {
+        for (int w = 0; w < DMVS_BLOCK / 64; ++w) {
+            r.x += red[w * 2];
+            r.y += red[w * 2 + 1];
+        }
+    }
+    return r;     // valid on thread 0
+}
+
+// partial[c][chunk] = (sum x, sum x^2)   |   backward: (sum dz, sum dz*xhat),  dz = dy * [act passes]
+template <bool BWD>
+__global__ void __launch_bounds__(DMVS_BLOCK)
+bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
+                  const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ rstd,
+                  float2* __restrict__ partial, int C, int S, int chunks_per_row, int relu) {
+    __shared__ float red[2 * DMVS_BLOCK / 64];
+    const int c = blockIdx.y, chunk = blockIdx.x;
+    const int b = chunk / chunks_per_row, k = chunk - b * chunks_per_row;
+    const size_t row = ((size_t)b * C + c) * S;
+    const int lo = k * BN_CHUNK, hi = lo + BN_CHUNK < S ? lo + BN_CHUNK : S;
+    float s0 = 0.0f, s1 = 0.0f;
+    float mu = 0.0f, rs = 0.0f, g = 1.0f, bt = 0.0f;
+    if (BWD) {
+        mu = mean[c];
+        rs = rstd[c];
+        g = gamma[c];
+        bt = beta[c];
+    }
+    const bool vec = (S & 3) == 0;
+    if (vec) {
+        const float4* x4 = reinterpret_cast<const float4*>(x + row);
+        const float4* d4 = BWD ? reinterpret_cast<const float4*>(dy + row) : nullptr;
+        for (int i = (lo >> 2) + threadIdx.x; i < (hi >> 2); i += DMVS_BLOCK) {
+            const float4 v = x4[i];
+            if (!BWD) {
+                s0 += (v.x + v.y) + (v.z + v.w);
+                s1 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            } else {
+                const float4 dv = d4[i];
+                const float xs[4] = {v.x, v.y, v.z, v.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = (xs[j] - mu) * rs;
+                    const float dz = (relu && xh * g + bt <= 0.0f) ? 0.0f : ds[j];
+                    s0 += dz;
+                    s1 = fmaf(dz, xh, s1);
+                }
+            }
+        }
+    } else {
+        for (int i = lo + threadIdx.x; i < hi; i += DMVS_BLOCK) {
+            const float v = x[row + i];
+            if (!BWD) {
+                s0 += v;
+                s1 = fmaf(v, v, s1);
+            } else {
+                const float xh = (v - mu) * rs;
+                const float dz = (relu && xh * g + bt <= 0.0f) ? 0.0f : dy[row + i];
+                s0 += dz;
+                s1 = fmaf(dz, xh, s1);
+            }
+        }
+    }
+    const float2 t = block_sum2(s0, s1, red);
+    if (threadIdx.x == 0) partial[(size_t)c * gridDim.x + chunk] = t;
+}
+
+// one workgroup per channel: fold the partials in double.
+// forward : mean, rstd (biased variance) -> save_*;  running stats <- (1-m)*running + m*(mean | unbiased variance)
+// backward: dbeta = sum dz, dgamma = sum dz*xhat
+template <bool BWD>
+__global__ void __launch_bounds__(DMVS_BLOCK)
+bn_finalize_kernel(const float2* __restrict__ partial, int nchunk, double count, float* __restrict__ out0,
+                   float* __restrict__ out1, float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+                   float eps) {
+    __shared__ double red[2 * DMVS_BLOCK / 64];
+    const int c = blockIdx.x;
+    double a = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < nchunk; i += DMVS_BLOCK) {
+        const float2 p = partial[(size_t)c * nchunk + i];
+        a += (double)p.x;
+        q += (double)p.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_down(a, o, 64);
+        q += __shfl_down(q, o, 64);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        red[wave * 2] = a;
+        red[wave * 2 + 1] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = q = 0.0;
+        for (int w = 0; w < DMVS_BLOCK / 64; ++w) {
+            a += red[w * 2];
+            q += red[w * 2 + 1];
+        }
+        if (BWD) {
+            out0[c] = (float)a;      // dbeta
+            out1[c] = (float)q;      // dgamma
+        } else {
+            const double mean = a / count;
+            double var = q / count - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            out0[c] = (float)mean;
+            out1[c] = (float)(1.0 / sqrt(var + (double)eps));
+            if (running_mean) {
+                const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+                running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+                running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+            }
+        }
+    }
+}
+
+// forward : y = act((x - mean) * rstd * gamma + beta)
+// backward: dx = gamma * rstd * (dz - dbeta/N - xhat * dgamma/N)
+template <bool BWD>
+__global__ void __launch_bounds__(DMVS_BLOCK)
+bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
+                const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ rstd,
+                const float* __restrict__ dbeta, const float* __restrict__ dgamma, float* __restrict__ out, int C, int S,
+                float inv_count, int relu) {
+    const int bc = blockIdx.y, c = bc % C;
+    const size_t row = (size_t)bc * S;
+    const float mu = mean[c], rs = rstd[c], g = gamma[c], bt = beta[c];
+    const float k1 = BWD ? dbeta[c] * inv_count : 0.0f, k2 = BWD ? dgamma[c] * inv_count : 0.0f;
+    const float a = rs * g, b0 = bt - mu * rs * g;
+    if ((S & 3) == 0) {
+        const int i = blockIdx.x * DMVS_BLOCK + threadIdx.x;
+        if (i >= (S >> 2)) return;
+        const float4 v = reinterpret_cast<const float4*>(x + row)[i];
+        float xs[4] = {v.x, v.y, v.z, v.w}, o[4];
+        if (!BWD) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float y = fmaf(xs[j], a, b0);
+                o[j] = relu ? fmaxf(y, 0.0f) : y;
+            }
+        } else {
+            const float4 dv = reinterpret_cast<const float4*>(dy + row)[i];
+            const float ds[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (xs[j] - mu) * rs;
+                const float dz = (relu && xh * g + bt <= 0.0f) ? 0.0f : ds[j];
+                o[j] = a * (dz - k1 - xh * k2);
+            }
+        }
+        reinterpret_cast<float4*>(out + row)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+        for (int j = 0; j < 4; ++j) {
+            const int i = (blockIdx.x * DMVS_BLOCK + threadIdx.x) * 4 + j;
+            if (i >= S) return;
+            const float xv = x[row + i];
+            if (!BWD) {
+                const float y = fmaf(xv, a, b0);
+                out[row + i] = relu ? fmaxf(y, 0.0f) : y;
+            } else {
+                const float xh = (xv - mu) * rs;
+                const float dz = (relu && xh * g + bt <= 0.0f) ? 0.0f : dy[row + i];
+                out[row + i] = a * (dz - k1 - xh * k2);
+            }
+        }
+    }
+}
+
+inline int chunks_per_row(int S) { return (S + BN_CHUNK - 1) / BN_CHUNK; }
+}  // namespace
+
+extern "C" int dmvs_batchnorm_workspace_f32(int32_t B, int32_t C, int32_t S, int64_t* bytes) {
+    if (!bytes || B <= 0 || C <= 0 || S <= 0) return DMVS_EINVAL;
+    *bytes = (int64_t)C * B * chunks_per_row(S) * (int64_t)sizeof(float2);
+    return 0;
+}
+
+extern "C" int dmvs_batchnorm_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* running_mean,
+                                            float* running_var, float* y, float* save_mean, float* save_rstd,
+                                            float* workspace, int64_t workspace_bytes, int32_t B, int32_t C, int32_t S,
+                                            float momentum, float eps, int32_t act, void* stream) {
+    if (!x || !gamma || !beta || !y || !save_mean || !save_rstd || !workspace || B <= 0 || C <= 0 || S <= 0) return DMVS_EINVAL;
+    if ((act != DMVS_ACT_NONE && act != DMVS_ACT_RELU) || (!running_mean) != (!running_var)) return DMVS_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)y) & 15) return DMVS_EINVAL;
+    const int cpr = chunks_per_row(S), nchunk = B * cpr;
+    if (workspace_bytes < (int64_t)C * nchunk * (int64_t)sizeof(float2)) return DMVS_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    float2* part = reinterpret_cast<float2*>(workspace);
+    hipLaunchKernelGGL((bn_partial_kernel<false>), dim3(nchunk, C), dim3(DMVS_BLOCK), 0, st, x, (const float*)nullptr, gamma, beta,
+                       (const float*)nullptr, (const float*)nullptr, part, C, S, cpr, 0);
+    hipLaunchKernelGGL((bn_finalize_kernel<false>), dim3(C), dim3(DMVS_BLOCK), 0, st, part, nchunk, (double)B * S, save_mean,
+                       save_rstd, running_mean, running_var, momentum, eps);
+    hipLaunchKernelGGL((bn_apply_kernel<false>), dim3(dmvs_ceil_div((S + 3) / 4, DMVS_BLOCK), B * C), dim3(DMVS_BLOCK), 0, st, x,
+                       (const float*)nullptr, gamma, beta, save_mean, save_rstd, (const float*)nullptr, (const float*)nullptr, y, C,
+                       S, 0.0f, act == DMVS_ACT_RELU);
+    return dmvs_launch_status();
+}
+
+extern "C" int dmvs_batchnorm_train_bwd_f32(const float* x, const float* dy, const float* gamma, const float* beta,
+                                            const float* save_mean, const float* save_rstd, float* dx, float* dgamma,
+                                            float* dbeta, float* workspace, int64_t workspace_bytes, int32_t B, int32_t C,
+                                            int32_t S, int32_t act, void* stream) {
+    if (!x || !dy || !gamma || !beta || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !workspace) return DMVS_EINVAL;
+    if (B <= 0 || C <= 0 || S <= 0 || (act != DMVS_ACT_NONE && act != DMVS_ACT_RELU)) return DMVS_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) return DMVS_EINVAL;
+    const int cpr = chunks_per_row(S), nchunk = B * cpr;
+    if (workspace_bytes < (int64_t)C * nchunk * (int64_t)sizeof(float2)) return DMVS_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    float2* part = reinterpret_cast<float2*>(workspace);
+    const int relu = act == DMVS_ACT_RELU;
+    hipLaunchKernelGGL((bn_partial_kernel<true>), dim3(nchunk, C), dim3(DMVS_BLOCK), 0, st, x, dy, gamma, beta, save_mean, save_rstd,
+                       part, C, S, cpr, relu);
+    hipLaunchKernelGGL((bn_finalize_kernel<true>), dim3(C), dim3(DMVS_BLOCK), 0, st, part, nchunk, (double)B * S, dbeta, dgamma,
+                       (float*)nullptr, (float*)nullptr, 0.0f, 0.0f);
+    hipLaunchKernelGGL((bn_apply_kernel<true>), dim3(dmvs_ceil_div((S + 3) / 4, DMVS_BLOCK), B * C), dim3(DMVS_BLOCK), 0, st, x, dy,
+                       gamma, beta, save_mean, save_rstd, dbeta, dgamma, dx, C, S, (float)(1.0 / ((double)B * S)), relu);
+    return dmvs_launch_status();
+}

@@ -431,6 +431,35 @@ class Ops:
         self._call("dmvs_nchw_to_nhwc_f32", _ptr(x), _ptr(out), B, Cc, H * W, self.stream())
         return out
 
+    # ------------------------------------------------------------------ training-mode BatchNorm
+    def _bn_ws(self, B, Cc, S):
+        n = C.c_int64(0)
+        self._call("dmvs_batchnorm_workspace_f32", B, Cc, S, C.byref(n))
+        return self.empty(max(n.value // 4, 1)), n.value
+
+    def batchnorm_train_fwd(self, x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, act=ACT_NONE):
+        """x [B,C,*spatial] -> y, save_mean [C], save_rstd [C]; running stats updated in place"""
+        self._chk(x, gamma, beta, running_mean, running_var)
+        B, Cc = x.shape[0], x.shape[1]
+        S = x.numel() // (B * Cc)
+        y = torch.empty_like(x)
+        mean, rstd = self.empty(Cc), self.empty(Cc)
+        ws, nb = self._bn_ws(B, Cc, S)
+        self._call("dmvs_batchnorm_train_fwd_f32", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(y),
+                   _ptr(mean), _ptr(rstd), _ptr(ws), nb, B, Cc, S, momentum, eps, act, self.stream())
+        return y, mean, rstd
+
+    def batchnorm_train_bwd(self, x, dy, gamma, beta, mean, rstd, act=ACT_NONE):
+        self._chk(x, dy, gamma, beta, mean, rstd)
+        B, Cc = x.shape[0], x.shape[1]
+        S = x.numel() // (B * Cc)
+        dx = torch.empty_like(x)
+        dgamma, dbeta = self.empty(Cc), self.empty(Cc)
+        ws, nb = self._bn_ws(B, Cc, S)
+        self._call("dmvs_batchnorm_train_bwd_f32", _ptr(x), _ptr(dy), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dx),
+                   _ptr(dgamma), _ptr(dbeta), _ptr(ws), nb, B, Cc, S, act, self.stream())
+        return dx, dgamma, dbeta
+
     # ------------------------------------------------------------------ training-step tail
     def sumsq(self, g, out=None):
         """sum of squares of a flat fp32 tensor -> device double scalar"""

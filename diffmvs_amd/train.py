@@ -46,22 +46,21 @@ class _Net:
     def conv2(self, x, k, stride=1, pad=0, in_mode=K.IN_PLAIN):
         return A.conv2d(self.o, x, self.p[k + ".weight"], self.p.get(k + ".bias"), stride=stride, pad=pad, in_mode=in_mode)
 
-    def bn(self, x, k):
-        """BatchNorm in training mode: batch statistics, running stats updated in place (momentum 0.1)"""
-        y = F.batch_norm(x, self.b[k + ".running_mean"], self.b[k + ".running_var"], self.p[k + ".weight"], self.p[k + ".bias"],
-                         True, 0.1, 1e-5)
+    def bn(self, x, k, relu):
+        """BatchNorm in training mode (+ReLU): batch statistics, running stats updated in place (momentum 0.1)"""
+        y = A.batchnorm_act(self.o, x, self.p[k + ".weight"], self.p[k + ".bias"], self.b[k + ".running_mean"],
+                            self.b[k + ".running_var"], 0.1, 1e-5, relu)
         self.b[k + ".num_batches_tracked"].add_(1)
         return y
 
     def cbr2(self, x, k, stride=1, pad=1, relu=True):
         """module.Conv2d / ConvBnReLU / ConvBn (module.py:24-58, :279-301)"""
         y = A.conv2d(self.o, x, self.p[k + ".conv.weight"], None, stride=stride, pad=pad)
-        y = self.bn(y, k + ".bn")
-        return F.relu(y) if relu else y
+        return self.bn(y, k + ".bn", relu)
 
     def cbr3(self, x, k, stride=1, transposed=False):
         y = A.conv3d(self.o, x, self.p[k + ".conv.weight"], None, stride=stride, transposed=transposed)
-        return F.relu(self.bn(y, k + ".bn"))
+        return self.bn(y, k + ".bn", True)
 
 
 def disp_to_depth(disp, min_depth, max_depth):

@@ -276,6 +276,26 @@ int dmvs_act_slice_f32(const float* in, float* out, int32_t act, int32_t B, int3
 int dmvs_upsample_nearest_f32(const float* in, float* out, int32_t N, int32_t H, int32_t W,
                               int32_t factor, void* stream);
 /* ---------------------------------------------------------------------------------------
+ * Training-mode BatchNorm (+ optional ReLU) on [B, C, S] fp32 (S = H*W or D*H*W).  Replaces nn.BatchNorm2d/3d in
+ * train mode inside module.Conv2d / Conv3d / ConvBnReLU / ConvBn            models/module.py:24-58, :60-96, :279-301.
+ *   fwd: mean/var over (B,S) per channel (biased var for the normalisation), y = act((x-mean)*rstd*gamma+beta);
+ *        running_mean/var (may both be NULL) <- (1-momentum)*running + momentum*(mean | unbiased var);
+ *        save_mean / save_rstd [C] are kept for the backward.
+ *   bwd: dz = dy * [y > 0 if act == RELU];  dbeta = sum dz;  dgamma = sum dz*xhat;
+ *        dx = gamma*rstd*(dz - dbeta/N - xhat*dgamma/N),  N = B*S.
+ * act in {DMVS_ACT_NONE, DMVS_ACT_RELU}.  x / y / dy / dx 16-byte aligned.  `workspace`: caller-owned scratch of
+ * dmvs_batchnorm_workspace_f32(B,C,S) bytes (per-chunk partial sums, folded in double; no atomics). */
+int dmvs_batchnorm_workspace_f32(int32_t B, int32_t C, int32_t S, int64_t* bytes);
+int dmvs_batchnorm_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* running_mean,
+                                 float* running_var, float* y, float* save_mean, float* save_rstd, float* workspace,
+                                 int64_t workspace_bytes, int32_t B, int32_t C, int32_t S, float momentum, float eps,
+                                 int32_t act, void* stream);
+int dmvs_batchnorm_train_bwd_f32(const float* x, const float* dy, const float* gamma, const float* beta,
+                                 const float* save_mean, const float* save_rstd, float* dx, float* dgamma, float* dbeta,
+                                 float* workspace, int64_t workspace_bytes, int32_t B, int32_t C, int32_t S, int32_t act,
+                                 void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Training-step tail on one flat fp32 parameter bucket (the buffer RCCL all-reduces).  Replaces
  * torch.nn.utils.clip_grad_norm_(model.parameters(), 2.0) + AdamW.step()   train.py:200-203, :321-326.
  * dmvs_sumsq_f32: *out (a device double) = sum g[i]^2;  `g` must be 16-byte aligned.

@@ -455,3 +455,31 @@ def test_conv3d_autograd(ops, cin, cout, stride, transposed):
     close(xd.grad, x.grad, 1e-4)
     close(wd.grad, w.grad, 1e-4)
     close(bd.grad, b.grad, 1e-4)
+
+
+@pytest.mark.parametrize("shape,relu", [((3, 8, 12, 20), True), ((2, 5, 7, 9), False), ((2, 16, 4, 6, 10), True),
+                                        ((1, 3, 200, 170), True)])
+def test_batchnorm_train_autograd(ops, shape, relu):
+    """training-mode BatchNorm(+ReLU): output, running stats, dx / dgamma / dbeta against ATen's batch_norm autograd"""
+    from diffmvs_amd import autograd as A
+    C_ = shape[1]
+    x = (rnd(*shape, seed=1) * 2 + 0.5).requires_grad_(True)
+    gamma = (rnd(C_, seed=2) * 0.5 + 1).requires_grad_(True)
+    beta = (rnd(C_, seed=3) * 0.3).requires_grad_(True)
+    rm, rv = rnd(C_, seed=4) * 0.1, rnd(C_, seed=5).abs() + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    ref = F.batch_norm(x, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
+    if relu:
+        ref = F.relu(ref)
+    g = rnd(*shape, seed=6)
+    ref.backward(g)
+    xd, gd, bd = [t.detach().to(ops.device).requires_grad_(True) for t in (x, gamma, beta)]
+    rmd, rvd = dev(ops, rm.clone(), rv.clone())
+    out = A.batchnorm_act(ops, xd, gd, bd, rmd, rvd, 0.1, 1e-5, relu)
+    close(out, ref.detach(), 2e-5)
+    close(rmd, rm_ref, 1e-5)
+    close(rvd, rv_ref, 1e-5)
+    out.backward(dev(ops, g))
+    close(xd.grad, x.grad, 1e-4)
+    close(gd.grad, gamma.grad, 1e-4)
+    close(bd.grad, beta.grad, 1e-4)
