@@ -7,6 +7,13 @@
 
 #define DMVS_BLOCK 256
 
+// Scheduling fence for unrolled per-hypothesis code: `var` (an input of the NEXT step) is redefined by an empty asm that
+// consumes `dep` (a result of THIS step), so the compiler cannot hoist the next step's address/projection arithmetic
+// above this step and keep all of it live at once.  (The host emulation predefines it as a no-op.)
+#ifndef DMVS_ORDER_AFTER
+#define DMVS_ORDER_AFTER(var, dep) asm volatile("" : "+v"(var) : "v"(dep))
+#endif
+
 static inline int dmvs_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

@@ -323,15 +323,32 @@ extern "C" int dmvs_warp_corr_init_f32(const float* ref, const float* src, const
     return DMVS_EINVAL;
 }
 
-extern "C" int dmvs_getcost_f32(const dmvs_getcost_desc* dp, void* stream) {
-    if (!dp) return DMVS_EINVAL;
-    const dmvs_getcost_desc& d = *dp;
+int dmvs_getcost_win_dispatch(const dmvs_getcost_desc& d, hipStream_t st);   // warp_win.hip
+
+static int getcost_check(const dmvs_getcost_desc& d) {
     if (d.G != 4 || !d.ref || !d.src || !d.rt || !d.inv_depth || !d.view_w || !d.out_cost || !d.out_samples)
         return DMVS_EINVAL;
+    if (d.n != 4 && d.n != 6) return DMVS_EINVAL;
     if ((long)d.S * d.B * d.H * d.W * d.C * 4 >= (1L << 32)) return DMVS_EINVAL;   // 32-bit byte offsets over the source stack
+    return 0;
+}
+
+// per-pixel gather through the texture path (every C; the only variant for C = 48)
+extern "C" int dmvs_getcost_gather_f32(const dmvs_getcost_desc* dp, void* stream) {
+    if (!dp) return DMVS_EINVAL;
+    const dmvs_getcost_desc& d = *dp;
+    if (int rc = getcost_check(d)) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (d.C == 48) return launch_getcost<48, 3>(d, st);
     if (d.C == 32) return launch_getcost<32, 4>(d, st);
     if (d.C == 16) return launch_getcost<16, 4>(d, st);
     return DMVS_EINVAL;
+}
+
+extern "C" int dmvs_getcost_f32(const dmvs_getcost_desc* dp, void* stream) {
+    if (!dp) return DMVS_EINVAL;
+    const dmvs_getcost_desc& d = *dp;
+    if (int rc = getcost_check(d)) return rc;
+    if (d.C == 32 || d.C == 16) return dmvs_getcost_win_dispatch(d, (hipStream_t)stream);   // LDS-staged source windows
+    return dmvs_getcost_gather_f32(dp, stream);
 }

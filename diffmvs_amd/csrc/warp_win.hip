@@ -1,0 +1,318 @@
+// GetCost through LDS-staged source windows (reference models/module.py:583-667; same arithmetic contract as
+// warp.hip's getcost_kernel, which stays as the per-pixel-gather variant for C = 48).
+//
+// Why: the per-pixel gather sends 4 taps x C*4 bytes per (pixel, view, distinct footprint) through the one
+// texture-address unit of a CU (64 B/clk) -- ~7x the algorithmic bytes, which caps that kernel near 20 % of the
+// HBM roofline.  Neighbouring reference pixels sample neighbouring source texels, so here a 16x16 pixel tile
+//   1. bounds the source footprint of ALL its hypotheses from the two end hypotheses (the projection of a depth
+//      interval is a straight image segment), reduces the boxes over the workgroup,
+//   2. streams that window (<= 24 x 22 texels) ONCE, row-contiguous, HBM/L2 -> LDS with LDS-DMA (no VGPRs),
+//   3. lets one lane own one pixel: projection computed once per (pixel, hypothesis), no cross-lane traffic at
+//      all; the 2x2 taps are ds_read_b128 from the window (128 B/clk/CU, twice the TA rate, and only for a
+//      footprint that differs from the previous hypothesis'), texel stride padded to C+4 floats so that
+//      neighbouring lanes hit disjoint bank groups;
+//   4. uses  sum_c ref_c * (sum_t w_t tex_t,c) = sum_t w_t * (sum_c ref_c tex_t,c):  one group dot per TEXEL
+//      (packed fp32 FMAs), then a 4-tap blend of 4 group values per hypothesis instead of C channels.
+// A view whose tile footprint does not fit the window (wide baseline at a depth edge, z sign change) falls back,
+// workgroup-uniformly, to per-lane global gathers of the same arithmetic: any geometry stays correct.
+#include "dmvs_common.h"
+
+namespace {
+
+typedef float f2 __attribute__((vector_size(8)));
+
+constexpr int TW = 16, TH = 16;      // reference-pixel tile of a workgroup (one lane per pixel)
+constexpr int WW = 24;               // window width in texels
+template <int C> struct WinCfg { static constexpr int WH = C == 32 ? 22 : 24; };   // rows: 76 KB (C=32) / 46 KB (C=16)
+
+#define DMVS_LDS3(p) ((__attribute__((address_space(3))) void*)(p))
+
+struct RayW {
+    float rx, ry, rz, tx, ty, tz;
+    __device__ __forceinline__ void init(const float* m, float x, float y) {
+        rx = m[0] * x + m[1] * y + m[2];
+        ry = m[3] * x + m[4] * y + m[5];
+        rz = m[6] * x + m[7] * y + m[8];
+        tx = m[9]; ty = m[10]; tz = m[11];
+    }
+};
+
+struct SampW {
+    int x0, y0;
+    float w00, w01, w10, w11;
+};
+
+__device__ __forceinline__ void project_uv(const RayW& r, float depth, float& u, float& v, float& pz, bool& fin) {
+    const float px = r.rx * depth + r.tx, py = r.ry * depth + r.ty;
+    pz = r.rz * depth + r.tz;
+    if (pz == 0.0f) pz += 1e-8f;
+    u = px / pz;
+    v = py / pz;
+    fin = fabsf(u) < 1.0e9f && fabsf(v) < 1.0e9f;
+}
+
+__device__ __forceinline__ SampW make_samp(float u, float v, bool fin, int Hs, int Ws) {
+    const float fx = floorf(u), fy = floorf(v);
+    SampW s;
+    s.x0 = fin ? (int)fx : -4;
+    s.y0 = fin ? (int)fy : -4;
+    const float wx1 = u - fx, wy1 = v - fy, wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+    const bool xa = s.x0 >= 0 && s.x0 < Ws, xb = s.x0 + 1 >= 0 && s.x0 + 1 < Ws;
+    const bool ya = s.y0 >= 0 && s.y0 < Hs, yb = s.y0 + 1 >= 0 && s.y0 + 1 < Hs;
+    s.w00 = (fin && xa && ya) ? wx0 * wy0 : 0.0f;
+    s.w01 = (fin && xb && ya) ? wx1 * wy0 : 0.0f;
+    s.w10 = (fin && xa && yb) ? wx0 * wy1 : 0.0f;
+    s.w11 = (fin && xb && yb) ? wx1 * wy1 : 0.0f;
+    return s;
+}
+
+// group dots of one texel with the lane's reference features: Dg[g] = sum_{c in group g} ref_c * tex_c
+template <int C>
+__device__ __forceinline__ void texel_dots(const float* tex, const f2 (&refp)[C / 2], float (&Dg)[4]) {
+    constexpr int NCH = C / 4, CPG = NCH / 4;          // 16-byte chunks per texel / per correlation group
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f2 a = {0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < CPG; ++j) {
+            const int ch = g * CPG + j;
+            const float4 q = *reinterpret_cast<const float4*>(tex + ch * 4);
+            const f2 lo = {q.x, q.y}, hi = {q.z, q.w};
+            a = lo * refp[2 * ch] + a;
+            a = hi * refp[2 * ch + 1] + a;
+        }
+        Dg[g] = a[0] + a[1];
+    }
+}
+
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+template <int C, int N>
+__global__ void __launch_bounds__(DMVS_BLOCK, 2) getcost_win_kernel(const dmvs_getcost_desc d, int tiles_x, int tiles_y) {
+    constexpr int G = 4, NCH = C / 4, TS = C + 4;       // texel stride in floats (padded: bank spread)
+    constexpr int WH = WinCfg<C>::WH;
+    constexpr int SLOTS = WW * (NCH + 1);               // 16-byte LDS slots per window row (one pad slot per texel)
+    constexpr int SUBS = (SLOTS + 63) / 64;             // DMA instructions per row and wave
+    static_assert(TW * TH == DMVS_BLOCK, "one lane per pixel");
+    __shared__ __attribute__((aligned(16))) float win[WW * WH * TS];
+    __shared__ int red[DMVS_BLOCK / 64][5];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = d.H, W = d.W;
+    const long hw = (long)H * W;
+    int tq = (int)dmvs_xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int txi = tq % tiles_x; tq /= tiles_x;
+    const int tyi = tq % tiles_y;
+    const int b = tq / tiles_y;
+    const int x = txi * TW + (tid & (TW - 1)), y = tyi * TH + (tid >> 4);
+    const bool live = x < W && y < H;
+    const int xc = min(x, W - 1), yc = min(y, H - 1);
+    const long yx = (long)yc * W + xc, pc = (long)b * hw + yx;
+
+    // hypotheses in normalised inverse depth (reference :259-276)
+    const float cur_inv = d.inv_depth[pc];
+    float radius = (float)(N / 2) * d.interval;
+    if (d.confidence) {
+        const float r0 = d.min_radius * radius, r1 = d.max_radius * radius;
+        radius = r0 + (1.0f - d.confidence[pc]) * (r1 - r0);
+    }
+    const float lo = cur_inv - radius, hi = cur_inv + radius;
+    const float step = (hi - lo) / (float)(N - 1);
+    const float dmin = d.disp_min[b], dmax = d.disp_max[b];
+    float depth[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        float sk = (float)k * step;
+        sk += lo;
+        sk = fminf(fmaxf(sk, 0.0f), 1.0f);
+        depth[k] = dmvs_disp_to_depth(sk, dmin, dmax);
+        if (live) d.out_samples[((long)b * d.samp_cstride + d.samp_coffset + k) * hw + yx] = sk;
+    }
+
+    f2 refp[C / 2];
+    {
+        const float inv_cg = 1.0f / (float)(C / G);
+        const float4* rp = reinterpret_cast<const float4*>(d.ref + pc * C);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const float4 q = rp[j];
+            refp[2 * j] = f2{q.x * inv_cg, q.y * inv_cg};
+            refp[2 * j + 1] = f2{q.z * inv_cg, q.w * inv_cg};
+        }
+    }
+
+    float acc[N][G];
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[k][g] = 0.0f;
+    float wsum = 1e-8f;
+    const int Hv = H >> d.vw_shift, Wv = W >> d.vw_shift;
+    const long vwi = (long)(yc >> d.vw_shift) * Wv + (xc >> d.vw_shift);
+
+    // this lane's share of a window row in the DMA: slot -> (texel column, 16-byte chunk)
+    int dcol[SUBS], dch[SUBS];
+#pragma unroll
+    for (int i = 0; i < SUBS; ++i) {
+        const int slot = i * 64 + lane;
+        dcol[i] = slot / (NCH + 1);
+        dch[i] = slot < SLOTS ? slot - dcol[i] * (NCH + 1) : NCH;      // NCH = pad slot / beyond the row: never loaded
+    }
+
+    for (int s = 0; s < d.S; ++s) {
+        const float w = d.view_w[((long)b * d.S + s) * Hv * Wv + vwi];
+        wsum += w;
+        RayW ray;
+        ray.init(d.rt + ((long)b * d.S + s) * 12, (float)xc, (float)yc);
+        const float* view = d.src + ((long)s * d.B + b) * hw * C;
+
+        // footprint box of this pixel from its two end hypotheses
+        float u0, v0, z0, u1, v1, z1;
+        bool f0, f1;
+        project_uv(ray, depth[0], u0, v0, z0, f0);
+        project_uv(ray, depth[N - 1], u1, v1, z1, f1);
+        int bad = live && (!f0 || !f1 || ((z0 < 0.0f) != (z1 < 0.0f)));
+        int bx0 = 0x3fffffff, by0 = 0x3fffffff, bx1 = -0x3fffffff, by1 = -0x3fffffff;
+        if (live && !bad) {
+            const int ax = max((int)floorf(fminf(u0, u1)), 0), cx = min((int)floorf(fmaxf(u0, u1)) + 1, W - 1);
+            const int ay = max((int)floorf(fminf(v0, v1)), 0), cy = min((int)floorf(fmaxf(v0, v1)) + 1, H - 1);
+            if (ax <= cx && ay <= cy) {      // else: every tap of every hypothesis is padding
+                bx0 = ax; bx1 = cx; by0 = ay; by1 = cy;
+            }
+        }
+        bx0 = wave_min(bx0); by0 = wave_min(by0); bx1 = wave_max(bx1); by1 = wave_max(by1); bad = wave_max(bad);
+        if (lane == 0) {
+            red[wave][0] = bx0; red[wave][1] = by0; red[wave][2] = bx1; red[wave][3] = by1; red[wave][4] = bad;
+        }
+        __syncthreads();        // also: every lane is done reading the previous view's window
+#pragma unroll
+        for (int q = 0; q < DMVS_BLOCK / 64; ++q) {
+            bx0 = min(bx0, red[q][0]); by0 = min(by0, red[q][1]);
+            bx1 = max(bx1, red[q][2]); by1 = max(by1, red[q][3]); bad = max(bad, red[q][4]);
+        }
+        const int ncols = bx1 - bx0 + 1, nrows = by1 - by0 + 1;
+        const bool empty = bx1 < bx0;
+        const bool fits = !bad && ncols <= WW && nrows <= WH;
+        if (!bad && empty) {
+            __syncthreads();    // keep the barrier count uniform across views (red[] reuse)
+            continue;
+        }
+        if (fits) {
+            // rows of the window: each a contiguous run of ncols*C floats in the NHWC source
+            for (int r = wave; r < nrows; r += DMVS_BLOCK / 64) {
+                const float* rowp = view + ((long)(by0 + r) * W + bx0) * C;
+#pragma unroll
+                for (int i = 0; i < SUBS; ++i) {
+                    if (dch[i] < NCH && dcol[i] < ncols) {
+                        const float* srcp = rowp + dcol[i] * C + dch[i] * 4;
+                        float* dstp = win + (r * SLOTS + i * 64) * 4;          // wave-uniform; lane l lands at +16*l bytes
+                        __builtin_amdgcn_global_load_lds(srcp, DMVS_LDS3(dstp), 16, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();        // window resident (the barrier drains the LDS-DMA)
+
+        int pfx = -0x40000000, pfy = -0x40000000;
+        float D[4][G];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < G; ++g) D[t][g] = 0.0f;
+        if (fits) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                float u, v, z;
+                bool fin;
+                project_uv(ray, depth[k], u, v, z, fin);
+                const SampW sp = make_samp(u, v, fin, H, W);
+                if (sp.x0 != pfx || sp.y0 != pfy) {      // LDS reads only for a footprint that moved
+                    pfx = sp.x0;
+                    pfy = sp.y0;
+                    const int xa = min(max(sp.x0 - bx0, 0), ncols - 1), xb = min(max(sp.x0 + 1 - bx0, 0), ncols - 1);
+                    const int ya = min(max(sp.y0 - by0, 0), nrows - 1), yb = min(max(sp.y0 + 1 - by0, 0), nrows - 1);
+                    const int ra = ya * (WW * TS), rb = yb * (WW * TS), ca = xa * TS, cb = xb * TS;
+                    // one tap (NCH x ds_read_b128) in flight at a time: hoisting all four costs 4*C VGPRs
+                    texel_dots<C>(win + ra + ca, refp, D[0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    texel_dots<C>(win + ra + cb, refp, D[1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    texel_dots<C>(win + rb + ca, refp, D[2]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    texel_dots<C>(win + rb + cb, refp, D[3]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const float dot = D[0][g] * sp.w00 + D[1][g] * sp.w01 + D[2][g] * sp.w10 + D[3][g] * sp.w11;
+                    acc[k][g] = fmaf(w, dot, acc[k][g]);
+                }
+                if (k + 1 < N) DMVS_ORDER_AFTER(depth[k + 1], acc[k][G - 1]);   // next hypothesis starts after this one
+            }
+        } else {
+            // the tile's footprint exceeds the window for this view: same arithmetic, taps gathered from global memory.
+            // Rare path, kept small: a rolled loop (hypothesis recomputed from k, accumulators picked by a select chain).
+#pragma unroll 1
+            for (int k = 0; k < N; ++k) {
+                float sk = (float)k * step;
+                sk += lo;
+                sk = fminf(fmaxf(sk, 0.0f), 1.0f);
+                float u, v, z;
+                bool fin;
+                project_uv(ray, dmvs_disp_to_depth(sk, dmin, dmax), u, v, z, fin);
+                const SampW sp = make_samp(u, v, fin, H, W);
+                if (sp.x0 != pfx || sp.y0 != pfy) {
+                    pfx = sp.x0;
+                    pfy = sp.y0;
+                    const int xa = min(max(sp.x0, 0), W - 1), xb = min(max(sp.x0 + 1, 0), W - 1);
+                    const int ya = min(max(sp.y0, 0), H - 1), yb = min(max(sp.y0 + 1, 0), H - 1);
+                    texel_dots<C>(view + ((long)ya * W + xa) * C, refp, D[0]);
+                    texel_dots<C>(view + ((long)ya * W + xb) * C, refp, D[1]);
+                    texel_dots<C>(view + ((long)yb * W + xa) * C, refp, D[2]);
+                    texel_dots<C>(view + ((long)yb * W + xb) * C, refp, D[3]);
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const float dot = w * (D[0][g] * sp.w00 + D[1][g] * sp.w01 + D[2][g] * sp.w10 + D[3][g] * sp.w11);
+#pragma unroll
+                    for (int kk = 0; kk < N; ++kk) acc[kk][g] += kk == k ? dot : 0.0f;
+                }
+            }
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int k = 0; k < N; ++k)
+                d.out_cost[((long)b * d.cost_cstride + d.cost_coffset + g * N + k) * hw + yx] = acc[k][g] / wsum;
+    }
+}
+
+template <int C>
+int launch_getcost_win(const dmvs_getcost_desc& d, hipStream_t st) {
+    const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + TH - 1) / TH;
+    dim3 grid((unsigned)(tiles_x * tiles_y * d.B)), block(DMVS_BLOCK);
+    if (d.n == 4) hipLaunchKernelGGL((getcost_win_kernel<C, 4>), grid, block, 0, st, d, tiles_x, tiles_y);
+    else if (d.n == 6) hipLaunchKernelGGL((getcost_win_kernel<C, 6>), grid, block, 0, st, d, tiles_x, tiles_y);
+    else return DMVS_EINVAL;
+    return dmvs_launch_status();
+}
+
+}  // namespace
+
+// called by dmvs_getcost_f32 (warp.hip) for C in {32, 16}
+int dmvs_getcost_win_dispatch(const dmvs_getcost_desc& d, hipStream_t st) {
+    if (d.C == 32) return launch_getcost_win<32>(d, st);
+    if (d.C == 16) return launch_getcost_win<16>(d, st);
+    return DMVS_EINVAL;
+}

@@ -273,7 +273,8 @@ class Ops:
 
     def getcost(self, ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, min_radius,
                 max_radius, vw_shift, out_cost=None, cost_cstride=None, cost_coffset=0, out_samples=None,
-                samp_cstride=None, samp_coffset=0, G=4):
+                samp_cstride=None, samp_coffset=0, G=4, gather=False):
+        """gather=True forces the per-pixel gather kernel (A/B measurements); default = LDS-window kernel for C 32|16"""
         self._chk(ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, out_cost, out_samples)
         B, H, W, Cc = ref.shape
         S = src.shape[0]
@@ -289,7 +290,7 @@ class Ops:
                              B=B, S=S, C=Cc, G=G, n=n, H=H, W=W, vw_shift=vw_shift, cost_cstride=cost_cstride,
                              cost_coffset=cost_coffset, samp_cstride=samp_cstride, samp_coffset=samp_coffset,
                              interval=interval, min_radius=min_radius, max_radius=max_radius)
-        self._call("dmvs_getcost_f32", C.byref(d), self.stream())
+        self._call("dmvs_getcost_gather_f32" if gather else "dmvs_getcost_f32", C.byref(d), self.stream())
         return out_cost, out_samples
 
     # ------------------------------------------------------------------ backward (training step)

@@ -190,6 +190,9 @@ typedef struct dmvs_getcost_desc {
 } dmvs_getcost_desc;
 
 int dmvs_getcost_f32(const dmvs_getcost_desc* d, void* stream);
+/* Same contract, forced onto the per-pixel gather variant (the only one for C = 48; dmvs_getcost_f32 stages source
+ * windows through LDS for C = 32 | 16 and is the faster of the two there).  Kept public for A/B measurements. */
+int dmvs_getcost_gather_f32(const dmvs_getcost_desc* d, void* stream);
 
 /* Stand-alone differentiable_warping (models/module.py:181-218) in the reference's layouts:
  * src [B,C,Hs,Ws] NCHW, rt [B,12] (rot row-major, trans) = src_proj * inverse(ref_proj),

@@ -302,3 +302,5 @@ static inline int max(int a, int b) { return a > b ? a : b; }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 static inline float __fdividef(float a, float b) { return a / b; }
+static inline void __builtin_amdgcn_sched_barrier(int) {}
+#define DMVS_ORDER_AFTER(var, dep) ((void)0)

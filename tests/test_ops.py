@@ -216,12 +216,38 @@ def test_getcost(ops, C, n, with_conf):
     want_cost, want_s = O.get_cost(feats, pm, inv, interval, dmax, dmin, n,
                                    F.interpolate(vw, scale_factor=2, mode="nearest"), conf, 4, 0.25, 4.0)
     rt = ops.compose_proj(dev(ops, pm))
-    cost, samp = ops.getcost(dev(ops, feats[0].permute(0, 2, 3, 1)),
-                             dev(ops, torch.stack([f.permute(0, 2, 3, 1) for f in feats[1:]])), rt,
-                             dev(ops, inv), dev(ops, conf), dev(ops, vw), dev(ops, 1 / (1 / dv0)), dev(ops, 1 / (1 / dv1)),
-                             n, interval, 0.25, 4.0, vw_shift=1)
+    for gather in (False, True):        # LDS-window kernel (C 32|16) and the per-pixel gather kernel
+        cost, samp = ops.getcost(dev(ops, feats[0].permute(0, 2, 3, 1)),
+                                 dev(ops, torch.stack([f.permute(0, 2, 3, 1) for f in feats[1:]])), rt,
+                                 dev(ops, inv), dev(ops, conf), dev(ops, vw), dev(ops, 1 / (1 / dv0)), dev(ops, 1 / (1 / dv1)),
+                                 n, interval, 0.25, 4.0, vw_shift=1, gather=gather)
+        close(samp, want_s, 1e-6)
+        close(cost, want_cost, 1e-4)
+
+
+@pytest.mark.parametrize("C,n,interval,H,W", [(32, 6, 2.0 / 384, 40, 56), (16, 4, 1.0 / 384, 36, 50), (32, 6, 0.15, 24, 40),
+                                              (16, 4, 0.3, 20, 36)])
+def test_getcost_window_tiles(ops, C, n, interval, H, W):
+    """several 16x16 tiles incl. partial ones; the large intervals spread a tile's footprint beyond the LDS window, so
+    those views take the workgroup-uniform global fallback.  Checked against the oracle and the gather kernel."""
+    B, S = 2, 3
+    pm = _cams(B, S + 1, H, W, 2)
+    feats = [rnd(B, C, H, W, seed=40 + v) for v in range(S + 1)]
+    inv = rnd(B, 1, H, W, seed=50, lo=-0.05, hi=1.05)
+    conf = rnd(B, H, W, seed=51, lo=0.0, hi=1.0)
+    vw = rnd(B, S, H // 2, W // 2, seed=52, lo=0.0, hi=1.0)
+    dv0, dv1 = torch.tensor([1 / 935.0, 1 / 700.0]), torch.tensor([1 / 425.0, 1 / 450.0])
+    dmax, dmin = (1 / dv0).view(-1, 1, 1, 1), (1 / dv1).view(-1, 1, 1, 1)
+    want_cost, want_s = O.get_cost(feats, pm, inv, interval, dmax, dmin, n,
+                                   F.interpolate(vw, scale_factor=2, mode="nearest"), conf, 4, 0.25, 4.0)
+    rt = ops.compose_proj(dev(ops, pm))
+    args = (dev(ops, feats[0].permute(0, 2, 3, 1)), dev(ops, torch.stack([f.permute(0, 2, 3, 1) for f in feats[1:]])), rt,
+            dev(ops, inv), dev(ops, conf), dev(ops, vw), dev(ops, 1 / (1 / dv0)), dev(ops, 1 / (1 / dv1)), n, interval, 0.25, 4.0)
+    cost, samp = ops.getcost(*args, vw_shift=1)
+    cost_g, samp_g = ops.getcost(*args, vw_shift=1, gather=True)
     close(samp, want_s, 1e-6)
     close(cost, want_cost, 1e-4)
+    close(cost, cost_g.cpu(), 1e-5)
 
 
 def test_getcost_extreme_geometry(ops, golden):
