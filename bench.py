@@ -9,7 +9,7 @@ views shard across GPUs with no data-path collective (inference is embarrassingl
 SURVEY section 8e) => weak scaling; value = all ranks' depth maps / max-over-ranks time.
 
 Also reported on the same JSON line:
-  roofline      the homography-warp kernel (getcost_kernel, launched stage_iters[1]=4 times per
+  roofline      the homography-warp kernel (getcost_win_kernel, launched stage_iters[1]=4 times per
                 step): algorithmic bytes per launch (SURVEY section 8d formula) / mean launch
                 duration from HIP events recorded on the launch stream inside the timed region
   cpu_baseline  oracle/diffmvs_oracle.py (CPU restatement pinned to the reference) timed on this
@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 from diffmvs_amd import synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 achievable)
+FP32_MFMA_PEAK_TFS = 157.3   # v_mfma_f32_16x16x4_f32, exact fp32 (MI355X_MICROARCH.md)
 
 
 def getcost_algorithmic_bytes(B, C, S, n, G, H, W):
@@ -105,7 +106,7 @@ def main():
     with torch.no_grad():
         for _ in range(a.warmup):
             model(imgs, proj, dv)
-        eng.ops.timers = {"dmvs_getcost_f32": [], "dmvs_warp_corr_init_f32": []}
+        eng.ops.timers = {"dmvs_getcost_f32": [], "dmvs_warp_corr_init_f32": [], "dmvs_conv2d_f32": []}
         barrier()
         t0 = time.perf_counter()
         for _ in range(a.steps):
@@ -126,6 +127,8 @@ def main():
     h1, w1 = H // 8, W // 8
     alg_init = 4 * B * h1 * w1 * (48 + S * 48 + S * 4 * 48)      # ref + src + per-view volumes out
     wi_avg_s = sum(wi_ms) / max(1, len(wi_ms)) * 1e-3
+    cv_s = sum(s.elapsed_time(e) for s, e in timers["dmvs_conv2d_f32"]) * 1e-3
+    cv_flops = sum(timers.get("_conv2d_flops", []))
 
     # HBM traffic per getcost launch from the PMC passes (rocprofv3 cannot run inside the timed process); only
     # quoted when the committed measurement was taken at this batch size
@@ -144,7 +147,7 @@ def main():
         "config": {"workload": f"DiffMVS DTU eval {W}x{H}, {S} src views, numdepth_initial=48, 1 DDIM step, fp32",
                    "ref_views_per_gpu_per_step": B, "parallelism": f"ref-view sharding x{world}, no collective",
                    "weights": "seeded random init (no checkpoint offline)"},
-        "roofline": {"kernel": "getcost_kernel<32,4,6> (homography warp + group corr + view aggregation)",
+        "roofline": {"kernel": "getcost_win_kernel<32,6> (homography warp + group corr + view aggregation, LDS-staged windows)",
                      "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(gc_avg_s * 1e6, 2),
@@ -154,6 +157,12 @@ def main():
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(alg_init / wi_avg_s / 1e9 / HBM_PEAK_GBS, 4) if wi_avg_s > 0 else 0.0,
                                "algorithmic_bytes_per_launch": alg_init, "avg_launch_us": round(wi_avg_s * 1e6, 2)},
+        # where the step's time actually goes: all 2-D convolution launches (exact-fp32 MFMA implicit GEMM) together
+        "roofline_conv2d": {"kernel": "conv2d_mfma_kernel<*> (all launches of the step)", "bound": "mfma",
+                            "achieved": round(cv_flops / cv_s / 1e12, 2) if cv_s > 0 else 0.0, "peak": FP32_MFMA_PEAK_TFS,
+                            "unit": "TFLOP/s", "frac": round(cv_flops / cv_s / 1e12 / FP32_MFMA_PEAK_TFS, 4) if cv_s > 0 else 0.0,
+                            "launches_timed": len(timers["dmvs_conv2d_f32"]),
+                            "share_of_step_time": round(cv_s / elapsed, 4)},
     }
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

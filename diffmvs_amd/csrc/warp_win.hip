@@ -46,23 +46,27 @@ __device__ __forceinline__ void project_uv(const RayW& r, float depth, float& u,
     const float px = r.rx * depth + r.tx, py = r.ry * depth + r.ty;
     pz = r.rz * depth + r.tz;
     if (pz == 0.0f) pz += 1e-8f;
-    u = px / pz;
-    v = py / pz;
+    // one reciprocal (hardware estimate + one Newton step: within an ulp of the IEEE quotient) shared by u and v
+    float inv = __builtin_amdgcn_rcpf(pz);
+    inv = fmaf(fmaf(-pz, inv, 1.0f), inv, inv);
+    u = px * inv;
+    v = py * inv;
     fin = fabsf(u) < 1.0e9f && fabsf(v) < 1.0e9f;
 }
 
 __device__ __forceinline__ SampW make_samp(float u, float v, bool fin, int Hs, int Ws) {
     const float fx = floorf(u), fy = floorf(v);
     SampW s;
-    s.x0 = fin ? (int)fx : -4;
+    s.x0 = fin ? (int)fx : -4;          // -4: all four taps fail the range tests below
     s.y0 = fin ? (int)fy : -4;
     const float wx1 = u - fx, wy1 = v - fy, wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
-    const bool xa = s.x0 >= 0 && s.x0 < Ws, xb = s.x0 + 1 >= 0 && s.x0 + 1 < Ws;
-    const bool ya = s.y0 >= 0 && s.y0 < Hs, yb = s.y0 + 1 >= 0 && s.y0 + 1 < Hs;
-    s.w00 = (fin && xa && ya) ? wx0 * wy0 : 0.0f;
-    s.w01 = (fin && xb && ya) ? wx1 * wy0 : 0.0f;
-    s.w10 = (fin && xa && yb) ? wx0 * wy1 : 0.0f;
-    s.w11 = (fin && xb && yb) ? wx1 * wy1 : 0.0f;
+    // zero padding folded into the 1-D weights: a tap outside the image contributes nothing (grid_sample zeros)
+    const float ax0 = (unsigned)s.x0 < (unsigned)Ws ? wx0 : 0.0f, ax1 = (unsigned)(s.x0 + 1) < (unsigned)Ws ? wx1 : 0.0f;
+    const float ay0 = (unsigned)s.y0 < (unsigned)Hs ? wy0 : 0.0f, ay1 = (unsigned)(s.y0 + 1) < (unsigned)Hs ? wy1 : 0.0f;
+    s.w00 = ax0 * ay0;
+    s.w01 = ax1 * ay0;
+    s.w10 = ax0 * ay1;
+    s.w11 = ax1 * ay1;
     return s;
 }
 
@@ -240,16 +244,11 @@ __global__ void __launch_bounds__(DMVS_BLOCK, 2) getcost_win_kernel(const dmvs_g
                     pfy = sp.y0;
                     const int xa = min(max(sp.x0 - bx0, 0), ncols - 1), xb = min(max(sp.x0 + 1 - bx0, 0), ncols - 1);
                     const int ya = min(max(sp.y0 - by0, 0), nrows - 1), yb = min(max(sp.y0 + 1 - by0, 0), nrows - 1);
-                    const int ra = ya * (WW * TS), rb = yb * (WW * TS), ca = xa * TS, cb = xb * TS;
-                    // one tap (NCH x ds_read_b128) in flight at a time: hoisting all four costs 4*C VGPRs
+                    const int ra = __mul24(ya, WW * TS), rb = __mul24(yb, WW * TS), ca = __mul24(xa, TS), cb = __mul24(xb, TS);
                     texel_dots<C>(win + ra + ca, refp, D[0]);
-                    __builtin_amdgcn_sched_barrier(0);
                     texel_dots<C>(win + ra + cb, refp, D[1]);
-                    __builtin_amdgcn_sched_barrier(0);
                     texel_dots<C>(win + rb + ca, refp, D[2]);
-                    __builtin_amdgcn_sched_barrier(0);
                     texel_dots<C>(win + rb + cb, refp, D[3]);
-                    __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int g = 0; g < G; ++g) {

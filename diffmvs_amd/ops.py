@@ -177,6 +177,8 @@ class Ops:
             res_mode=res_mode, res_after_act=int(res_after_act), out_layout=out_layout, out_cstride=out_cstride,
             out_coffset=out_coffset, post_scale=post_scale)
         self._call("dmvs_conv2d_f32", C.byref(d), self.stream())
+        if self.timers is not None and "dmvs_conv2d_f32" in self.timers:      # bench: MFMA roofline over every conv launch
+            self.timers.setdefault("_conv2d_flops", []).append(2.0 * B * Hout * Wout * pc.cout * pc.cin * kh * kw)
         return out
 
     def conv2d_wgrad(self, pc: PackedConv, x0, grad_out, x1=None, *, mul0=None, in_mode=IN_PLAIN, want_bias=False):

@@ -303,4 +303,6 @@ static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+static inline int __mul24(int a, int b) { return a * b; }
 #define DMVS_ORDER_AFTER(var, dep) ((void)0)

@@ -23,8 +23,12 @@ def main():
     ap.add_argument("--n", type=int, default=6)
     ap.add_argument("--conf", type=float, default=0.5)
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--lib", default=None, help="alternative libdmvs .so (kernel experiments)")
     a = ap.parse_args()
     o = Ops.for_device("cuda:0")
+    if a.lib:
+        from diffmvs_amd import _lib
+        o = Ops(_lib.Lib(os.path.abspath(a.lib)), "cuda:0")
     dev = o.device
     imgs, proj, dv, gt, _ = synth.synth_inputs(a.H, a.W, a.src, B=a.batch, seed=0, with_gt=True)
     name = f"stage{a.stage}"
