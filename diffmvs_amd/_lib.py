@@ -45,7 +45,7 @@ class Conv3dDesc(C.Structure):
 class GetCostDesc(C.Structure):
     _fields_ = [
         ("ref", _P), ("src", _P), ("rt", _P), ("inv_depth", _P), ("confidence", _P), ("view_w", _P),
-        ("disp_min", _P), ("disp_max", _P), ("out_cost", _P), ("out_samples", _P),
+        ("disp_min", _P), ("disp_max", _P), ("out_cost", _P), ("out_samples", _P), ("worklist", _P),
         ("B", _I), ("S", _I), ("C", _I), ("G", _I), ("n", _I), ("H", _I), ("W", _I), ("vw_shift", _I),
         ("cost_cstride", _I), ("cost_coffset", _I), ("samp_cstride", _I), ("samp_coffset", _I),
         ("interval", _F), ("min_radius", _F), ("max_radius", _F),
@@ -81,9 +81,9 @@ SIGNATURES = {
     "dmvs_act_slice_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "dmvs_upsample_nearest_f32": [_P, _P, _I, _I, _I, _I, _P],
     "dmvs_nchw_to_nhwc_f32": [_P, _P, _I, _I, _I, _P],
-    "dmvs_batchnorm_workspace_f32": [_I, _I, _I, C.POINTER(C.c_int64)],
-    "dmvs_batchnorm_train_fwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _I, _I, _I, _F, _F, _I, _P],
-    "dmvs_batchnorm_train_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _I, _I, _I, _I, _P],
+    "dmvs_batchnorm_workspace_f32": [_I, _I, _I, _I, C.POINTER(C.c_int64)],
+    "dmvs_batchnorm_train_fwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _I, _I, _I, _I, _I, _F, _F, _I, _P],
+    "dmvs_batchnorm_train_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _I, _I, _I, _I, _I, _I, _P],
     "dmvs_sumsq_f32": [_P, C.c_int64, _P, _P],
     "dmvs_adamw_step_f32": [_P, _P, _P, _P, C.c_int64, _F, _F, _F, _F, _F, _I, _F, _P, _F, _P],
 }

@@ -161,22 +161,27 @@ def view_aggregate(ops: Ops, cor, w):
 
 
 class _BatchNormActFn(torch.autograd.Function):
-    """BatchNorm in training mode (batch statistics, running stats updated in place) with the ReLU fused."""
+    """BatchNorm in training mode (batch statistics per view, running stats updated in place) with the ReLU fused."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, ops: Ops, momentum, eps, relu):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, ops: Ops, momentum, eps, relu, views, view_major):
         act = K.ACT_RELU if relu else K.ACT_NONE
-        y, mean, rstd = ops.batchnorm_train_fwd(x, gamma.detach(), beta.detach(), running_mean, running_var, momentum, eps, act)
+        y, mean, rstd = ops.batchnorm_train_fwd(x, gamma.detach(), beta.detach(), running_mean, running_var, momentum, eps, act,
+                                                views, view_major)
         ctx.save_for_backward(x, gamma, beta, mean, rstd)     # x only: the ReLU mask is recomputed from it
-        ctx.ops, ctx.act = ops, act
+        ctx.ops, ctx.act, ctx.views, ctx.view_major = ops, act, views, view_major
         return y
 
     @staticmethod
     def backward(ctx, g):
         x, gamma, beta, mean, rstd = ctx.saved_tensors
-        dx, dgamma, dbeta = ctx.ops.batchnorm_train_bwd(x, g.contiguous(), gamma.detach(), beta.detach(), mean, rstd, ctx.act)
-        return dx, dgamma, dbeta, None, None, None, None, None, None
+        dx, dgamma, dbeta = ctx.ops.batchnorm_train_bwd(x, g.contiguous(), gamma.detach(), beta.detach(), mean, rstd, ctx.act,
+                                                        ctx.views, ctx.view_major)
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
-def batchnorm_act(ops: Ops, x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, relu=True):
-    return _BatchNormActFn.apply(x.contiguous(), gamma, beta, running_mean, running_var, ops, momentum, eps, relu)
+def batchnorm_act(ops: Ops, x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, relu=True, views=1,
+                  view_major=True):
+    """`views` independent BatchNorm calls batched in one tensor (rows view-major [V*B] or view-minor [B*V])"""
+    return _BatchNormActFn.apply(x.contiguous(), gamma, beta, running_mean, running_var, ops, momentum, eps, relu, views,
+                                 view_major)

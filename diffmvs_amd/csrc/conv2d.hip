@@ -54,7 +54,10 @@ struct ConvCfg {
     static constexpr int W_IT = (CK * WPAD / 4 + DMVS_BLOCK - 1) / DMVS_BLOCK;         // 16-byte DMA pieces per thread
 };
 
-template <int KH, int KW, int S, int NT, int MT>
+// ZI = the zero-insert input mode (training only: input gradient of a stride-2 layer).  It is a separate instantiation
+// because its extra predicate in the staging path costs the inference kernels scalar-register spills (measured: +30 %
+// on the 3x3 NT=1 MT=4 kernel when it was a run-time branch of the same code).
+template <int KH, int KW, int S, int NT, int MT, bool ZI>
 __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_mfma_kernel(const dmvs_conv2d_desc d, int tiles_x, int tiles_y) {
     using Cfg = ConvCfg<KH, KW, S, NT, MT>;
     constexpr int T = Cfg::T, TW = Cfg::TW, TH = Cfg::TH, PLANE = Cfg::PLANE, NW = Cfg::NW, WPAD = Cfg::WPAD;
@@ -73,10 +76,9 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_mfma_kernel(const dmvs_conv
     const int gy0 = oy0 * S - d.pad_h, gx0 = ox0 * S - d.pad_w;
 
     // ---- addressing of the logical input, all in 32-bit element offsets from per-batch bases
-    const int mode = d.in_mode;
-    const bool halfres = mode == DMVS_IN_UPSAMPLE2 || mode == DMVS_IN_ZEROINSERT2;
-    const int pW = halfres ? (d.Win >> 1) : (mode == DMVS_IN_UNSHUFFLE2 ? (d.Win << 1) : d.Win);
-    const int pH = halfres ? (d.Hin >> 1) : (mode == DMVS_IN_UNSHUFFLE2 ? (d.Hin << 1) : d.Hin);
+    const int mode = ZI ? DMVS_IN_UPSAMPLE2 : d.in_mode;      // zero-insert addresses like nearest-x2 (plus a parity predicate)
+    const int pW = mode == DMVS_IN_UPSAMPLE2 ? (d.Win >> 1) : (mode == DMVS_IN_UNSHUFFLE2 ? (d.Win << 1) : d.Win);
+    const int pH = mode == DMVS_IN_UPSAMPLE2 ? (d.Hin >> 1) : (mode == DMVS_IN_UNSHUFFLE2 ? (d.Hin << 1) : d.Hin);
     const int plane0 = pH * pW, plane1 = d.Hin * d.Win;
     const int pc0 = mode == DMVS_IN_UNSHUFFLE2 ? (d.c0 >> 2) : d.c0;
     const float* in0b = d.in0 + (size_t)b * pc0 * plane0;
@@ -88,11 +90,10 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_mfma_kernel(const dmvs_conv
         const int ci = e / PLANE, rem = e - ci * PLANE;
         const int r = rem / TW, c = rem - r * TW;
         const int cig = c0 + ci, iy = gy0 + r, ix = gx0 + c;
-        const bool ok = rem < TH * TW && cig < cin && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win &&
-                        !(mode == DMVS_IN_ZEROINSERT2 && ((iy | ix) & 1));
+        const bool ok = rem < TH * TW && cig < cin && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win && !(ZI && ((iy | ix) & 1));
         int off;
         if (mode == DMVS_IN_PLAIN) off = cig * plane0 + iy * pW + ix;
-        else if (halfres) off = cig * plane0 + (iy >> 1) * pW + (ix >> 1);
+        else if (mode == DMVS_IN_UPSAMPLE2) off = cig * plane0 + (iy >> 1) * pW + (ix >> 1);
         else off = (cig >> 2) * plane0 + (iy * 2 + ((cig >> 1) & 1)) * pW + ix * 2 + (cig & 1);
         off_out = (ok && cig < d.c0) ? off : -1;
         if (!ok) return nullptr;
@@ -312,15 +313,15 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_mfma_kernel(const dmvs_conv
     }
 }
 
-template <int KH, int KW, int S, int MT>
+template <int KH, int KW, int S, int MT, bool ZI>
 int launch_conv2d_mt(const dmvs_conv2d_desc& d, hipStream_t st, int nt, int ngroups) {
     const int tiles_x = (d.Wout + 15) / 16, tiles_y = (d.Hout + 4 * MT - 1) / (4 * MT);
     dim3 grid((unsigned)(tiles_x * tiles_y * d.B), (unsigned)ngroups), block(DMVS_BLOCK);
     switch (nt) {
-        case 1: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 1, MT>), grid, block, 0, st, d, tiles_x, tiles_y); break;
-        case 2: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 2, MT>), grid, block, 0, st, d, tiles_x, tiles_y); break;
-        case 3: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 3, MT>), grid, block, 0, st, d, tiles_x, tiles_y); break;
-        default: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 4, MT>), grid, block, 0, st, d, tiles_x, tiles_y); break;
+        case 1: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 1, MT, ZI>), grid, block, 0, st, d, tiles_x, tiles_y); break;
+        case 2: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 2, MT, ZI>), grid, block, 0, st, d, tiles_x, tiles_y); break;
+        case 3: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 3, MT, ZI>), grid, block, 0, st, d, tiles_x, tiles_y); break;
+        default: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 4, MT, ZI>), grid, block, 0, st, d, tiles_x, tiles_y); break;
     }
     return dmvs_launch_status();
 }
@@ -331,14 +332,19 @@ int launch_conv2d(const dmvs_conv2d_desc& d, hipStream_t st) {
     // output channels per workgroup: up to 4 MFMA n-tiles share one staged input tile
     const int nt = ntiles <= 4 ? ntiles : (ntiles % 3 == 0 ? 3 : 4);
     const int ngroups = (ntiles + nt - 1) / nt;
+    if (d.in_mode == DMVS_IN_ZEROINSERT2) {        // training: input gradient of the 3x3 / 5x5 stride-2 layers
+        if constexpr (S == 1 && ((KH == 3 && KW == 3) || (KH == 5 && KW == 5)))
+            return launch_conv2d_mt<KH, KW, S, 2, true>(d, st, nt, ngroups);
+        return DMVS_EINVAL;
+    }
     // pixel tile = 16 x (4*MT).  Tall tiles amortise the halo and the weight slab; small images take
     // 16x4 tiles so that the 256 CUs still see a few workgroups each; stride-2 / many-tap / wide-N
     // shapes stop at MT=2 to keep the staging registers + accumulators inside the VGPR file.
     constexpr bool heavy = (S == 2) || (KH * KW >= 25);
     const long wg16 = (long)((d.Wout + 15) / 16) * ((d.Hout + 15) / 16) * d.B * ngroups;
-    if (wg16 * 4 < 1024) return launch_conv2d_mt<KH, KW, S, 1>(d, st, nt, ngroups);
-    if (heavy || nt == 4 || wg16 * 2 < 1024) return launch_conv2d_mt<KH, KW, S, 2>(d, st, nt, ngroups);
-    if constexpr (!heavy) return launch_conv2d_mt<KH, KW, S, 4>(d, st, nt, ngroups);
+    if (wg16 * 4 < 1024) return launch_conv2d_mt<KH, KW, S, 1, false>(d, st, nt, ngroups);
+    if (heavy || nt == 4 || wg16 * 2 < 1024) return launch_conv2d_mt<KH, KW, S, 2, false>(d, st, nt, ngroups);
+    if constexpr (!heavy) return launch_conv2d_mt<KH, KW, S, 4, false>(d, st, nt, ngroups);
     return DMVS_EINVAL;
 }
 

@@ -3,6 +3,11 @@
 // in train mode (reference models/module.py:24-58, :60-96, :279-301).  HBM-bound: forward reads x twice and writes y,
 // backward reads (x, dy) twice and writes dx.  No atomics: per-chunk partial sums go through caller-owned scratch
 // and are folded in double precision by one workgroup per channel => run-to-run reproducible statistics/gradients.
+//
+// `views` > 1 normalises V independent sub-batches in one launch: the reference applies FeatureNet once per image of
+// the view stack and PixelViewWeight once per source view (diffusion.py:156-157, module.py:533), so every such call
+// has its own batch statistics and updates the running statistics once, in view order.  Batching the V calls into one
+// tensor (rows b = v*B/V + i if view_major, else b = i*V + v) keeps those semantics with V times fewer launches.
 #include "dmvs_common.h"
 
 namespace {
@@ -35,7 +40,8 @@ template <bool BWD>
 __global__ void __launch_bounds__(DMVS_BLOCK)
 bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
                   const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ rstd,
-                  float2* __restrict__ partial, int C, int S, int chunks_per_row, int relu) {
+                  float2* __restrict__ partial, int C, int S, int chunks_per_row, int relu, int views, int rows_per_view,
+                  int view_major) {
     __shared__ float red[2 * DMVS_BLOCK / 64];
     const int c = blockIdx.y, chunk = blockIdx.x;
     const int b = chunk / chunks_per_row, k = chunk - b * chunks_per_row;
@@ -44,8 +50,9 @@ bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy, con
     float s0 = 0.0f, s1 = 0.0f;
     float mu = 0.0f, rs = 0.0f, g = 1.0f, bt = 0.0f;
     if (BWD) {
-        mu = mean[c];
-        rs = rstd[c];
+        const int v = view_major ? b / rows_per_view : b % views;
+        mu = mean[v * C + c];
+        rs = rstd[v * C + c];
         g = gamma[c];
         bt = beta[c];
     }
@@ -88,53 +95,77 @@ bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy, con
     if (threadIdx.x == 0) partial[(size_t)c * gridDim.x + chunk] = t;
 }
 
-// one workgroup per channel: fold the partials in double.
-// forward : mean, rstd (biased variance) -> save_*;  running stats <- (1-m)*running + m*(mean | unbiased variance)
-// backward: dbeta = sum dz, dgamma = sum dz*xhat
+// one workgroup per channel: fold the partials of every view in double, views in order.
+// forward : mean, rstd (biased variance) per view -> out0/out1 [views][C];  running stats <- (1-m)*running +
+//           m*(mean | unbiased variance), once per view, sequentially (the reference's per-call updates)
+// backward: per view dbeta_v = sum dz, dgamma_v = sum dz*xhat -> out0/out1 [views][C]; totals -> tot0/tot1 [C]
 template <bool BWD>
 __global__ void __launch_bounds__(DMVS_BLOCK)
-bn_finalize_kernel(const float2* __restrict__ partial, int nchunk, double count, float* __restrict__ out0,
-                   float* __restrict__ out1, float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
-                   float eps) {
+bn_finalize_kernel(const float2* __restrict__ partial, int nchunk, int chunks_per_row, double count, float* __restrict__ out0,
+                   float* __restrict__ out1, float* __restrict__ tot0, float* __restrict__ tot1,
+                   float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps, int C,
+                   int views, int rows_per_view, int view_major) {
     __shared__ double red[2 * DMVS_BLOCK / 64];
     const int c = blockIdx.x;
-    double a = 0.0, q = 0.0;
-    for (int i = threadIdx.x; i < nchunk; i += DMVS_BLOCK) {
-        const float2 p = partial[(size_t)c * nchunk + i];
-        a += (double)p.x;
-        q += (double)p.y;
+    double t0 = 0.0, t1 = 0.0;
+    float rm = 0.0f, rv = 0.0f;
+    if (!BWD && running_mean && threadIdx.x == 0) {
+        rm = running_mean[c];
+        rv = running_var[c];
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        a += __shfl_down(a, o, 64);
-        q += __shfl_down(q, o, 64);
-    }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) {
-        red[wave * 2] = a;
-        red[wave * 2 + 1] = q;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        a = q = 0.0;
-        for (int w = 0; w < DMVS_BLOCK / 64; ++w) {
-            a += red[w * 2];
-            q += red[w * 2 + 1];
+    for (int v = 0; v < views; ++v) {
+        double a = 0.0, q = 0.0;
+        for (int i = threadIdx.x; i < nchunk; i += DMVS_BLOCK) {
+            const int b = i / chunks_per_row;
+            if ((view_major ? b / rows_per_view : b % views) != v) continue;
+            const float2 p = partial[(size_t)c * nchunk + i];
+            a += (double)p.x;
+            q += (double)p.y;
         }
-        if (BWD) {
-            out0[c] = (float)a;      // dbeta
-            out1[c] = (float)q;      // dgamma
-        } else {
-            const double mean = a / count;
-            double var = q / count - mean * mean;
-            var = var > 0.0 ? var : 0.0;
-            out0[c] = (float)mean;
-            out1[c] = (float)(1.0 / sqrt(var + (double)eps));
-            if (running_mean) {
-                const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-                running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
-                running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_down(a, o, 64);
+            q += __shfl_down(q, o, 64);
+        }
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        __syncthreads();
+        if (lane == 0) {
+            red[wave * 2] = a;
+            red[wave * 2 + 1] = q;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            a = q = 0.0;
+            for (int w = 0; w < DMVS_BLOCK / 64; ++w) {
+                a += red[w * 2];
+                q += red[w * 2 + 1];
             }
+            if (BWD) {
+                out0[v * C + c] = (float)a;      // dbeta of this view
+                out1[v * C + c] = (float)q;      // dgamma of this view
+                t0 += a;
+                t1 += q;
+            } else {
+                const double mean = a / count;
+                double var = q / count - mean * mean;
+                var = var > 0.0 ? var : 0.0;
+                out0[v * C + c] = (float)mean;
+                out1[v * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+                if (running_mean) {
+                    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+                    rm = (float)((1.0 - momentum) * rm + momentum * mean);
+                    rv = (float)((1.0 - momentum) * rv + momentum * unbiased);
+                }
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (BWD) {
+            tot0[c] = (float)t0;
+            tot1[c] = (float)t1;
+        } else if (running_mean) {
+            running_mean[c] = rm;
+            running_var[c] = rv;
         }
     }
 }
@@ -146,11 +177,12 @@ __global__ void __launch_bounds__(DMVS_BLOCK)
 bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
                 const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ rstd,
                 const float* __restrict__ dbeta, const float* __restrict__ dgamma, float* __restrict__ out, int C, int S,
-                float inv_count, int relu) {
-    const int bc = blockIdx.y, c = bc % C;
+                float inv_count, int relu, int views, int rows_per_view, int view_major) {
+    const int bc = blockIdx.y, c = bc % C, b = bc / C;
+    const int vc = (view_major ? b / rows_per_view : b % views) * C + c;
     const size_t row = (size_t)bc * S;
-    const float mu = mean[c], rs = rstd[c], g = gamma[c], bt = beta[c];
-    const float k1 = BWD ? dbeta[c] * inv_count : 0.0f, k2 = BWD ? dgamma[c] * inv_count : 0.0f;
+    const float mu = mean[vc], rs = rstd[vc], g = gamma[c], bt = beta[c];
+    const float k1 = BWD ? dbeta[vc] * inv_count : 0.0f, k2 = BWD ? dgamma[vc] * inv_count : 0.0f;
     const float a = rs * g, b0 = bt - mu * rs * g;
     if ((S & 3) == 0) {
         const int i = blockIdx.x * DMVS_BLOCK + threadIdx.x;
@@ -194,50 +226,60 @@ bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const
 inline int chunks_per_row(int S) { return (S + BN_CHUNK - 1) / BN_CHUNK; }
 }  // namespace
 
-extern "C" int dmvs_batchnorm_workspace_f32(int32_t B, int32_t C, int32_t S, int64_t* bytes) {
-    if (!bytes || B <= 0 || C <= 0 || S <= 0) return DMVS_EINVAL;
-    *bytes = (int64_t)C * B * chunks_per_row(S) * (int64_t)sizeof(float2);
+static int64_t bn_ws_bytes(int B, int C, int S, int views) {
+    return (int64_t)C * B * chunks_per_row(S) * (int64_t)sizeof(float2) + (int64_t)2 * views * C * (int64_t)sizeof(float);
+}
+
+extern "C" int dmvs_batchnorm_workspace_f32(int32_t B, int32_t C, int32_t S, int32_t views, int64_t* bytes) {
+    if (!bytes || B <= 0 || C <= 0 || S <= 0 || views <= 0 || B % views) return DMVS_EINVAL;
+    *bytes = bn_ws_bytes(B, C, S, views);
     return 0;
 }
 
 extern "C" int dmvs_batchnorm_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* running_mean,
                                             float* running_var, float* y, float* save_mean, float* save_rstd,
                                             float* workspace, int64_t workspace_bytes, int32_t B, int32_t C, int32_t S,
-                                            float momentum, float eps, int32_t act, void* stream) {
+                                            int32_t views, int32_t view_major, float momentum, float eps, int32_t act,
+                                            void* stream) {
     if (!x || !gamma || !beta || !y || !save_mean || !save_rstd || !workspace || B <= 0 || C <= 0 || S <= 0) return DMVS_EINVAL;
+    if (views <= 0 || B % views) return DMVS_EINVAL;
     if ((act != DMVS_ACT_NONE && act != DMVS_ACT_RELU) || (!running_mean) != (!running_var)) return DMVS_EINVAL;
     if (((uintptr_t)x | (uintptr_t)y) & 15) return DMVS_EINVAL;
-    const int cpr = chunks_per_row(S), nchunk = B * cpr;
-    if (workspace_bytes < (int64_t)C * nchunk * (int64_t)sizeof(float2)) return DMVS_EINVAL;
+    const int cpr = chunks_per_row(S), nchunk = B * cpr, rpv = B / views;
+    if (workspace_bytes < bn_ws_bytes(B, C, S, views)) return DMVS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     float2* part = reinterpret_cast<float2*>(workspace);
     hipLaunchKernelGGL((bn_partial_kernel<false>), dim3(nchunk, C), dim3(DMVS_BLOCK), 0, st, x, (const float*)nullptr, gamma, beta,
-                       (const float*)nullptr, (const float*)nullptr, part, C, S, cpr, 0);
-    hipLaunchKernelGGL((bn_finalize_kernel<false>), dim3(C), dim3(DMVS_BLOCK), 0, st, part, nchunk, (double)B * S, save_mean,
-                       save_rstd, running_mean, running_var, momentum, eps);
+                       (const float*)nullptr, (const float*)nullptr, part, C, S, cpr, 0, views, rpv, view_major);
+    hipLaunchKernelGGL((bn_finalize_kernel<false>), dim3(C), dim3(DMVS_BLOCK), 0, st, part, nchunk, cpr, (double)rpv * S, save_mean,
+                       save_rstd, (float*)nullptr, (float*)nullptr, running_mean, running_var, momentum, eps, C, views, rpv,
+                       view_major);
     hipLaunchKernelGGL((bn_apply_kernel<false>), dim3(dmvs_ceil_div((S + 3) / 4, DMVS_BLOCK), B * C), dim3(DMVS_BLOCK), 0, st, x,
                        (const float*)nullptr, gamma, beta, save_mean, save_rstd, (const float*)nullptr, (const float*)nullptr, y, C,
-                       S, 0.0f, act == DMVS_ACT_RELU);
+                       S, 0.0f, act == DMVS_ACT_RELU, views, rpv, view_major);
     return dmvs_launch_status();
 }
 
 extern "C" int dmvs_batchnorm_train_bwd_f32(const float* x, const float* dy, const float* gamma, const float* beta,
                                             const float* save_mean, const float* save_rstd, float* dx, float* dgamma,
                                             float* dbeta, float* workspace, int64_t workspace_bytes, int32_t B, int32_t C,
-                                            int32_t S, int32_t act, void* stream) {
+                                            int32_t S, int32_t views, int32_t view_major, int32_t act, void* stream) {
     if (!x || !dy || !gamma || !beta || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !workspace) return DMVS_EINVAL;
-    if (B <= 0 || C <= 0 || S <= 0 || (act != DMVS_ACT_NONE && act != DMVS_ACT_RELU)) return DMVS_EINVAL;
+    if (B <= 0 || C <= 0 || S <= 0 || views <= 0 || B % views || (act != DMVS_ACT_NONE && act != DMVS_ACT_RELU)) return DMVS_EINVAL;
     if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) return DMVS_EINVAL;
-    const int cpr = chunks_per_row(S), nchunk = B * cpr;
-    if (workspace_bytes < (int64_t)C * nchunk * (int64_t)sizeof(float2)) return DMVS_EINVAL;
+    const int cpr = chunks_per_row(S), nchunk = B * cpr, rpv = B / views;
+    if (workspace_bytes < bn_ws_bytes(B, C, S, views)) return DMVS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     float2* part = reinterpret_cast<float2*>(workspace);
+    float* dbeta_v = reinterpret_cast<float*>(part + (size_t)C * nchunk);      // per-view sums [views][C]
+    float* dgamma_v = dbeta_v + (size_t)views * C;
     const int relu = act == DMVS_ACT_RELU;
     hipLaunchKernelGGL((bn_partial_kernel<true>), dim3(nchunk, C), dim3(DMVS_BLOCK), 0, st, x, dy, gamma, beta, save_mean, save_rstd,
-                       part, C, S, cpr, relu);
-    hipLaunchKernelGGL((bn_finalize_kernel<true>), dim3(C), dim3(DMVS_BLOCK), 0, st, part, nchunk, (double)B * S, dbeta, dgamma,
-                       (float*)nullptr, (float*)nullptr, 0.0f, 0.0f);
+                       part, C, S, cpr, relu, views, rpv, view_major);
+    hipLaunchKernelGGL((bn_finalize_kernel<true>), dim3(C), dim3(DMVS_BLOCK), 0, st, part, nchunk, cpr, (double)rpv * S, dbeta_v,
+                       dgamma_v, dbeta, dgamma, (float*)nullptr, (float*)nullptr, 0.0f, 0.0f, C, views, rpv, view_major);
     hipLaunchKernelGGL((bn_apply_kernel<true>), dim3(dmvs_ceil_div((S + 3) / 4, DMVS_BLOCK), B * C), dim3(DMVS_BLOCK), 0, st, x, dy,
-                       gamma, beta, save_mean, save_rstd, dbeta, dgamma, dx, C, S, (float)(1.0 / ((double)B * S)), relu);
+                       gamma, beta, save_mean, save_rstd, dbeta_v, dgamma_v, dx, C, S, (float)(1.0 / ((double)rpv * S)), relu, views,
+                       rpv, view_major);
     return dmvs_launch_status();
 }

@@ -209,19 +209,41 @@ warp_corr_init_kernel(const float* __restrict__ ref, const float* __restrict__ s
 
 // ------------------------------------------------------------------------------------------
 // GetCost: hypotheses + S warps + correlation + view-weighted aggregation in one pass.
-template <int C, int CPL, int N>
+// TILED: the launch covers the 16x16 pixel tiles that the LDS-window kernel (warp_win.hip) could not take, listed in
+// d.worklist ([0] = count, then tile ids); workgroups beyond the count retire at once.
+template <int C, int CPL, int N, bool TILED>
 __global__ void __launch_bounds__(DMVS_BLOCK) getcost_kernel(const dmvs_getcost_desc d) {
     constexpr int G = 4, LPP = C / CPL, LPG = LPP / G, PPB = DMVS_BLOCK / LPP, KPL = (N + LPP - 1) / LPP;
     const int sub = threadIdx.x % LPP, slot = threadIdx.x / LPP;
     const int H = d.H, W = d.W;
-    const long npix = (long)d.B * H * W;
-    const long pix = (long)dmvs_xcd_contiguous_block(blockIdx.x, gridDim.x) * PPB + slot;
-    const bool live = pix < npix;
-    const long pc = live ? pix : npix - 1;
-    const int x = (int)(pc % W);
-    const int y = (int)((pc / W) % H);
-    const int b = (int)(pc / ((long)W * H));
-    const long hw = (long)H * W, yx = (long)y * W + x;
+    const long hw = (long)H * W;
+    bool live;
+    int x, y, b;
+    if (TILED) {
+        constexpr int T = DMVS_GETCOST_TILE, BPT = T * T / PPB;       // workgroups per tile
+        const int entry = blockIdx.x / BPT;
+        if (entry >= d.worklist[0]) return;
+        int tq = d.worklist[1 + entry];
+        const int tiles_x = (W + T - 1) / T, tiles_y = (H + T - 1) / T;
+        const int txi = tq % tiles_x; tq /= tiles_x;
+        const int tyi = tq % tiles_y;
+        b = tq / tiles_y;
+        const int p = (blockIdx.x % BPT) * PPB + slot;
+        x = txi * T + (p & (T - 1));
+        y = tyi * T + p / T;
+        live = x < W && y < H;
+        x = min(x, W - 1);
+        y = min(y, H - 1);
+    } else {
+        const long npix = (long)d.B * hw;
+        const long pix = (long)dmvs_xcd_contiguous_block(blockIdx.x, gridDim.x) * PPB + slot;
+        live = pix < npix;
+        const long pq = live ? pix : npix - 1;
+        x = (int)(pq % W);
+        y = (int)((pq / W) % H);
+        b = (int)(pq / hw);
+    }
+    const long yx = (long)y * W + x, pc = (long)b * hw + yx;
 
     // hypotheses in normalised inverse depth (reference :259-276)
     const float cur_inv = d.inv_depth[pc];
@@ -293,8 +315,20 @@ template <int C, int CPL>
 int launch_getcost(const dmvs_getcost_desc& d, hipStream_t st) {
     constexpr int PPB = DMVS_BLOCK / (C / CPL);
     dim3 grid(dmvs_ceil_div((long)d.B * d.H * d.W, PPB)), block(DMVS_BLOCK);
-    if (d.n == 4) hipLaunchKernelGGL((getcost_kernel<C, CPL, 4>), grid, block, 0, st, d);
-    else if (d.n == 6) hipLaunchKernelGGL((getcost_kernel<C, CPL, 6>), grid, block, 0, st, d);
+    if (d.n == 4) hipLaunchKernelGGL((getcost_kernel<C, CPL, 4, false>), grid, block, 0, st, d);
+    else if (d.n == 6) hipLaunchKernelGGL((getcost_kernel<C, CPL, 6, false>), grid, block, 0, st, d);
+    else return DMVS_EINVAL;
+    return dmvs_launch_status();
+}
+
+// the tiles the window kernel listed in d.worklist
+template <int C, int CPL>
+int launch_getcost_tiles(const dmvs_getcost_desc& d, hipStream_t st) {
+    constexpr int PPB = DMVS_BLOCK / (C / CPL), T = DMVS_GETCOST_TILE, BPT = T * T / PPB;
+    const long tiles = (long)d.B * ((d.H + T - 1) / T) * ((d.W + T - 1) / T);
+    dim3 grid((unsigned)(tiles * BPT)), block(DMVS_BLOCK);
+    if (d.n == 4) hipLaunchKernelGGL((getcost_kernel<C, CPL, 4, true>), grid, block, 0, st, d);
+    else if (d.n == 6) hipLaunchKernelGGL((getcost_kernel<C, CPL, 6, true>), grid, block, 0, st, d);
     else return DMVS_EINVAL;
     return dmvs_launch_status();
 }
@@ -349,6 +383,10 @@ extern "C" int dmvs_getcost_f32(const dmvs_getcost_desc* dp, void* stream) {
     if (!dp) return DMVS_EINVAL;
     const dmvs_getcost_desc& d = *dp;
     if (int rc = getcost_check(d)) return rc;
-    if (d.C == 32 || d.C == 16) return dmvs_getcost_win_dispatch(d, (hipStream_t)stream);   // LDS-staged source windows
-    return dmvs_getcost_gather_f32(dp, stream);
+    if ((d.C != 32 && d.C != 16) || !d.worklist) return dmvs_getcost_gather_f32(dp, stream);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(d.worklist, 0, sizeof(int32_t), st);
+    if (e != hipSuccess) return (int)e;
+    if (int rc = dmvs_getcost_win_dispatch(d, st)) return rc;          // tiles whose source windows fit LDS
+    return d.C == 32 ? launch_getcost_tiles<32, 4>(d, st) : launch_getcost_tiles<16, 4>(d, st);   // the rest
 }

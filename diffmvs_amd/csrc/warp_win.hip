@@ -13,8 +13,9 @@
 //      neighbouring lanes hit disjoint bank groups;
 //   4. uses  sum_c ref_c * (sum_t w_t tex_t,c) = sum_t w_t * (sum_c ref_c tex_t,c):  one group dot per TEXEL
 //      (packed fp32 FMAs), then a 4-tap blend of 4 group values per hypothesis instead of C channels.
-// A view whose tile footprint does not fit the window (wide baseline at a depth edge, z sign change) falls back,
-// workgroup-uniformly, to per-lane global gathers of the same arithmetic: any geometry stays correct.
+// A tile whose footprint does not fit the window in some view (depth discontinuity, very wide baseline, a z sign
+// change along a ray) is appended to d.worklist and left to the gather kernel (warp.hip, TILED launch): any geometry
+// stays correct, and smooth regions -- the bulk of a real depth map -- take the fast path.
 #include "dmvs_common.h"
 
 namespace {
@@ -108,12 +109,15 @@ __global__ void __launch_bounds__(DMVS_BLOCK, 2) getcost_win_kernel(const dmvs_g
     constexpr int SUBS = (SLOTS + 63) / 64;             // DMA instructions per row and wave
     static_assert(TW * TH == DMVS_BLOCK, "one lane per pixel");
     __shared__ __attribute__((aligned(16))) float win[WW * WH * TS];
-    __shared__ int red[DMVS_BLOCK / 64][5];
+    constexpr int MAXS = 16;
+    __shared__ int red[2][DMVS_BLOCK / 64][5];
+    __shared__ int sbox[MAXS][4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = d.H, W = d.W;
     const long hw = (long)H * W;
-    int tq = (int)dmvs_xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int tile = (int)dmvs_xcd_contiguous_block(blockIdx.x, gridDim.x);
+    int tq = tile;
     const int txi = tq % tiles_x; tq /= tiles_x;
     const int tyi = tq % tiles_y;
     const int b = tq / tiles_y;
@@ -139,19 +143,6 @@ __global__ void __launch_bounds__(DMVS_BLOCK, 2) getcost_win_kernel(const dmvs_g
         sk += lo;
         sk = fminf(fmaxf(sk, 0.0f), 1.0f);
         depth[k] = dmvs_disp_to_depth(sk, dmin, dmax);
-        if (live) d.out_samples[((long)b * d.samp_cstride + d.samp_coffset + k) * hw + yx] = sk;
-    }
-
-    f2 refp[C / 2];
-    {
-        const float inv_cg = 1.0f / (float)(C / G);
-        const float4* rp = reinterpret_cast<const float4*>(d.ref + pc * C);
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const float4 q = rp[j];
-            refp[2 * j] = f2{q.x * inv_cg, q.y * inv_cg};
-            refp[2 * j + 1] = f2{q.z * inv_cg, q.w * inv_cg};
-        }
     }
 
     float acc[N][G];
@@ -172,55 +163,87 @@ __global__ void __launch_bounds__(DMVS_BLOCK, 2) getcost_win_kernel(const dmvs_g
         dch[i] = slot < SLOTS ? slot - dcol[i] * (NCH + 1) : NCH;      // NCH = pad slot / beyond the row: never loaded
     }
 
+    // ---- every view's footprint box of the tile, up front: a tile whose box exceeds the window in ANY view is handed
+    // to the gather kernel through the worklist and this workgroup retires without touching the sources
+    bool allfit = d.S <= MAXS;
+    for (int s = 0; s < d.S && s < MAXS; ++s) {
+        RayW ray;
+        ray.init(d.rt + ((long)b * d.S + s) * 12, (float)xc, (float)yc);
+        float u0, v0, z0, u1, v1, z1;
+        bool f0, f1;
+        project_uv(ray, depth[0], u0, v0, z0, f0);
+        project_uv(ray, depth[N - 1], u1, v1, z1, f1);
+        int bad = live && (!f0 || !f1 || ((z0 < 0.0f) != (z1 < 0.0f)));     // a pole between the ends: not a segment
+        int bx0 = 0x3fffffff, by0 = 0x3fffffff, bx1 = -0x3fffffff, by1 = -0x3fffffff;
+        if (live && !bad) {
+            const int ax = max((int)floorf(fminf(u0, u1)), 0), cx = min((int)floorf(fmaxf(u0, u1)) + 1, W - 1);
+            const int ay = max((int)floorf(fminf(v0, v1)), 0), cy = min((int)floorf(fmaxf(v0, v1)) + 1, H - 1);
+            if (ax <= cx && ay <= cy) {      // else: every tap of every hypothesis of this pixel is padding
+                bx0 = ax; bx1 = cx; by0 = ay; by1 = cy;
+            }
+        }
+        bx0 = wave_min(bx0); by0 = wave_min(by0); bx1 = wave_max(bx1); by1 = wave_max(by1); bad = wave_max(bad);
+        int (*rd)[5] = red[s & 1];           // double-buffered: a fast wave may already be writing the next view's
+        if (lane == 0) {
+            rd[wave][0] = bx0; rd[wave][1] = by0; rd[wave][2] = bx1; rd[wave][3] = by1; rd[wave][4] = bad;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < DMVS_BLOCK / 64; ++q) {
+            bx0 = min(bx0, rd[q][0]); by0 = min(by0, rd[q][1]);
+            bx1 = max(bx1, rd[q][2]); by1 = max(by1, rd[q][3]); bad = max(bad, rd[q][4]);
+        }
+        const int nc = bx1 - bx0 + 1, nr = by1 - by0 + 1;
+        if (bad || (bx1 >= bx0 && (nc > WW || nr > WH))) allfit = false;
+        if (tid == 0) {
+            sbox[s][0] = bx0; sbox[s][1] = by0; sbox[s][2] = nc; sbox[s][3] = nr;
+        }
+    }
+    if (!allfit) {
+        if (tid == 0) {
+            const int slot = atomicAdd(d.worklist, 1);
+            d.worklist[1 + slot] = tile;
+        }
+        return;
+    }
+    f2 refp[C / 2];
+    {
+        const float inv_cg = 1.0f / (float)(C / G);
+        const float4* rp = reinterpret_cast<const float4*>(d.ref + pc * C);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const float4 q = rp[j];
+            refp[2 * j] = f2{q.x * inv_cg, q.y * inv_cg};
+            refp[2 * j + 1] = f2{q.z * inv_cg, q.w * inv_cg};
+        }
+    }
+
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        float sk = (float)k * step;
+        sk += lo;
+        sk = fminf(fmaxf(sk, 0.0f), 1.0f);
+        if (live) d.out_samples[((long)b * d.samp_cstride + d.samp_coffset + k) * hw + yx] = sk;
+    }
+
     for (int s = 0; s < d.S; ++s) {
         const float w = d.view_w[((long)b * d.S + s) * Hv * Wv + vwi];
         wsum += w;
         RayW ray;
         ray.init(d.rt + ((long)b * d.S + s) * 12, (float)xc, (float)yc);
         const float* view = d.src + ((long)s * d.B + b) * hw * C;
-
-        // footprint box of this pixel from its two end hypotheses
-        float u0, v0, z0, u1, v1, z1;
-        bool f0, f1;
-        project_uv(ray, depth[0], u0, v0, z0, f0);
-        project_uv(ray, depth[N - 1], u1, v1, z1, f1);
-        int bad = live && (!f0 || !f1 || ((z0 < 0.0f) != (z1 < 0.0f)));
-        int bx0 = 0x3fffffff, by0 = 0x3fffffff, bx1 = -0x3fffffff, by1 = -0x3fffffff;
-        if (live && !bad) {
-            const int ax = max((int)floorf(fminf(u0, u1)), 0), cx = min((int)floorf(fmaxf(u0, u1)) + 1, W - 1);
-            const int ay = max((int)floorf(fminf(v0, v1)), 0), cy = min((int)floorf(fmaxf(v0, v1)) + 1, H - 1);
-            if (ax <= cx && ay <= cy) {      // else: every tap of every hypothesis is padding
-                bx0 = ax; bx1 = cx; by0 = ay; by1 = cy;
-            }
-        }
-        bx0 = wave_min(bx0); by0 = wave_min(by0); bx1 = wave_max(bx1); by1 = wave_max(by1); bad = wave_max(bad);
-        if (lane == 0) {
-            red[wave][0] = bx0; red[wave][1] = by0; red[wave][2] = bx1; red[wave][3] = by1; red[wave][4] = bad;
-        }
-        __syncthreads();        // also: every lane is done reading the previous view's window
+        __syncthreads();        // the boxes are published (s = 0) / every lane is done reading the previous view's window
+        const int bx0 = sbox[s][0], by0 = sbox[s][1], ncols = sbox[s][2], nrows = sbox[s][3];
+        if (ncols <= 0) continue;           // every tap of the tile is padding in this view (workgroup-uniform)
+        // rows of the window: each a contiguous run of ncols*C floats in the NHWC source
+        for (int r = wave; r < nrows; r += DMVS_BLOCK / 64) {
+            const float* rowp = view + ((long)(by0 + r) * W + bx0) * C;
 #pragma unroll
-        for (int q = 0; q < DMVS_BLOCK / 64; ++q) {
-            bx0 = min(bx0, red[q][0]); by0 = min(by0, red[q][1]);
-            bx1 = max(bx1, red[q][2]); by1 = max(by1, red[q][3]); bad = max(bad, red[q][4]);
-        }
-        const int ncols = bx1 - bx0 + 1, nrows = by1 - by0 + 1;
-        const bool empty = bx1 < bx0;
-        const bool fits = !bad && ncols <= WW && nrows <= WH;
-        if (!bad && empty) {
-            __syncthreads();    // keep the barrier count uniform across views (red[] reuse)
-            continue;
-        }
-        if (fits) {
-            // rows of the window: each a contiguous run of ncols*C floats in the NHWC source
-            for (int r = wave; r < nrows; r += DMVS_BLOCK / 64) {
-                const float* rowp = view + ((long)(by0 + r) * W + bx0) * C;
-#pragma unroll
-                for (int i = 0; i < SUBS; ++i) {
-                    if (dch[i] < NCH && dcol[i] < ncols) {
-                        const float* srcp = rowp + dcol[i] * C + dch[i] * 4;
-                        float* dstp = win + (r * SLOTS + i * 64) * 4;          // wave-uniform; lane l lands at +16*l bytes
-                        __builtin_amdgcn_global_load_lds(srcp, DMVS_LDS3(dstp), 16, 0, 0);
-                    }
+            for (int i = 0; i < SUBS; ++i) {
+                if (dch[i] < NCH && dcol[i] < ncols) {
+                    const float* srcp = rowp + dcol[i] * C + dch[i] * 4;
+                    float* dstp = win + (r * SLOTS + i * 64) * 4;          // wave-uniform; lane l lands at +16*l bytes
+                    __builtin_amdgcn_global_load_lds(srcp, DMVS_LDS3(dstp), 16, 0, 0);
                 }
             }
         }
@@ -232,60 +255,29 @@ __global__ void __launch_bounds__(DMVS_BLOCK, 2) getcost_win_kernel(const dmvs_g
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int g = 0; g < G; ++g) D[t][g] = 0.0f;
-        if (fits) {
 #pragma unroll
-            for (int k = 0; k < N; ++k) {
-                float u, v, z;
-                bool fin;
-                project_uv(ray, depth[k], u, v, z, fin);
-                const SampW sp = make_samp(u, v, fin, H, W);
-                if (sp.x0 != pfx || sp.y0 != pfy) {      // LDS reads only for a footprint that moved
-                    pfx = sp.x0;
-                    pfy = sp.y0;
-                    const int xa = min(max(sp.x0 - bx0, 0), ncols - 1), xb = min(max(sp.x0 + 1 - bx0, 0), ncols - 1);
-                    const int ya = min(max(sp.y0 - by0, 0), nrows - 1), yb = min(max(sp.y0 + 1 - by0, 0), nrows - 1);
-                    const int ra = __mul24(ya, WW * TS), rb = __mul24(yb, WW * TS), ca = __mul24(xa, TS), cb = __mul24(xb, TS);
-                    texel_dots<C>(win + ra + ca, refp, D[0]);
-                    texel_dots<C>(win + ra + cb, refp, D[1]);
-                    texel_dots<C>(win + rb + ca, refp, D[2]);
-                    texel_dots<C>(win + rb + cb, refp, D[3]);
-                }
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const float dot = D[0][g] * sp.w00 + D[1][g] * sp.w01 + D[2][g] * sp.w10 + D[3][g] * sp.w11;
-                    acc[k][g] = fmaf(w, dot, acc[k][g]);
-                }
-                if (k + 1 < N) DMVS_ORDER_AFTER(depth[k + 1], acc[k][G - 1]);   // next hypothesis starts after this one
+        for (int k = 0; k < N; ++k) {
+            float u, v, z;
+            bool fin;
+            project_uv(ray, depth[k], u, v, z, fin);
+            const SampW sp = make_samp(u, v, fin, H, W);
+            if (sp.x0 != pfx || sp.y0 != pfy) {      // LDS reads only for a footprint that moved
+                pfx = sp.x0;
+                pfy = sp.y0;
+                const int xa = min(max(sp.x0 - bx0, 0), ncols - 1), xb = min(max(sp.x0 + 1 - bx0, 0), ncols - 1);
+                const int ya = min(max(sp.y0 - by0, 0), nrows - 1), yb = min(max(sp.y0 + 1 - by0, 0), nrows - 1);
+                const int ra = __mul24(ya, WW * TS), rb = __mul24(yb, WW * TS), ca = __mul24(xa, TS), cb = __mul24(xb, TS);
+                texel_dots<C>(win + ra + ca, refp, D[0]);
+                texel_dots<C>(win + ra + cb, refp, D[1]);
+                texel_dots<C>(win + rb + ca, refp, D[2]);
+                texel_dots<C>(win + rb + cb, refp, D[3]);
             }
-        } else {
-            // the tile's footprint exceeds the window for this view: same arithmetic, taps gathered from global memory.
-            // Rare path, kept small: a rolled loop (hypothesis recomputed from k, accumulators picked by a select chain).
-#pragma unroll 1
-            for (int k = 0; k < N; ++k) {
-                float sk = (float)k * step;
-                sk += lo;
-                sk = fminf(fmaxf(sk, 0.0f), 1.0f);
-                float u, v, z;
-                bool fin;
-                project_uv(ray, dmvs_disp_to_depth(sk, dmin, dmax), u, v, z, fin);
-                const SampW sp = make_samp(u, v, fin, H, W);
-                if (sp.x0 != pfx || sp.y0 != pfy) {
-                    pfx = sp.x0;
-                    pfy = sp.y0;
-                    const int xa = min(max(sp.x0, 0), W - 1), xb = min(max(sp.x0 + 1, 0), W - 1);
-                    const int ya = min(max(sp.y0, 0), H - 1), yb = min(max(sp.y0 + 1, 0), H - 1);
-                    texel_dots<C>(view + ((long)ya * W + xa) * C, refp, D[0]);
-                    texel_dots<C>(view + ((long)ya * W + xb) * C, refp, D[1]);
-                    texel_dots<C>(view + ((long)yb * W + xa) * C, refp, D[2]);
-                    texel_dots<C>(view + ((long)yb * W + xb) * C, refp, D[3]);
-                }
 #pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const float dot = w * (D[0][g] * sp.w00 + D[1][g] * sp.w01 + D[2][g] * sp.w10 + D[3][g] * sp.w11);
-#pragma unroll
-                    for (int kk = 0; kk < N; ++kk) acc[kk][g] += kk == k ? dot : 0.0f;
-                }
+            for (int g = 0; g < G; ++g) {
+                const float dot = D[0][g] * sp.w00 + D[1][g] * sp.w01 + D[2][g] * sp.w10 + D[3][g] * sp.w11;
+                acc[k][g] = fmaf(w, dot, acc[k][g]);
             }
+            if (k + 1 < N) DMVS_ORDER_AFTER(depth[k + 1], acc[k][G - 1]);   // next hypothesis starts after this one
         }
     }
     if (live) {

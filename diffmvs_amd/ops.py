@@ -8,6 +8,7 @@ gfx950 library and refuses anything else.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -276,7 +277,9 @@ class Ops:
     def getcost(self, ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, min_radius,
                 max_radius, vw_shift, out_cost=None, cost_cstride=None, cost_coffset=0, out_samples=None,
                 samp_cstride=None, samp_coffset=0, G=4, gather=False):
-        """gather=True forces the per-pixel gather kernel (A/B measurements); default = LDS-window kernel for C 32|16"""
+        """gather=True forces the per-pixel gather kernel (A/B measurements; also DMVS_GETCOST=gather in the environment);
+        default = LDS-window kernel for C 32|16 with the gather kernel behind it for the tiles that do not fit"""
+        gather = gather or os.environ.get("DMVS_GETCOST") == "gather"
         self._chk(ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, out_cost, out_samples)
         B, H, W, Cc = ref.shape
         S = src.shape[0]
@@ -286,13 +289,15 @@ class Ops:
         if out_samples is None:
             samp_cstride = n
             out_samples = self.empty(B, n, H, W)
+        wl = None if gather else torch.empty(1 + B * ((H + 15) // 16) * ((W + 15) // 16), dtype=torch.int32, device=self.device)
         d = _lib.GetCostDesc(ref=_ptr(ref), src=_ptr(src), rt=_ptr(rt), inv_depth=_ptr(inv_depth),
                              confidence=_ptr(confidence), view_w=_ptr(view_w), disp_min=_ptr(disp_min),
                              disp_max=_ptr(disp_max), out_cost=_ptr(out_cost), out_samples=_ptr(out_samples),
-                             B=B, S=S, C=Cc, G=G, n=n, H=H, W=W, vw_shift=vw_shift, cost_cstride=cost_cstride,
+                             worklist=_ptr(wl), B=B, S=S, C=Cc, G=G, n=n, H=H, W=W, vw_shift=vw_shift, cost_cstride=cost_cstride,
                              cost_coffset=cost_coffset, samp_cstride=samp_cstride, samp_coffset=samp_coffset,
                              interval=interval, min_radius=min_radius, max_radius=max_radius)
         self._call("dmvs_getcost_gather_f32" if gather else "dmvs_getcost_f32", C.byref(d), self.stream())
+        self.last_getcost_worklist = wl      # diagnostics: [0] = number of tiles that fell through to the gather path
         return out_cost, out_samples
 
     # ------------------------------------------------------------------ backward (training step)
@@ -319,7 +324,8 @@ class Ops:
             gsrc = torch.zeros_like(src)
         d = _lib.GetCostDesc(ref=_ptr(ref), src=_ptr(src), rt=_ptr(rt), inv_depth=_ptr(inv_depth),
                              confidence=_ptr(confidence), view_w=_ptr(view_w), disp_min=_ptr(disp_min),
-                             disp_max=_ptr(disp_max), out_cost=None, out_samples=None, B=B, S=S, C=Cc, G=G, n=n, H=H, W=W,
+                             disp_max=_ptr(disp_max), out_cost=None, out_samples=None, worklist=None, B=B, S=S, C=Cc, G=G, n=n,
+                             H=H, W=W,
                              vw_shift=vw_shift, cost_cstride=G * n, cost_coffset=0, samp_cstride=n, samp_coffset=0,
                              interval=interval, min_radius=min_radius, max_radius=max_radius)
         self._call("dmvs_getcost_bwd_f32", C.byref(d), _ptr(gcost), _ptr(gref), _ptr(gsrc), self.stream())
@@ -435,32 +441,33 @@ class Ops:
         return out
 
     # ------------------------------------------------------------------ training-mode BatchNorm
-    def _bn_ws(self, B, Cc, S):
+    def _bn_ws(self, B, Cc, S, views):
         n = C.c_int64(0)
-        self._call("dmvs_batchnorm_workspace_f32", B, Cc, S, C.byref(n))
+        self._call("dmvs_batchnorm_workspace_f32", B, Cc, S, views, C.byref(n))
         return self.empty(max(n.value // 4, 1)), n.value
 
-    def batchnorm_train_fwd(self, x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, act=ACT_NONE):
-        """x [B,C,*spatial] -> y, save_mean [C], save_rstd [C]; running stats updated in place"""
+    def batchnorm_train_fwd(self, x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, act=ACT_NONE, views=1,
+                            view_major=True):
+        """x [B,C,*spatial] -> y, save_mean [views,C], save_rstd [views,C]; running stats updated in place (once per view)"""
         self._chk(x, gamma, beta, running_mean, running_var)
         B, Cc = x.shape[0], x.shape[1]
         S = x.numel() // (B * Cc)
         y = torch.empty_like(x)
-        mean, rstd = self.empty(Cc), self.empty(Cc)
-        ws, nb = self._bn_ws(B, Cc, S)
+        mean, rstd = self.empty(views, Cc), self.empty(views, Cc)
+        ws, nb = self._bn_ws(B, Cc, S, views)
         self._call("dmvs_batchnorm_train_fwd_f32", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(y),
-                   _ptr(mean), _ptr(rstd), _ptr(ws), nb, B, Cc, S, momentum, eps, act, self.stream())
+                   _ptr(mean), _ptr(rstd), _ptr(ws), nb, B, Cc, S, views, int(view_major), momentum, eps, act, self.stream())
         return y, mean, rstd
 
-    def batchnorm_train_bwd(self, x, dy, gamma, beta, mean, rstd, act=ACT_NONE):
+    def batchnorm_train_bwd(self, x, dy, gamma, beta, mean, rstd, act=ACT_NONE, views=1, view_major=True):
         self._chk(x, dy, gamma, beta, mean, rstd)
         B, Cc = x.shape[0], x.shape[1]
         S = x.numel() // (B * Cc)
         dx = torch.empty_like(x)
         dgamma, dbeta = self.empty(Cc), self.empty(Cc)
-        ws, nb = self._bn_ws(B, Cc, S)
+        ws, nb = self._bn_ws(B, Cc, S, views)
         self._call("dmvs_batchnorm_train_bwd_f32", _ptr(x), _ptr(dy), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dx),
-                   _ptr(dgamma), _ptr(dbeta), _ptr(ws), nb, B, Cc, S, act, self.stream())
+                   _ptr(dgamma), _ptr(dbeta), _ptr(ws), nb, B, Cc, S, views, int(view_major), act, self.stream())
         return dx, dgamma, dbeta
 
     # ------------------------------------------------------------------ training-step tail

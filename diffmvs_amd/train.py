@@ -46,21 +46,22 @@ class _Net:
     def conv2(self, x, k, stride=1, pad=0, in_mode=K.IN_PLAIN):
         return A.conv2d(self.o, x, self.p[k + ".weight"], self.p.get(k + ".bias"), stride=stride, pad=pad, in_mode=in_mode)
 
-    def bn(self, x, k, relu):
-        """BatchNorm in training mode (+ReLU): batch statistics, running stats updated in place (momentum 0.1)"""
+    def bn(self, x, k, relu, views=1, view_major=True):
+        """BatchNorm in training mode (+ReLU): batch statistics, running stats updated in place (momentum 0.1).
+        `views` independent calls of the reference batched in one tensor (per-view statistics, `views` updates)."""
         y = A.batchnorm_act(self.o, x, self.p[k + ".weight"], self.p[k + ".bias"], self.b[k + ".running_mean"],
-                            self.b[k + ".running_var"], 0.1, 1e-5, relu)
-        self.b[k + ".num_batches_tracked"].add_(1)
+                            self.b[k + ".running_var"], 0.1, 1e-5, relu, views, view_major)
+        self.b[k + ".num_batches_tracked"].add_(views)
         return y
 
-    def cbr2(self, x, k, stride=1, pad=1, relu=True):
+    def cbr2(self, x, k, stride=1, pad=1, relu=True, views=1):
         """module.Conv2d / ConvBnReLU / ConvBn (module.py:24-58, :279-301)"""
         y = A.conv2d(self.o, x, self.p[k + ".conv.weight"], None, stride=stride, pad=pad)
-        return self.bn(y, k + ".bn", relu)
+        return self.bn(y, k + ".bn", relu, views)
 
-    def cbr3(self, x, k, stride=1, transposed=False):
+    def cbr3(self, x, k, stride=1, transposed=False, views=1, view_major=True):
         y = A.conv3d(self.o, x, self.p[k + ".conv.weight"], None, stride=stride, transposed=transposed)
-        return self.bn(y, k + ".bn", True)
+        return self.bn(y, k + ".bn", True, views, view_major)
 
 
 def disp_to_depth(disp, min_depth, max_depth):
@@ -74,11 +75,14 @@ def depth_to_disp(depth, min_depth, max_depth):
     return (1 / depth - min_disp) / (max_disp - min_disp)
 
 
-def feature_net(n: _Net, x, p="feature"):
-    c0 = n.cbr2(n.cbr2(x, p + ".conv0.0"), p + ".conv0.1")
-    c1 = n.cbr2(n.cbr2(n.cbr2(c0, p + ".conv1.0", 2, 2), p + ".conv1.1"), p + ".conv1.2")
-    c2 = n.cbr2(n.cbr2(n.cbr2(c1, p + ".conv2.0", 2, 2), p + ".conv2.1"), p + ".conv2.2")
-    c3 = n.cbr2(n.cbr2(n.cbr2(c2, p + ".conv3.0", 2, 2), p + ".conv3.1"), p + ".conv3.2")
+def feature_net(n: _Net, x, views, p="feature"):
+    """FeatureNet on the whole view stack at once: x [V*B,3,H,W] view-major.  The reference calls it once per view
+    (diffusion.py:156-157); BatchNorm keeps per-view statistics, everything else is per-sample anyway."""
+    V = views
+    c0 = n.cbr2(n.cbr2(x, p + ".conv0.0", views=V), p + ".conv0.1", views=V)
+    c1 = n.cbr2(n.cbr2(n.cbr2(c0, p + ".conv1.0", 2, 2, views=V), p + ".conv1.1", views=V), p + ".conv1.2", views=V)
+    c2 = n.cbr2(n.cbr2(n.cbr2(c1, p + ".conv2.0", 2, 2, views=V), p + ".conv2.1", views=V), p + ".conv2.2", views=V)
+    c3 = n.cbr2(n.cbr2(n.cbr2(c2, p + ".conv3.0", 2, 2, views=V), p + ".conv3.1", views=V), p + ".conv3.2", views=V)
     out = {"stage1": n.conv2(c3, p + ".out1")}
     intra = F.interpolate(c3, scale_factor=2, mode="nearest") + n.conv2(c2, p + ".inner1")
     out["stage2"] = n.conv2(intra, p + ".out2", pad=1)
@@ -117,26 +121,25 @@ def upsample_depth(depth, mask, ratio):
     return (m * nb).sum(2).permute(0, 1, 4, 2, 5, 3).reshape(N, ratio * H, ratio * W)
 
 
-def _nhwc(feats):
-    """list of V [B,C,h,w] -> ref [B,h,w,C], src [S,B,h,w,C] (layout of the warp kernels; autograd-tracked)"""
-    nhwc = [f.permute(0, 2, 3, 1).contiguous() for f in feats]
-    return nhwc[0], torch.stack(nhwc[1:], 0)
+def _nhwc(f, B):
+    """[V*B,C,h,w] view-major -> ref [B,h,w,C], src [S,B,h,w,C] (layout of the warp kernels; autograd-tracked)"""
+    nhwc = f.permute(0, 2, 3, 1).contiguous()
+    return nhwc[:B], nhwc[B:].view(-1, B, *nhwc.shape[1:])
 
 
-def initial_cost(n: _Net, feats, context, rt, disp_min, disp_max, dmin, dmax, D, G, p="depthnet"):
+def initial_cost(n: _Net, feat, B, context, rt, disp_min, disp_max, dmin, dmax, D, G, p="depthnet"):
     """InitialCost.forward, training branch (module.py:487-573)"""
     o = n.o
-    ref, src = _nhwc(feats)
-    B, H, W, _ = ref.shape
+    ref, src = _nhwc(feat, B)
+    _, H, W, _ = ref.shape
     S = src.shape[0]
     mask = mask_head(n, context, p + ".mask")
     cor = A.warp_corr_init(o, ref, src, rt, disp_min, disp_max, D)             # [B,S,G,D,H,W]
-    ws = []
-    for s in range(S):                                                          # PixelViewWeight per view (BN stats per call)
-        x = n.cbr3(cor[:, s].contiguous(), p + ".pixel_view_weight.conv.0")
-        x = A.conv3d(o, x, n.p[p + ".pixel_view_weight.conv.1.weight"], n.p[p + ".pixel_view_weight.conv.1.bias"])
-        ws.append(torch.sigmoid(x.squeeze(1)).max(dim=1)[0].unsqueeze(1))
-    vw = torch.cat(ws, 1)                                                       # [B,S,H,W]
+    # PixelViewWeight on all source views at once (rows b*S+s: view-minor); BatchNorm statistics per view as in the
+    # reference's per-view calls (module.py:533)
+    x = n.cbr3(cor.view(B * S, G, D, H, W), p + ".pixel_view_weight.conv.0", views=S, view_major=False)
+    x = A.conv3d(o, x, n.p[p + ".pixel_view_weight.conv.1.weight"], n.p[p + ".pixel_view_weight.conv.1.bias"])
+    vw = torch.sigmoid(x.squeeze(1)).max(dim=1)[0].view(B, S, H, W)
     agg = A.view_aggregate(o, cor, vw)
     r = p + ".cost_regularization"
     c1 = n.cbr3(n.cbr3(agg, r + ".conv0"), r + ".conv1")
@@ -273,7 +276,8 @@ def forward_train(model, imgs, proj_matrices, depth_values, depth_gt_ms, ops: Op
     kmin, kmax = (1.0 / dmax).reshape(-1).contiguous(), (1.0 / dmin).reshape(-1).contiguous()   # kernel-side disp range
     interval = 1.0 / depth_values.size(1)
 
-    feats = [feature_net(n, im.to(dev).float()) for im in imgs]
+    V, B = len(imgs), imgs[0].shape[0]
+    feats = feature_net(n, torch.cat([im.to(dev).float() for im in imgs], 0), V)
     ctx = context_net(n, imgs[0].to(dev).float())
     depths, confs, confs_full = [], [], []
     view_w = init_depth = None
@@ -282,12 +286,12 @@ def forward_train(model, imgs, proj_matrices, depth_values, depth_gt_ms, ops: Op
             continue
         name = f"stage{s + 1}"
         inv_gt = depth_to_disp(depth_gt_ms[name].to(dev).unsqueeze(1), dmin, dmax) if s > 0 else None
-        fs = [f[name] for f in feats]
-        B, _, H, W = fs[0].shape
+        fs = feats[name]
+        _, _, H, W = fs.shape
         rt = o.compose_proj(proj_matrices[name].to(dev).float().contiguous())
         if s == 0:
             mask, inv_depth, init_depth, view_w, conf = initial_cost(
-                n, fs, torch.relu(ctx[name]), rt, kmin, kmax, dmin, dmax, a.numdepth_initial, a.cost_dim_stage[0])
+                n, fs, B, torch.relu(ctx[name]), rt, kmin, kmax, dmin, dmax, a.numdepth_initial, a.cost_dim_stage[0])
             depths.append(init_depth)
             confs_full.append(F.interpolate(conf, scale_factor=8, mode="nearest").squeeze(1))
             up = upsample_depth(inv_depth, mask, 2).unsqueeze(1)
@@ -305,7 +309,7 @@ def forward_train(model, imgs, proj_matrices, depth_values, depth_gt_ms, ops: Op
         hidden = torch.tanh(A.conv2d(o, hidden, n.p[f"{hp}.{s}.weight"], None, pad=1))
         context = torch.relu(context)
         inv_init = depth_to_disp(F.interpolate(init_depth.unsqueeze(1), scale_factor=2 ** s, mode="nearest"), dmin, dmax).detach()
-        ref, src = _nhwc(fs)
+        ref, src = _nhwc(fs, B)
         nsamp = a.CostNum[s]
 
         def cost_fn(inv, confidence, ref=ref, src=src, rt=rt, vw=vw, nsamp=nsamp, s=s):

@@ -171,7 +171,17 @@ int dmvs_warp_corr_init_f32(const float* ref, const float* src, const float* rt,
  *   out_cost   [B,G*n,H,W]  written at channel offset cost_coffset of a tensor with
  *              cost_cstride channels;   out_samples [B,n,H,W] likewise
  * n in {4,6}; interval = depth_interval * ratio (models/diffusion.py:246).
+ *
+ * Two device paths share the arithmetic.  (1) "window": a 16x16 pixel tile stages the source texels its hypotheses
+ * can touch through LDS once per view (C = 32 | 16; needs every view's footprint of the tile to fit a 24 x 22|24
+ * texel window -- true where the depth map is locally smooth) -- the fast path.  (2) "gather": every pixel fetches its
+ * own 2x2 taps through the texture path; any geometry, any C.  dmvs_getcost_f32 runs (1) and lets the tiles that do
+ * not fit fall through to (2) via `worklist`: caller-owned int32 scratch of DMVS_GETCOST_WORKLIST_INTS(B,H,W)
+ * elements (contents irrelevant on entry).  worklist == NULL, or C == 48: path (2) for everything.
  */
+#define DMVS_GETCOST_TILE 16
+#define DMVS_GETCOST_WORKLIST_INTS(B, H, W) \
+    (1 + (B) * (((H) + DMVS_GETCOST_TILE - 1) / DMVS_GETCOST_TILE) * (((W) + DMVS_GETCOST_TILE - 1) / DMVS_GETCOST_TILE))
 typedef struct dmvs_getcost_desc {
     const float* ref;       /* [B,H,W,C] NHWC */
     const float* src;       /* [S][B,H,W,C] NHWC */
@@ -183,6 +193,7 @@ typedef struct dmvs_getcost_desc {
     const float* disp_max;  /* [B] */
     float* out_cost;
     float* out_samples;
+    int32_t* worklist;      /* scratch, DMVS_GETCOST_WORKLIST_INTS(B,H,W) ints, or NULL */
     int32_t B, S, C, G, n, H, W;
     int32_t vw_shift;
     int32_t cost_cstride, cost_coffset, samp_cstride, samp_coffset;
@@ -190,8 +201,7 @@ typedef struct dmvs_getcost_desc {
 } dmvs_getcost_desc;
 
 int dmvs_getcost_f32(const dmvs_getcost_desc* d, void* stream);
-/* Same contract, forced onto the per-pixel gather variant (the only one for C = 48; dmvs_getcost_f32 stages source
- * windows through LDS for C = 32 | 16 and is the faster of the two there).  Kept public for A/B measurements. */
+/* Same contract, everything on path (2) regardless of `worklist`.  Kept public for A/B measurements. */
 int dmvs_getcost_gather_f32(const dmvs_getcost_desc* d, void* stream);
 
 /* Stand-alone differentiable_warping (models/module.py:181-218) in the reference's layouts:
@@ -281,22 +291,25 @@ int dmvs_upsample_nearest_f32(const float* in, float* out, int32_t N, int32_t H,
 /* ---------------------------------------------------------------------------------------
  * Training-mode BatchNorm (+ optional ReLU) on [B, C, S] fp32 (S = H*W or D*H*W).  Replaces nn.BatchNorm2d/3d in
  * train mode inside module.Conv2d / Conv3d / ConvBnReLU / ConvBn            models/module.py:24-58, :60-96, :279-301.
- *   fwd: mean/var over (B,S) per channel (biased var for the normalisation), y = act((x-mean)*rstd*gamma+beta);
- *        running_mean/var (may both be NULL) <- (1-momentum)*running + momentum*(mean | unbiased var);
- *        save_mean / save_rstd [C] are kept for the backward.
- *   bwd: dz = dy * [y > 0 if act == RELU];  dbeta = sum dz;  dgamma = sum dz*xhat;
- *        dx = gamma*rstd*(dz - dbeta/N - xhat*dgamma/N),  N = B*S.
- * act in {DMVS_ACT_NONE, DMVS_ACT_RELU}.  x / y / dy / dx 16-byte aligned.  `workspace`: caller-owned scratch of
- * dmvs_batchnorm_workspace_f32(B,C,S) bytes (per-chunk partial sums, folded in double; no atomics). */
-int dmvs_batchnorm_workspace_f32(int32_t B, int32_t C, int32_t S, int64_t* bytes);
+ *   fwd: mean/var over (rows of the view, S) per channel (biased var for the normalisation),
+ *        y = act((x-mean)*rstd*gamma+beta); running_mean/var (may both be NULL) <- (1-momentum)*running +
+ *        momentum*(mean | unbiased var), once per view in view order; save_mean / save_rstd [views][C] for the backward.
+ *   bwd: dz = dy * [y > 0 if act == RELU];  per view dbeta_v = sum dz, dgamma_v = sum dz*xhat,
+ *        dx = gamma*rstd*(dz - dbeta_v/N - xhat*dgamma_v/N), N = (B/views)*S;  dgamma / dbeta [C] = sums over views.
+ * `views` (B % views == 0) batches that many independent BatchNorm calls: the reference runs FeatureNet once per image
+ * of the view stack and PixelViewWeight once per source view (diffusion.py:156-157, module.py:533); row b belongs to
+ * view b / (B/views) if view_major, else b % views.  act in {DMVS_ACT_NONE, DMVS_ACT_RELU}; x / y / dy / dx 16-byte
+ * aligned; `workspace`: caller-owned scratch of dmvs_batchnorm_workspace_f32() bytes (per-chunk partial sums folded
+ * in double, no atomics). */
+int dmvs_batchnorm_workspace_f32(int32_t B, int32_t C, int32_t S, int32_t views, int64_t* bytes);
 int dmvs_batchnorm_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* running_mean,
                                  float* running_var, float* y, float* save_mean, float* save_rstd, float* workspace,
-                                 int64_t workspace_bytes, int32_t B, int32_t C, int32_t S, float momentum, float eps,
-                                 int32_t act, void* stream);
+                                 int64_t workspace_bytes, int32_t B, int32_t C, int32_t S, int32_t views, int32_t view_major,
+                                 float momentum, float eps, int32_t act, void* stream);
 int dmvs_batchnorm_train_bwd_f32(const float* x, const float* dy, const float* gamma, const float* beta,
                                  const float* save_mean, const float* save_rstd, float* dx, float* dgamma, float* dbeta,
-                                 float* workspace, int64_t workspace_bytes, int32_t B, int32_t C, int32_t S, int32_t act,
-                                 void* stream);
+                                 float* workspace, int64_t workspace_bytes, int32_t B, int32_t C, int32_t S, int32_t views,
+                                 int32_t view_major, int32_t act, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Training-step tail on one flat fp32 parameter bucket (the buffer RCCL all-reduces).  Replaces

@@ -509,3 +509,40 @@ def test_batchnorm_train_autograd(ops, shape, relu):
     close(xd.grad, x.grad, 1e-4)
     close(gd.grad, gamma.grad, 1e-4)
     close(bd.grad, beta.grad, 1e-4)
+
+
+@pytest.mark.parametrize("view_major", [True, False])
+def test_batchnorm_train_views(ops, view_major):
+    """V batched BatchNorm calls (per-view statistics, V sequential running-stat updates) == V separate ATen calls"""
+    from diffmvs_amd import autograd as A
+    V, Bv, C_, H, W = 3, 2, 6, 9, 12
+    xs = [(rnd(Bv, C_, H, W, seed=10 + v) * (1 + v) + v).requires_grad_(True) for v in range(V)]
+    gamma = (rnd(C_, seed=2) * 0.5 + 1).requires_grad_(True)
+    beta = (rnd(C_, seed=3) * 0.3).requires_grad_(True)
+    rm_ref, rv_ref = rnd(C_, seed=4) * 0.1, rnd(C_, seed=5).abs() + 0.5
+    rm, rv = rm_ref.clone(), rv_ref.clone()
+    gs = [rnd(Bv, C_, H, W, seed=20 + v) for v in range(V)]
+    refs = []
+    for v in range(V):
+        y = F.relu(F.batch_norm(xs[v], rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5))
+        y.backward(gs[v])
+        refs.append(y.detach())
+    if view_major:
+        xcat, gcat = torch.cat([x.detach() for x in xs], 0), torch.cat(gs, 0)
+    else:
+        xcat, gcat = torch.stack([x.detach() for x in xs], 1).reshape(V * Bv, C_, H, W), torch.stack(gs, 1).reshape(V * Bv, C_, H, W)
+    xd = xcat.to(ops.device).requires_grad_(True)
+    gd, bd = [t.detach().to(ops.device).requires_grad_(True) for t in (gamma, beta)]
+    rmd, rvd = dev(ops, rm, rv)
+    out = A.batchnorm_act(ops, xd, gd, bd, rmd, rvd, 0.1, 1e-5, True, V, view_major)
+    out.backward(dev(ops, gcat))
+    o_ = out.detach().cpu()
+    gx = xd.grad.cpu()
+    for v in range(V):
+        sel = (lambda t: t[v * Bv:(v + 1) * Bv]) if view_major else (lambda t: t.view(Bv, V, C_, H, W)[:, v])
+        close(sel(o_), refs[v], 2e-5)
+        close(sel(gx), xs[v].grad, 1e-4)
+    close(rmd, rm_ref, 1e-5)
+    close(rvd, rv_ref, 1e-5)
+    close(gd.grad, gamma.grad, 1e-4)
+    close(bd.grad, beta.grad, 1e-4)

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--n", type=int, default=6)
     ap.add_argument("--conf", type=float, default=0.5)
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--noise", type=float, default=0.01, help="sigma of the noise added to the true normalised inverse depth")
     ap.add_argument("--lib", default=None, help="alternative libdmvs .so (kernel experiments)")
     a = ap.parse_args()
     o = Ops.for_device("cuda:0")
@@ -42,7 +43,7 @@ def main():
     d = gt[name]
     d = torch.where(torch.isfinite(d) & (d > 0), d, torch.full_like(d, 600.0)).to(dev)
     inv = ((1.0 / d) - kmin.view(-1, 1, 1)) / (kmax - kmin).view(-1, 1, 1)
-    inv = (inv + 0.01 * torch.randn(inv.shape, generator=g).to(dev)).clamp(0, 1).unsqueeze(1).contiguous()
+    inv = (inv + a.noise * torch.randn(inv.shape, generator=g).to(dev)).clamp(0, 1).unsqueeze(1).contiguous()
     conf = torch.full((a.batch, h, w), a.conf, device=dev) if a.conf >= 0 else None
     vshift = a.stage - 1
     vw = torch.rand(a.batch, a.src, h >> vshift, w >> vshift, generator=g).to(dev)
@@ -61,6 +62,10 @@ def main():
         en.record()
         torch.cuda.synchronize()
         res["gather_us" if gather else "window_us"] = st.elapsed_time(en) * 1e3 / a.iters
+    o.getcost(*args)
+    torch.cuda.synchronize()
+    res["tiles_total"] = int(o.last_getcost_worklist.numel() - 1)
+    res["tiles_on_gather_path"] = int(o.last_getcost_worklist[0])
     diff = float((outs[False][0] - outs[True][0]).abs().max() / outs[True][0].abs().max())
     hw = h * w
     alg = 4.0 * a.batch * (a.C * hw + a.src * a.C * hw + hw + (hw >> (2 * vshift)) * a.src + (hw if conf is not None else 0)
