@@ -106,7 +106,7 @@ def main():
     with torch.no_grad():
         for _ in range(a.warmup):
             model(imgs, proj, dv)
-        eng.ops.timers = {"dmvs_getcost_f32": [], "dmvs_warp_corr_init_f32": []}
+        eng.ops.timers = {"dmvs_getcost_f32": [], "dmvs_getcost_gather_f32": [], "dmvs_warp_corr_init_f32": []}
         barrier()
         t0 = time.perf_counter()
         for _ in range(a.steps):
@@ -124,12 +124,12 @@ def main():
         conv_step_s = time.perf_counter() - t1
     timers.update(eng.ops.timers)
     eng.ops.timers = None
-    wl = getattr(eng.ops, "last_getcost_worklist", None)      # last GetCost launch of the step
-    gather_tiles = (int(wl[0]), int(wl.numel() - 1)) if wl is not None else (None, None)
+    gather_tiles = eng.ops.getcost_tiles or (None, None)      # last lazily read-back probe of the hybrid launch
 
     maps = B * a.steps * world
     value = maps / elapsed
-    gc_ms = [s.elapsed_time(e) for s, e in timers["dmvs_getcost_f32"]]
+    gc_ms = [s.elapsed_time(e) for s, e in timers["dmvs_getcost_f32"] + timers["dmvs_getcost_gather_f32"]]
+    n_hybrid, n_plain = len(timers["dmvs_getcost_f32"]), len(timers["dmvs_getcost_gather_f32"])
     wi_ms = [s.elapsed_time(e) for s, e in timers["dmvs_warp_corr_init_f32"]]
     gc_avg_s = sum(gc_ms) / max(1, len(gc_ms)) * 1e-3
     h2, w2 = H // 4, W // 4
@@ -158,11 +158,12 @@ def main():
         "config": {"workload": f"DiffMVS DTU eval {W}x{H}, {S} src views, numdepth_initial=48, 1 DDIM step, fp32",
                    "ref_views_per_gpu_per_step": B, "parallelism": f"ref-view sharding x{world}, no collective",
                    "weights": "seeded random init (no checkpoint offline)"},
-        "roofline": {"kernel": "getcost_win_kernel<32,6> (homography warp + group corr + view aggregation, LDS-staged windows)",
+        "roofline": {"kernel": "GetCost: getcost_win_kernel<32,6> (LDS-staged source windows) / getcost_kernel<32,4,6> (per-pixel gather), picked per launch",
                      "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(gc_avg_s * 1e6, 2),
                      "launches_timed": len(gc_ms),
+                     "launches_hybrid": n_hybrid, "launches_plain_gather": n_plain,
                      "tiles_on_gather_path": gather_tiles[0], "tiles_total": gather_tiles[1]},
         "roofline_warp_init": {"kernel": "warp_corr_init_kernel<48,3>", "bound": "hbm",
                                "achieved": round(alg_init / wi_avg_s / 1e9, 2) if wi_avg_s > 0 else 0.0,

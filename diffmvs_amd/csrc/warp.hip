@@ -210,7 +210,7 @@ warp_corr_init_kernel(const float* __restrict__ ref, const float* __restrict__ s
 // ------------------------------------------------------------------------------------------
 // GetCost: hypotheses + S warps + correlation + view-weighted aggregation in one pass.
 // TILED: the launch covers the 16x16 pixel tiles that the LDS-window kernel (warp_win.hip) could not take, listed in
-// d.worklist ([0] = count, then tile ids); workgroups beyond the count retire at once.
+// d.worklist (layout: warp_win.hip; [0] = count, [1] = "every tile" flag of the pre-pass); workgroups beyond the count retire.
 template <int C, int CPL, int N, bool TILED>
 __global__ void __launch_bounds__(DMVS_BLOCK) getcost_kernel(const dmvs_getcost_desc d) {
     constexpr int G = 4, LPP = C / CPL, LPG = LPP / G, PPB = DMVS_BLOCK / LPP, KPL = (N + LPP - 1) / LPP;
@@ -221,20 +221,25 @@ __global__ void __launch_bounds__(DMVS_BLOCK) getcost_kernel(const dmvs_getcost_
     int x, y, b;
     if (TILED) {
         constexpr int T = DMVS_GETCOST_TILE, BPT = T * T / PPB;       // workgroups per tile
-        const int entry = blockIdx.x / BPT;
-        if (entry >= d.worklist[0]) return;
-        int tq = d.worklist[1 + entry];
+        // the first count*BPT workgroups carry the work; each XCD (blockIdx % 8) walks a contiguous run of listed tiles
+        if (d.worklist[1]) return;                         // pre-pass verdict: the plain launch below takes every pixel
+        const unsigned nvalid = (unsigned)d.worklist[0] * BPT;
+        if (blockIdx.x >= nvalid) return;
+        const unsigned vb = dmvs_xcd_contiguous_block(blockIdx.x, nvalid);
+        const int entry = (int)(vb / BPT);
+        int tq = d.worklist[4 + gridDim.x / BPT + entry];      // list[] follows flags[ntiles]
         const int tiles_x = (W + T - 1) / T, tiles_y = (H + T - 1) / T;
         const int txi = tq % tiles_x; tq /= tiles_x;
         const int tyi = tq % tiles_y;
         b = tq / tiles_y;
-        const int p = (blockIdx.x % BPT) * PPB + slot;
+        const int p = (int)(vb % BPT) * PPB + slot;
         x = txi * T + (p & (T - 1));
         y = tyi * T + p / T;
         live = x < W && y < H;
         x = min(x, W - 1);
         y = min(y, H - 1);
     } else {
+        if (d.worklist && !d.worklist[1]) return;          // hybrid launch: only needed when the pre-pass said "gather everything"
         const long npix = (long)d.B * hw;
         const long pix = (long)dmvs_xcd_contiguous_block(blockIdx.x, gridDim.x) * PPB + slot;
         live = pix < npix;
@@ -373,9 +378,11 @@ extern "C" int dmvs_getcost_gather_f32(const dmvs_getcost_desc* dp, void* stream
     const dmvs_getcost_desc& d = *dp;
     if (int rc = getcost_check(d)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (d.C == 48) return launch_getcost<48, 3>(d, st);
-    if (d.C == 32) return launch_getcost<32, 4>(d, st);
-    if (d.C == 16) return launch_getcost<16, 4>(d, st);
+    dmvs_getcost_desc g = d;
+    g.worklist = nullptr;          // plain launch, unconditional
+    if (g.C == 48) return launch_getcost<48, 3>(g, st);
+    if (g.C == 32) return launch_getcost<32, 4>(g, st);
+    if (g.C == 16) return launch_getcost<16, 4>(g, st);
     return DMVS_EINVAL;
 }
 
@@ -385,8 +392,9 @@ extern "C" int dmvs_getcost_f32(const dmvs_getcost_desc* dp, void* stream) {
     if (int rc = getcost_check(d)) return rc;
     if ((d.C != 32 && d.C != 16) || !d.worklist) return dmvs_getcost_gather_f32(dp, stream);
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(d.worklist, 0, sizeof(int32_t), st);
-    if (e != hipSuccess) return (int)e;
-    if (int rc = dmvs_getcost_win_dispatch(d, st)) return rc;          // tiles whose source windows fit LDS
-    return d.C == 32 ? launch_getcost_tiles<32, 4>(d, st) : launch_getcost_tiles<16, 4>(d, st);   // the rest
+    if (int rc = dmvs_getcost_win_dispatch(d, st)) return rc;          // pre-pass + tiles whose source windows fit LDS
+    // the rest: the listed tiles, or (pre-pass: most tiles do not fit) everything through the plain pixel-order launch;
+    // the launch that is not needed retires at once on the mode flag
+    if (int rc = d.C == 32 ? launch_getcost_tiles<32, 4>(d, st) : launch_getcost_tiles<16, 4>(d, st)) return rc;
+    return d.C == 32 ? launch_getcost<32, 4>(d, st) : launch_getcost<16, 4>(d, st);
 }

@@ -101,6 +101,135 @@ __device__ __forceinline__ int wave_max(int v) {
     return v;
 }
 
+// Footprint boxes of one 16x16 tile in every view, from the two end hypotheses of each pixel (the projection of a
+// depth interval is a straight image segment); returns whether all of them fit a win_w x win_h texel window.
+// Workgroup-collective (one barrier per view).  sbox == nullptr: only the verdict is wanted.
+__device__ __forceinline__ bool tile_boxes(const dmvs_getcost_desc& d, int b, int xc, int yc, bool live, float depth_first,
+                                           float depth_last, int (*red)[DMVS_BLOCK / 64][5], int (*sbox)[4], int max_s, int win_w,
+                                           int win_h) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = d.H, W = d.W;
+    bool allfit = d.S <= max_s;
+    for (int s = 0; s < d.S && s < max_s; ++s) {
+        RayW ray;
+        ray.init(d.rt + ((long)b * d.S + s) * 12, (float)xc, (float)yc);
+        float u0, v0, z0, u1, v1, z1;
+        bool f0, f1;
+        project_uv(ray, depth_first, u0, v0, z0, f0);
+        project_uv(ray, depth_last, u1, v1, z1, f1);
+        int bad = live && (!f0 || !f1 || ((z0 < 0.0f) != (z1 < 0.0f)));     // a pole between the ends: not a segment
+        int bx0 = 0x3fffffff, by0 = 0x3fffffff, bx1 = -0x3fffffff, by1 = -0x3fffffff;
+        if (live && !bad) {
+            const int ax = max((int)floorf(fminf(u0, u1)), 0), cx = min((int)floorf(fmaxf(u0, u1)) + 1, W - 1);
+            const int ay = max((int)floorf(fminf(v0, v1)), 0), cy = min((int)floorf(fmaxf(v0, v1)) + 1, H - 1);
+            if (ax <= cx && ay <= cy) {      // else: every tap of every hypothesis of this pixel is padding
+                bx0 = ax; bx1 = cx; by0 = ay; by1 = cy;
+            }
+        }
+        bx0 = wave_min(bx0); by0 = wave_min(by0); bx1 = wave_max(bx1); by1 = wave_max(by1); bad = wave_max(bad);
+        int (*rd)[5] = red[s & 1];           // double-buffered: a fast wave may already be writing the next view's
+        if (lane == 0) {
+            rd[wave][0] = bx0; rd[wave][1] = by0; rd[wave][2] = bx1; rd[wave][3] = by1; rd[wave][4] = bad;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < DMVS_BLOCK / 64; ++q) {
+            bx0 = min(bx0, rd[q][0]); by0 = min(by0, rd[q][1]);
+            bx1 = max(bx1, rd[q][2]); by1 = max(by1, rd[q][3]); bad = max(bad, rd[q][4]);
+        }
+        const int nc = bx1 - bx0 + 1, nr = by1 - by0 + 1;
+        if (bad || (bx1 >= bx0 && (nc > win_w || nr > win_h))) allfit = false;
+        if (sbox && tid == 0) {
+            sbox[s][0] = bx0; sbox[s][1] = by0; sbox[s][2] = nc; sbox[s][3] = nr;
+        }
+    }
+    return allfit;
+}
+
+// this tile's position and the two end hypotheses of the lane's pixel (reference module.py:259-276)
+template <int N>
+__device__ __forceinline__ void tile_pixel(const dmvs_getcost_desc& d, int tile, int tiles_x, int tiles_y, int& b, int& xc, int& yc,
+                                           bool& live, float& lo, float& step) {
+    int tq = tile;
+    const int txi = tq % tiles_x; tq /= tiles_x;
+    const int tyi = tq % tiles_y;
+    b = tq / tiles_y;
+    const int x = txi * TW + (threadIdx.x & (TW - 1)), y = tyi * TH + (threadIdx.x >> 4);
+    live = x < d.W && y < d.H;
+    xc = min(x, d.W - 1);
+    yc = min(y, d.H - 1);
+    const long pc = ((long)b * d.H + yc) * d.W + xc;
+    const float cur_inv = d.inv_depth[pc];
+    float radius = (float)(N / 2) * d.interval;
+    if (d.confidence) {
+        const float r0 = d.min_radius * radius, r1 = d.max_radius * radius;
+        radius = r0 + (1.0f - d.confidence[pc]) * (r1 - r0);
+    }
+    lo = cur_inv - radius;
+    step = (cur_inv + radius - lo) / (float)(N - 1);
+}
+
+__device__ __forceinline__ float hyp_depth(int k, float lo, float step, float dmin, float dmax) {
+    float sk = (float)k * step;
+    sk += lo;
+    return dmvs_disp_to_depth(fminf(fmaxf(sk, 0.0f), 1.0f), dmin, dmax);
+}
+
+// Scratch layout (int32), n = number of tiles:  [0] tiles listed for the gather kernel, [1] mode (1 = the gather
+// kernel takes every tile), [2..3] unused, flags[n] (1 = some view's footprint exceeds the window), list[n] (the
+// flagged tiles, ascending), boxes[n][MAXS][4] (x0, y0, ncols, nrows per view).  No atomics anywhere: same-address
+// device atomics from ~10^3 workgroups serialise at ~0.1 us each, more than the whole pre-pass costs.
+constexpr int MAXS = 16;
+__device__ __forceinline__ int* ws_flags(int* ws) { return ws + 4; }
+__device__ __forceinline__ int* ws_list(int* ws, int ntiles) { return ws + 4 + ntiles; }
+__device__ __forceinline__ int* ws_boxes(int* ws, int ntiles) { return ws + 4 + 2 * ntiles; }
+
+// Pre-pass 1: every tile's per-view footprint boxes and its fit flag.
+template <int N>
+__global__ void __launch_bounds__(DMVS_BLOCK) getcost_fit_kernel(const dmvs_getcost_desc d, int tiles_x, int tiles_y, int win_w,
+                                                                 int win_h) {
+    __shared__ int red[2][DMVS_BLOCK / 64][5];
+    __shared__ int sbox[MAXS][4];
+    const int tile = blockIdx.x, ntiles = gridDim.x;
+    int b, xc, yc;
+    bool live;
+    float lo, step;
+    tile_pixel<N>(d, tile, tiles_x, tiles_y, b, xc, yc, live, lo, step);
+    const float dmin = d.disp_min[b], dmax = d.disp_max[b];
+    const bool fits = tile_boxes(d, b, xc, yc, live, hyp_depth(0, lo, step, dmin, dmax), hyp_depth(N - 1, lo, step, dmin, dmax), red,
+                                 sbox, MAXS, win_w, win_h);
+    __syncthreads();
+    if (threadIdx.x < 4 * MAXS && threadIdx.x < 4 * d.S)
+        ws_boxes(d.worklist, ntiles)[(size_t)tile * (4 * MAXS) + threadIdx.x] = sbox[threadIdx.x >> 2][threadIdx.x & 3];
+    if (threadIdx.x == 0) ws_flags(d.worklist)[tile] = fits ? 0 : 1;
+}
+
+// Pre-pass 2 (one workgroup): count the flagged tiles, pick the mode, list the flagged tiles in ascending order.
+// If most tiles are flagged (a depth map that is noise rather than surfaces, e.g. an untrained network) the window
+// kernel stands down and the gather kernel takes every tile: the hybrid only pays off while the windows carry a good
+// share of the work.
+__global__ void __launch_bounds__(DMVS_BLOCK) getcost_compact_kernel(int* __restrict__ ws, int ntiles) {
+    __shared__ int cnt[DMVS_BLOCK + 1];
+    const int tid = threadIdx.x;
+    const int seg = (ntiles + DMVS_BLOCK - 1) / DMVS_BLOCK, t0 = tid * seg, t1 = min(t0 + seg, ntiles);
+    const int* flags = ws_flags(ws);
+    int c = 0;
+    for (int t = t0; t < t1; ++t) c += flags[t];
+    cnt[tid + 1] = c;
+    __syncthreads();
+    if (tid == 0) {
+        cnt[0] = 0;
+        for (int i = 1; i <= DMVS_BLOCK; ++i) cnt[i] += cnt[i - 1];
+        ws[0] = cnt[DMVS_BLOCK];
+        ws[1] = (long)cnt[DMVS_BLOCK] * 4 > (long)ntiles * 3 ? 1 : 0;      // > 75 % flagged: gather everything
+    }
+    __syncthreads();
+    int* list = ws_list(ws, ntiles);
+    int o = cnt[tid];
+    for (int t = t0; t < t1; ++t)
+        if (flags[t]) list[o++] = t;
+}
+
 template <int C, int N>
 __global__ void __launch_bounds__(DMVS_BLOCK, 2) getcost_win_kernel(const dmvs_getcost_desc d, int tiles_x, int tiles_y) {
     constexpr int G = 4, NCH = C / 4, TS = C + 4;       // texel stride in floats (padded: bank spread)
@@ -109,14 +238,14 @@ __global__ void __launch_bounds__(DMVS_BLOCK, 2) getcost_win_kernel(const dmvs_g
     constexpr int SUBS = (SLOTS + 63) / 64;             // DMA instructions per row and wave
     static_assert(TW * TH == DMVS_BLOCK, "one lane per pixel");
     __shared__ __attribute__((aligned(16))) float win[WW * WH * TS];
-    constexpr int MAXS = 16;
-    __shared__ int red[2][DMVS_BLOCK / 64][5];
     __shared__ int sbox[MAXS][4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = d.H, W = d.W;
     const long hw = (long)H * W;
+    if (d.worklist[1]) return;           // the pre-pass sent every tile to the gather kernel
     const int tile = (int)dmvs_xcd_contiguous_block(blockIdx.x, gridDim.x);
+    if (ws_flags(d.worklist)[tile]) return;      // this one too
     int tq = tile;
     const int txi = tq % tiles_x; tq /= tiles_x;
     const int tyi = tq % tiles_y;
@@ -165,47 +294,8 @@ __global__ void __launch_bounds__(DMVS_BLOCK, 2) getcost_win_kernel(const dmvs_g
 
     // ---- every view's footprint box of the tile, up front: a tile whose box exceeds the window in ANY view is handed
     // to the gather kernel through the worklist and this workgroup retires without touching the sources
-    bool allfit = d.S <= MAXS;
-    for (int s = 0; s < d.S && s < MAXS; ++s) {
-        RayW ray;
-        ray.init(d.rt + ((long)b * d.S + s) * 12, (float)xc, (float)yc);
-        float u0, v0, z0, u1, v1, z1;
-        bool f0, f1;
-        project_uv(ray, depth[0], u0, v0, z0, f0);
-        project_uv(ray, depth[N - 1], u1, v1, z1, f1);
-        int bad = live && (!f0 || !f1 || ((z0 < 0.0f) != (z1 < 0.0f)));     // a pole between the ends: not a segment
-        int bx0 = 0x3fffffff, by0 = 0x3fffffff, bx1 = -0x3fffffff, by1 = -0x3fffffff;
-        if (live && !bad) {
-            const int ax = max((int)floorf(fminf(u0, u1)), 0), cx = min((int)floorf(fmaxf(u0, u1)) + 1, W - 1);
-            const int ay = max((int)floorf(fminf(v0, v1)), 0), cy = min((int)floorf(fmaxf(v0, v1)) + 1, H - 1);
-            if (ax <= cx && ay <= cy) {      // else: every tap of every hypothesis of this pixel is padding
-                bx0 = ax; bx1 = cx; by0 = ay; by1 = cy;
-            }
-        }
-        bx0 = wave_min(bx0); by0 = wave_min(by0); bx1 = wave_max(bx1); by1 = wave_max(by1); bad = wave_max(bad);
-        int (*rd)[5] = red[s & 1];           // double-buffered: a fast wave may already be writing the next view's
-        if (lane == 0) {
-            rd[wave][0] = bx0; rd[wave][1] = by0; rd[wave][2] = bx1; rd[wave][3] = by1; rd[wave][4] = bad;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < DMVS_BLOCK / 64; ++q) {
-            bx0 = min(bx0, rd[q][0]); by0 = min(by0, rd[q][1]);
-            bx1 = max(bx1, rd[q][2]); by1 = max(by1, rd[q][3]); bad = max(bad, rd[q][4]);
-        }
-        const int nc = bx1 - bx0 + 1, nr = by1 - by0 + 1;
-        if (bad || (bx1 >= bx0 && (nc > WW || nr > WH))) allfit = false;
-        if (tid == 0) {
-            sbox[s][0] = bx0; sbox[s][1] = by0; sbox[s][2] = nc; sbox[s][3] = nr;
-        }
-    }
-    if (!allfit) {
-        if (tid == 0) {
-            const int slot = atomicAdd(d.worklist, 1);
-            d.worklist[1 + slot] = tile;
-        }
-        return;
-    }
+    if (tid < 4 * MAXS && tid < 4 * d.S)
+        sbox[tid >> 2][tid & 3] = ws_boxes(d.worklist, (int)gridDim.x)[(size_t)tile * (4 * MAXS) + tid];
     f2 refp[C / 2];
     {
         const float inv_cg = 1.0f / (float)(C / G);
@@ -293,9 +383,17 @@ template <int C>
 int launch_getcost_win(const dmvs_getcost_desc& d, hipStream_t st) {
     const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + TH - 1) / TH;
     dim3 grid((unsigned)(tiles_x * tiles_y * d.B)), block(DMVS_BLOCK);
-    if (d.n == 4) hipLaunchKernelGGL((getcost_win_kernel<C, 4>), grid, block, 0, st, d, tiles_x, tiles_y);
-    else if (d.n == 6) hipLaunchKernelGGL((getcost_win_kernel<C, 6>), grid, block, 0, st, d, tiles_x, tiles_y);
-    else return DMVS_EINVAL;
+    if (d.n == 4) {
+        hipLaunchKernelGGL((getcost_fit_kernel<4>), grid, block, 0, st, d, tiles_x, tiles_y, WW, WinCfg<C>::WH);
+        hipLaunchKernelGGL(getcost_compact_kernel, dim3(1), block, 0, st, d.worklist, (int)grid.x);
+        hipLaunchKernelGGL((getcost_win_kernel<C, 4>), grid, block, 0, st, d, tiles_x, tiles_y);
+    } else if (d.n == 6) {
+        hipLaunchKernelGGL((getcost_fit_kernel<6>), grid, block, 0, st, d, tiles_x, tiles_y, WW, WinCfg<C>::WH);
+        hipLaunchKernelGGL(getcost_compact_kernel, dim3(1), block, 0, st, d.worklist, (int)grid.x);
+        hipLaunchKernelGGL((getcost_win_kernel<C, 6>), grid, block, 0, st, d, tiles_x, tiles_y);
+    } else {
+        return DMVS_EINVAL;
+    }
     return dmvs_launch_status();
 }
 

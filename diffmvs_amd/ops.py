@@ -107,6 +107,9 @@ class Ops:
         # optional per-entry-point HIP-event timing on the launch stream (bench.py roofline leg):
         # {"dmvs_getcost_f32": [(start_event, end_event), ...]}
         self.timers = None
+        self._getcost_state = {}     # per launch shape: which GetCost device path the last probe favoured (see getcost)
+        self.getcost_tiles = None
+        self.last_getcost_worklist = None
 
     def _call(self, name, *args):
         if self.timers is not None and name in self.timers:
@@ -289,15 +292,36 @@ class Ops:
         if out_samples is None:
             samp_cstride = n
             out_samples = self.empty(B, n, H, W)
-        wl = None if gather else torch.empty(1 + B * ((H + 15) // 16) * ((W + 15) // 16), dtype=torch.int32, device=self.device)
+        # Which device path: the hybrid launch (LDS windows + gather for the tiles that do not fit) costs ~35 us of
+        # pre-pass and extra launches, which only pays off while the windows carry the work.  The verdict of the last
+        # hybrid launch of the same shape is read back lazily (async copy + event, never a sync): if most tiles went
+        # to the gather path -- a depth map that is noise, e.g. an untrained network -- later calls launch the plain
+        # gather kernel alone and re-probe every 64th call.
+        ntiles = B * ((H + 15) // 16) * ((W + 15) // 16)
+        st = self._getcost_state.setdefault((B, H, W, Cc, n), {"gather": False, "pending": None, "calls": 0})
+        if st["pending"] is not None and st["pending"][0].query():
+            host = st["pending"][1]
+            st["gather"] = bool(host[1]) or int(host[0]) * 2 > ntiles
+            st["last"] = (ntiles if bool(host[1]) else int(host[0]), ntiles)
+            st["pending"] = None
+        st["calls"] += 1
+        plain = gather or Cc == 48 or (st["gather"] and st["calls"] % 64 != 0)
+        wl = None if plain else torch.empty(4 + 66 * ntiles, dtype=torch.int32, device=self.device)
         d = _lib.GetCostDesc(ref=_ptr(ref), src=_ptr(src), rt=_ptr(rt), inv_depth=_ptr(inv_depth),
                              confidence=_ptr(confidence), view_w=_ptr(view_w), disp_min=_ptr(disp_min),
                              disp_max=_ptr(disp_max), out_cost=_ptr(out_cost), out_samples=_ptr(out_samples),
                              worklist=_ptr(wl), B=B, S=S, C=Cc, G=G, n=n, H=H, W=W, vw_shift=vw_shift, cost_cstride=cost_cstride,
                              cost_coffset=cost_coffset, samp_cstride=samp_cstride, samp_coffset=samp_coffset,
                              interval=interval, min_radius=min_radius, max_radius=max_radius)
-        self._call("dmvs_getcost_gather_f32" if gather else "dmvs_getcost_f32", C.byref(d), self.stream())
-        self.last_getcost_worklist = wl      # diagnostics: [0] = number of tiles that fell through to the gather path
+        self._call("dmvs_getcost_gather_f32" if plain else "dmvs_getcost_f32", C.byref(d), self.stream())
+        if wl is not None and self.device.type == "cuda" and st["pending"] is None and not torch.cuda.is_current_stream_capturing():
+            host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            host.copy_(wl[:2], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            st["pending"] = (ev, host)
+        self.getcost_tiles = st.get("last")      # diagnostics: (tiles on the gather path, tiles) of the last probe read back
+        self.last_getcost_worklist = wl      # diagnostics: [0] tiles handed to the gather path, [1] = 1: all of them (pre-pass)
         return out_cost, out_samples
 
     # ------------------------------------------------------------------ backward (training step)

@@ -177,11 +177,13 @@ int dmvs_warp_corr_init_f32(const float* ref, const float* src, const float* rt,
  * texel window -- true where the depth map is locally smooth) -- the fast path.  (2) "gather": every pixel fetches its
  * own 2x2 taps through the texture path; any geometry, any C.  dmvs_getcost_f32 runs (1) and lets the tiles that do
  * not fit fall through to (2) via `worklist`: caller-owned int32 scratch of DMVS_GETCOST_WORKLIST_INTS(B,H,W)
- * elements (contents irrelevant on entry).  worklist == NULL, or C == 48: path (2) for everything.
+ * elements (contents irrelevant on entry; holds per-tile fit flags, the list of flagged tiles and the per-view window
+ * boxes).  A pre-pass counts the tiles that would fall through; above 75 % the window kernel stands down and (2)
+ * takes everything.  worklist == NULL, or C == 48: path (2) for everything.
  */
 #define DMVS_GETCOST_TILE 16
 #define DMVS_GETCOST_WORKLIST_INTS(B, H, W) \
-    (1 + (B) * (((H) + DMVS_GETCOST_TILE - 1) / DMVS_GETCOST_TILE) * (((W) + DMVS_GETCOST_TILE - 1) / DMVS_GETCOST_TILE))
+    (4 + 66 * (B) * (((H) + DMVS_GETCOST_TILE - 1) / DMVS_GETCOST_TILE) * (((W) + DMVS_GETCOST_TILE - 1) / DMVS_GETCOST_TILE))
 typedef struct dmvs_getcost_desc {
     const float* ref;       /* [B,H,W,C] NHWC */
     const float* src;       /* [S][B,H,W,C] NHWC */

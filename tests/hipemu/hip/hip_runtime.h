@@ -303,6 +303,7 @@ static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline int __mul24(int a, int b) { return a * b; }
 #define DMVS_ORDER_AFTER(var, dep) ((void)0)

@@ -62,10 +62,9 @@ def main():
         en.record()
         torch.cuda.synchronize()
         res["gather_us" if gather else "window_us"] = st.elapsed_time(en) * 1e3 / a.iters
-    o.getcost(*args)
     torch.cuda.synchronize()
-    res["tiles_total"] = int(o.last_getcost_worklist.numel() - 1)
-    res["tiles_on_gather_path"] = int(o.last_getcost_worklist[0])
+    o.getcost(*args)
+    res["adaptive_state"] = {str(k): {"gather": v["gather"], "last": v.get("last")} for k, v in o._getcost_state.items()}
     diff = float((outs[False][0] - outs[True][0]).abs().max() / outs[True][0].abs().max())
     hw = h * w
     alg = 4.0 * a.batch * (a.C * hw + a.src * a.C * hw + hw + (hw >> (2 * vshift)) * a.src + (hw if conf is not None else 0)
