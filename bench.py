@@ -37,6 +37,47 @@ def getcost_algorithmic_bytes(B, C, S, n, G, H, W):
     return 4 * B * H * W * (C + S * C + n + S + G * n)
 
 
+def scene_geometry_getcost(ops, B, H, W, S, n, iters=20):
+    """The GetCost kernels on the geometry a TRAINED network produces: hypotheses centred on the synthetic scene's true
+    depth (sigma 0.01 of the normalised inverse-depth range).  The timed model above runs random-init weights, whose
+    depth maps are noise: there every 16x16 tile's source footprint exceeds the LDS window and the per-pixel gather
+    kernel does the work; on surfaces the window kernel does.  Untimed side measurement, same stage-2 shapes."""
+    from diffmvs_amd.ops import Ops
+    o = Ops(ops.lib, ops.device)                     # fresh adaptive state
+    dev = ops.device
+    gi = synth.getcost_scene_inputs(H, W, S, B, stage=2, C=32, noise=0.01, conf=0.5)
+    t = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in gi.items()}
+    rt = o.compose_proj(t["proj"].float().contiguous())
+    call = (t["ref"], t["src"], rt, t["inv"], t["conf"], t["view_w"], t["disp_min"], t["disp_max"], n, t["interval"], 0.2, 2.0,
+            t["vw_shift"])
+    out = {}
+    for gather in (False, True):
+        for _ in range(5):
+            o.getcost(*call, gather=gather)
+        torch.cuda.synchronize()
+        st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        st.record()
+        for _ in range(iters):
+            o.getcost(*call, gather=gather)
+        en.record()
+        torch.cuda.synchronize()
+        out[gather] = st.elapsed_time(en) * 1e-3 / iters
+    h2, w2 = H // 4, W // 4
+    alg = getcost_algorithmic_bytes(B, 32, S, n, 4, h2, w2)
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "r1b_getcost_traffic.json")
+    if os.path.exists(tj):
+        with open(tj) as f:
+            ti = json.load(f)
+        if ti.get("batch") == B and (H, W, S) == (512, 640, 5):
+            traffic = ti["traffic_bytes_per_launch"]
+    return {"kernel": "getcost_win_kernel<32,6> incl. its pre-pass (hypotheses around the scene's true depth, sigma 0.01)",
+            "bound": "hbm", "achieved": round(alg / out[False] / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(alg / out[False] / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": alg,
+            "avg_launch_us": round(out[False] * 1e6, 2), "tiles_on_gather_path": (o.getcost_tiles or (None, None))[0],
+            "gather_kernel_same_inputs_us": round(out[True] * 1e6, 2), "gather_kernel_frac": round(alg / out[True] / 1e9 / HBM_PEAK_GBS, 4)}
+
+
 def cpu_baseline(a):
     """oracle/diffmvs_oracle.py (the CPU restatement pinned to the reference) on the host cores."""
     from oracle import diffmvs_oracle as O
@@ -125,6 +166,7 @@ def main():
     timers.update(eng.ops.timers)
     eng.ops.timers = None
     gather_tiles = eng.ops.getcost_tiles or (None, None)      # last lazily read-back probe of the hybrid launch
+    scene = scene_geometry_getcost(eng.ops, B, H, W, S, args.CostNum[1]) if rank == 0 else None
 
     maps = B * a.steps * world
     value = maps / elapsed
@@ -144,7 +186,7 @@ def main():
     # HBM traffic per getcost launch from the PMC passes (rocprofv3 cannot run inside the timed process); only
     # quoted when the committed measurement was taken at this batch size
     traffic = None
-    tj = os.path.join(ROOT, "profiles", "r1b_getcost_traffic.json")
+    tj = os.path.join(ROOT, "profiles", "r1_getcost_traffic.json")      # the per-pixel gather kernel, which runs in the timed steps
     if os.path.exists(tj):
         with open(tj) as f:
             tinfo = json.load(f)
@@ -170,6 +212,7 @@ def main():
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(alg_init / wi_avg_s / 1e9 / HBM_PEAK_GBS, 4) if wi_avg_s > 0 else 0.0,
                                "algorithmic_bytes_per_launch": alg_init, "avg_launch_us": round(wi_avg_s * 1e6, 2)},
+        "roofline_scene_geometry": scene,
         # where the step's time actually goes: all 2-D convolution launches (exact-fp32 MFMA implicit GEMM) together
         "roofline_conv2d": {"kernel": "conv2d_mfma_kernel<*> (all launches of the step)", "bound": "mfma",
                             "achieved": round(cv_flops / cv_s / 1e12, 2) if cv_s > 0 else 0.0, "peak": FP32_MFMA_PEAK_TFS,

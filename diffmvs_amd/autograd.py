@@ -119,10 +119,12 @@ def warp_corr_init(ops: Ops, ref, src, rt, disp_min, disp_max, D):
 
 class _GetCostFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, ops: Ops, n, interval, rmin, rmax, shift):
-        cost, samples = ops.getcost(ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, rmin, rmax, shift)
+    def forward(ctx, ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, ops: Ops, n, interval, rmin, rmax, shift, key):
+        cost, samples = ops.getcost(ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, rmin, rmax, shift,
+                                    policy_key=key)
         ctx.save_for_backward(ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max)
         ctx.ops, ctx.meta = ops, (n, interval, rmin, rmax, shift)
+        ctx.plain = ops.last_getcost_plain      # same geometry in the backward: same device path
         ctx.mark_non_differentiable(samples)
         return cost, samples
 
@@ -131,14 +133,15 @@ class _GetCostFn(torch.autograd.Function):
         ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max = ctx.saved_tensors
         n, interval, rmin, rmax, shift = ctx.meta
         gref, gsrc = ctx.ops.getcost_bwd(ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, rmin,
-                                         rmax, shift, g.contiguous())
-        return (gref, gsrc) + (None,) * 12
+                                         rmax, shift, g.contiguous(), gather=ctx.plain)
+        return (gref, gsrc) + (None,) * 13
 
 
-def getcost(ops: Ops, ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, rmin, rmax, vw_shift):
+def getcost(ops: Ops, ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, rmin, rmax, vw_shift,
+            policy_key=None):
     """GetCost with gradients to the image features only (hypotheses / view weights are detached in the reference)."""
     return _GetCostFn.apply(ref.contiguous(), src.contiguous(), rt, inv_depth, confidence, view_w, disp_min, disp_max, ops, n,
-                            interval, rmin, rmax, vw_shift)
+                            interval, rmin, rmax, vw_shift, policy_key)
 
 
 class _ViewAggregateFn(torch.autograd.Function):

@@ -152,17 +152,41 @@ warp_corr_init_bwd_kernel(const float* __restrict__ ref, const float* __restrict
 
 // ------------------------------------------------------------------------------------------
 // backward of dmvs_getcost_f32 w.r.t. the features.  gcost [B,G*n,H,W] (contiguous) -> gref (written), gsrc (+=)
-template <int C, int CPL, int N>
+// TILED: only the 16x16 tiles the window kernel (warp_bwd_win.hip) left in d.worklist; plain launch inside a hybrid call
+// (d.worklist set): only when the pre-pass said "everything here".
+template <int C, int CPL, int N, bool TILED>
 __global__ void __launch_bounds__(DMVS_BLOCK) getcost_bwd_kernel(const dmvs_getcost_desc d, const float* __restrict__ gcost,
                                                                  float* __restrict__ gref, float* __restrict__ gsrc) {
     constexpr int G = 4, LPP = C / CPL, LPG = LPP / G, PPB = DMVS_BLOCK / LPP;
     const int sub = threadIdx.x % LPP, slot = threadIdx.x / LPP;
     const int H = d.H, W = d.W;
-    const long npix = (long)d.B * H * W;
-    const long pix = (long)blockIdx.x * PPB + slot;
-    if (pix >= npix) return;
-    const int x = (int)(pix % W), y = (int)((pix / W) % H), b = (int)(pix / ((long)W * H));
-    const long hw = (long)H * W, yx = (long)y * W + x;
+    const long hw = (long)H * W;
+    int x, y, b;
+    if (TILED) {
+        constexpr int T = DMVS_GETCOST_TILE, BPT = T * T / PPB;
+        if (d.worklist[1]) return;
+        const unsigned nvalid = (unsigned)d.worklist[0] * BPT;
+        if (blockIdx.x >= nvalid) return;
+        const unsigned vb = dmvs_xcd_contiguous_block(blockIdx.x, nvalid);
+        int tq = d.worklist[4 + gridDim.x / BPT + (int)(vb / BPT)];
+        const int tiles_x = (W + T - 1) / T, tiles_y = (H + T - 1) / T;
+        const int txi = tq % tiles_x; tq /= tiles_x;
+        const int tyi = tq % tiles_y;
+        b = tq / tiles_y;
+        const int p = (int)(vb % BPT) * PPB + slot;
+        x = txi * T + (p & (T - 1));
+        y = tyi * T + p / T;
+        if (x >= W || y >= H) return;
+    } else {
+        if (d.worklist && !d.worklist[1]) return;
+        const long npix = (long)d.B * hw;
+        const long pix0 = (long)blockIdx.x * PPB + slot;
+        if (pix0 >= npix) return;
+        x = (int)(pix0 % W);
+        y = (int)((pix0 / W) % H);
+        b = (int)(pix0 / hw);
+    }
+    const long yx = (long)y * W + x, pix = (long)b * hw + yx;
     const float cur_inv = d.inv_depth[pix];
     float radius = (float)(N / 2) * d.interval;
     if (d.confidence) {
@@ -239,17 +263,39 @@ extern "C" int dmvs_warp_corr_init_bwd_f32(const float* ref, const float* src, c
 template <int C, int CPL>
 static int launch_getcost_bwd(const dmvs_getcost_desc& d, const float* gcost, float* gref, float* gsrc, hipStream_t st) {
     dim3 grid(dmvs_ceil_div((long)d.B * d.H * d.W, DMVS_BLOCK / (C / CPL))), block(DMVS_BLOCK);
-    if (d.n == 4) hipLaunchKernelGGL((getcost_bwd_kernel<C, CPL, 4>), grid, block, 0, st, d, gcost, gref, gsrc);
-    else if (d.n == 6) hipLaunchKernelGGL((getcost_bwd_kernel<C, CPL, 6>), grid, block, 0, st, d, gcost, gref, gsrc);
+    if (d.n == 4) hipLaunchKernelGGL((getcost_bwd_kernel<C, CPL, 4, false>), grid, block, 0, st, d, gcost, gref, gsrc);
+    else if (d.n == 6) hipLaunchKernelGGL((getcost_bwd_kernel<C, CPL, 6, false>), grid, block, 0, st, d, gcost, gref, gsrc);
     else return DMVS_EINVAL;
     return dmvs_launch_status();
 }
 
+template <int C, int CPL>
+static int launch_getcost_bwd_tiles(const dmvs_getcost_desc& d, const float* gcost, float* gref, float* gsrc, hipStream_t st) {
+    constexpr int PPB = DMVS_BLOCK / (C / CPL), T = DMVS_GETCOST_TILE, BPT = T * T / PPB;
+    const long tiles = (long)d.B * ((d.H + T - 1) / T) * ((d.W + T - 1) / T);
+    dim3 grid((unsigned)(tiles * BPT)), block(DMVS_BLOCK);
+    if (d.n == 4) hipLaunchKernelGGL((getcost_bwd_kernel<C, CPL, 4, true>), grid, block, 0, st, d, gcost, gref, gsrc);
+    else if (d.n == 6) hipLaunchKernelGGL((getcost_bwd_kernel<C, CPL, 6, true>), grid, block, 0, st, d, gcost, gref, gsrc);
+    else return DMVS_EINVAL;
+    return dmvs_launch_status();
+}
+
+int dmvs_getcost_bwd_win_dispatch(const dmvs_getcost_desc& d, const float* gcost, float* gref, float* gsrc, hipStream_t st);
+
 extern "C" int dmvs_getcost_bwd_f32(const dmvs_getcost_desc* dp, const float* gcost, float* gref, float* gsrc, void* stream) {
     if (!dp || !gcost || !gref || !gsrc) return DMVS_EINVAL;
-    const dmvs_getcost_desc& d = *dp;
-    if (d.G != 4 || !d.ref || !d.src || !d.rt || !d.inv_depth || !d.view_w) return DMVS_EINVAL;
+    dmvs_getcost_desc d = *dp;
+    if (d.G != 4 || !d.ref || !d.src || !d.rt || !d.inv_depth || !d.view_w || (d.n != 4 && d.n != 6)) return DMVS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    if (d.worklist && (d.C == 32 || d.C == 16)) {
+        // LDS-window tiles first, then the listed tiles, then (pre-pass: mostly misfits) everything per pixel; the
+        // launch that is not needed retires on the mode flag
+        if (int rc = dmvs_getcost_bwd_win_dispatch(d, gcost, gref, gsrc, st)) return rc;
+        if (int rc = d.C == 32 ? launch_getcost_bwd_tiles<32, 4>(d, gcost, gref, gsrc, st)
+                               : launch_getcost_bwd_tiles<16, 4>(d, gcost, gref, gsrc, st)) return rc;
+        return d.C == 32 ? launch_getcost_bwd<32, 4>(d, gcost, gref, gsrc, st) : launch_getcost_bwd<16, 4>(d, gcost, gref, gsrc, st);
+    }
+    d.worklist = nullptr;
     if (d.C == 48) return launch_getcost_bwd<48, 3>(d, gcost, gref, gsrc, st);
     if (d.C == 32) return launch_getcost_bwd<32, 4>(d, gcost, gref, gsrc, st);
     if (d.C == 16) return launch_getcost_bwd<16, 4>(d, gcost, gref, gsrc, st);

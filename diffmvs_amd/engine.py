@@ -405,9 +405,10 @@ class Engine:
             delta, new = o.delta_update(inv_depth, img, None, img_scale, new2=X, new2_cstride=2 * cd, new2_coffset=2 * cd - 1)
             img, img_scale = delta, 1.0
             cur_hidden, confidence = hidden, None
-            for _ in range(ub.iters):
+            for it in range(ub.iters):
                 cost, samples = o.getcost(feats_ref, feats_src, rt, new, confidence, view_w, disp_min, disp_max, n,
-                                          interval, a.min_radius, a.max_radius, vw_shift, G=self.G_cost)
+                                          interval, a.min_radius, a.max_radius, vw_shift, G=self.G_cost,
+                                          policy_key=(vw_shift, it))
                 run_encoder(o, ub.enc, cost, samples, out=X, out_cstride=2 * cd, out_coffset=cd)
                 cur_hidden, upd, conf = run_unet(o, self.arena, ub, X, cur_hidden, ss_of)
                 confidence = conf.view(B, H, W)

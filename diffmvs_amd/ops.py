@@ -107,6 +107,7 @@ class Ops:
         # optional per-entry-point HIP-event timing on the launch stream (bench.py roofline leg):
         # {"dmvs_getcost_f32": [(start_event, end_event), ...]}
         self.timers = None
+        self.last_getcost_plain = False
         self._getcost_state = {}     # per launch shape: which GetCost device path the last probe favoured (see getcost)
         self.getcost_tiles = None
         self.last_getcost_worklist = None
@@ -279,10 +280,12 @@ class Ops:
 
     def getcost(self, ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, min_radius,
                 max_radius, vw_shift, out_cost=None, cost_cstride=None, cost_coffset=0, out_samples=None,
-                samp_cstride=None, samp_coffset=0, G=4, gather=False):
+                samp_cstride=None, samp_coffset=0, G=4, gather=False, policy_key=None):
         """gather=True forces the per-pixel gather kernel (A/B measurements; also DMVS_GETCOST=gather in the environment);
         default = LDS-window kernel for C 32|16 with the gather kernel behind it for the tiles that do not fit"""
         gather = gather or os.environ.get("DMVS_GETCOST") == "gather"
+        # policy_key: the caller's name for this call site (e.g. (stage, iteration)): the first iteration of a diffusion
+        # stage starts from white noise (scale * randn, update.py:472) and never fits the windows, the later ones do
         self._chk(ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, out_cost, out_samples)
         B, H, W, Cc = ref.shape
         S = src.shape[0]
@@ -298,7 +301,7 @@ class Ops:
         # to the gather path -- a depth map that is noise, e.g. an untrained network -- later calls launch the plain
         # gather kernel alone and re-probe every 64th call.
         ntiles = B * ((H + 15) // 16) * ((W + 15) // 16)
-        st = self._getcost_state.setdefault((B, H, W, Cc, n), {"gather": False, "pending": None, "calls": 0})
+        st = self._getcost_state.setdefault((B, H, W, Cc, n, policy_key), {"gather": False, "pending": None, "calls": 0})
         if st["pending"] is not None and st["pending"][0].query():
             host = st["pending"][1]
             st["gather"] = bool(host[1]) or int(host[0]) * 2 > ntiles
@@ -320,6 +323,7 @@ class Ops:
             ev = torch.cuda.Event()
             ev.record()
             st["pending"] = (ev, host)
+        self.last_getcost_plain = plain
         self.getcost_tiles = st.get("last")      # diagnostics: (tiles on the gather path, tiles) of the last probe read back
         self.last_getcost_worklist = wl      # diagnostics: [0] tiles handed to the gather path, [1] = 1: all of them (pre-pass)
         return out_cost, out_samples
@@ -339,18 +343,19 @@ class Ops:
         return gref, gsrc
 
     def getcost_bwd(self, ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, min_radius,
-                    max_radius, vw_shift, gcost, gsrc=None, G=4):
+                    max_radius, vw_shift, gcost, gsrc=None, G=4, gather=False):
         self._chk(ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, gcost, gsrc)
         B, H, W, Cc = ref.shape
         S = src.shape[0]
         gref = torch.empty_like(ref)
         if gsrc is None:
             gsrc = torch.zeros_like(src)
+        ntiles = B * ((H + 15) // 16) * ((W + 15) // 16)
+        wl = None if (gather or Cc == 48) else torch.empty(4 + 66 * ntiles, dtype=torch.int32, device=self.device)
         d = _lib.GetCostDesc(ref=_ptr(ref), src=_ptr(src), rt=_ptr(rt), inv_depth=_ptr(inv_depth),
                              confidence=_ptr(confidence), view_w=_ptr(view_w), disp_min=_ptr(disp_min),
-                             disp_max=_ptr(disp_max), out_cost=None, out_samples=None, worklist=None, B=B, S=S, C=Cc, G=G, n=n,
-                             H=H, W=W,
-                             vw_shift=vw_shift, cost_cstride=G * n, cost_coffset=0, samp_cstride=n, samp_coffset=0,
+                             disp_max=_ptr(disp_max), out_cost=None, out_samples=None, worklist=_ptr(wl), B=B, S=S, C=Cc, G=G, n=n,
+                             H=H, W=W, vw_shift=vw_shift, cost_cstride=G * n, cost_coffset=0, samp_cstride=n, samp_coffset=0,
                              interval=interval, min_radius=min_radius, max_radius=max_radius)
         self._call("dmvs_getcost_bwd_f32", C.byref(d), _ptr(gcost), _ptr(gref), _ptr(gsrc), self.stream())
         return gref, gsrc

@@ -212,3 +212,28 @@ class NoiseSource:
         n = synth_noise(shape, self.seed, self.index)
         self.index += 1
         return n.to(device)
+
+
+def getcost_scene_inputs(H, W, n_src, B, stage=2, C=32, noise=0.01, conf=0.5, seed=0, numdepth=None):
+    """GetCost inputs with the geometry a trained network produces: inverse-depth hypotheses centred on the synthetic
+    scene's true depth (+ Gaussian noise of `noise` in normalised inverse depth), random features / view weights.
+    Returns CPU tensors: ref [B,h,w,C], src [S,B,h,w,C], proj (stage matrices [B,V,2,4,4]), inv [B,1,h,w], conf [B,h,w] or
+    None, view_w [B,S,h>>vs,w>>vs], disp_min [B], disp_max [B], interval, vw_shift."""
+    imgs, proj, dv, gt, _ = synth_inputs(H, W, n_src, B=B, seed=seed, with_gt=True)
+    name = f"stage{stage}"
+    sc = 2 ** (4 - stage)
+    h, w = H // sc, W // sc
+    g = torch.Generator().manual_seed(seed + 1)
+    ref = torch.randn(B, h, w, C, generator=g)
+    src = torch.randn(n_src, B, h, w, C, generator=g)
+    kmin, kmax = dv[:, 0].contiguous(), dv[:, -1].contiguous()
+    d = gt[name]
+    d = torch.where(torch.isfinite(d) & (d > 0), d, torch.full_like(d, 600.0))
+    inv = ((1.0 / d) - kmin.view(-1, 1, 1)) / (kmax - kmin).view(-1, 1, 1)
+    inv = (inv + noise * torch.randn(inv.shape, generator=g)).clamp(0, 1).unsqueeze(1).contiguous()
+    cf = torch.full((B, h, w), float(conf)) if conf is not None and conf >= 0 else None
+    vshift = stage - 1
+    vw = torch.rand(B, n_src, h >> vshift, w >> vshift, generator=g)
+    interval = (1.0 / dv.shape[1]) * (2 if stage == 2 else 1)
+    return {"ref": ref, "src": src, "proj": proj[name], "inv": inv, "conf": cf, "view_w": vw, "disp_min": kmin, "disp_max": kmax,
+            "interval": interval, "vw_shift": vshift}

@@ -12,7 +12,7 @@ LIB = os.path.join(HERE, "libdmvs_emu.so")
 
 def build_emu(force=False):
     srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
-    deps = srcs + [os.path.join(CSRC, "dmvs_common.h"), os.path.join(ROOT, "include", "dmvs.h"),
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [ os.path.join(ROOT, "include", "dmvs.h"),
                    os.path.join(HERE, "hip", "hip_runtime.h")]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
         return LIB

@@ -390,9 +390,13 @@ def test_warp_corr_init_backward(ops, C):
         close(gsrc[v].permute(0, 3, 1, 2), feats[v + 1].grad, 1e-4)
 
 
-@pytest.mark.parametrize("C,n,with_conf", [(32, 6, True), (16, 4, False)])
-def test_getcost_backward(ops, C, n, with_conf):
-    B, S, H, W = 2, 3, 10, 12
+@pytest.mark.parametrize("C,n,with_conf,H,W,interval", [(32, 6, True, 10, 12, 2.0 / 384), (16, 4, False, 10, 12, 2.0 / 384),
+                                                        (32, 6, True, 36, 44, 2.0 / 384), (16, 4, True, 40, 24, 1.0 / 384),
+                                                        (32, 4, False, 20, 36, 0.2)])
+def test_getcost_backward(ops, C, n, with_conf, H, W, interval):
+    """grad_ref / grad_src of GetCost against autograd through the oracle: LDS-window kernel (several tiles, partial
+    tiles; the large interval sends the tiles to the per-pixel kernel through the worklist) and the per-pixel kernel"""
+    B, S = 2, 3
     pm = _cams(B, S + 1, H, W, 5)
     feats = [rnd(B, C, H, W, seed=60 + v).requires_grad_(True) for v in range(S + 1)]
     inv = rnd(B, 1, H, W, seed=70, lo=-0.1, hi=1.1)
@@ -400,18 +404,19 @@ def test_getcost_backward(ops, C, n, with_conf):
     vw = rnd(B, S, H // 2, W // 2, seed=72, lo=0.0, hi=1.0)
     dv0, dv1 = torch.tensor([1 / 935.0, 1 / 700.0]), torch.tensor([1 / 425.0, 1 / 450.0])
     dmax, dmin = (1 / dv0).view(-1, 1, 1, 1), (1 / dv1).view(-1, 1, 1, 1)
-    cost, _ = O.get_cost(feats, pm, inv, 2.0 / 384, dmax, dmin, n, F.interpolate(vw, scale_factor=2, mode="nearest"),
+    cost, _ = O.get_cost(feats, pm, inv, interval, dmax, dmin, n, F.interpolate(vw, scale_factor=2, mode="nearest"),
                          conf, 4, 0.25, 4.0)
     gcost = rnd(*cost.shape, seed=73)
     cost.backward(gcost)
     rt = ops.compose_proj(dev(ops, pm))
-    gref, gsrc = ops.getcost_bwd(dev(ops, feats[0].detach().permute(0, 2, 3, 1)),
-                                 dev(ops, torch.stack([f.detach().permute(0, 2, 3, 1) for f in feats[1:]])), rt,
-                                 dev(ops, inv), dev(ops, conf), dev(ops, vw), dev(ops, 1 / (1 / dv0)), dev(ops, 1 / (1 / dv1)),
-                                 n, 2.0 / 384, 0.25, 4.0, 1, dev(ops, gcost))
-    close(gref.permute(0, 3, 1, 2), feats[0].grad, 1e-4)
-    for v in range(S):
-        close(gsrc[v].permute(0, 3, 1, 2), feats[v + 1].grad, 1e-4)
+    for gather in (False, True):
+        gref, gsrc = ops.getcost_bwd(dev(ops, feats[0].detach().permute(0, 2, 3, 1)),
+                                     dev(ops, torch.stack([f.detach().permute(0, 2, 3, 1) for f in feats[1:]])), rt,
+                                     dev(ops, inv), dev(ops, conf), dev(ops, vw), dev(ops, 1 / (1 / dv0)), dev(ops, 1 / (1 / dv1)),
+                                     n, interval, 0.25, 4.0, 1, dev(ops, gcost), gather=gather)
+        close(gref.permute(0, 3, 1, 2), feats[0].grad, 1e-4)
+        for v in range(S):
+            close(gsrc[v].permute(0, 3, 1, 2), feats[v + 1].grad, 1e-4)
 
 
 def test_view_aggregate_backward(ops):

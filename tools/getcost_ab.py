@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--conf", type=float, default=0.5)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--noise", type=float, default=0.01, help="sigma of the noise added to the true normalised inverse depth")
+    ap.add_argument("--bwd", action="store_true", help="time the backward (grad_ref / grad_src) instead of the forward")
     ap.add_argument("--lib", default=None, help="alternative libdmvs .so (kernel experiments)")
     a = ap.parse_args()
     o = Ops.for_device("cuda:0")
@@ -31,41 +32,37 @@ def main():
         from diffmvs_amd import _lib
         o = Ops(_lib.Lib(os.path.abspath(a.lib)), "cuda:0")
     dev = o.device
-    imgs, proj, dv, gt, _ = synth.synth_inputs(a.H, a.W, a.src, B=a.batch, seed=0, with_gt=True)
-    name = f"stage{a.stage}"
-    sc = 2 ** (4 - a.stage)
-    h, w = a.H // sc, a.W // sc
-    g = torch.Generator().manual_seed(1)
-    ref = torch.randn(a.batch, h, w, a.C, generator=g).to(dev)
-    src = torch.randn(a.src, a.batch, h, w, a.C, generator=g).to(dev)
-    rt = o.compose_proj(proj[name].to(dev).float().contiguous())
-    kmin, kmax = dv[:, 0].contiguous().to(dev), dv[:, -1].contiguous().to(dev)
-    d = gt[name]
-    d = torch.where(torch.isfinite(d) & (d > 0), d, torch.full_like(d, 600.0)).to(dev)
-    inv = ((1.0 / d) - kmin.view(-1, 1, 1)) / (kmax - kmin).view(-1, 1, 1)
-    inv = (inv + a.noise * torch.randn(inv.shape, generator=g).to(dev)).clamp(0, 1).unsqueeze(1).contiguous()
-    conf = torch.full((a.batch, h, w), a.conf, device=dev) if a.conf >= 0 else None
-    vshift = a.stage - 1
-    vw = torch.rand(a.batch, a.src, h >> vshift, w >> vshift, generator=g).to(dev)
-    interval = (1.0 / dv.shape[1]) * (2 if a.stage == 2 else 1)
+    gi = synth.getcost_scene_inputs(a.H, a.W, a.src, a.batch, stage=a.stage, C=a.C, noise=a.noise, conf=a.conf)
+    h, w = gi["ref"].shape[1], gi["ref"].shape[2]
+    ref, src, inv, vw = gi["ref"].to(dev), gi["src"].to(dev), gi["inv"].to(dev), gi["view_w"].to(dev)
+    conf = None if gi["conf"] is None else gi["conf"].to(dev)
+    rt = o.compose_proj(gi["proj"].to(dev).float().contiguous())
+    kmin, kmax = gi["disp_min"].to(dev), gi["disp_max"].to(dev)
+    interval, vshift = gi["interval"], gi["vw_shift"]
     res = {}
     outs = {}
+    args = (ref, src, rt, inv, conf, vw, kmin, kmax, a.n, interval, 0.2, 2.0, vshift)
+    gcost = torch.randn(a.batch, 4 * a.n, h, w, device=dev)
+    gbuf = torch.zeros_like(src)
     for gather in (False, True):
-        args = (ref, src, rt, inv, conf, vw, kmin, kmax, a.n, interval, 0.2, 2.0, vshift)
+        def run():
+            if a.bwd:
+                return o.getcost_bwd(*args, gcost, gsrc=gbuf.zero_(), gather=gather)
+            return o.getcost(*args, gather=gather)
         for _ in range(5):
-            outs[gather] = o.getcost(*args, gather=gather)
+            outs[gather] = [t.clone() for t in run()]
         torch.cuda.synchronize()
         st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         st.record()
         for _ in range(a.iters):
-            o.getcost(*args, gather=gather)
+            run()
         en.record()
         torch.cuda.synchronize()
         res["gather_us" if gather else "window_us"] = st.elapsed_time(en) * 1e3 / a.iters
     torch.cuda.synchronize()
     o.getcost(*args)
     res["adaptive_state"] = {str(k): {"gather": v["gather"], "last": v.get("last")} for k, v in o._getcost_state.items()}
-    diff = float((outs[False][0] - outs[True][0]).abs().max() / outs[True][0].abs().max())
+    diff = max(float((x - y).abs().max() / y.abs().max()) for x, y in zip(outs[False], outs[True]))
     hw = h * w
     alg = 4.0 * a.batch * (a.C * hw + a.src * a.C * hw + hw + (hw >> (2 * vshift)) * a.src + (hw if conf is not None else 0)
                            + 4 * a.n * hw + a.n * hw)
