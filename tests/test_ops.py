@@ -62,6 +62,17 @@ def test_conv2d_basic(ops, cin, cout, k, stride, pad, act):
         close(out, ref, 2e-5)
 
 
+@pytest.mark.parametrize("cin,cout,stride,H,W", [(3, 8, 1, 250, 262), (8, 8, 1, 256, 256), (8, 16, 2, 260, 500), (8, 24, 1, 256, 258)])
+def test_conv2d_large_image_stem(ops, cin, cout, stride, H, W):
+    """image sizes that select the 16x16-pixel tile (MT=4) instantiations of the FeatureNet / ContextNet stem layers"""
+    B = 2
+    x = rnd(B, cin, H, W, seed=1)
+    w, bias = rnd(cout, cin, 3, 3, seed=2) * 0.3, rnd(cout, seed=3)
+    ref = F.relu(F.conv2d(x, w, bias, stride, 1))
+    out = ops.conv2d(K.pack_conv2d(*dev(ops, w, bias), stride=stride, pad=1), dev(ops, x), act=K.ACT_RELU)
+    close(out, ref, 2e-5)
+
+
 def test_conv2d_fusions(ops):
     B, H, W = 2, 10, 12
     # concat + r*h gating + GRU blend  (reference models/module.py:164-177)
