@@ -1,0 +1,176 @@
+// FeatureNet stem: conv0.0 (3->8, 3x3) + BN + ReLU + conv0.1 (8->8, 3x3) + BN + ReLU at full resolution in ONE kernel
+// (reference models/module.py:364-367, :399).  As two conv2d launches these layers move 3.4 GB per 96-image step
+// (write + re-read of the 8-channel full-resolution intermediate) at ~2.3 TB/s; fused, the intermediate lives in LDS:
+// 0.38 GB in, 1.0 GB out.
+//   * persistent workgroups walk 16x16 output tiles; the next tile's 3 x 20 x 20 input halo streams in by LDS-DMA
+//     while this tile computes;
+//   * conv0.0 on the 18x18 halo'd intermediate as an implicit GEMM with K = 27 (ci, tap) padded to 28:
+//     7 x v_mfma_f32_16x16x4_f32 per 16 pixels, B operand gathered from the LDS halo through per-lane k offsets;
+//     BN + ReLU, zeroed outside the image (it is conv0.1's zero padding), written to LDS [8][18x18];
+//   * conv0.1 from that LDS image exactly like conv2d_mfma_kernel<3,3,1,1,4>; BN + ReLU; NCHW store.
+// Exact-fp32 MFMA; conv0.0's 27 products are summed in (ci, tap) order here and in (tap, ci) order by the generic
+// kernel, so the two agree to the last bits, not bitwise.
+#include "dmvs_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define DMVS_LDS_S(p) ((__attribute__((address_space(3))) void*)(p))
+
+constexpr int TS = 16;                 // output tile
+constexpr int MW = TS + 2, MP = MW * MW;          // intermediate tile 18 x 18 = 324
+constexpr int IW = TS + 4, IP = IW * IW;          // input tile 20 x 20 = 400
+constexpr int MPLANE = 336;                        // 324 padded to 16 mod 32 (bank spread over the 4 k-groups)
+constexpr int IN_FLOATS = 3 * IP;                  // 1200
+constexpr int W1S = 9 * 16;                        // conv0.1 weight slab stride per input channel (144 = 16 mod 32)
+
+__device__ __attribute__((aligned(16))) const float stem_zero16[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+
+__global__ void __launch_bounds__(DMVS_BLOCK)
+featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0, const float* __restrict__ scale0,
+                       const float* __restrict__ shift0, const float* __restrict__ w1, const float* __restrict__ scale1,
+                       const float* __restrict__ shift1, float* __restrict__ y, int N, int H, int W, int tiles_x, int tiles_y) {
+    __shared__ __attribute__((aligned(16))) float s_in[2][IN_FLOATS];
+    __shared__ __attribute__((aligned(16))) float s_mid[8 * MPLANE];
+    __shared__ float s_w0[28 * 16];
+    __shared__ float s_w1[8 * W1S];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const long plane = (long)H * W;
+    const int ntiles = tiles_x * tiles_y * N;
+
+    // weights -> LDS once per workgroup, output channels zero-padded to the 16 MFMA rows
+    for (int e = tid; e < 28 * 16; e += DMVS_BLOCK) {
+        const int k = e >> 4, co = e & 15;
+        s_w0[e] = (k < 27 && co < 8) ? w0[k * 8 + co] : 0.0f;
+    }
+    for (int e = tid; e < 8 * W1S; e += DMVS_BLOCK) {
+        const int ci = e / W1S, r = e - ci * W1S, t = r >> 4, co = r & 15;
+        s_w1[e] = co < 8 ? w1[(ci * 9 + t) * 8 + co] : 0.0f;
+    }
+
+    // stage the 3 x 20 x 20 input halo of `tile` (zero padded) into buf: 4-byte LDS-DMA, 64 consecutive words per wave
+    auto stage = [&](int tile, float* buf) {
+        int tq = tile;
+        const int tx = tq % tiles_x; tq /= tiles_x;
+        const int ty = tq % tiles_y;
+        const int n = tq / tiles_y;
+        const int gy0 = ty * TS - 2, gx0 = tx * TS - 2;
+        const float* xb = x + (long)n * 3 * plane;
+#pragma unroll
+        for (int i = 0; i < (IN_FLOATS + DMVS_BLOCK - 1) / DMVS_BLOCK; ++i) {
+            const int e = i * DMVS_BLOCK + tid;
+            if (e < IN_FLOATS) {
+                const int ci = e / IP, rem = e - ci * IP;
+                const int r = rem / IW, c = rem - r * IW;
+                const int iy = gy0 + r, ix = gx0 + c;
+                const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                const float* src = ok ? xb + ci * plane + (long)iy * W + ix : stem_zero16;
+                __builtin_amdgcn_global_load_lds(src, DMVS_LDS_S(buf + i * DMVS_BLOCK + wave * 64), 4, 0, 0);
+            }
+        }
+    };
+
+    // this lane's conv0.0 operands: A = w0[k = 4j + kq][cout = m], B offsets of (ci, ky, kx) = k inside the input halo
+    float a0[7];
+    int koff[7];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int k = 4 * j + kq;
+        a0[j] = s_w0[k * 16 + m];
+        const int kk = k < 27 ? k : 0;           // the 28th k has zero weights: any valid address
+        const int ci = kk / 9, t = kk - ci * 9;
+        koff[j] = ci * IP + (t / 3) * IW + (t % 3);
+    }
+    float sc0[4], sh0[4], sc1[4], sh1[4];       // this lane's output channels 4*kq + r (lanes with kq >= 2 hold padding)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = (4 * kq + r) & 7;
+        sc0[r] = scale0 ? scale0[co] : 1.0f;
+        sh0[r] = shift0 ? shift0[co] : 0.0f;
+        sc1[r] = scale1 ? scale1[co] : 1.0f;
+        sh1[r] = shift1 ? shift1[co] : 0.0f;
+    }
+
+    int tile = blockIdx.x, cur = 0;
+    if (tile < ntiles) stage(tile, s_in[0]);
+    for (; tile < ntiles; tile += gridDim.x, cur ^= 1) {
+        int tq = tile;
+        const int tx = tq % tiles_x; tq /= tiles_x;
+        const int ty = tq % tiles_y;
+        const int n = tq / tiles_y;
+        const int ox0 = tx * TS, oy0 = ty * TS;
+        __syncthreads();        // this tile's halo has landed; everyone is done with s_mid and the other input buffer
+        if (tile + (int)gridDim.x < ntiles) stage(tile + gridDim.x, s_in[cur ^ 1]);
+        const float* in = s_in[cur];
+
+        // ---- conv0.0 -> s_mid: 21 groups of 16 intermediate pixels (row-major over 18 x 18), waves take groups round-robin
+        for (int gidx = wave; gidx < (MP + 15) / 16; gidx += DMVS_BLOCK / 64) {
+            const int p = min(gidx * 16 + m, MP - 1);
+            const int py = p / MW, px = p - py * MW;
+            const float* ip = in + py * IW + px;
+            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int j = 0; j < 7; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], ip[koff[j]], acc, 0, 0, 0);
+            // D[row = 4*kq + r][col = m]: this lane holds intermediate channels 4*kq + r of pixel p
+            const int gy = oy0 - 1 + py, gx = ox0 - 1 + px;
+            const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            if (kq < 2 && gidx * 16 + m < MP) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    s_mid[(4 * kq + r) * MPLANE + p] = inside ? fmaxf(fmaf(acc[r], sc0[r], sh0[r]), 0.0f) : 0.0f;
+            }
+        }
+        __syncthreads();
+
+        // ---- conv0.1 from s_mid: wave = 4 output rows, 2 k-groups x 9 taps
+        f32x4 acc[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int c4 = 0; c4 < 2; ++c4) {
+            const int ci = c4 * 4 + kq;
+            const float* wp = s_w1 + ci * W1S + m;
+            const float* mp = s_mid + ci * MPLANE + (wave * 4) * MW + m;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float av = wp[(ky * 3 + kx) * 16];
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, mp[(mt + ky) * MW + kx], acc[mt], 0, 0, 0);
+                }
+        }
+        if (kq < 2) {
+            const int ox = ox0 + m;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int oy = oy0 + wave * 4 + mt;
+                if (ox < W && oy < H) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        y[((long)n * 8 + 4 * kq + r) * plane + (long)oy * W + ox] = fmaxf(fmaf(acc[mt][r], sc1[r], sh1[r]), 0.0f);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int dmvs_featurenet_stem_f32(const float* x, const float* w0, const float* scale0, const float* shift0,
+                                        const float* w1, const float* scale1, const float* shift1, float* y, int32_t N,
+                                        int32_t H, int32_t W, void* stream) {
+    if (!x || !w0 || !w1 || !y || N <= 0 || H <= 0 || W <= 0) return DMVS_EINVAL;
+    if ((long)3 * H * W >= (1L << 31)) return DMVS_EINVAL;
+    const int tiles_x = (W + TS - 1) / TS, tiles_y = (H + TS - 1) / TS;
+    const long ntiles = (long)tiles_x * tiles_y * N;
+    if (ntiles >= (1L << 31)) return DMVS_EINVAL;
+    const unsigned grid = (unsigned)(ntiles < 256 * 6 ? ntiles : 256 * 6);      // persistent: ~6 workgroups per CU (22 KB LDS each)
+    hipLaunchKernelGGL(featurenet_stem_kernel, dim3(grid), dim3(DMVS_BLOCK), 0, (hipStream_t)stream, x, w0, scale0, shift0, w1,
+                       scale1, shift1, y, N, H, W, tiles_x, tiles_y);
+    return dmvs_launch_status();
+}

@@ -55,7 +55,7 @@ def run_feature(o: Ops, f, x, layout=K.LAYOUT_NHWC):
     """x [N,3,H,W] -> {'stage1': [N,H/8,W/8,48], 'stage2': [N,H/4,W/4,32], ('stage3': [N,H/2,W/2,16])} (NHWC by
     default: the layout the warp kernels read)."""
     R = K.ACT_RELU
-    c0 = o.conv2d(f["conv0.1"], o.conv2d(f["conv0.0"], x, act=R), act=R)
+    c0 = o.featurenet_stem(f["conv0.0"], f["conv0.1"], x)      # conv0.0 + conv0.1 fused: the 8-channel intermediate stays in LDS
     c1 = o.conv2d(f["conv1.2"], o.conv2d(f["conv1.1"], o.conv2d(f["conv1.0"], c0, act=R), act=R), act=R)
     c2 = o.conv2d(f["conv2.2"], o.conv2d(f["conv2.1"], o.conv2d(f["conv2.0"], c1, act=R), act=R), act=R)
     c3 = o.conv2d(f["conv3.2"], o.conv2d(f["conv3.1"], o.conv2d(f["conv3.0"], c2, act=R), act=R), act=R)

@@ -186,6 +186,19 @@ class Ops:
             self.timers.setdefault("_conv2d_flops", []).append(2.0 * B * Hout * Wout * pc.cout * pc.cin * kh * kw)
         return out
 
+    def featurenet_stem(self, pc0: PackedConv, pc1: PackedConv, x):
+        """relu(bn(conv0.1(relu(bn(conv0.0(x)))))) of FeatureNet in one kernel: x [N,3,H,W] -> [N,8,H,W]"""
+        self._chk(x)
+        N, cin, H, W = x.shape
+        if not (cin == 3 and pc0.cin == 3 and pc0.cout == 8 and pc1.cin == 8 and pc1.cout == 8 and pc0.k == (3, 3) and
+                pc1.k == (3, 3) and pc0.stride == 1 and pc1.stride == 1 and pc0.pad == (1, 1) and pc1.pad == (1, 1) and
+                pc0.cout_pad == 8 and pc1.cout_pad == 8):
+            raise _lib.DmvsError("featurenet_stem: expects the 3->8->8 3x3 stem of FeatureNet")
+        y = self.empty(N, 8, H, W)
+        self._call("dmvs_featurenet_stem_f32", _ptr(x), _ptr(pc0.weight), _ptr(pc0.scale), _ptr(pc0.shift), _ptr(pc1.weight),
+                   _ptr(pc1.scale), _ptr(pc1.shift), _ptr(y), N, H, W, self.stream())
+        return y
+
     def conv2d_wgrad(self, pc: PackedConv, x0, grad_out, x1=None, *, mul0=None, in_mode=IN_PLAIN, want_bias=False):
         """Weight gradient of conv2d(pc, x0, x1, mul0=..., in_mode=...) in torch layout [cout, cin, kh, kw]
         (and the bias gradient [cout] when want_bias) -> gw | (gw, gb)."""

@@ -87,6 +87,14 @@ typedef struct dmvs_conv2d_desc {
 
 int dmvs_conv2d_f32(const dmvs_conv2d_desc* d, void* stream);
 
+/* FeatureNet stem in one kernel: relu(bn1(conv3x3(relu(bn0(conv3x3(x)))))) with 3 -> 8 -> 8 channels, padding 1, at full
+ * resolution (models/module.py:364-367 conv0, applied at :399); the 8-channel intermediate never leaves LDS.
+ *   x [N,3,H,W], y [N,8,H,W] NCHW;  w0 [3][3][3][8], w1 [8][3][3][8] in the kernel weight layout of dmvs_conv2d_f32
+ *   (cout_pad = 8); scale / shift [8] = folded eval BatchNorm (NULL = 1 / 0).  Agrees with the two dmvs_conv2d_f32
+ *   launches it replaces to the last bits (different summation grouping of conv0.0's 27 products). */
+int dmvs_featurenet_stem_f32(const float* x, const float* w0, const float* scale0, const float* shift0, const float* w1,
+                             const float* scale1, const float* shift1, float* y, int32_t N, int32_t H, int32_t W, void* stream);
+
 /* Weight (and bias) gradient of the convolution described by `d` (its input side: in0 / in1 / mul0 / in_mode / kh /
  * kw / stride / pad / cout / cout_pad / B / Hin / Win / Hout / Wout; epilogue fields are ignored):
  *   gw[co][ci][ky][kx] = sum_{b,y,x} grad_out[b,co,y,x] * X[b,ci,y*stride+ky-pad,x*stride+kx-pad]     (torch layout)

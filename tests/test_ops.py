@@ -562,3 +562,25 @@ def test_batchnorm_train_views(ops, view_major):
     close(rvd, rv_ref, 1e-5)
     close(gd.grad, gamma.grad, 1e-4)
     close(bd.grad, beta.grad, 1e-4)
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 32, 48), (3, 37, 53), (1, 16, 16)])
+def test_featurenet_stem_fused(ops, N, H, W):
+    """conv0.0 + BN + ReLU + conv0.1 + BN + ReLU in one kernel == the two conv2d launches == ATen (partial tiles, image
+    borders: the intermediate must be ZERO outside the image, not conv0.0 of padding)"""
+    x = rnd(N, 3, H, W, seed=1)
+    w0, w1 = rnd(8, 3, 3, 3, seed=2) * 0.4, rnd(8, 8, 3, 3, seed=3) * 0.3
+
+    def bn(seed):
+        return {"weight": rnd(8, seed=seed, lo=0.5, hi=1.5), "bias": rnd(8, seed=seed + 1) * 0.3,
+                "running_mean": rnd(8, seed=seed + 2) * 0.2, "running_var": rnd(8, seed=seed + 3, lo=0.5, hi=1.5)}
+    b0, b1 = bn(10), bn(20)
+    ref = F.relu(F.batch_norm(F.conv2d(x, w0, None, 1, 1), b0["running_mean"], b0["running_var"], b0["weight"], b0["bias"], False, 0.0, 1e-5))
+    ref = F.relu(F.batch_norm(F.conv2d(ref, w1, None, 1, 1), b1["running_mean"], b1["running_var"], b1["weight"], b1["bias"], False, 0.0, 1e-5))
+    d = lambda b: {k_: v.to(ops.device) for k_, v in b.items()}
+    pc0 = K.pack_conv2d(dev(ops, w0), bn=d(b0), pad=1)
+    pc1 = K.pack_conv2d(dev(ops, w1), bn=d(b1), pad=1)
+    out = ops.featurenet_stem(pc0, pc1, dev(ops, x))
+    close(out, ref, 2e-5)
+    two = ops.conv2d(pc1, ops.conv2d(pc0, dev(ops, x), act=K.ACT_RELU), act=K.ACT_RELU)
+    close(out, two.cpu(), 1e-6)          # conv0.0 sums its 27 products in a different grouping: last-bit differences only
