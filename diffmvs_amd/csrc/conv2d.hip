@@ -100,29 +100,58 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_mfma_kernel(const dmvs_conv
         return cig < d.c0 ? in0b + off : in1b + ((cig - d.c0) * plane1 + iy * d.Win + ix);
     };
 
+    // Everything about a staged element that does not depend on the chunk is decoded ONCE per tile: element i of this
+    // lane = (channel ci within the chunk, spatial offset or -1 for padding); per chunk only the channel term is added.
+    // (Decoding e -> (ci, row, col) with its integer divisions in every chunk was ~80 % of the non-MFMA instructions.)
+    int e_ci[IN_IT], e_sp[IN_IT];
+#pragma unroll
+    for (int i = 0; i < IN_IT; ++i) {
+        const int e = i * DMVS_BLOCK + tid;
+        const int ci = e / PLANE, rem = e - ci * PLANE;
+        const int r = rem / TW, c = rem - r * TW;
+        const int iy = gy0 + r, ix = gx0 + c;
+        const bool ok = e < CK * PLANE && rem < TH * TW && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win && !(ZI && ((iy | ix) & 1));
+        int sp;
+        if (mode == DMVS_IN_PLAIN) sp = iy * pW + ix;
+        else if (mode == DMVS_IN_UPSAMPLE2) sp = (iy >> 1) * pW + (ix >> 1);
+        else sp = iy * 2 * pW + ix * 2;
+        e_ci[i] = ci;
+        e_sp[i] = ok ? sp : -1;
+    }
+    int w_ci[W_IT], w_off[W_IT];           // weight slab piece -> (channel within the chunk, offset inside its [T][cout_pad] block)
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+        const int e4 = i * DMVS_BLOCK + tid;
+        const int ci = e4 / (WPAD / 4), rem4 = e4 - ci * (WPAD / 4);
+        const int t = rem4 / (NW / 4), n4 = rem4 - t * (NW / 4);
+        const bool ok = e4 < CK * WPAD / 4 && rem4 < T * NW / 4 && nbase + n4 * 4 < d.cout_pad;
+        w_ci[i] = ci;
+        w_off[i] = ok ? t * d.cout_pad + nbase + n4 * 4 : -1;
+    }
+
     // Stage chunk c0 into `buf` with LDS-DMA (global_load_lds): no VGPR round trip, fully asynchronous.
     // A wave-instruction fills 64 consecutive LDS words (4-byte form, input halo tile -- its rows are
     // not 16-byte multiples) or 64 consecutive 16-byte slots (weight slab) from per-lane sources.
     auto stage = [&](int c0, float* buf) {
-#pragma unroll 2
+#pragma unroll
         for (int i = 0; i < IN_IT; ++i) {
-            const int e = i * DMVS_BLOCK + tid;
-            if (e < CK * PLANE) {
-                int off;
-                const float* src = in_src(c0, e, off);
-                if (!src) src = dmvs_zero16;
+            if (i * DMVS_BLOCK + tid < CK * PLANE) {
+                const int cig = c0 + e_ci[i];
+                const float* src = dmvs_zero16;
+                if (e_sp[i] >= 0 && cig < cin) {
+                    if (cig >= d.c0) src = in1b + ((cig - d.c0) * plane1 + e_sp[i]);       // second concat input: always PLAIN
+                    else if (mode == DMVS_IN_UNSHUFFLE2) src = in0b + ((cig >> 2) * plane0 + ((cig >> 1) & 1) * pW + (cig & 1) + e_sp[i]);
+                    else src = in0b + (cig * plane0 + e_sp[i]);
+                }
                 __builtin_amdgcn_global_load_lds(src, DMVS_LDS(buf + i * DMVS_BLOCK + wave * 64), 4, 0, 0);
             }
         }
         float* wbuf = buf + CK * PLANE;
-#pragma unroll 2
+#pragma unroll
         for (int i = 0; i < W_IT; ++i) {
-            const int e4 = i * DMVS_BLOCK + tid;
-            if (e4 < CK * WPAD / 4) {
-                const int ci = e4 / (WPAD / 4), rem4 = e4 - ci * (WPAD / 4);
-                const int t = rem4 / (NW / 4), n4 = rem4 - t * (NW / 4);
-                const bool ok = rem4 < T * NW / 4 && c0 + ci < cin && nbase + n4 * 4 < d.cout_pad;
-                const float* src = ok ? d.weight + (((c0 + ci) * T + t) * d.cout_pad + nbase + n4 * 4) : dmvs_zero16;
+            if (i * DMVS_BLOCK + tid < CK * WPAD / 4) {
+                const int cw = c0 + w_ci[i];
+                const float* src = (w_off[i] >= 0 && cw < cin) ? d.weight + (cw * T * d.cout_pad + w_off[i]) : dmvs_zero16;
                 __builtin_amdgcn_global_load_lds(src, DMVS_LDS(wbuf + (i * DMVS_BLOCK + wave * 64) * 4), 16, 0, 0);
             }
         }

@@ -1,0 +1,48 @@
+"""Per-layer timing of dmvs_conv2d_f32 at the shapes of the cfg2 step (B=16, 6 views): us and TFLOP/s against the
+157 TF fp32-MFMA peak."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from diffmvs_amd import ops as K  # noqa: E402
+
+SHAPES = [  # name, N, cin, cout, k, stride, H, W
+    ("feat conv1.1 16->16 1/2", 96, 16, 16, 3, 1, 256, 320), ("feat conv2.1 32->32 1/4", 96, 32, 32, 3, 1, 128, 160),
+    ("feat conv3.1 64->64 1/8", 96, 64, 64, 3, 1, 64, 80), ("feat conv1.0 8->16 5x5s2", 96, 8, 16, 5, 2, 512, 640),
+    ("feat conv2.0 16->32 5x5s2", 96, 16, 32, 5, 2, 256, 320), ("feat conv3.0 32->64 5x5s2", 96, 32, 64, 5, 2, 128, 160),
+    ("unet init 64->16 7x7 1/4", 16, 64, 16, 7, 1, 128, 160), ("enc 24->32 3x3 1/4", 16, 24, 32, 3, 1, 128, 160),
+    ("unet 32->32 3x3 1/8", 16, 32, 32, 3, 1, 64, 80), ("ctx 16->16 1/2", 16, 16, 16, 3, 1, 256, 320),
+]
+
+
+def main():
+    o = K.Ops.for_device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    only = os.environ.get("CONV_ONLY")
+    for name, N, cin, cout, k, s, H, W in SHAPES:
+        if only and only not in name:
+            continue
+        x = torch.randn(N, cin, H, W, generator=g).cuda()
+        w = torch.randn(cout, cin, k, k, generator=g).cuda() * 0.1
+        pc = K.pack_conv2d(w, None, stride=s, pad=k // 2)
+        for _ in range(3):
+            y = o.conv2d(pc, x, act=K.ACT_RELU)
+        torch.cuda.synchronize()
+        st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        st.record()
+        for _ in range(10):
+            o.conv2d(pc, x, act=K.ACT_RELU)
+        en.record()
+        torch.cuda.synchronize()
+        us = st.elapsed_time(en) * 100.0
+        flops = 2.0 * N * y.shape[2] * y.shape[3] * cout * cin * k * k
+        gb = 4.0 * (x.numel() + y.numel()) / 1e9
+        print(json.dumps({"layer": name, "us": round(us, 1), "TFLOPs": round(flops / us / 1e6, 1), "frac_mfma": round(flops / us / 1e6 / 157.3, 3),
+                          "GB": round(gb, 3), "TBs": round(gb / us * 1e3, 2)}))
+
+
+if __name__ == "__main__":
+    main()
