@@ -132,18 +132,38 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_mfma_kernel(const dmvs_conv
     // Stage chunk c0 into `buf` with LDS-DMA (global_load_lds): no VGPR round trip, fully asynchronous.
     // A wave-instruction fills 64 consecutive LDS words (4-byte form, input halo tile -- its rows are
     // not 16-byte multiples) or 64 consecutive 16-byte slots (weight slab) from per-lane sources.
-    auto stage = [&](int c0, float* buf) {
+    // Padding is written ONCE per workgroup, not per chunk: spatial padding stays padding in every chunk, and channels
+    // beyond cin only ever meet zero weights, so they just must not hold non-finite LDS garbage on their first use.
+    // The per-chunk DMA then touches valid elements only (exec-masked), with no zero-source pointer to select.
 #pragma unroll
-        for (int i = 0; i < IN_IT; ++i) {
-            if (i * DMVS_BLOCK + tid < CK * PLANE) {
+    for (int i = 0; i < IN_IT; ++i) {
+        const int e = i * DMVS_BLOCK + tid;
+        if (e < CK * PLANE) {
+            if (e_sp[i] < 0 || e_ci[i] >= cin) lds[e] = 0.0f;
+            if (e_sp[i] < 0 || CK + e_ci[i] >= cin) lds[BUF + e] = 0.0f;
+        }
+    }
+    const bool simple = d.c1 == 0 && mode != DMVS_IN_UNSHUFFLE2;      // one input tensor, offset = channel plane + spatial
+    auto stage = [&](int c0, float* buf) {
+        if (simple) {
+#pragma unroll
+            for (int i = 0; i < IN_IT; ++i) {
                 const int cig = c0 + e_ci[i];
-                const float* src = dmvs_zero16;
+                if (e_sp[i] >= 0 && cig < cin)
+                    __builtin_amdgcn_global_load_lds(in0b + (unsigned)(cig * plane0 + e_sp[i]), DMVS_LDS(buf + i * DMVS_BLOCK + wave * 64),
+                                                     4, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < IN_IT; ++i) {
+                const int cig = c0 + e_ci[i];
                 if (e_sp[i] >= 0 && cig < cin) {
-                    if (cig >= d.c0) src = in1b + ((cig - d.c0) * plane1 + e_sp[i]);       // second concat input: always PLAIN
-                    else if (mode == DMVS_IN_UNSHUFFLE2) src = in0b + ((cig >> 2) * plane0 + ((cig >> 1) & 1) * pW + (cig & 1) + e_sp[i]);
-                    else src = in0b + (cig * plane0 + e_sp[i]);
+                    const float* src;
+                    if (cig >= d.c0) src = in1b + (unsigned)((cig - d.c0) * plane1 + e_sp[i]);       // second concat input: always PLAIN
+                    else if (mode == DMVS_IN_UNSHUFFLE2) src = in0b + (unsigned)((cig >> 2) * plane0 + ((cig >> 1) & 1) * pW + (cig & 1) + e_sp[i]);
+                    else src = in0b + (unsigned)(cig * plane0 + e_sp[i]);
+                    __builtin_amdgcn_global_load_lds(src, DMVS_LDS(buf + i * DMVS_BLOCK + wave * 64), 4, 0, 0);
                 }
-                __builtin_amdgcn_global_load_lds(src, DMVS_LDS(buf + i * DMVS_BLOCK + wave * 64), 4, 0, 0);
             }
         }
         float* wbuf = buf + CK * PLANE;
