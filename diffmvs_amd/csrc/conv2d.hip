@@ -57,8 +57,12 @@ struct ConvCfg {
 // ZI = the zero-insert input mode (training only: input gradient of a stride-2 layer).  It is a separate instantiation
 // because its extra predicate in the staging path costs the inference kernels scalar-register spills (measured: +30 %
 // on the 3x3 NT=1 MT=4 kernel when it was a run-time branch of the same code).
+// minimum waves per SIMD the register allocator must leave room for: the 32->32 (NT=2, MT=4) and 64->64 (NT=4, MT=2)
+// shapes otherwise settle at 160 / 212 VGPRs = 3 / 2 waves, too few to cover the per-chunk barrier + DMA latency
+constexpr int conv_min_waves(int nt, int mt) { return (nt == 2 && mt == 4) ? 4 : ((nt == 4 && mt == 2) ? 3 : 1); }
+
 template <int KH, int KW, int S, int NT, int MT, bool ZI>
-__global__ void __launch_bounds__(DMVS_BLOCK) conv2d_mfma_kernel(const dmvs_conv2d_desc d, int tiles_x, int tiles_y) {
+__global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfma_kernel(const dmvs_conv2d_desc d, int tiles_x, int tiles_y) {
     using Cfg = ConvCfg<KH, KW, S, NT, MT>;
     constexpr int T = Cfg::T, TW = Cfg::TW, TH = Cfg::TH, PLANE = Cfg::PLANE, NW = Cfg::NW, WPAD = Cfg::WPAD;
     constexpr int CK = Cfg::CK, BUF = Cfg::BUF, IN_IT = Cfg::IN_IT, W_IT = Cfg::W_IT;
