@@ -207,7 +207,7 @@ def main():
                      "launches_timed": len(gc_ms),
                      "launches_hybrid": n_hybrid, "launches_plain_gather": n_plain,
                      "tiles_on_gather_path": gather_tiles[0], "tiles_total": gather_tiles[1]},
-        "roofline_warp_init": {"kernel": "warp_corr_init_kernel<48,3>", "bound": "hbm",
+        "roofline_warp_init": {"kernel": "warp_init_win_kernel<48> (stage-1 plane sweep, LDS-staged source windows)", "bound": "hbm",
                                "achieved": round(alg_init / wi_avg_s / 1e9, 2) if wi_avg_s > 0 else 0.0,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(alg_init / wi_avg_s / 1e9 / HBM_PEAK_GBS, 4) if wi_avg_s > 0 else 0.0,

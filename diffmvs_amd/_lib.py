@@ -65,6 +65,7 @@ SIGNATURES = {
     "dmvs_conv3d_wgrad_f32": [C.POINTER(Conv3dDesc), _P, _P, _P, _P, C.c_int64, _P],
     "dmvs_compose_proj_f32": [_P, _P, _I, _I, _P],
     "dmvs_warp_corr_init_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "dmvs_warp_corr_init_gather_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "dmvs_warp_volume_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dmvs_getcost_f32": [C.POINTER(GetCostDesc), _P],
     "dmvs_getcost_gather_f32": [C.POINTER(GetCostDesc), _P],

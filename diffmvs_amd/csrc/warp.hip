@@ -349,9 +349,13 @@ int launch_init(const float* ref, const float* src, const float* rt, const float
 
 }  // namespace
 
-extern "C" int dmvs_warp_corr_init_f32(const float* ref, const float* src, const float* rt, const float* disp_min,
-                                       const float* disp_max, float* out, int32_t B, int32_t S, int32_t C, int32_t G,
-                                       int32_t D, int32_t H, int32_t W, int32_t Hs, int32_t Ws, void* stream) {
+int dmvs_warp_init_win_dispatch(const float* ref, const float* src, const float* rt, const float* disp_min, const float* disp_max,
+                                float* out, int B, int S, int C, int D, int H, int W, int Hs, int Ws, hipStream_t st);   // warp_init_win.hip
+
+// per-pixel gather through the texture path (every C)
+extern "C" int dmvs_warp_corr_init_gather_f32(const float* ref, const float* src, const float* rt, const float* disp_min,
+                                              const float* disp_max, float* out, int32_t B, int32_t S, int32_t C, int32_t G,
+                                              int32_t D, int32_t H, int32_t W, int32_t Hs, int32_t Ws, void* stream) {
     if (G != 4 || D < 2 || !ref || !src || !rt || !out) return DMVS_EINVAL;
     if ((long)S * B * Hs * Ws * C * 4 >= (1L << 32)) return DMVS_EINVAL;   // 32-bit byte offsets over the source stack
     hipStream_t st = (hipStream_t)stream;
@@ -360,6 +364,15 @@ extern "C" int dmvs_warp_corr_init_f32(const float* ref, const float* src, const
     if (C == 32) return launch_init<32, 4, 8>(ref, src, rt, disp_min, disp_max, out, B, S, D, H, W, Hs, Ws, st);
     if (C == 16) return launch_init<16, 4, 4>(ref, src, rt, disp_min, disp_max, out, B, S, D, H, W, Hs, Ws, st);
     return DMVS_EINVAL;
+}
+
+extern "C" int dmvs_warp_corr_init_f32(const float* ref, const float* src, const float* rt, const float* disp_min,
+                                       const float* disp_max, float* out, int32_t B, int32_t S, int32_t C, int32_t G,
+                                       int32_t D, int32_t H, int32_t W, int32_t Hs, int32_t Ws, void* stream) {
+    if (G != 4 || D < 2 || !ref || !src || !rt || !out) return DMVS_EINVAL;
+    if (C == 48 && D <= 256)           // the model's stage 1: LDS-staged source windows (warp_init_win.hip)
+        return dmvs_warp_init_win_dispatch(ref, src, rt, disp_min, disp_max, out, B, S, C, D, H, W, Hs, Ws, (hipStream_t)stream);
+    return dmvs_warp_corr_init_gather_f32(ref, src, rt, disp_min, disp_max, out, B, S, C, G, D, H, W, Hs, Ws, stream);
 }
 
 int dmvs_getcost_win_dispatch(const dmvs_getcost_desc& d, hipStream_t st);   // warp_win.hip

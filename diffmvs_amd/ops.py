@@ -271,14 +271,14 @@ class Ops:
         self._call("dmvs_compose_proj_f32", _ptr(proj), _ptr(out), B, V, self.stream())
         return out
 
-    def warp_corr_init(self, ref, src, rt, disp_min, disp_max, D, G=4):
-        """ref [B,H,W,C], src [S,B,Hs,Ws,C] (NHWC) -> [B,S,G,D,H,W]."""
+    def warp_corr_init(self, ref, src, rt, disp_min, disp_max, D, G=4, gather=False):
+        """ref [B,H,W,C], src [S,B,Hs,Ws,C] (NHWC) -> [B,S,G,D,H,W].  gather=True: per-pixel kernel (A/B measurements)."""
         self._chk(ref, src, rt, disp_min, disp_max)
         B, H, W, Cc = ref.shape
         S, _, Hs, Ws, _ = src.shape
         out = self.empty(B, S, G, D, H, W)
-        self._call("dmvs_warp_corr_init_f32", _ptr(ref), _ptr(src), _ptr(rt), _ptr(disp_min), _ptr(disp_max),
-                      _ptr(out), B, S, Cc, G, D, H, W, Hs, Ws, self.stream())
+        self._call("dmvs_warp_corr_init_gather_f32" if gather else "dmvs_warp_corr_init_f32", _ptr(ref), _ptr(src), _ptr(rt),
+                   _ptr(disp_min), _ptr(disp_max), _ptr(out), B, S, Cc, G, D, H, W, Hs, Ws, self.stream())
         return out
 
     def warp_volume(self, src, rt, depth):

@@ -168,6 +168,12 @@ int dmvs_warp_corr_init_f32(const float* ref, const float* src, const float* rt,
                             const float* disp_min, const float* disp_max, float* out,
                             int32_t B, int32_t S, int32_t C, int32_t G, int32_t D,
                             int32_t H, int32_t W, int32_t Hs, int32_t Ws, void* stream);
+/* Same contract on the per-pixel gather kernel (dmvs_warp_corr_init_f32 stages source windows through LDS for C = 48,
+ * the model's stage 1).  Kept public for A/B measurements. */
+int dmvs_warp_corr_init_gather_f32(const float* ref, const float* src, const float* rt,
+                                   const float* disp_min, const float* disp_max, float* out,
+                                   int32_t B, int32_t S, int32_t C, int32_t G, int32_t D,
+                                   int32_t H, int32_t W, int32_t Hs, int32_t Ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * GetCost.forward (models/module.py:583-667) in ONE kernel: hypothesis generation

@@ -7,6 +7,7 @@ import torch
 import torch.nn.functional as F
 
 from diffmvs_amd import ops as K
+from diffmvs_amd import synth
 from oracle import diffmvs_oracle as O
 
 
@@ -179,8 +180,38 @@ def test_warp_corr_init(ops, C):
     rt = ops.compose_proj(dev(ops, pm))
     ref_nhwc = dev(ops, feats[0].permute(0, 2, 3, 1))
     src_nhwc = dev(ops, torch.stack([f.permute(0, 2, 3, 1) for f in feats[1:]]))
+    for gather in (False, True):
+        out = ops.warp_corr_init(ref_nhwc, src_nhwc, rt, dev(ops, disp_min), dev(ops, disp_max), D, gather=gather)
+        close(out, want, 1e-4)
+
+
+@pytest.mark.parametrize("H,W,D,scene", [(40, 56, 16, True), (36, 30, 48, True), (24, 40, 9, False)])
+def test_warp_corr_init_window_tiles(ops, H, W, D, scene):
+    """stage-1 plane sweep through LDS windows (C = 48): several tiles incl. partial ones, depth chunks; `scene` uses the
+    synthetic cameras (chunks fit), else strongly rotated cameras (chunks fall back to global gathers).  Against the
+    oracle and the per-pixel kernel."""
+    B, S, C = 2, 3, 48
+    feats = [rnd(B, C, H, W, seed=80 + v) for v in range(S + 1)]
+    if scene:
+        _, proj, dvs = synth.synth_inputs(H * 8, W * 8, S, B=B, seed=7)
+        pm = proj["stage1"]
+        dv = torch.stack([dvs[:, 0], dvs[:, -1]], 1)
+    else:
+        pm = _cams(B, S + 1, H, W, 9)
+        dv = torch.tensor([[1 / 935.0, 1 / 425.0], [1 / 800.0, 1 / 500.0]])
+    disp_min, disp_max = dv[:, 0].contiguous(), dv[:, 1].contiguous()
+    hyp = (torch.arange(D).view(1, -1, 1, 1) / (D - 1.0)).repeat(B, 1, H, W)
+    hyp = O.disp_to_depth(hyp, (1 / dv[:, 1]).view(-1, 1, 1, 1), (1 / dv[:, 0]).view(-1, 1, 1, 1))[1]
+    ref_proj = O.compose_proj(pm[:, 0])
+    want = torch.stack([O.group_corr(O.warp(feats[v], O.compose_proj(pm[:, v]), ref_proj, hyp), feats[0], 4)
+                        for v in range(1, S + 1)], 1)
+    rt = ops.compose_proj(dev(ops, pm))
+    ref_nhwc = dev(ops, feats[0].permute(0, 2, 3, 1))
+    src_nhwc = dev(ops, torch.stack([f.permute(0, 2, 3, 1) for f in feats[1:]]))
     out = ops.warp_corr_init(ref_nhwc, src_nhwc, rt, dev(ops, disp_min), dev(ops, disp_max), D)
+    out_g = ops.warp_corr_init(ref_nhwc, src_nhwc, rt, dev(ops, disp_min), dev(ops, disp_max), D, gather=True)
     close(out, want, 1e-4)
+    close(out, out_g.cpu(), 2e-5)
 
 
 def test_warp_golden_edge_cases(ops, golden):
