@@ -26,6 +26,144 @@ constexpr int pad16mod32_3d(int n) {
 __device__ __attribute__((aligned(16))) const float dmvs_zero16_3d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #define DMVS_LDS(p) ((__attribute__((address_space(3))) void*)(p))
 
+// cin <= 4 (PixelViewWeight conv0 and CostReg conv0: 4 -> 8 on the full S-view / aggregated cost volumes): the whole
+// K dimension is one LDS chunk, so a workgroup of the generic kernel is load -> wait -> 108 MFMAs -> store with nothing
+// to overlap.  This variant keeps workgroups resident and walks 16x4x4 voxel tiles: the next tile's halo streams into
+// the other LDS buffer (LDS-DMA) while the matrix cores work on this one; the weight slab is staged once.
+template <int NT>
+__global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_kernel(const dmvs_conv3d_desc d, int tiles_x, int tiles_y, int tiles_d) {
+    constexpr int TX = 16, TY = 4, TD = 4, CK = 4;
+    constexpr int IW = TX + 2, IH = TY + 2, ID = TD + 2;
+    constexpr int PLANE = pad16mod32_3d(ID * IH * IW);
+    constexpr int NW = NT * 16;
+    constexpr int WPAD = pad16mod32_3d(27 * NW);
+    constexpr int IN_IT = (CK * PLANE + DMVS_BLOCK - 1) / DMVS_BLOCK, W_IT = (CK * WPAD / 4 + DMVS_BLOCK - 1) / DMVS_BLOCK;
+    __shared__ __attribute__((aligned(16))) float s_in2[2][CK * PLANE];
+    __shared__ __attribute__((aligned(16))) float s_w[CK * WPAD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int nbase = blockIdx.y * NW;
+    const size_t ivol = (size_t)d.Din * d.Hin * d.Win, ovol = (size_t)d.Dout * d.Hout * d.Wout;
+    const int vol = (int)ivol;
+    const int ntiles = tiles_x * tiles_y * tiles_d * d.B;
+
+    // element i of this lane inside a halo tile: (channel, z, y, x) is tile-independent -- decoded once
+    int e_off[IN_IT];                    // ci * vol + (zz * Hin + yy) * Win + xx, relative to the tile origin (may be "negative" near borders)
+    int e_zyx[IN_IT];                    // packed zz | yy << 8 | xx << 16, or -1 for lanes beyond the tile / channels beyond cin
+#pragma unroll
+    for (int i = 0; i < IN_IT; ++i) {
+        const int e = i * DMVS_BLOCK + tid;
+        const int ci = e / PLANE, rem = e - ci * PLANE;
+        const int zz = rem / (IH * IW), rem2 = rem - zz * (IH * IW);
+        const int yy = rem2 / IW, xx = rem2 - yy * IW;
+        const bool ok = e < CK * PLANE && rem < ID * IH * IW && ci < d.cin;
+        e_off[i] = ci * vol + (zz * d.Hin + yy) * d.Win + xx;
+        e_zyx[i] = ok ? (zz | (yy << 8) | (xx << 16)) : -1;
+        // padding of the halo image that is never a real element: zero once in both buffers (and channels beyond cin)
+        if (e < CK * PLANE && !ok) {
+            s_in2[0][e] = 0.0f;
+            s_in2[1][e] = 0.0f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+        const int e4 = i * DMVS_BLOCK + tid;
+        if (e4 < CK * WPAD / 4) {
+            const int ci = e4 / (WPAD / 4), rem4 = e4 - ci * (WPAD / 4);
+            const int t = rem4 / (NW / 4), n4 = rem4 - t * (NW / 4);
+            const bool ok = rem4 < 27 * NW / 4 && ci < d.cin && nbase + n4 * 4 < d.cout_pad;
+            const float* src = ok ? d.weight + ((ci * 27 + t) * d.cout_pad + nbase + n4 * 4) : dmvs_zero16_3d;
+            __builtin_amdgcn_global_load_lds(src, DMVS_LDS(s_w + (i * DMVS_BLOCK + wave * 64) * 4), 16, 0, 0);
+        }
+    }
+
+    auto stage = [&](int tile, float* buf) {
+        int tq = tile;
+        const int tx = tq % tiles_x; tq /= tiles_x;
+        const int ty = tq % tiles_y; tq /= tiles_y;
+        const int td = tq % tiles_d;
+        const int b = tq / tiles_d;
+        const int gx0 = tx * TX - 1, gy0 = ty * TY - 1, gd0 = td * TD - 1;
+        const float* base = d.in + (size_t)b * d.cin * ivol + ((long)gd0 * d.Hin + gy0) * d.Win + gx0;
+#pragma unroll
+        for (int i = 0; i < IN_IT; ++i) {
+            if (e_zyx[i] >= 0) {
+                const int gd = gd0 + (e_zyx[i] & 255), gy = gy0 + ((e_zyx[i] >> 8) & 255), gx = gx0 + (e_zyx[i] >> 16);
+                const bool in = gd >= 0 && gd < d.Din && gy >= 0 && gy < d.Hin && gx >= 0 && gx < d.Win;
+                const float* src = in ? base + e_off[i] : dmvs_zero16_3d;      // the border moves with the tile: zero source
+                __builtin_amdgcn_global_load_lds(src, DMVS_LDS(buf + i * DMVS_BLOCK + wave * 64), 4, 0, 0);
+            }
+        }
+    };
+
+    int tile = blockIdx.x, cur = 0;
+    if (tile < ntiles) stage(tile, s_in2[0]);
+    for (; tile < ntiles; tile += gridDim.x, cur ^= 1) {
+        __syncthreads();            // this tile's halo (and, first time, the weights) landed; the other buffer is free
+        if (tile + (int)gridDim.x < ntiles) stage(tile + gridDim.x, s_in2[cur ^ 1]);
+        const float* s_in = s_in2[cur];
+        f32x4 acc[4][NT];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        {
+            const int ci = kq;
+            const float* wp = s_w + ci * WPAD + m;
+            const float* ipb = s_in + ci * PLANE + wave * (IH * IW) + m;
+#pragma unroll 1
+            for (int kd = 0; kd < 3; ++kd) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        float av[NT];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) av[nt] = wp[((kd * 3 + ky) * 3 + kx) * NW + nt * 16];
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) {
+                            const float bv = ipb[(kd * IH + ky + mt) * IW + kx];
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[nt], bv, acc[mt][nt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        int tq = tile;
+        const int tx = tq % tiles_x; tq /= tiles_x;
+        const int ty = tq % tiles_y; tq /= tiles_y;
+        const int td = tq % tiles_d;
+        const int b = tq / tiles_d;
+        const int ox = tx * TX + m, od = td * TD + wave;
+        if (ox < d.Wout && od < d.Dout) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int oy = ty * TY + mt;
+                if (oy >= d.Hout) continue;
+                const size_t ovox = ((size_t)od * d.Hout + oy) * d.Wout + ox;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int cg = nbase + nt * 16 + kq * 4 + r;
+                        if (cg >= d.cout) continue;
+                        float y = acc[mt][nt][r];
+                        if (d.scale) y *= d.scale[cg];
+                        if (d.shift) y += d.shift[cg];
+                        y = dmvs_act(y, d.act);
+                        const size_t oi = ((size_t)b * d.cout + cg) * ovol + ovox;
+                        if (d.residual) y += d.residual[oi];
+                        d.out[oi] = y;
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <int NT>
 __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_kernel(const dmvs_conv3d_desc d, int tiles_x, int tiles_y, int tiles_d) {
     constexpr int TX = 16, TY = 4, TD = 4;
@@ -370,6 +508,12 @@ extern "C" int dmvs_conv3d_f32(const dmvs_conv3d_desc* dp, void* stream) {
         const int tiles_x = (d.Wout + 15) / 16, tiles_y = (d.Hout + 3) / 4, tiles_d = (d.Dout + 3) / 4;
         const int ntiles = (d.cout_pad + 15) / 16;
         dim3 g((unsigned)(tiles_x * tiles_y * tiles_d * d.B), (unsigned)((ntiles + 1) / 2));
+        const long vtiles = (long)tiles_x * tiles_y * tiles_d * d.B;
+        if (d.cin <= 4 && ntiles == 1 && vtiles >= 256 * 5) {      // one K chunk, many tiles: resident workgroups, pipelined tiles
+            dim3 gs((unsigned)(256 * 5), 1);
+            hipLaunchKernelGGL((conv3d_mfma_stream_kernel<1>), gs, block, 0, st, d, tiles_x, tiles_y, tiles_d);
+            return dmvs_launch_status();
+        }
         if (ntiles == 1) hipLaunchKernelGGL((conv3d_mfma_kernel<1>), g, block, 0, st, d, tiles_x, tiles_y, tiles_d);
         else hipLaunchKernelGGL((conv3d_mfma_kernel<2>), g, block, 0, st, d, tiles_x, tiles_y, tiles_d);
     } else {

@@ -615,3 +615,21 @@ def test_featurenet_stem_fused(ops, N, H, W):
     close(out, ref, 2e-5)
     two = ops.conv2d(pc1, ops.conv2d(pc0, dev(ops, x), act=K.ACT_RELU), act=K.ACT_RELU)
     close(out, two.cpu(), 1e-6)          # conv0.0 sums its 27 products in a different grouping: last-bit differences only
+
+
+@pytest.mark.parametrize("cin,cout,with_res", [(4, 8, False), (3, 8, True)])
+def test_conv3d_streamed_tiles(ops, cin, cout, with_res):
+    """cin <= 4 on a volume with more tiles than resident workgroups: the persistent, tile-pipelined instantiation
+    (PixelViewWeight conv0 / CostReg conv0 shapes), ragged sizes so that border tiles and partial tiles are hit"""
+    B, D, H, W = 2, 23, 62, 100
+    x = rnd(B, cin, D, H, W, seed=1)
+    w = rnd(cout, cin, 3, 3, 3, seed=2) * 0.2
+    bn = {"weight": rnd(cout, seed=4, lo=0.5, hi=1.5), "bias": rnd(cout, seed=5),
+          "running_mean": rnd(cout, seed=6), "running_var": rnd(cout, seed=7, lo=0.5, hi=1.5)}
+    ref = F.relu(F.batch_norm(F.conv3d(x, w, None, 1, 1), bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"], False, 0.0, 1e-5))
+    res = rnd(*ref.shape, seed=9) if with_res else None
+    if with_res:
+        ref = ref + res
+    pc = K.pack_conv3d(dev(ops, w), bn={k_: v.to(ops.device) for k_, v in bn.items()})
+    out = ops.conv3d(pc, dev(ops, x), act=K.ACT_RELU, residual=dev(ops, res))
+    close(out, ref, 2e-5)

@@ -18,8 +18,41 @@ SHAPES = [  # name, N, cin, cout, k, stride, H, W
 ]
 
 
+SHAPES3D = [  # name, N, cin, cout, D, H, W, stride
+    ("pvw conv0 4->8 (5 views)", 80, 4, 8, 48, 64, 80, 1), ("costreg conv0 4->8", 16, 4, 8, 48, 64, 80, 1),
+    ("costreg conv1 8->8", 16, 8, 8, 48, 64, 80, 1), ("costreg conv3 16->16", 16, 16, 16, 24, 32, 40, 1),
+    ("costreg conv5 32->32", 16, 32, 32, 12, 16, 20, 1),
+]
+
+
 def main():
     o = K.Ops.for_device("cuda:0")
+    if os.environ.get("CONV_LIB"):
+        from diffmvs_amd import _lib
+        o = K.Ops(_lib.Lib(os.path.abspath(os.environ["CONV_LIB"])), "cuda:0")
+    g3 = torch.Generator().manual_seed(1)
+    for name, N, cin, cout, D, H, W, s in SHAPES3D:
+        if os.environ.get("CONV_ONLY") and os.environ["CONV_ONLY"] not in name:
+            continue
+        x = torch.randn(N, cin, D, H, W, generator=g3).cuda()
+        w = torch.randn(cout, cin, 3, 3, 3, generator=g3).cuda() * 0.1
+        pc = K.pack_conv3d(w, None, stride=s)
+        for _ in range(3):
+            y = o.conv3d(pc, x, act=K.ACT_RELU)
+        torch.cuda.synchronize()
+        st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        st.record()
+        for _ in range(10):
+            o.conv3d(pc, x, act=K.ACT_RELU)
+        en.record()
+        torch.cuda.synchronize()
+        us = st.elapsed_time(en) * 100.0
+        flops = 2.0 * y.numel() * cin * 27
+        gb = 4.0 * (x.numel() + y.numel()) / 1e9
+        print(json.dumps({"layer": name, "us": round(us, 1), "TFLOPs": round(flops / us / 1e6, 1), "GB": round(gb, 3),
+                          "TBs": round(gb / us * 1e3, 2)}))
+    if os.environ.get("CONV_3D_ONLY"):
+        return
     g = torch.Generator().manual_seed(0)
     only = os.environ.get("CONV_ONLY")
     for name, N, cin, cout, k, s, H, W in SHAPES:
