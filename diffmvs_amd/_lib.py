@@ -83,6 +83,8 @@ SIGNATURES = {
     "dmvs_act_slice_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "dmvs_upsample_nearest_f32": [_P, _P, _I, _I, _I, _I, _P],
     "dmvs_nchw_to_nhwc_f32": [_P, _P, _I, _I, _I, _P],
+    "dmvs_groupnorm_silu_bwd_workspace_f32": [_I, _I, _I, C.POINTER(C.c_int64)],
+    "dmvs_groupnorm_silu_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _I, _I, _I, _I, _F, _P],
     "dmvs_batchnorm_workspace_f32": [_I, _I, _I, _I, C.POINTER(C.c_int64)],
     "dmvs_batchnorm_train_fwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _I, _I, _I, _I, _I, _F, _F, _I, _P],
     "dmvs_batchnorm_train_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _I, _I, _I, _I, _I, _I, _P],

@@ -188,3 +188,27 @@ def batchnorm_act(ops: Ops, x, gamma, beta, running_mean, running_var, momentum=
     """`views` independent BatchNorm calls batched in one tensor (rows view-major [V*B] or view-minor [B*V])"""
     return _BatchNormActFn.apply(x.contiguous(), gamma, beta, running_mean, running_var, ops, momentum, eps, relu, views,
                                  view_major)
+
+
+class _GroupNormSiLUFn(torch.autograd.Function):
+    """silu(GroupNorm(x) * (scale + 1) + shift) of the diffusion Unet's Block (update.py:124-133), HIP forward and backward."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, scale_shift, ops: Ops, groups, eps):
+        y, stats = ops.groupnorm_silu_train(x, gamma.detach(), beta.detach(), groups, None if scale_shift is None else scale_shift.detach(), eps)
+        ctx.save_for_backward(x, gamma, beta, scale_shift, stats)
+        ctx.ops, ctx.groups, ctx.eps = ops, groups, eps
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma, beta, scale_shift, stats = ctx.saved_tensors
+        dx, dgamma, dbeta, dss = ctx.ops.groupnorm_silu_bwd(x, g.contiguous(), gamma.detach(), beta.detach(), ctx.groups, stats,
+                                                            None if scale_shift is None else scale_shift.detach(), ctx.eps)
+        return dx, dgamma, dbeta, dss, None, None, None
+
+
+def groupnorm_silu(ops: Ops, x, gamma, beta, groups, scale_shift=None, eps=1e-5):
+    """scale_shift [B, 2C] = (scale | shift) as produced by the block's time-embedding Linear, or None"""
+    ss = None if scale_shift is None else scale_shift.contiguous()
+    return _GroupNormSiLUFn.apply(x.contiguous(), gamma, beta, ss, ops, groups, eps)

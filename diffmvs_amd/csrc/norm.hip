@@ -283,3 +283,152 @@ extern "C" int dmvs_batchnorm_train_bwd_f32(const float* x, const float* dy, con
                        rpv, view_major);
     return dmvs_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------
+// Backward of  y = silu(((x - mean_g) * rstd_g * gamma + beta) * (scale + 1) + shift)   (Block.forward of the diffusion
+// Unet, reference models/update.py:124-133, in training).  `stats` = the (sum, sum of squares) per (batch, group) that the
+// forward accumulated (dmvs_groupnorm_silu_f32 or the convolution's fused epilogue).
+//   du = dy * silu'(u);  per (b, c): S1 = sum du, S2 = sum du * xhat
+//   dshift = S1, dscale = gamma*S2 + beta*S1, dbeta = sum_b s1*S1, dgamma = sum_b s1*S2            (s1 = scale + 1)
+//   dx = rstd * (gamma*s1*du - m1 - xhat*m2),  m1 | m2 = sum_{c in group} gamma*s1*(S1 | S2) / n
+// Three launches (row partial sums -> per-row fold + small outputs -> apply), no atomics.
+namespace {
+
+__device__ __forceinline__ void gn_row_consts(const double* stats, int b, int c, int C, int HW, int groups, float eps, float& mean,
+                                              float& rstd) {
+    const int cg = C / groups, g = c / cg;
+    const double n = (double)cg * HW;
+    const double m = stats[2 * (b * groups + g)] / n;
+    double var = stats[2 * (b * groups + g) + 1] / n - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__device__ __forceinline__ float silu_grad(float u) {
+    const float s = dmvs_sigmoid(u);
+    return s * (1.0f + u * (1.0f - s));
+}
+
+constexpr int GN_CHUNK = 8192;
+
+__global__ void __launch_bounds__(DMVS_BLOCK)
+gn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
+                      const float* __restrict__ beta, const float* __restrict__ scale_shift, const double* __restrict__ stats,
+                      float2* __restrict__ partial, int C, int HW, int groups, float eps, int chunks) {
+    __shared__ float red[2 * DMVS_BLOCK / 64];
+    const int bc = blockIdx.y, b = bc / C, c = bc % C;
+    float mean, rstd;
+    gn_row_consts(stats, b, c, C, HW, groups, eps, mean, rstd);
+    const float s1 = scale_shift ? scale_shift[(long)b * 2 * C + c] + 1.0f : 1.0f, s0 = scale_shift ? scale_shift[(long)b * 2 * C + C + c] : 0.0f;
+    const float g = gamma[c], bt = beta[c];
+    const long base = (long)bc * HW;
+    const int lo = blockIdx.x * GN_CHUNK, hi = min(lo + GN_CHUNK, HW);
+    float a1 = 0.0f, a2 = 0.0f;
+    for (int i = lo + threadIdx.x; i < hi; i += DMVS_BLOCK) {
+        const float xh = (x[base + i] - mean) * rstd;
+        const float u = fmaf(fmaf(xh, g, bt), s1, s0);
+        const float du = dy[base + i] * silu_grad(u);
+        a1 += du;
+        a2 = fmaf(du, xh, a2);
+    }
+    const float2 t = block_sum2(a1, a2, red);
+    if (threadIdx.x == 0) partial[(long)bc * chunks + blockIdx.x] = t;
+}
+
+// one workgroup per batch item: fold the chunk partials of every channel row, per-(b,c) outputs and the group means
+__global__ void __launch_bounds__(DMVS_BLOCK)
+gn_bwd_fold_kernel(const float2* __restrict__ partial, const float* __restrict__ gamma, const float* __restrict__ beta,
+                   const float* __restrict__ scale_shift, float* __restrict__ rows /* [B][C][2] = S1, S2 */,
+                   float* __restrict__ dscale_shift, int C, int chunks) {
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += DMVS_BLOCK) {
+        double a = 0.0, q = 0.0;
+        for (int k = 0; k < chunks; ++k) {
+            const float2 p = partial[((long)b * C + c) * chunks + k];
+            a += (double)p.x;
+            q += (double)p.y;
+        }
+        rows[((long)b * C + c) * 2] = (float)a;
+        rows[((long)b * C + c) * 2 + 1] = (float)q;
+        if (dscale_shift) {
+            dscale_shift[(long)b * 2 * C + c] = (float)(gamma[c] * q + beta[c] * a);       // d scale
+            dscale_shift[(long)b * 2 * C + C + c] = (float)a;                              // d shift
+        }
+    }
+}
+
+// dgamma / dbeta: one thread per channel, sum over the batch
+__global__ void gn_bwd_param_kernel(const float* __restrict__ rows, const float* __restrict__ scale_shift, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta, int B, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double dg = 0.0, db = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const double s1 = scale_shift ? (double)scale_shift[(long)b * 2 * C + c] + 1.0 : 1.0;
+        db += s1 * rows[((long)b * C + c) * 2];
+        dg += s1 * rows[((long)b * C + c) * 2 + 1];
+    }
+    dgamma[c] = (float)dg;
+    dbeta[c] = (float)db;
+}
+
+__global__ void __launch_bounds__(DMVS_BLOCK)
+gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
+                    const float* __restrict__ beta, const float* __restrict__ scale_shift, const double* __restrict__ stats,
+                    const float* __restrict__ rows, float* __restrict__ dx, int C, int HW, int groups, float eps) {
+    const int bc = blockIdx.y, b = bc / C, c = bc % C;
+    float mean, rstd;
+    gn_row_consts(stats, b, c, C, HW, groups, eps, mean, rstd);
+    const int cg = C / groups, g0 = (c / cg) * cg;
+    float m1 = 0.0f, m2 = 0.0f;
+    for (int cc = g0; cc < g0 + cg; ++cc) {
+        const float s1c = scale_shift ? scale_shift[(long)b * 2 * C + cc] + 1.0f : 1.0f;
+        const float w = gamma[cc] * s1c;
+        m1 = fmaf(w, rows[((long)b * C + cc) * 2], m1);
+        m2 = fmaf(w, rows[((long)b * C + cc) * 2 + 1], m2);
+    }
+    const float inv_n = 1.0f / ((float)cg * (float)HW);
+    m1 *= inv_n;
+    m2 *= inv_n;
+    const float s1 = scale_shift ? scale_shift[(long)b * 2 * C + c] + 1.0f : 1.0f, s0 = scale_shift ? scale_shift[(long)b * 2 * C + C + c] : 0.0f;
+    const float g = gamma[c], bt = beta[c], gs = g * s1;
+    const long base = (long)bc * HW;
+    for (long i = (long)blockIdx.x * DMVS_BLOCK + threadIdx.x; i < HW; i += (long)gridDim.x * DMVS_BLOCK) {
+        const float xh = (x[base + i] - mean) * rstd;
+        const float u = fmaf(fmaf(xh, g, bt), s1, s0);
+        const float du = dy[base + i] * silu_grad(u);
+        dx[base + i] = rstd * (gs * du - m1 - xh * m2);
+    }
+}
+
+}  // namespace
+
+extern "C" int dmvs_groupnorm_silu_bwd_workspace_f32(int32_t B, int32_t C, int32_t HW, int64_t* bytes) {
+    if (!bytes || B <= 0 || C <= 0 || HW <= 0) return DMVS_EINVAL;
+    const int chunks = (HW + GN_CHUNK - 1) / GN_CHUNK;
+    *bytes = (int64_t)B * C * chunks * (int64_t)sizeof(float2) + (int64_t)B * C * 2 * (int64_t)sizeof(float);
+    return 0;
+}
+
+extern "C" int dmvs_groupnorm_silu_bwd_f32(const float* x, const float* dy, const float* gamma, const float* beta,
+                                           const float* scale_shift, const double* stats, float* dx, float* dgamma, float* dbeta,
+                                           float* dscale_shift, float* workspace, int64_t workspace_bytes, int32_t B, int32_t C,
+                                           int32_t HW, int32_t groups, float eps, void* stream) {
+    if (!x || !dy || !gamma || !beta || !stats || !dx || !dgamma || !dbeta || !workspace) return DMVS_EINVAL;
+    if (B <= 0 || C <= 0 || HW <= 0 || groups <= 0 || C % groups || (scale_shift && !dscale_shift)) return DMVS_EINVAL;
+    const int chunks = (HW + GN_CHUNK - 1) / GN_CHUNK;
+    int64_t need = 0;
+    dmvs_groupnorm_silu_bwd_workspace_f32(B, C, HW, &need);
+    if (workspace_bytes < need) return DMVS_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    float2* part = reinterpret_cast<float2*>(workspace);
+    float* rows = reinterpret_cast<float*>(part + (size_t)B * C * chunks);
+    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(chunks, B * C), dim3(DMVS_BLOCK), 0, st, x, dy, gamma, beta, scale_shift, stats, part,
+                       C, HW, groups, eps, chunks);
+    hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3(B), dim3(DMVS_BLOCK), 0, st, part, gamma, beta, scale_shift, rows, dscale_shift, C, chunks);
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(dmvs_ceil_div(C, 64)), dim3(64), 0, st, rows, scale_shift, dgamma, dbeta, B, C);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(dmvs_ceil_div(HW, DMVS_BLOCK * 4), B * C), dim3(DMVS_BLOCK), 0, st, x, dy, gamma, beta,
+                       scale_shift, stats, rows, dx, C, HW, groups, eps);
+    return dmvs_launch_status();
+}

@@ -60,8 +60,11 @@ def pack_conv2d(w: torch.Tensor, bias=None, bn: Optional[dict] = None, stride=1,
         w = (w - mean) * torch.rsqrt(var + 1e-5)
     cout, cin, kh, kw = w.shape
     cp = _pad_cout(cout)
-    wk = torch.zeros(cin, kh, kw, cp, dtype=torch.float32, device=w.device)
-    wk[..., :cout] = w.permute(1, 2, 3, 0)
+    if cp == cout:                  # the usual case: no padding columns, one permuting copy
+        wk = w.permute(1, 2, 3, 0).contiguous()
+    else:
+        wk = torch.zeros(cin, kh, kw, cp, dtype=torch.float32, device=w.device)
+        wk[..., :cout] = w.permute(1, 2, 3, 0)
     scale = shift = None
     if bn is not None:
         scale, shift = fold_bn(bn)
@@ -84,8 +87,11 @@ def pack_conv3d(w: torch.Tensor, bias=None, bn: Optional[dict] = None, stride=1,
         cout, cin = w.shape[0], w.shape[1]
         wk_src = w.permute(1, 2, 3, 4, 0)
     cp = _pad_cout(cout)
-    wk = torch.zeros(cin, 27, cp, dtype=torch.float32, device=w.device)
-    wk[..., :cout] = wk_src.reshape(cin, 27, cout)
+    if cp == cout:
+        wk = wk_src.reshape(cin, 27, cout).contiguous()
+    else:
+        wk = torch.zeros(cin, 27, cp, dtype=torch.float32, device=w.device)
+        wk[..., :cout] = wk_src.reshape(cin, 27, cout)
     scale = shift = None
     if bn is not None:
         scale, shift = fold_bn(bn)
@@ -426,6 +432,29 @@ class Ops:
         self._call("dmvs_groupnorm_silu_f32", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(scale_shift), _ptr(residual),
                       _ptr(out), _ptr(stats), B, Cc, H * W, groups, eps, self.stream())
         return out
+
+    def groupnorm_silu_train(self, x, gamma, beta, groups, scale_shift=None, eps=1e-5):
+        """forward that also returns the statistics buffer the backward needs"""
+        self._chk(x, gamma, beta, scale_shift)
+        B, Cc, H, W = x.shape
+        out = self.empty(B, Cc, H, W)
+        stats = torch.empty(B * groups * 2, dtype=torch.float64, device=self.device)
+        self._call("dmvs_groupnorm_silu_f32", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(scale_shift), None, _ptr(out), _ptr(stats), B, Cc,
+                   H * W, groups, eps, self.stream())
+        return out, stats
+
+    def groupnorm_silu_bwd(self, x, dy, gamma, beta, groups, stats, scale_shift=None, eps=1e-5):
+        self._chk(x, dy, gamma, beta, scale_shift)
+        B, Cc, H, W = x.shape
+        dx = torch.empty_like(x)
+        dgamma, dbeta = self.empty(Cc), self.empty(Cc)
+        dss = self.empty(B, 2 * Cc) if scale_shift is not None else None
+        n = C.c_int64(0)
+        self._call("dmvs_groupnorm_silu_bwd_workspace_f32", B, Cc, H * W, C.byref(n))
+        ws = self.empty(max(n.value // 4, 1))
+        self._call("dmvs_groupnorm_silu_bwd_f32", _ptr(x), _ptr(dy), _ptr(gamma), _ptr(beta), _ptr(scale_shift), _ptr(stats), _ptr(dx),
+                   _ptr(dgamma), _ptr(dbeta), _ptr(dss), _ptr(ws), n.value, B, Cc, H * W, groups, eps, self.stream())
+        return dx, dgamma, dbeta, dss
 
     def groupnorm_apply(self, x, gamma, beta, groups, stats, scale_shift=None, residual=None, out=None, eps=1e-5):
         """normalise + scale/shift + SiLU (+ residual) with statistics accumulated by conv2d(gn_stats=...)."""

@@ -170,17 +170,14 @@ def _ws_conv(n: _Net, x, k):
 
 
 def _block(n: _Net, x, k, scale_shift=None):
-    x = F.group_norm(_ws_conv(n, x, k + ".proj"), 4, n.p[k + ".norm.weight"], n.p[k + ".norm.bias"], 1e-5)
-    if scale_shift is not None:
-        x = x * (scale_shift[0] + 1) + scale_shift[1]
-    return F.silu(x)
+    """Block.forward (update.py:124-133): WS conv -> GroupNorm(4) -> x*(scale+1)+shift -> SiLU; scale_shift [B, 2C] or None"""
+    return A.groupnorm_silu(n.o, _ws_conv(n, x, k + ".proj"), n.p[k + ".norm.weight"], n.p[k + ".norm.bias"], 4, scale_shift, 1e-5)
 
 
 def resnet_block(n: _Net, x, k, t_emb=None):
     ss = None
     if t_emb is not None and n.has(k + ".mlp.1.weight"):
-        e = F.linear(F.silu(t_emb), n.p[k + ".mlp.1.weight"], n.p[k + ".mlp.1.bias"])
-        ss = e[:, :, None, None].chunk(2, dim=1)
+        ss = F.linear(F.silu(t_emb), n.p[k + ".mlp.1.weight"], n.p[k + ".mlp.1.bias"])      # [B, 2C] = (scale | shift)
     h = _block(n, _block(n, x, k + ".block1", ss), k + ".block2")
     res = n.conv2(x, k + ".res_conv") if n.has(k + ".res_conv.weight") else x
     return h + res

@@ -304,6 +304,15 @@ int dmvs_act_slice_f32(const float* in, float* out, int32_t act, int32_t B, int3
                        void* stream);
 int dmvs_upsample_nearest_f32(const float* in, float* out, int32_t N, int32_t H, int32_t W,
                               int32_t factor, void* stream);
+/* Backward of dmvs_groupnorm_silu_f32 without the residual (Block.forward in training, models/update.py:124-133):
+ * `stats` [B*groups*2] doubles as left by the forward; dx [B,C,HW]; dgamma / dbeta [C]; dscale_shift [B,2C] (required when
+ * scale_shift is given); `workspace`: caller scratch of dmvs_groupnorm_silu_bwd_workspace_f32() bytes.  No atomics. */
+int dmvs_groupnorm_silu_bwd_workspace_f32(int32_t B, int32_t C, int32_t HW, int64_t* bytes);
+int dmvs_groupnorm_silu_bwd_f32(const float* x, const float* dy, const float* gamma, const float* beta, const float* scale_shift,
+                                const double* stats, float* dx, float* dgamma, float* dbeta, float* dscale_shift,
+                                float* workspace, int64_t workspace_bytes, int32_t B, int32_t C, int32_t HW, int32_t groups,
+                                float eps, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Training-mode BatchNorm (+ optional ReLU) on [B, C, S] fp32 (S = H*W or D*H*W).  Replaces nn.BatchNorm2d/3d in
  * train mode inside module.Conv2d / Conv3d / ConvBnReLU / ConvBn            models/module.py:24-58, :60-96, :279-301.

@@ -633,3 +633,30 @@ def test_conv3d_streamed_tiles(ops, cin, cout, with_res):
     pc = K.pack_conv3d(dev(ops, w), bn={k_: v.to(ops.device) for k_, v in bn.items()})
     out = ops.conv3d(pc, dev(ops, x), act=K.ACT_RELU, residual=dev(ops, res))
     close(out, ref, 2e-5)
+
+
+@pytest.mark.parametrize("B,C_,H,W,with_ss", [(2, 8, 9, 13, True), (3, 16, 20, 24, False), (1, 32, 100, 90, True)])
+def test_groupnorm_silu_autograd(ops, B, C_, H, W, with_ss):
+    """Block.forward of the diffusion Unet in training: silu(GroupNorm(x)*(scale+1)+shift) forward and all five gradients"""
+    from diffmvs_amd import autograd as A
+    x = (rnd(B, C_, H, W, seed=1) * 2 + 0.3).requires_grad_(True)
+    gamma = (rnd(C_, seed=2) * 0.5 + 1).requires_grad_(True)
+    beta = (rnd(C_, seed=3) * 0.3).requires_grad_(True)
+    ss = (rnd(B, 2 * C_, seed=4) * 0.5).requires_grad_(True) if with_ss else None
+    ref = F.group_norm(x, 4, gamma, beta, 1e-5)
+    if with_ss:
+        sc, sh = ss[:, :, None, None].chunk(2, dim=1)
+        ref = ref * (sc + 1) + sh
+    ref = F.silu(ref)
+    g = rnd(B, C_, H, W, seed=5)
+    ref.backward(g)
+    xd, gd, bd = [t.detach().to(ops.device).requires_grad_(True) for t in (x, gamma, beta)]
+    sd = ss.detach().to(ops.device).requires_grad_(True) if with_ss else None
+    out = A.groupnorm_silu(ops, xd, gd, bd, 4, sd, 1e-5)
+    close(out, ref.detach(), 2e-5)
+    out.backward(dev(ops, g))
+    close(xd.grad, x.grad, 1e-4)
+    close(gd.grad, gamma.grad, 1e-4)
+    close(bd.grad, beta.grad, 1e-4)
+    if with_ss:
+        close(sd.grad, ss.grad, 1e-4)
