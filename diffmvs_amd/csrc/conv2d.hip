@@ -446,6 +446,28 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_wgrad_kernel(const dmvs_con
     for (int nt = 0; nt < NTN; ++nt) acc[nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     const float bias_one = (want_bias && blockIdx.y == 0) ? 1.0f : 0.0f;
 
+    // tile-independent decode of this lane's staged elements (the integer divisions used to run for every element of
+    // every tile and outweighed the MFMA work): halo element -> (input channel, row, column); dY element -> (cout, pixel)
+    int in_cig[IN_IT], in_rc[IN_IT];
+#pragma unroll
+    for (int i = 0; i < IN_IT; ++i) {
+        const int e = i * DMVS_BLOCK + tid;
+        const int ci = e / PLANE, rem = e - ci * PLANE;
+        const int r = rem / TW, c = rem - r * TW;
+        const bool ok = e < CK * PLANE && rem < TH * TW && c0 + ci < cin;
+        in_cig[i] = c0 + ci;
+        in_rc[i] = ok ? (r | (c << 16)) : -1;
+    }
+    int g_off[G_IT], g_pp[G_IT];
+#pragma unroll
+    for (int i = 0; i < G_IT; ++i) {
+        const int e = i * DMVS_BLOCK + tid;
+        const int co = e / GROW, p = e - co * GROW;
+        const bool ok = e < 16 * GROW && p < 256 && cobase + co < d.cout;
+        g_off[i] = (cobase + co) * (int)oplane + (p >> 4) * d.Wout + (p & 15);       // relative to the tile's first pixel
+        g_pp[i] = ok ? p : -1;
+    }
+
     const int ntiles = tiles_x * tiles_y * d.B;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int tq = tile;
@@ -457,16 +479,13 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_wgrad_kernel(const dmvs_con
         const float* in0b = d.in0 + (size_t)b * pc0 * plane0;
         const float* mul0b = d.mul0 ? d.mul0 + (size_t)b * pc0 * plane0 : nullptr;
         const float* in1b = d.in1 ? d.in1 + (size_t)b * d.c1 * plane1 : d.in0;
-        const float* gb = gout + (size_t)b * d.cout * oplane;
+        const float* gb = gout + (size_t)b * d.cout * oplane + (size_t)oy0 * d.Wout + ox0;
         __syncthreads();                              // previous tile fully consumed
-#pragma unroll 2
+#pragma unroll
         for (int i = 0; i < IN_IT; ++i) {
-            const int e = i * DMVS_BLOCK + tid;
-            if (e < CK * PLANE) {
-                const int ci = e / PLANE, rem = e - ci * PLANE;
-                const int r = rem / TW, c = rem - r * TW;
-                const int cig = c0 + ci, iy = gy0 + r, ix = gx0 + c;
-                const bool ok = rem < TH * TW && cig < cin && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win &&
+            if (i * DMVS_BLOCK + tid < CK * PLANE) {
+                const int cig = in_cig[i], iy = gy0 + (in_rc[i] & 0xffff), ix = gx0 + (in_rc[i] >> 16);
+                const bool ok = in_rc[i] >= 0 && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win &&
                                 !(mode == DMVS_IN_ZEROINSERT2 && ((iy | ix) & 1));
                 int off;
                 if (mode == DMVS_IN_PLAIN) off = cig * plane0 + iy * pW + ix;
@@ -476,14 +495,12 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_wgrad_kernel(const dmvs_con
                 __builtin_amdgcn_global_load_lds(src, DMVS_LDS(s_in + i * DMVS_BLOCK + wave * 64), 4, 0, 0);
             }
         }
-#pragma unroll 2
+#pragma unroll
         for (int i = 0; i < G_IT; ++i) {
-            const int e = i * DMVS_BLOCK + tid;
-            if (e < 16 * GROW) {
-                const int co = e / GROW, p = e - co * GROW;
-                const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
-                const bool ok = p < 256 && cobase + co < d.cout && oy < d.Hout && ox < d.Wout;
-                const float* src = ok ? gb + ((size_t)(cobase + co) * oplane + (size_t)oy * d.Wout + ox) : dmvs_zero16;
+            if (i * DMVS_BLOCK + tid < 16 * GROW) {
+                const int p = g_pp[i];
+                const bool ok = p >= 0 && oy0 + (p >> 4) < d.Hout && ox0 + (p & 15) < d.Wout;
+                const float* src = ok ? gb + g_off[i] : dmvs_zero16;
                 __builtin_amdgcn_global_load_lds(src, DMVS_LDS(s_g + i * DMVS_BLOCK + wave * 64), 4, 0, 0);
             }
         }
