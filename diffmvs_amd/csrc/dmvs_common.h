@@ -20,6 +20,7 @@ static inline int dmvs_launch_status() {
 }
 
 static inline unsigned dmvs_ceil_div(long a, long b) { return (unsigned)((a + b - 1) / b); }
+__device__ __forceinline__ unsigned dmvs_ceil_div_dev(long a, long b) { return (unsigned)((a + b - 1) / b); }
 
 __device__ __forceinline__ float dmvs_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
 

@@ -209,7 +209,8 @@ warp_corr_init_kernel(const float* __restrict__ ref, const float* __restrict__ s
 
 // ------------------------------------------------------------------------------------------
 // GetCost: hypotheses + S warps + correlation + view-weighted aggregation in one pass.
-// TILED: the launch covers the 16x16 pixel tiles that the LDS-window kernel (warp_win.hip) could not take, listed in
+// TILED: the launch covers the 16x16 pixel tiles that the LDS-window kernel (warp_win.hip) could not take (or, on the
+// pre-pass' "every tile" verdict, all pixels in plain order), listed in
 // d.worklist (layout: warp_win.hip; [0] = count, [1] = "every tile" flag of the pre-pass); workgroups beyond the count retire.
 template <int C, int CPL, int N, bool TILED>
 __global__ void __launch_bounds__(DMVS_BLOCK) getcost_kernel(const dmvs_getcost_desc d) {
@@ -219,10 +220,16 @@ __global__ void __launch_bounds__(DMVS_BLOCK) getcost_kernel(const dmvs_getcost_
     const long hw = (long)H * W;
     bool live;
     int x, y, b;
-    if (TILED) {
+    bool flat = !TILED;
+    unsigned nflat = gridDim.x;
+    if (TILED && d.worklist[1]) {           // pre-pass verdict "every tile": this launch degenerates to the plain pixel order
+        flat = true;
+        nflat = dmvs_ceil_div_dev((long)d.B * hw, PPB);
+        if (blockIdx.x >= nflat) return;
+    }
+    if (!flat) {
         constexpr int T = DMVS_GETCOST_TILE, BPT = T * T / PPB;       // workgroups per tile
         // the first count*BPT workgroups carry the work; each XCD (blockIdx % 8) walks a contiguous run of listed tiles
-        if (d.worklist[1]) return;                         // pre-pass verdict: the plain launch below takes every pixel
         const unsigned nvalid = (unsigned)d.worklist[0] * BPT;
         if (blockIdx.x >= nvalid) return;
         const unsigned vb = dmvs_xcd_contiguous_block(blockIdx.x, nvalid);
@@ -239,9 +246,8 @@ __global__ void __launch_bounds__(DMVS_BLOCK) getcost_kernel(const dmvs_getcost_
         x = min(x, W - 1);
         y = min(y, H - 1);
     } else {
-        if (d.worklist && !d.worklist[1]) return;          // hybrid launch: only needed when the pre-pass said "gather everything"
         const long npix = (long)d.B * hw;
-        const long pix = (long)dmvs_xcd_contiguous_block(blockIdx.x, gridDim.x) * PPB + slot;
+        const long pix = (long)dmvs_xcd_contiguous_block(blockIdx.x, nflat) * PPB + slot;
         live = pix < npix;
         const long pq = live ? pix : npix - 1;
         x = (int)(pq % W);
@@ -406,8 +412,6 @@ extern "C" int dmvs_getcost_f32(const dmvs_getcost_desc* dp, void* stream) {
     if ((d.C != 32 && d.C != 16) || !d.worklist) return dmvs_getcost_gather_f32(dp, stream);
     hipStream_t st = (hipStream_t)stream;
     if (int rc = dmvs_getcost_win_dispatch(d, st)) return rc;          // pre-pass + tiles whose source windows fit LDS
-    // the rest: the listed tiles, or (pre-pass: most tiles do not fit) everything through the plain pixel-order launch;
-    // the launch that is not needed retires at once on the mode flag
-    if (int rc = d.C == 32 ? launch_getcost_tiles<32, 4>(d, st) : launch_getcost_tiles<16, 4>(d, st)) return rc;
-    return d.C == 32 ? launch_getcost<32, 4>(d, st) : launch_getcost<16, 4>(d, st);
+    // the rest, one launch: the listed tiles, or (pre-pass: most tiles do not fit) every pixel in plain order
+    return d.C == 32 ? launch_getcost_tiles<32, 4>(d, st) : launch_getcost_tiles<16, 4>(d, st);
 }

@@ -162,9 +162,13 @@ __global__ void __launch_bounds__(DMVS_BLOCK) getcost_bwd_kernel(const dmvs_getc
     const int H = d.H, W = d.W;
     const long hw = (long)H * W;
     int x, y, b;
-    if (TILED) {
+    bool flat = !TILED;
+    if (TILED && d.worklist[1]) {           // pre-pass verdict "every tile": plain pixel order inside this launch
+        flat = true;
+        if (blockIdx.x >= dmvs_ceil_div_dev((long)d.B * hw, PPB)) return;
+    }
+    if (!flat) {
         constexpr int T = DMVS_GETCOST_TILE, BPT = T * T / PPB;
-        if (d.worklist[1]) return;
         const unsigned nvalid = (unsigned)d.worklist[0] * BPT;
         if (blockIdx.x >= nvalid) return;
         const unsigned vb = dmvs_xcd_contiguous_block(blockIdx.x, nvalid);
@@ -178,7 +182,6 @@ __global__ void __launch_bounds__(DMVS_BLOCK) getcost_bwd_kernel(const dmvs_getc
         y = tyi * T + p / T;
         if (x >= W || y >= H) return;
     } else {
-        if (d.worklist && !d.worklist[1]) return;
         const long npix = (long)d.B * hw;
         const long pix0 = (long)blockIdx.x * PPB + slot;
         if (pix0 >= npix) return;
@@ -288,12 +291,10 @@ extern "C" int dmvs_getcost_bwd_f32(const dmvs_getcost_desc* dp, const float* gc
     if (d.G != 4 || !d.ref || !d.src || !d.rt || !d.inv_depth || !d.view_w || (d.n != 4 && d.n != 6)) return DMVS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (d.worklist && (d.C == 32 || d.C == 16)) {
-        // LDS-window tiles first, then the listed tiles, then (pre-pass: mostly misfits) everything per pixel; the
-        // launch that is not needed retires on the mode flag
+        // LDS-window tiles first, then one launch for the rest: the listed tiles, or (pre-pass: mostly misfits) every pixel
         if (int rc = dmvs_getcost_bwd_win_dispatch(d, gcost, gref, gsrc, st)) return rc;
-        if (int rc = d.C == 32 ? launch_getcost_bwd_tiles<32, 4>(d, gcost, gref, gsrc, st)
-                               : launch_getcost_bwd_tiles<16, 4>(d, gcost, gref, gsrc, st)) return rc;
-        return d.C == 32 ? launch_getcost_bwd<32, 4>(d, gcost, gref, gsrc, st) : launch_getcost_bwd<16, 4>(d, gcost, gref, gsrc, st);
+        return d.C == 32 ? launch_getcost_bwd_tiles<32, 4>(d, gcost, gref, gsrc, st)
+                         : launch_getcost_bwd_tiles<16, 4>(d, gcost, gref, gsrc, st);
     }
     d.worklist = nullptr;
     if (d.C == 48) return launch_getcost_bwd<48, 3>(d, gcost, gref, gsrc, st);
