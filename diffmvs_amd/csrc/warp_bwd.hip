@@ -240,12 +240,18 @@ __global__ void __launch_bounds__(DMVS_BLOCK) getcost_bwd_kernel(const dmvs_getc
 
 }  // namespace
 
+int dmvs_warp_init_bwd_win_dispatch(const float* ref, const float* src, const float* rt, const float* disp_min, const float* disp_max,
+                                    const float* gcor, float* gref, float* gsrc, int B, int S, int C, int D, int H, int W, int Hs,
+                                    int Ws, hipStream_t st);      // warp_init_bwd_win.hip
+
 extern "C" int dmvs_warp_corr_init_bwd_f32(const float* ref, const float* src, const float* rt, const float* disp_min,
                                            const float* disp_max, const float* gcor, float* gref, float* gsrc, int32_t B,
                                            int32_t S, int32_t C, int32_t G, int32_t D, int32_t H, int32_t W, int32_t Hs,
-                                           int32_t Ws, void* stream) {
+                                           int32_t Ws, int32_t gather, void* stream) {
     if (G != 4 || D < 2 || !ref || !src || !rt || !gcor || !gref || !gsrc) return DMVS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    if (!gather && C == 48 && D <= 256)        // the model's stage 1: LDS windows (warp_init_bwd_win.hip)
+        return dmvs_warp_init_bwd_win_dispatch(ref, src, rt, disp_min, disp_max, gcor, gref, gsrc, B, S, C, D, H, W, Hs, Ws, st);
     const long npix = (long)B * H * W;
     dim3 block(DMVS_BLOCK);
     if (C == 48) {

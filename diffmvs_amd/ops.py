@@ -348,8 +348,10 @@ class Ops:
         return out_cost, out_samples
 
     # ------------------------------------------------------------------ backward (training step)
-    def warp_corr_init_bwd(self, ref, src, rt, disp_min, disp_max, gcor, gsrc=None):
-        """-> gref [B,H,W,C], gsrc [S,B,Hs,Ws,C] (accumulated into `gsrc` if given)."""
+    def warp_corr_init_bwd(self, ref, src, rt, disp_min, disp_max, gcor, gsrc=None, gather=True):
+        """-> gref [B,H,W,C], gsrc [S,B,Hs,Ws,C] (accumulated into `gsrc` if given).  gather=False selects the LDS-window
+        kernel (C = 48); measured slower than the per-pixel kernel at training sizes (10.9 vs 8.4 ms at cfg4: only ~10^3
+        long-running tile x view workgroups), so it is not the default."""
         self._chk(ref, src, rt, disp_min, disp_max, gcor, gsrc)
         B, H, W, Cc = ref.shape
         S, _, Hs, Ws, _ = src.shape
@@ -358,7 +360,7 @@ class Ops:
         if gsrc is None:
             gsrc = torch.zeros_like(src)
         self._call("dmvs_warp_corr_init_bwd_f32", _ptr(ref), _ptr(src), _ptr(rt), _ptr(disp_min), _ptr(disp_max), _ptr(gcor),
-                   _ptr(gref), _ptr(gsrc), B, S, Cc, G, D, H, W, Hs, Ws, self.stream())
+                   _ptr(gref), _ptr(gsrc), B, S, Cc, G, D, H, W, Hs, Ws, int(gather), self.stream())
         return gref, gsrc
 
     def getcost_bwd(self, ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, min_radius,

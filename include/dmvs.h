@@ -234,10 +234,11 @@ int dmvs_warp_volume_f32(const float* src, const float* rt, const float* depth, 
  *   gref [B,H,W,C] is WRITTEN; gsrc [S][B,Hs,Ws,C] is ACCUMULATED with fp32 atomics (caller zeroes it,
  *   or passes the running gradient of the source features).
  */
+/* gather != 0: per-pixel atomics kernel only (A/B measurements); 0: LDS-window kernel for C = 48 (the model's stage 1) */
 int dmvs_warp_corr_init_bwd_f32(const float* ref, const float* src, const float* rt,
                                 const float* disp_min, const float* disp_max, const float* gcor,
                                 float* gref, float* gsrc, int32_t B, int32_t S, int32_t C, int32_t G,
-                                int32_t D, int32_t H, int32_t W, int32_t Hs, int32_t Ws, void* stream);
+                                int32_t D, int32_t H, int32_t W, int32_t Hs, int32_t Ws, int32_t gather, void* stream);
 /* gcost [B,G*n,H,W] contiguous; d->out_cost / out_samples are ignored */
 int dmvs_getcost_bwd_f32(const dmvs_getcost_desc* d, const float* gcost, float* gref, float* gsrc, void* stream);
 /* backward of dmvs_view_aggregate_f32 (InitialCost, where the view weights DO require grad, :539-548):

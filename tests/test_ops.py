@@ -425,7 +425,34 @@ def test_warp_corr_init_backward(ops, C):
     rt = ops.compose_proj(dev(ops, pm))
     ref_nhwc = dev(ops, feats[0].detach().permute(0, 2, 3, 1))
     src_nhwc = dev(ops, torch.stack([f.detach().permute(0, 2, 3, 1) for f in feats[1:]]))
-    gref, gsrc = ops.warp_corr_init_bwd(ref_nhwc, src_nhwc, rt, dev(ops, 1 / (1 / dv[:, 0])), dev(ops, 1 / (1 / dv[:, 1])),
+    for gather in (False, True):
+        gref, gsrc = ops.warp_corr_init_bwd(ref_nhwc, src_nhwc, rt, dev(ops, 1 / (1 / dv[:, 0])), dev(ops, 1 / (1 / dv[:, 1])),
+                                            dev(ops, gcor), gather=gather)
+        close(gref.permute(0, 3, 1, 2), feats[0].grad, 1e-4)
+        for v in range(S):
+            close(gsrc[v].permute(0, 3, 1, 2), feats[v + 1].grad, 1e-4)
+
+
+@pytest.mark.parametrize("H,W,D,scene", [(36, 44, 12, True), (20, 36, 7, False)])
+def test_warp_corr_init_backward_window_tiles(ops, H, W, D, scene):
+    """plane-sweep backward through LDS windows (C = 48): several tiles, depth chunks; synthetic cameras (windows fit) and
+    strongly rotated cameras (chunks scatter in global memory)"""
+    B, S, C = 2, 2, 48
+    feats = [rnd(B, C, H, W, seed=90 + v).requires_grad_(True) for v in range(S + 1)]
+    if scene:
+        _, proj, dvs = synth.synth_inputs(H * 8, W * 8, S, B=B, seed=7)
+        pm = proj["stage1"]
+        dv = torch.stack([dvs[:, 0], dvs[:, -1]], 1)
+    else:
+        pm = _cams(B, S + 1, H, W, 9)
+        dv = torch.tensor([[1 / 935.0, 1 / 425.0], [1 / 800.0, 1 / 500.0]])
+    cor = _oracle_init_cor(feats, pm, dv, D)
+    gcor = rnd(*cor.shape, seed=95)
+    cor.backward(gcor)
+    rt = ops.compose_proj(dev(ops, pm))
+    ref_nhwc = dev(ops, feats[0].detach().permute(0, 2, 3, 1))
+    src_nhwc = dev(ops, torch.stack([f.detach().permute(0, 2, 3, 1) for f in feats[1:]]))
+    gref, gsrc = ops.warp_corr_init_bwd(ref_nhwc, src_nhwc, rt, dev(ops, dv[:, 0].contiguous()), dev(ops, dv[:, 1].contiguous()),
                                         dev(ops, gcor))
     close(gref.permute(0, 3, 1, 2), feats[0].grad, 1e-4)
     for v in range(S):
