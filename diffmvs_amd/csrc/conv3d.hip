@@ -26,10 +26,149 @@ constexpr int pad16mod32_3d(int n) {
 __device__ __attribute__((aligned(16))) const float dmvs_zero16_3d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #define DMVS_LDS(p) ((__attribute__((address_space(3))) void*)(p))
 
+// ---- staging and epilogue pieces shared by the three stride-1 kernels ---------------------------------------------
+// Halo tiles go HBM/L2 -> LDS by LDS-DMA, 4 bytes per lane (their rows are not 16-byte multiples).  Which (z, y, x) of
+// a channel plane of the halo tile a lane's elements are never changes, so it is decoded ONCE per workgroup; per tile
+// only the border test remains, done for all three coordinates at once on the packed form:  with a guard bit above
+// each 7-bit field, ((f | 128) - lo) keeps the guard iff f >= lo and ((hi-1 | 128) - f) keeps it iff f <= hi-1, and no
+// field ever borrows from its neighbour.  (The earlier per-element `&&` chains compiled to four nested branches and
+// ~90 instructions per staged element: 560 VALU + 590 SALU per 108 MFMAs, SQ PMC on the 4->8 layer.)
+constexpr unsigned kHaloGuard = 0x00808080u;
+
+template <int ID, int IH, int IW, int PLANE>
+struct HaloMap {
+    static constexpr int P_IT = (PLANE + DMVS_BLOCK - 1) / DMVS_BLOCK;
+    int off[P_IT];       // (zz * Hin + yy) * Win + xx, relative to the tile's halo origin
+    int zyx[P_IT];       // zz | yy << 8 | xx << 16, or -1: not an element of the plane (row padding / beyond it)
+    __device__ __forceinline__ void init(int tid, int Hin, int Win) {
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it) {
+            const int rem = it * DMVS_BLOCK + tid;
+            const int zz = rem / (IH * IW), rem2 = rem - zz * (IH * IW);
+            const int yy = rem2 / IW, xx = rem2 - yy * IW;
+            off[it] = (zz * Hin + yy) * Win + xx;
+            zyx[it] = rem < ID * IH * IW ? (zz | (yy << 8) | (xx << 16)) : -1;
+        }
+    }
+    // packed bounds of the part of the halo tile at origin (gd0, gy0, gx0) that lies inside the volume
+    static __device__ __forceinline__ void bounds(int gd0, int gy0, int gx0, int Din, int Hin, int Win, unsigned& lo, unsigned& him1) {
+        const int zl = max(0, -gd0), yl = max(0, -gy0), xl = max(0, -gx0);
+        const int zh = min(ID, Din - gd0) - 1, yh = min(IH, Hin - gy0) - 1, xh = min(IW, Win - gx0) - 1;
+        lo = (unsigned)(zl | (yl << 8) | (xl << 16));
+        him1 = (unsigned)(zh | (yh << 8) | (xh << 16)) | kHaloGuard;
+    }
+    // one channel plane: `origin` = the halo origin inside this channel (may lie outside the tensor for border tiles --
+    // only in-range elements are dereferenced); a dead channel (beyond cin) is staged as zeros
+    __device__ __forceinline__ void stage(const float* origin, bool chan_live, unsigned lo, unsigned him1, float* dst_plane, int wave) const {
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it) {
+            if (zyx[it] >= 0) {
+                const unsigned z = (unsigned)zyx[it];
+                const bool in = chan_live && ((((z | kHaloGuard) - lo) & (him1 - z) & kHaloGuard) == kHaloGuard);
+                const float* srcp = in ? origin + off[it] : dmvs_zero16_3d;
+                float* dstp = dst_plane + it * DMVS_BLOCK + wave * 64;
+                __builtin_amdgcn_global_load_lds(srcp, DMVS_LDS(dstp), 4, 0, 0);
+            }
+        }
+    }
+};
+
+// weight slab [CK][27][NW] (+ row padding to WPAD), 16 bytes per lane; decoded once per workgroup like the halo
+template <int CK, int NW, int WPAD>
+struct SlabMap {
+    static constexpr int W_IT = (CK * WPAD / 4 + DMVS_BLOCK - 1) / DMVS_BLOCK;
+    int ci[W_IT], off[W_IT];             // channel within the chunk; offset inside its [27][cout_pad] block, -1: zero / skip
+    __device__ __forceinline__ void init(int tid, int nbase, int cout_pad) {
+#pragma unroll
+        for (int i = 0; i < W_IT; ++i) {
+            const int e4 = i * DMVS_BLOCK + tid;
+            const int c = e4 / (WPAD / 4), rem4 = e4 - c * (WPAD / 4);
+            const int t = rem4 / (NW / 4), n4 = rem4 - t * (NW / 4);
+            const bool ok = rem4 < 27 * NW / 4 && nbase + n4 * 4 < cout_pad;
+            ci[i] = e4 < CK * WPAD / 4 ? c : -1;
+            off[i] = ok ? t * cout_pad + nbase + n4 * 4 : -1;
+        }
+    }
+    __device__ __forceinline__ void stage(const float* weight, int c0, int cin, int cout_pad, float* wbuf, int wave) const {
+#pragma unroll
+        for (int i = 0; i < W_IT; ++i) {
+            if (ci[i] >= 0) {
+                const int cw = c0 + ci[i];
+                const float* srcp = (off[i] >= 0 && cw < cin) ? weight + (cw * 27 * cout_pad + off[i]) : dmvs_zero16_3d;
+                float* dstp = wbuf + (i * DMVS_BLOCK + wave * 64) * 4;
+                __builtin_amdgcn_global_load_lds(srcp, DMVS_LDS(dstp), 16, 0, 0);
+            }
+        }
+    }
+};
+
+// Epilogue constants of an MFMA output tile: this lane holds channels nbase + nt*16 + kq*4 + r.  Folded BN scale /
+// shift sit in registers for the whole kernel (they were re-read from global memory, with a wait each, per VALUE).
+template <int NT>
+struct TileEpi {
+    float sc[NT][4], sh[NT][4];
+    int cg0[NT];
+    __device__ __forceinline__ void init(const dmvs_conv3d_desc& d, int nbase, int kq) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            cg0[nt] = nbase + nt * 16 + kq * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cg = cg0[nt] + r;
+                const bool okc = cg < d.cout;
+                sc[nt][r] = d.scale ? d.scale[okc ? cg : 0] : 1.0f;
+                sh[nt][r] = d.shift ? d.shift[okc ? cg : 0] : 0.0f;
+            }
+        }
+    }
+    // rows y0 .. y0+3 of depth slice od at column ox; outb / resb = this batch item's [cout][Dout][Hout][Wout] block,
+    // addressed with 32-bit element offsets (the entry point rejects cout * volume >= 2^31)
+    __device__ __forceinline__ void store(const dmvs_conv3d_desc& d, const f32x4 (&acc)[4][NT], float* outb, const float* resb, int ox,
+                                          int od, int y0, int ovol) const {
+        if (ox >= d.Wout || od >= d.Dout) return;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int oy = y0 + mt;
+            if (oy >= d.Hout) continue;
+            const int ovox = (od * d.Hout + oy) * d.Wout + ox;
+            float y[NT][4];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[nt][r] = acc[mt][nt][r] * sc[nt][r] + sh[nt][r];
+            if (d.act == DMVS_ACT_RELU) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[nt][r] = fmaxf(y[nt][r], 0.0f);
+            } else if (d.act != DMVS_ACT_NONE) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[nt][r] = dmvs_act(y[nt][r], d.act);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (cg0[nt] + r < d.cout) {
+                        const int o = (cg0[nt] + r) * ovol + ovox;
+                        float v = y[nt][r];
+                        if (resb) v += resb[o];
+                        outb[o] = v;
+                    }
+                }
+        }
+    }
+};
+
 // cin <= 4 (PixelViewWeight conv0 and CostReg conv0: 4 -> 8 on the full S-view / aggregated cost volumes): the whole
 // K dimension is one LDS chunk, so a workgroup of the generic kernel is load -> wait -> 108 MFMAs -> store with nothing
 // to overlap.  This variant keeps workgroups resident and walks 16x4x4 voxel tiles: the next tile's halo streams into
 // the other LDS buffer (LDS-DMA) while the matrix cores work on this one; the weight slab is staged once.
+// One __shared__ array on purpose: with the two halo buffers and the weights as separate LDS objects hipcc attaches
+// alias scopes and then waits vmcnt(0) before the first ds_read of a halo buffer while the DMA into the OTHER half is
+// in flight (same object) -- which serialised the pipeline this kernel exists for.
 template <int NT>
 __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_kernel(const dmvs_conv3d_desc d, int tiles_x, int tiles_y, int tiles_d) {
     constexpr int TX = 16, TY = 4, TD = 4, CK = 4;
@@ -37,72 +176,56 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_kernel(const dm
     constexpr int PLANE = pad16mod32_3d(ID * IH * IW);
     constexpr int NW = NT * 16;
     constexpr int WPAD = pad16mod32_3d(27 * NW);
-    constexpr int IN_IT = (CK * PLANE + DMVS_BLOCK - 1) / DMVS_BLOCK, W_IT = (CK * WPAD / 4 + DMVS_BLOCK - 1) / DMVS_BLOCK;
-    __shared__ __attribute__((aligned(16))) float s_in2[2][CK * PLANE];
-    __shared__ __attribute__((aligned(16))) float s_w[CK * WPAD];
+    using Halo = HaloMap<ID, IH, IW, PLANE>;
+    using Slab = SlabMap<CK, NW, WPAD>;
+    __shared__ __attribute__((aligned(16))) float lds[2 * CK * PLANE + CK * WPAD];
+    float* const s_w = lds + 2 * CK * PLANE;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA bases stay in SGPRs
     const int m = lane & 15, kq = lane >> 4;
     const int nbase = blockIdx.y * NW;
-    const size_t ivol = (size_t)d.Din * d.Hin * d.Win, ovol = (size_t)d.Dout * d.Hout * d.Wout;
-    const int vol = (int)ivol;
+    const int vol = d.Din * d.Hin * d.Win, ovol = d.Dout * d.Hout * d.Wout;
     const int ntiles = tiles_x * tiles_y * tiles_d * d.B;
 
-    // element i of this lane inside a halo tile: (channel, z, y, x) is tile-independent -- decoded once
-    int e_off[IN_IT];                    // ci * vol + (zz * Hin + yy) * Win + xx, relative to the tile origin (may be "negative" near borders)
-    int e_zyx[IN_IT];                    // packed zz | yy << 8 | xx << 16, or -1 for lanes beyond the tile / channels beyond cin
-#pragma unroll
-    for (int i = 0; i < IN_IT; ++i) {
-        const int e = i * DMVS_BLOCK + tid;
-        const int ci = e / PLANE, rem = e - ci * PLANE;
-        const int zz = rem / (IH * IW), rem2 = rem - zz * (IH * IW);
-        const int yy = rem2 / IW, xx = rem2 - yy * IW;
-        const bool ok = e < CK * PLANE && rem < ID * IH * IW && ci < d.cin;
-        e_off[i] = ci * vol + (zz * d.Hin + yy) * d.Win + xx;
-        e_zyx[i] = ok ? (zz | (yy << 8) | (xx << 16)) : -1;
-        // padding of the halo image that is never a real element: zero once in both buffers (and channels beyond cin)
-        if (e < CK * PLANE && !ok) {
-            s_in2[0][e] = 0.0f;
-            s_in2[1][e] = 0.0f;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < W_IT; ++i) {
-        const int e4 = i * DMVS_BLOCK + tid;
-        if (e4 < CK * WPAD / 4) {
-            const int ci = e4 / (WPAD / 4), rem4 = e4 - ci * (WPAD / 4);
-            const int t = rem4 / (NW / 4), n4 = rem4 - t * (NW / 4);
-            const bool ok = rem4 < 27 * NW / 4 && ci < d.cin && nbase + n4 * 4 < d.cout_pad;
-            const float* src = ok ? d.weight + ((ci * 27 + t) * d.cout_pad + nbase + n4 * 4) : dmvs_zero16_3d;
-            __builtin_amdgcn_global_load_lds(src, DMVS_LDS(s_w + (i * DMVS_BLOCK + wave * 64) * 4), 16, 0, 0);
-        }
+    Halo halo;
+    halo.init(tid, d.Hin, d.Win);
+    TileEpi<NT> epi;
+    epi.init(d, nbase, kq);
+    {
+        Slab slab;
+        slab.init(tid, nbase, d.cout_pad);
+        slab.stage(d.weight, 0, d.cin, d.cout_pad, s_w, wave);
     }
 
-    auto stage = [&](int tile, float* buf) {
-        int tq = tile;
-        const int tx = tq % tiles_x; tq /= tiles_x;
-        const int ty = tq % tiles_y; tq /= tiles_y;
-        const int td = tq % tiles_d;
-        const int b = tq / tiles_d;
+    auto stage = [&](int b, int td, int ty, int tx, float* buf) {
         const int gx0 = tx * TX - 1, gy0 = ty * TY - 1, gd0 = td * TD - 1;
-        const float* base = d.in + (size_t)b * d.cin * ivol + ((long)gd0 * d.Hin + gy0) * d.Win + gx0;
+        unsigned lo, him1;
+        Halo::bounds(gd0, gy0, gx0, d.Din, d.Hin, d.Win, lo, him1);
+        const float* origin = d.in + (size_t)b * d.cin * vol + ((long)gd0 * d.Hin + gy0) * d.Win + gx0;
 #pragma unroll
-        for (int i = 0; i < IN_IT; ++i) {
-            if (e_zyx[i] >= 0) {
-                const int gd = gd0 + (e_zyx[i] & 255), gy = gy0 + ((e_zyx[i] >> 8) & 255), gx = gx0 + (e_zyx[i] >> 16);
-                const bool in = gd >= 0 && gd < d.Din && gy >= 0 && gy < d.Hin && gx >= 0 && gx < d.Win;
-                const float* src = in ? base + e_off[i] : dmvs_zero16_3d;      // the border moves with the tile: zero source
-                __builtin_amdgcn_global_load_lds(src, DMVS_LDS(buf + i * DMVS_BLOCK + wave * 64), 4, 0, 0);
-            }
-        }
+        for (int ci = 0; ci < CK; ++ci) halo.stage(origin + (long)ci * vol, ci < d.cin, lo, him1, buf + ci * PLANE, wave);
+    };
+    auto decode = [&](int tile, int& b, int& td, int& ty, int& tx) {
+        tx = tile % tiles_x; tile /= tiles_x;
+        ty = tile % tiles_y; tile /= tiles_y;
+        td = tile % tiles_d;
+        b = tile / tiles_d;
     };
 
     int tile = blockIdx.x, cur = 0;
-    if (tile < ntiles) stage(tile, s_in2[0]);
+    int b = 0, td = 0, ty = 0, tx = 0;
+    if (tile < ntiles) {
+        decode(tile, b, td, ty, tx);
+        stage(b, td, ty, tx, lds);
+    }
     for (; tile < ntiles; tile += gridDim.x, cur ^= 1) {
         __syncthreads();            // this tile's halo (and, first time, the weights) landed; the other buffer is free
-        if (tile + (int)gridDim.x < ntiles) stage(tile + gridDim.x, s_in2[cur ^ 1]);
-        const float* s_in = s_in2[cur];
+        int nb = 0, ntd = 0, nty = 0, ntx = 0;
+        if (tile + (int)gridDim.x < ntiles) {
+            decode(tile + gridDim.x, nb, ntd, nty, ntx);
+            stage(nb, ntd, nty, ntx, lds + (cur ^ 1) * (CK * PLANE));
+        }
+        const float* s_in = lds + cur * (CK * PLANE);
         f32x4 acc[4][NT];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -132,35 +255,9 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_kernel(const dm
                 }
             }
         }
-        int tq = tile;
-        const int tx = tq % tiles_x; tq /= tiles_x;
-        const int ty = tq % tiles_y; tq /= tiles_y;
-        const int td = tq % tiles_d;
-        const int b = tq / tiles_d;
-        const int ox = tx * TX + m, od = td * TD + wave;
-        if (ox < d.Wout && od < d.Dout) {
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int oy = ty * TY + mt;
-                if (oy >= d.Hout) continue;
-                const size_t ovox = ((size_t)od * d.Hout + oy) * d.Wout + ox;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int cg = nbase + nt * 16 + kq * 4 + r;
-                        if (cg >= d.cout) continue;
-                        float y = acc[mt][nt][r];
-                        if (d.scale) y *= d.scale[cg];
-                        if (d.shift) y += d.shift[cg];
-                        y = dmvs_act(y, d.act);
-                        const size_t oi = ((size_t)b * d.cout + cg) * ovol + ovox;
-                        if (d.residual) y += d.residual[oi];
-                        d.out[oi] = y;
-                    }
-                }
-            }
-        }
+        const size_t ob = (size_t)b * d.cout * ovol;
+        epi.store(d, acc, d.out + ob, d.residual ? d.residual + ob : nullptr, tx * TX + m, td * TD + wave, ty * TY, ovol);
+        b = nb; td = ntd; ty = nty; tx = ntx;
     }
 }
 
@@ -174,10 +271,11 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_kernel(const dmvs_conv
     // input channels per LDS chunk (double buffered): 8 if that stays within 48 KB, else 4
     constexpr int kCK = (2 * 8 * (PLANE + WPAD) * 4 > 49152) ? 4 : 8;
     constexpr int BUF = kCK * (PLANE + WPAD);
-    constexpr int IN_IT = (kCK * PLANE + DMVS_BLOCK - 1) / DMVS_BLOCK, W_IT = (kCK * WPAD / 4 + DMVS_BLOCK - 1) / DMVS_BLOCK;
+    using Halo = HaloMap<ID, IH, IW, PLANE>;
+    using Slab = SlabMap<kCK, NW, WPAD>;
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, kq = lane >> 4;
     int tile = blockIdx.x;
     const int tx = tile % tiles_x; tile /= tiles_x;
@@ -186,38 +284,21 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_kernel(const dmvs_conv
     const int b = tile / tiles_d;
     const int x0 = tx * TX, y0 = ty * TY, d0 = td * TD;
     const int nbase = blockIdx.y * NW;
-    const size_t ivol = (size_t)d.Din * d.Hin * d.Win;
-    const float* inb = d.in + (size_t)b * d.cin * ivol;
-    const int vol = (int)ivol;
+    const int vol = d.Din * d.Hin * d.Win, ovol = d.Dout * d.Hout * d.Wout;
+
+    Halo halo;
+    halo.init(tid, d.Hin, d.Win);
+    Slab slab;
+    slab.init(tid, nbase, d.cout_pad);
+    unsigned lo, him1;
+    Halo::bounds(d0 - 1, y0 - 1, x0 - 1, d.Din, d.Hin, d.Win, lo, him1);
+    const float* origin = d.in + (size_t)b * d.cin * vol + ((long)(d0 - 1) * d.Hin + (y0 - 1)) * d.Win + (x0 - 1);
 
     // LDS-DMA staging (global_load_lds): halo tile 4 bytes per lane, weight slab 16 bytes per lane
     auto stage = [&](int c0, float* buf) {
-#pragma unroll 2
-        for (int i = 0; i < IN_IT; ++i) {
-            const int e = i * DMVS_BLOCK + tid;
-            if (e < kCK * PLANE) {
-                const int ci = e / PLANE, rem = e - ci * PLANE;
-                const int zz = rem / (IH * IW), rem2 = rem - zz * (IH * IW);
-                const int yy = rem2 / IW, xx = rem2 - yy * IW;
-                const int gd = d0 - 1 + zz, gy = y0 - 1 + yy, gx = x0 - 1 + xx;
-                const bool ok = rem < ID * IH * IW && c0 + ci < d.cin && gd >= 0 && gd < d.Din && gy >= 0 && gy < d.Hin &&
-                                gx >= 0 && gx < d.Win;
-                const float* src = ok ? inb + ((c0 + ci) * vol + (gd * d.Hin + gy) * d.Win + gx) : dmvs_zero16_3d;
-                __builtin_amdgcn_global_load_lds(src, DMVS_LDS(buf + i * DMVS_BLOCK + wave * 64), 4, 0, 0);
-            }
-        }
-        float* wbuf = buf + kCK * PLANE;
-#pragma unroll 2
-        for (int i = 0; i < W_IT; ++i) {
-            const int e4 = i * DMVS_BLOCK + tid;
-            if (e4 < kCK * WPAD / 4) {
-                const int ci = e4 / (WPAD / 4), rem4 = e4 - ci * (WPAD / 4);
-                const int t = rem4 / (NW / 4), n4 = rem4 - t * (NW / 4);
-                const bool ok = rem4 < 27 * NW / 4 && c0 + ci < d.cin && nbase + n4 * 4 < d.cout_pad;
-                const float* src = ok ? d.weight + (((c0 + ci) * 27 + t) * d.cout_pad + nbase + n4 * 4) : dmvs_zero16_3d;
-                __builtin_amdgcn_global_load_lds(src, DMVS_LDS(wbuf + (i * DMVS_BLOCK + wave * 64) * 4), 16, 0, 0);
-            }
-        }
+#pragma unroll
+        for (int ci = 0; ci < kCK; ++ci) halo.stage(origin + (long)(c0 + ci) * vol, c0 + ci < d.cin, lo, him1, buf + ci * PLANE, wave);
+        slab.stage(d.weight, c0, d.cin, d.cout_pad, buf + kCK * PLANE, wave);
     };
 
     f32x4 acc[4][NT];
@@ -262,30 +343,10 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_kernel(const dmvs_conv
         }
     }
 
-    const int ox = x0 + m, od = d0 + wave;
-    if (ox >= d.Wout || od >= d.Dout) return;
-    const size_t ovol = (size_t)d.Dout * d.Hout * d.Wout;
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int oy = y0 + mt;
-        if (oy >= d.Hout) continue;
-        const size_t ovox = ((size_t)od * d.Hout + oy) * d.Wout + ox;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int cg = nbase + nt * 16 + kq * 4 + r;
-                if (cg >= d.cout) continue;
-                float y = acc[mt][nt][r];
-                if (d.scale) y *= d.scale[cg];
-                if (d.shift) y += d.shift[cg];
-                y = dmvs_act(y, d.act);
-                const size_t oi = ((size_t)b * d.cout + cg) * ovol + ovox;
-                if (d.residual) y += d.residual[oi];
-                d.out[oi] = y;
-            }
-        }
-    }
+    TileEpi<NT> epi;
+    epi.init(d, nbase, kq);
+    const size_t ob = (size_t)b * d.cout * ovol;
+    epi.store(d, acc, d.out + ob, d.residual ? d.residual + ob : nullptr, x0 + m, d0 + wave, y0, ovol);
 }
 
 
@@ -294,47 +355,48 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_kernel(const dmvs_conv
 // 16-wide MFMA N-tile would be 94 % padding, so this is a direct form.  Workgroup = 32(x) x 8(y)
 // x 4(d) voxels, one lane = 4 consecutive x of one (y, d): per (ci, kd, ky) it reads a 6-float row
 // from the LDS halo tile (3 x ds_read_b64) and slides the 3 x-taps over it -- 12 FMAs per row.
-// The 27*cin weights sit in LDS and are read as wave-wide broadcasts.
+// The 27 weights of a channel sit in LDS and are read as wave-wide broadcasts.  Chunks of CK1 input channels are
+// double-buffered: chunk c+1 streams in by LDS-DMA while chunk c is being consumed.
 template <int CK1>
 __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_c1_kernel(const dmvs_conv3d_desc d, int tiles_x, int tiles_y, int tiles_d) {
     constexpr int TX = 32, TY = 8, TD = 4;
     constexpr int IW = TX + 4, IH = TY + 2, ID = TD + 2;      // row pitch 36: x halo 1 left, 3 right (8-byte aligned rows)
     constexpr int PLANE = ID * IH * IW;
-    __shared__ __attribute__((aligned(16))) float s_in[CK1 * PLANE];
-    __shared__ float s_w[CK1 * 27];
-    const int tid = threadIdx.x, wave = tid >> 6;
+    constexpr int BUF = CK1 * PLANE + 32 * CK1;               // halo planes + 27 weights per channel (padded to 32)
+    using Halo = HaloMap<ID, IH, IW, PLANE>;
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile = blockIdx.x;
     const int tx = tile % tiles_x; tile /= tiles_x;
     const int ty = tile % tiles_y; tile /= tiles_y;
     const int td = tile % tiles_d;
     const int b = tile / tiles_d;
     const int x0 = tx * TX, y0 = ty * TY, d0 = td * TD;
-    const size_t ivol = (size_t)d.Din * d.Hin * d.Win;
-    const float* inb = d.in + (size_t)b * d.cin * ivol;
-    const int vol = (int)ivol;
+    const int vol = d.Din * d.Hin * d.Win;
     const int lx = (tid & 7) * 4, ly = (tid >> 3) & 7, ld = tid >> 6;
+
+    Halo halo;
+    halo.init(tid, d.Hin, d.Win);
+    unsigned lo, him1;
+    Halo::bounds(d0 - 1, y0 - 1, x0 - 1, d.Din, d.Hin, d.Win, lo, him1);
+    const float* origin = d.in + (size_t)b * d.cin * vol + ((long)(d0 - 1) * d.Hin + (y0 - 1)) * d.Win + (x0 - 1);
+    auto stage = [&](int c0, float* buf) {
+#pragma unroll
+        for (int ci = 0; ci < CK1; ++ci) halo.stage(origin + (long)(c0 + ci) * vol, c0 + ci < d.cin, lo, him1, buf + ci * PLANE, wave);
+        if (tid < 32 * CK1) {
+            const int ci = tid >> 5, t = tid & 31;
+            buf[CK1 * PLANE + tid] = (t < 27 && c0 + ci < d.cin) ? d.weight[((c0 + ci) * 27 + t) * d.cout_pad] : 0.0f;
+        }
+    };
+
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    constexpr int IN_IT = (CK1 * PLANE + DMVS_BLOCK - 1) / DMVS_BLOCK;
-    for (int c0 = 0; c0 < d.cin; c0 += CK1) {
-        __syncthreads();
-#pragma unroll 2
-        for (int i = 0; i < IN_IT; ++i) {
-            const int e = i * DMVS_BLOCK + tid;
-            if (e < CK1 * PLANE) {
-                const int ci = e / PLANE, rem = e - ci * PLANE;
-                const int zz = rem / (IH * IW), rem2 = rem - zz * (IH * IW);
-                const int yy = rem2 / IW, xx = rem2 - yy * IW;
-                const int gd = d0 - 1 + zz, gy = y0 - 1 + yy, gx = x0 - 1 + xx;
-                const bool ok = c0 + ci < d.cin && gd >= 0 && gd < d.Din && gy >= 0 && gy < d.Hin && gx >= 0 && gx < d.Win;
-                const float* src = ok ? inb + ((c0 + ci) * vol + (gd * d.Hin + gy) * d.Win + gx) : dmvs_zero16_3d;
-                __builtin_amdgcn_global_load_lds(src, DMVS_LDS(s_in + i * DMVS_BLOCK + wave * 64), 4, 0, 0);
-            }
-        }
-        if (tid < CK1 * 27) {
-            const int ci = tid / 27, t = tid - ci * 27;
-            s_w[tid] = c0 + ci < d.cin ? d.weight[((c0 + ci) * 27 + t) * d.cout_pad] : 0.0f;
-        }
-        __syncthreads();
+    stage(0, lds);
+    int cur = 0;
+    for (int c0 = 0; c0 < d.cin; c0 += CK1, cur ^= 1) {
+        const float* s_in = lds + cur * BUF;
+        const float* s_w = s_in + CK1 * PLANE;
+        __syncthreads();     // chunk c0 landed (DMA drained, weights written); the other buffer is free
+        if (c0 + CK1 < d.cin) stage(c0 + CK1, lds + (cur ^ 1) * BUF);
         const int live_c = d.cin - c0 < CK1 ? d.cin - c0 : CK1;
         for (int ci = 0; ci < live_c; ++ci) {
 #pragma unroll
@@ -346,7 +408,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_c1_kernel(const dmvs_conv3d
                     const float2 r23 = *reinterpret_cast<const float2*>(row + 2);
                     const float2 r45 = *reinterpret_cast<const float2*>(row + 4);
                     const float in6[6] = {r01.x, r01.y, r23.x, r23.y, r45.x, r45.y};
-                    const float* wr = s_w + ci * 27 + (kd * 3 + ky) * 3;
+                    const float* wr = s_w + ci * 32 + (kd * 3 + ky) * 3;
                     const float w0 = wr[0], w1 = wr[1], w2 = wr[2];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[j] = fmaf(in6[j], w0, fmaf(in6[j + 1], w1, fmaf(in6[j + 2], w2, acc[j])));
@@ -356,16 +418,17 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_c1_kernel(const dmvs_conv3d
     }
     const int od = d0 + ld, oy = y0 + ly;
     if (od >= d.Dout || oy >= d.Hout) return;
-    const size_t ovol = (size_t)d.Dout * d.Hout * d.Wout;
+    const int ovol = d.Dout * d.Hout * d.Wout;
     const float sc = d.scale ? d.scale[0] : 1.0f, sh = d.shift ? d.shift[0] : 0.0f;
+    float* outb = d.out + (size_t)b * ovol;
+    const float* resb = d.residual ? d.residual + (size_t)b * ovol : nullptr;
+    const int o0 = (od * d.Hout + oy) * d.Wout + x0 + lx;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int ox = x0 + lx + j;
-        if (ox >= d.Wout) continue;
-        const size_t oi = (size_t)b * ovol + ((size_t)od * d.Hout + oy) * d.Wout + ox;
+        if (x0 + lx + j >= d.Wout) continue;
         float y = dmvs_act(acc[j] * sc + sh, d.act);
-        if (d.residual) y += d.residual[oi];
-        d.out[oi] = y;
+        if (resb) y += resb[o0 + j];
+        outb[o0 + j] = y;
     }
 }
 
@@ -498,10 +561,13 @@ extern "C" int dmvs_conv3d_f32(const dmvs_conv3d_desc* dp, void* stream) {
     if (ed != d.Dout || eh != d.Hout || ew != d.Wout) return DMVS_EINVAL;
     const long total = (long)d.B * d.Dout * d.Hout * d.Wout;
     dim3 grid(dmvs_ceil_div(total, DMVS_BLOCK), d.cout_pad / co);
+    // the stride-1 kernels address one batch item's input / output block with 32-bit element offsets
+    if (d.stride == 1 && ((long)d.cin * d.Din * d.Hin * d.Win >= (1L << 31) || (long)d.cout * d.Dout * d.Hout * d.Wout >= (1L << 31)))
+        return DMVS_EINVAL;
     if (d.stride == 1 && d.cout == 1) {
         const int tiles_x = (d.Wout + 31) / 32, tiles_y = (d.Hout + 7) / 8, tiles_d = (d.Dout + 3) / 4;
         dim3 g((unsigned)(tiles_x * tiles_y * tiles_d * d.B));
-        hipLaunchKernelGGL((conv3d_c1_kernel<4>), g, block, 0, st, d, tiles_x, tiles_y, tiles_d);
+        hipLaunchKernelGGL((conv3d_c1_kernel<2>), g, block, 0, st, d, tiles_x, tiles_y, tiles_d);
         return dmvs_launch_status();
     }
     if (d.stride == 1) {

@@ -306,4 +306,6 @@ static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline int __mul24(int a, int b) { return a * b; }
+// only ever applied to wave-uniform values (the wave index): identity under one-fiber-per-thread emulation
+static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }
 #define DMVS_ORDER_AFTER(var, dep) ((void)0)

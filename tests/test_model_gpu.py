@@ -122,6 +122,23 @@ def test_casdiffmvs_cfg3_size_properties():
     assert rel_l1(again["depth"][-1].cpu(), out["depth"][-1].cpu()) < 1e-6
 
 
+def test_casdiffmvs_cfg5_size_properties():
+    """BASELINE.json configs[4] geometry in fp32 (1920x1056, 11 src views = 12 images, numdepth_initial 96): the
+    largest case the reference names -- the most source views the kernels see, twice the plane-sweep depth, a
+    stage-1 grid (132x240) that is not a multiple of the 16-pixel tiles.  Size-independent properties only."""
+    model, _, _ = make_model("casdiffmvs", 96)
+    imgs, proj, dv = synth.synth_inputs(1056, 1920, 11, B=1, seed=17)
+    out = run(model, imgs, proj, dv, 5)
+    assert [tuple(d.shape) for d in out["depth"]] == [(1, 132, 240), (1, 264, 480), (1, 264, 480), (1, 528, 960),
+                                                      (1, 528, 960), (1, 1056, 1920)]
+    assert out["photometric_confidence"][-1].shape == (1, 1056, 1920)
+    for d in out["depth"]:
+        assert torch.isfinite(d).all() and float(d.min()) >= 424.9 and float(d.max()) <= 935.1
+    again = run(model, imgs, proj, dv, 5)
+    assert torch.equal(again["depth"][0], out["depth"][0])
+    assert rel_l1(again["depth"][-1].cpu(), out["depth"][-1].cpu()) < 1e-6
+
+
 @pytest.mark.parametrize("H,W", [(96, 160), (160, 224)])
 def test_sizes_not_multiple_of_tile(H, W):
     """H/8, W/8 not multiples of the 16-pixel conv tile or the 4-row wave tile; ragged workgroups everywhere"""
