@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     constexpr int CK = Cfg::CK, BUF = Cfg::BUF, IN_IT = Cfg::IN_IT, W_IT = Cfg::W_IT;
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA bases in SGPRs
     const int m = lane & 15, kq = lane >> 4;
     int tile = blockIdx.x;   // round-robin over XCDs: an XCD-contiguous remap measured 6-8 % SLOWER here (HBM channel spread)
     const int tx = tile % tiles_x; tile /= tiles_x;
@@ -104,23 +104,26 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
         return cig < d.c0 ? in0b + off : in1b + ((cig - d.c0) * plane1 + iy * d.Win + ix);
     };
 
-    // Everything about a staged element that does not depend on the chunk is decoded ONCE per tile: element i of this
-    // lane = (channel ci within the chunk, spatial offset or -1 for padding); per chunk only the channel term is added.
-    // (Decoding e -> (ci, row, col) with its integer divisions in every chunk was ~80 % of the non-MFMA instructions.)
-    int e_ci[IN_IT], e_sp[IN_IT];
+    // Staging map.  The LDS image of a chunk is [CK][PLANE]; a lane stages the SAME positions of every channel plane
+    // (plane iteration it -> position it*256 + tid), so the (row, column) decode, the image-border test and the spatial
+    // offset are computed ONCE per tile for P_IT positions -- not for every (channel, position) element of a chunk.
+    // (Decoding e -> (ci, row, col) with its integer divisions in every chunk was ~80 % of the non-MFMA instructions;
+    // decoding it once per tile for all CK*PLANE/256 elements was still ~600 VALU per workgroup: a third of the issue
+    // slots of the 16-channel layers.)  The channel is then a scalar loop variable: the DMA address is an SGPR base
+    // plus a 32-bit lane offset.
+    constexpr int P_IT = (PLANE + DMVS_BLOCK - 1) / DMVS_BLOCK;
+    int p_sp[P_IT];                        // spatial source offset of plane position it*256 + tid, -1: padding / not staged
 #pragma unroll
-    for (int i = 0; i < IN_IT; ++i) {
-        const int e = i * DMVS_BLOCK + tid;
-        const int ci = e / PLANE, rem = e - ci * PLANE;
+    for (int it = 0; it < P_IT; ++it) {
+        const int rem = it * DMVS_BLOCK + tid;
         const int r = rem / TW, c = rem - r * TW;
         const int iy = gy0 + r, ix = gx0 + c;
-        const bool ok = e < CK * PLANE && rem < TH * TW && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win && !(ZI && ((iy | ix) & 1));
+        const bool ok = rem < TH * TW && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win && !(ZI && ((iy | ix) & 1));
         int sp;
         if (mode == DMVS_IN_PLAIN) sp = iy * pW + ix;
         else if (mode == DMVS_IN_UPSAMPLE2) sp = (iy >> 1) * pW + (ix >> 1);
         else sp = iy * 2 * pW + ix * 2;
-        e_ci[i] = ci;
-        e_sp[i] = ok ? sp : -1;
+        p_sp[it] = ok ? sp : -1;
     }
     int w_ci[W_IT], w_off[W_IT];           // weight slab piece -> (channel within the chunk, offset inside its [T][cout_pad] block)
 #pragma unroll
@@ -140,33 +143,32 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     // beyond cin only ever meet zero weights, so they just must not hold non-finite LDS garbage on their first use.
     // The per-chunk DMA then touches valid elements only (exec-masked), with no zero-source pointer to select.
 #pragma unroll
-    for (int i = 0; i < IN_IT; ++i) {
-        const int e = i * DMVS_BLOCK + tid;
-        if (e < CK * PLANE) {
-            if (e_sp[i] < 0 || e_ci[i] >= cin) lds[e] = 0.0f;
-            if (e_sp[i] < 0 || CK + e_ci[i] >= cin) lds[BUF + e] = 0.0f;
+    for (int it = 0; it < P_IT; ++it) {
+        const int rem = it * DMVS_BLOCK + tid;
+        if (rem < PLANE) {
+#pragma unroll
+            for (int ci = 0; ci < CK; ++ci) {
+                if (p_sp[it] < 0 || ci >= cin) lds[ci * PLANE + rem] = 0.0f;
+                if (p_sp[it] < 0 || CK + ci >= cin) lds[BUF + ci * PLANE + rem] = 0.0f;
+            }
         }
     }
-    const bool simple = d.c1 == 0 && mode != DMVS_IN_UNSHUFFLE2;      // one input tensor, offset = channel plane + spatial
     auto stage = [&](int c0, float* buf) {
-        if (simple) {
 #pragma unroll
-            for (int i = 0; i < IN_IT; ++i) {
-                const int cig = c0 + e_ci[i];
-                if (e_sp[i] >= 0 && cig < cin)
-                    __builtin_amdgcn_global_load_lds(in0b + (unsigned)(cig * plane0 + e_sp[i]), DMVS_LDS(buf + i * DMVS_BLOCK + wave * 64),
-                                                     4, 0, 0);
-            }
-        } else {
+        for (int ci = 0; ci < CK; ++ci) {
+            const int cig = c0 + ci;
+            if (cig < cin) {
+                const float* cb;                                       // wave-uniform base of this channel
+                if (cig >= d.c0) cb = in1b + (size_t)(cig - d.c0) * plane1;        // second concat input: always PLAIN
+                else if (mode == DMVS_IN_UNSHUFFLE2) cb = in0b + ((size_t)(cig >> 2) * plane0 + ((cig >> 1) & 1) * pW + (cig & 1));
+                else cb = in0b + (size_t)cig * plane0;
 #pragma unroll
-            for (int i = 0; i < IN_IT; ++i) {
-                const int cig = c0 + e_ci[i];
-                if (e_sp[i] >= 0 && cig < cin) {
-                    const float* src;
-                    if (cig >= d.c0) src = in1b + (unsigned)((cig - d.c0) * plane1 + e_sp[i]);       // second concat input: always PLAIN
-                    else if (mode == DMVS_IN_UNSHUFFLE2) src = in0b + (unsigned)((cig >> 2) * plane0 + ((cig >> 1) & 1) * pW + (cig & 1) + e_sp[i]);
-                    else src = in0b + (unsigned)(cig * plane0 + e_sp[i]);
-                    __builtin_amdgcn_global_load_lds(src, DMVS_LDS(buf + i * DMVS_BLOCK + wave * 64), 4, 0, 0);
+                for (int it = 0; it < P_IT; ++it) {
+                    if (p_sp[it] >= 0) {
+                        const float* srcp = cb + (unsigned)p_sp[it];
+                        float* dstp = buf + ci * PLANE + it * DMVS_BLOCK + wave * 64;
+                        __builtin_amdgcn_global_load_lds(srcp, DMVS_LDS(dstp), 4, 0, 0);
+                    }
                 }
             }
         }
@@ -175,8 +177,9 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
         for (int i = 0; i < W_IT; ++i) {
             if (i * DMVS_BLOCK + tid < CK * WPAD / 4) {
                 const int cw = c0 + w_ci[i];
-                const float* src = (w_off[i] >= 0 && cw < cin) ? d.weight + (cw * T * d.cout_pad + w_off[i]) : dmvs_zero16;
-                __builtin_amdgcn_global_load_lds(src, DMVS_LDS(wbuf + (i * DMVS_BLOCK + wave * 64) * 4), 16, 0, 0);
+                const float* srcp = (w_off[i] >= 0 && cw < cin) ? d.weight + (cw * T * d.cout_pad + w_off[i]) : dmvs_zero16;
+                float* dstp = wbuf + (i * DMVS_BLOCK + wave * 64) * 4;
+                __builtin_amdgcn_global_load_lds(srcp, DMVS_LDS(dstp), 16, 0, 0);
             }
         }
     };
