@@ -117,7 +117,8 @@ def test_conv2d_fusions(ops):
 
 
 @pytest.mark.parametrize("cin,cout,stride,transposed", [(4, 8, 1, False), (8, 16, 2, False), (16, 12, 1, False),
-                                                         (16, 8, 2, True), (8, 1, 1, False), (12, 20, 2, True)])
+                                                         (16, 8, 2, True), (8, 1, 1, False), (12, 20, 2, True),
+                                                         (20, 8, 2, False), (24, 16, 2, True)])
 def test_conv3d(ops, cin, cout, stride, transposed):
     B, D, H, W = 2, 6, 7, 10
     if transposed:
@@ -659,6 +660,23 @@ def test_conv3d_streamed_tiles(ops, cin, cout, with_res):
         ref = ref + res
     pc = K.pack_conv3d(dev(ops, w), bn={k_: v.to(ops.device) for k_, v in bn.items()})
     out = ops.conv3d(pc, dev(ops, x), act=K.ACT_RELU, residual=dev(ops, res))
+    close(out, ref, 2e-5)
+
+
+@pytest.mark.parametrize("W,act", [(72, "sigmoid"), (36, "none"), (30, "none")])
+def test_conv3d_single_output_channel(ops, W, act):
+    """cout = 1 (PixelViewWeight conv1 with its sigmoid, CostRegNet's prob head): rows that are 16-byte multiples take the
+    16-byte LDS-DMA form with the halo starting 4 columns left of the tile, others the 4-byte form; several tiles per
+    axis with ragged last tiles, 8 input channels = 4 double-buffered chunks"""
+    B, cin, D, H = 2, 8, 6, 11
+    x = rnd(B, cin, D, H, W, seed=1)
+    w = rnd(1, cin, 3, 3, 3, seed=2) * 0.2
+    bias = rnd(1, seed=3)
+    ref = F.conv3d(x, w, bias, 1, 1)
+    if act == "sigmoid":
+        ref = torch.sigmoid(ref)
+    pc = K.pack_conv3d(dev(ops, w), dev(ops, bias))
+    out = ops.conv3d(pc, dev(ops, x), act=K.ACT_SIGMOID if act == "sigmoid" else K.ACT_NONE)
     close(out, ref, 2e-5)
 
 
