@@ -212,8 +212,15 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_kernel(const dm
         b = tile / tiles_d;
     };
 
+    auto store = [&](const f32x4 (&a)[4][NT], int sb, int std_, int sty, int stx) {
+        const size_t ob = (size_t)sb * d.cout * ovol;
+        epi.store(d, a, d.out + ob, d.residual ? d.residual + ob : nullptr, stx * TX + m, std_ * TD + wave, sty * TY, ovol);
+    };
+
     int tile = blockIdx.x, cur = 0;
     int b = 0, td = 0, ty = 0, tx = 0;
+    f32x4 pend[4][NT];                  // the previous tile's accumulators: stored one iteration late, after the barrier, so
+    int pb = -1, ptd = 0, pty = 0, ptx = 0;     // that the barrier's vmcnt(0) (needed for the LDS-DMA) does not wait out fresh stores
     if (tile < ntiles) {
         decode(tile, b, td, ty, tx);
         stage(b, td, ty, tx, lds);
@@ -225,6 +232,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_kernel(const dm
             decode(tile + gridDim.x, nb, ntd, nty, ntx);
             stage(nb, ntd, nty, ntx, lds + (cur ^ 1) * (CK * PLANE));
         }
+        if (pb >= 0) store(pend, pb, ptd, pty, ptx);
         const float* s_in = lds + cur * (CK * PLANE);
         f32x4 acc[4][NT];
 #pragma unroll
@@ -255,10 +263,14 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_kernel(const dm
                 }
             }
         }
-        const size_t ob = (size_t)b * d.cout * ovol;
-        epi.store(d, acc, d.out + ob, d.residual ? d.residual + ob : nullptr, tx * TX + m, td * TD + wave, ty * TY, ovol);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) pend[i][j] = acc[i][j];
+        pb = b; ptd = td; pty = ty; ptx = tx;
         b = nb; td = ntd; ty = nty; tx = ntx;
     }
+    if (pb >= 0) store(pend, pb, ptd, pty, ptx);
 }
 
 template <int NT>

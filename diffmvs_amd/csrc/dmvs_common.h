@@ -14,6 +14,13 @@
 #define DMVS_ORDER_AFTER(var, dep) asm volatile("" : "+v"(var) : "v"(dep))
 #endif
 
+// Workgroup barrier that publishes LDS writes (ds_write: lgkmcnt) but does NOT drain this wave's outstanding vector-memory
+// operations: __syncthreads() waits vmcnt(0), which would wait out an LDS-DMA prefetch that is meant to stay in flight
+// across the barrier.  Only for barriers whose producers are ds_writes.  (The host emulation predefines it as a plain barrier.)
+#ifndef DMVS_LDS_BARRIER
+#define DMVS_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
 static inline int dmvs_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

@@ -30,12 +30,16 @@ __global__ void __launch_bounds__(DMVS_BLOCK)
 featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0, const float* __restrict__ scale0,
                        const float* __restrict__ shift0, const float* __restrict__ w1, const float* __restrict__ scale1,
                        const float* __restrict__ shift1, float* __restrict__ y, int N, int H, int W, int tiles_x, int tiles_y) {
-    __shared__ __attribute__((aligned(16))) float s_in[2][IN_FLOATS];
-    __shared__ __attribute__((aligned(16))) float s_mid[8 * MPLANE];
-    __shared__ float s_w0[28 * 16];
-    __shared__ float s_w1[8 * W1S];
+    // ONE LDS object: with the input buffers, the intermediate and the weights as separate __shared__ arrays hipcc
+    // tags the accesses with alias scopes and then waits vmcnt(0) before the first ds_read of an input buffer while
+    // the LDS-DMA into the OTHER buffer (same object) is in flight -- the prefetch this kernel is built around would
+    // be waited out immediately.
+    __shared__ __attribute__((aligned(16))) float lds[2 * IN_FLOATS + 8 * MPLANE + 28 * 16 + 8 * W1S];
+    float* const s_mid = lds + 2 * IN_FLOATS;
+    float* const s_w0 = s_mid + 8 * MPLANE;
+    float* const s_w1 = s_w0 + 28 * 16;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, kq = lane >> 4;
     const long plane = (long)H * W;
     const int ntiles = tiles_x * tiles_y * N;
@@ -50,24 +54,37 @@ featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0
         s_w1[e] = co < 8 ? w1[(ci * 9 + t) * 8 + co] : 0.0f;
     }
 
-    // stage the 3 x 20 x 20 input halo of `tile` (zero padded) into buf: 4-byte LDS-DMA, 64 consecutive words per wave
+    // Input halo staging (3 x 20 x 20, zero padded): 4-byte LDS-DMA, 64 consecutive words per wave.  Which (channel,
+    // row, column) a lane's pieces are is tile-independent: decoded once; per tile the border test is one packed compare
+    // (guard bit above each 7-bit field: ((f | 128) - lo) keeps it iff f >= lo, ((hi-1 | 128) - f) iff f <= hi-1).
+    constexpr int S_IT = (IN_FLOATS + DMVS_BLOCK - 1) / DMVS_BLOCK;
+    constexpr unsigned kGuard = 0x8080u;
+    int e_off[S_IT], e_rc[S_IT];             // ci * plane + r * W + c from the halo origin; r | c << 8, or -1 beyond the tile
+#pragma unroll
+    for (int i = 0; i < S_IT; ++i) {
+        const int e = i * DMVS_BLOCK + tid;
+        const int ci = e / IP, rem = e - ci * IP;
+        const int r = rem / IW, c = rem - r * IW;
+        e_off[i] = ci * (int)plane + r * W + c;
+        e_rc[i] = e < IN_FLOATS ? (r | (c << 8)) : -1;
+    }
     auto stage = [&](int tile, float* buf) {
         int tq = tile;
         const int tx = tq % tiles_x; tq /= tiles_x;
         const int ty = tq % tiles_y;
         const int n = tq / tiles_y;
         const int gy0 = ty * TS - 2, gx0 = tx * TS - 2;
-        const float* xb = x + (long)n * 3 * plane;
+        const float* origin = x + (long)n * 3 * plane + (long)gy0 * W + gx0;       // may lie outside the tensor: only in-range pieces are read
+        const unsigned lo = (unsigned)(max(0, -gy0) | (max(0, -gx0) << 8));
+        const unsigned him1 = (unsigned)((min(IW, H - gy0) - 1) | ((min(IW, W - gx0) - 1) << 8)) | kGuard;
 #pragma unroll
-        for (int i = 0; i < (IN_FLOATS + DMVS_BLOCK - 1) / DMVS_BLOCK; ++i) {
-            const int e = i * DMVS_BLOCK + tid;
-            if (e < IN_FLOATS) {
-                const int ci = e / IP, rem = e - ci * IP;
-                const int r = rem / IW, c = rem - r * IW;
-                const int iy = gy0 + r, ix = gx0 + c;
-                const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-                const float* src = ok ? xb + ci * plane + (long)iy * W + ix : stem_zero16;
-                __builtin_amdgcn_global_load_lds(src, DMVS_LDS_S(buf + i * DMVS_BLOCK + wave * 64), 4, 0, 0);
+        for (int i = 0; i < S_IT; ++i) {
+            if (e_rc[i] >= 0) {
+                const unsigned rc = (unsigned)e_rc[i];
+                const bool ok = (((rc | kGuard) - lo) & (him1 - rc) & kGuard) == kGuard;
+                const float* srcp = ok ? origin + e_off[i] : stem_zero16;
+                float* dstp = buf + i * DMVS_BLOCK + wave * 64;
+                __builtin_amdgcn_global_load_lds(srcp, DMVS_LDS_S(dstp), 4, 0, 0);
             }
         }
     };
@@ -94,8 +111,27 @@ featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0
         sh1[r] = shift1 ? shift1[co] : 0.0f;
     }
 
+    // BN + ReLU + NCHW store of a finished tile.  Issued one iteration LATE (after the next tile's barrier): the
+    // barrier's vmcnt(0) -- needed for the LDS-DMA -- would otherwise also wait out stores issued just before it.
+    auto store_tile = [&](const f32x4 (&a)[4], int n, int ox0, int oy0) {
+        if (kq < 2) {
+            const int ox = ox0 + m;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int oy = oy0 + wave * 4 + mt;
+                if (ox < W && oy < H) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        y[((long)n * 8 + 4 * kq + r) * plane + (long)oy * W + ox] = fmaxf(fmaf(a[mt][r], sc1[r], sh1[r]), 0.0f);
+                }
+            }
+        }
+    };
+
     int tile = blockIdx.x, cur = 0;
-    if (tile < ntiles) stage(tile, s_in[0]);
+    f32x4 pend[4];                       // conv0.1 accumulators of the previous tile, not stored yet
+    int pn = -1, pox0 = 0, poy0 = 0;
+    if (tile < ntiles) stage(tile, lds);
     for (; tile < ntiles; tile += gridDim.x, cur ^= 1) {
         int tq = tile;
         const int tx = tq % tiles_x; tq /= tiles_x;
@@ -103,8 +139,9 @@ featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0
         const int n = tq / tiles_y;
         const int ox0 = tx * TS, oy0 = ty * TS;
         __syncthreads();        // this tile's halo has landed; everyone is done with s_mid and the other input buffer
-        if (tile + (int)gridDim.x < ntiles) stage(tile + gridDim.x, s_in[cur ^ 1]);
-        const float* in = s_in[cur];
+        if (tile + (int)gridDim.x < ntiles) stage(tile + gridDim.x, lds + (cur ^ 1) * IN_FLOATS);
+        if (pn >= 0) store_tile(pend, pn, pox0, poy0);
+        const float* in = lds + cur * IN_FLOATS;
 
         // ---- conv0.0 -> s_mid: 21 groups of 16 intermediate pixels (row-major over 18 x 18), waves take groups round-robin
         for (int gidx = wave; gidx < (MP + 15) / 16; gidx += DMVS_BLOCK / 64) {
@@ -123,7 +160,7 @@ featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0
                     s_mid[(4 * kq + r) * MPLANE + p] = inside ? fmaxf(fmaf(acc[r], sc0[r], sh0[r]), 0.0f) : 0.0f;
             }
         }
-        __syncthreads();
+        DMVS_LDS_BARRIER();     // s_mid complete (ds_writes only); the next tile's input DMA stays in flight
 
         // ---- conv0.1 from s_mid: wave = 4 output rows, 2 k-groups x 9 taps
         f32x4 acc[4];
@@ -144,19 +181,11 @@ featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0
                         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, mp[(mt + ky) * MW + kx], acc[mt], 0, 0, 0);
                 }
         }
-        if (kq < 2) {
-            const int ox = ox0 + m;
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int oy = oy0 + wave * 4 + mt;
-                if (ox < W && oy < H) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        y[((long)n * 8 + 4 * kq + r) * plane + (long)oy * W + ox] = fmaxf(fmaf(acc[mt][r], sc1[r], sh1[r]), 0.0f);
-                }
-            }
-        }
+        for (int mt = 0; mt < 4; ++mt) pend[mt] = acc[mt];
+        pn = n; pox0 = ox0; poy0 = oy0;
     }
+    if (pn >= 0) store_tile(pend, pn, pox0, poy0);
 }
 
 }  // namespace

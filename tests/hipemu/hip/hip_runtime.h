@@ -309,3 +309,4 @@ static inline int __mul24(int a, int b) { return a * b; }
 // only ever applied to wave-uniform values (the wave index): identity under one-fiber-per-thread emulation
 static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }
 #define DMVS_ORDER_AFTER(var, dep) ((void)0)
+#define DMVS_LDS_BARRIER() __syncthreads()
