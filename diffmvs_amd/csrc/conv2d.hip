@@ -238,9 +238,18 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
 
     // ---- epilogue: this lane holds couts nbase + nt*16 + 4*kq + r of pixels (oy0 + MT*wave + mt, ox0 + m)
     const int ox = ox0 + m;
-    const size_t oplane = (size_t)d.Hout * d.Wout;
+    const int oplane = d.Hout * d.Wout;
     const bool rup = d.res_mode == DMVS_IN_UPSAMPLE2;
     const int rW = rup ? (d.Wout >> 1) : d.Wout, rH = rup ? (d.Hout >> 1) : d.Hout;
+    // per-batch-item bases (wave-uniform, 64-bit) + 32-bit element offsets `channel * plane + pixel` (one full-rate
+    // v_mad_u32_u24 per value; the 64-bit multiply-adds this replaces are quarter rate and were ~30 % of the VALU time
+    // of the 16-channel layers).  The entry point rejects planes >= 2^24 pixels and tensors >= 2^31 elements per item.
+    const int rplane = rH * rW;
+    float* const outb = d.out_layout == DMVS_LAYOUT_NCHW ? d.out + ((size_t)b * d.out_cstride + d.out_coffset) * oplane
+                                                         : d.out + (size_t)b * oplane * d.out_cstride + d.out_coffset;
+    const float* const resb = d.residual ? d.residual + (size_t)b * d.cout * rplane : nullptr;
+    const float* const gzb = d.gru_z ? d.gru_z + (size_t)b * d.cout * oplane : nullptr;
+    const float* const ghb = d.gru_z ? d.gru_h + (size_t)b * d.cout * oplane : nullptr;
     float sc[NT][4], sh[NT][4];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -258,8 +267,8 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     for (int mt = 0; mt < MT; ++mt) {
         const int oy = oy0 + wave * MT + mt;
         const bool okp = ox < d.Wout && oy < d.Hout;
-        const size_t opix = (size_t)oy * d.Wout + ox;
-        const size_t rpix = rup ? (size_t)(oy >> 1) * rW + (ox >> 1) : opix;
+        const int opix = oy * d.Wout + ox;
+        const int rpix = rup ? (oy >> 1) * rW + (ox >> 1) : opix;
         float y[NT][4];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -288,7 +297,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
                 for (int r = 0; r < 4; ++r) {
                     const int cg = nbase + nt * 16 + kq * 4 + r;
                     const bool okr = okp && cg < d.cout;
-                    const float rv = d.residual[okr ? ((size_t)b * d.cout + cg) * ((size_t)rH * rW) + rpix : 0];
+                    const float rv = resb[okr ? (unsigned)(__mul24(cg, rplane) + rpix) : 0u];
                     res[nt][r] = okr ? rv : 0.0f;
                     if (!d.res_after_act) y[nt][r] += res[nt][r];
                 }
@@ -320,9 +329,9 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int cg = nbase + nt * 16 + kq * 4 + r;
-                    const size_t gi = (okp && cg < d.cout) ? ((size_t)b * d.cout + cg) * oplane + opix : 0;
-                    const float z = d.gru_z[gi];
-                    y[nt][r] = (1.0f - z) * d.gru_h[gi] + z * y[nt][r];
+                    const unsigned gi = (okp && cg < d.cout) ? (unsigned)(__mul24(cg, oplane) + opix) : 0u;
+                    const float z = gzb[gi];
+                    y[nt][r] = (1.0f - z) * ghb[gi] + z * y[nt][r];
                 }
         }
         if (d.out_layout == DMVS_LAYOUT_NCHW) {
@@ -331,7 +340,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int cg = nbase + nt * 16 + kq * 4 + r;
-                    if (okp && cg < d.cout) d.out[((size_t)b * d.out_cstride + d.out_coffset + cg) * oplane + opix] = y[nt][r];
+                    if (okp && cg < d.cout) outb[(unsigned)(__mul24(cg, oplane) + opix)] = y[nt][r];
                 }
         } else {
 #pragma unroll
@@ -339,7 +348,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int cg = nbase + nt * 16 + kq * 4 + r;
-                    if (okp && cg < d.cout) d.out[((size_t)b * oplane + opix) * d.out_cstride + d.out_coffset + cg] = y[nt][r];
+                    if (okp && cg < d.cout) outb[(unsigned)(__mul24(opix, d.out_cstride) + cg)] = y[nt][r];
                 }
         }
     }
@@ -643,6 +652,9 @@ extern "C" int dmvs_conv2d_f32(const dmvs_conv2d_desc* dp, void* stream) {
     if (eh != d.Hout || ew != d.Wout) return DMVS_EINVAL;
     // 32-bit element offsets inside one batch item
     if ((long)(d.c0 + d.c1) * d.Hin * d.Win * (d.in_mode == DMVS_IN_UNSHUFFLE2 ? 4 : 1) >= (1L << 31)) return DMVS_EINVAL;
+    // epilogue: channel * plane + pixel in 24-bit x 24-bit multiplies and 32-bit sums
+    const int ocs = d.out_cstride > d.cout ? d.out_cstride : d.cout;
+    if ((long)d.Hout * d.Wout >= (1L << 24) || ocs >= (1 << 24) || (long)ocs * d.Hout * d.Wout >= (1L << 31)) return DMVS_EINVAL;
     const int key = d.kh * 100 + d.kw * 10 + d.stride;
     switch (key) {
         case 111: return launch_conv2d<1, 1, 1>(d, st);
