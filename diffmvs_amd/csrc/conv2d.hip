@@ -22,6 +22,8 @@
 // upsampling, pixel-unshuffle, r*h gating, zero padding) or into the epilogue (folded BN /
 // bias, residual adds, activations, post-scale, GRU blend, NHWC / channel-offset output);
 // see include/dmvs.h for the contract.
+#include <type_traits>
+
 #include "dmvs_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -153,15 +155,19 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
             }
         }
     }
-    auto stage = [&](int c0, float* buf) {
+    const bool simple = d.c1 == 0 && mode != DMVS_IN_UNSHUFFLE2;      // one input tensor: the channel base just advances by a plane
+    auto stage_as = [&](auto simple_tag, int c0, float* buf) __attribute__((always_inline)) {
+        constexpr bool kSimple = decltype(simple_tag)::value;          // two instantiations: no mode decisions inside the simple one
+        const float* cb = in0b + (size_t)c0 * plane0;                  // wave-uniform base of the channel being staged
 #pragma unroll
         for (int ci = 0; ci < CK; ++ci) {
             const int cig = c0 + ci;
             if (cig < cin) {
-                const float* cb;                                       // wave-uniform base of this channel
-                if (cig >= d.c0) cb = in1b + (size_t)(cig - d.c0) * plane1;        // second concat input: always PLAIN
-                else if (mode == DMVS_IN_UNSHUFFLE2) cb = in0b + ((size_t)(cig >> 2) * plane0 + ((cig >> 1) & 1) * pW + (cig & 1));
-                else cb = in0b + (size_t)cig * plane0;
+                if constexpr (!kSimple) {
+                    if (cig >= d.c0) cb = in1b + (size_t)(cig - d.c0) * plane1;        // second concat input: always PLAIN
+                    else if (mode == DMVS_IN_UNSHUFFLE2) cb = in0b + ((size_t)(cig >> 2) * plane0 + ((cig >> 1) & 1) * pW + (cig & 1));
+                    else cb = in0b + (size_t)cig * plane0;
+                }
 #pragma unroll
                 for (int it = 0; it < P_IT; ++it) {
                     if (p_sp[it] >= 0) {
@@ -171,6 +177,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
                     }
                 }
             }
+            cb += plane0;
         }
         float* wbuf = buf + CK * PLANE;
 #pragma unroll
@@ -182,6 +189,10 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
                 __builtin_amdgcn_global_load_lds(srcp, DMVS_LDS(dstp), 16, 0, 0);
             }
         }
+    };
+    auto stage = [&](int c0, float* buf) __attribute__((always_inline)) {
+        if (simple) stage_as(std::true_type{}, c0, buf);
+        else stage_as(std::false_type{}, c0, buf);
     };
 
     f32x4 acc[MT][NT];
