@@ -85,6 +85,8 @@ typedef struct dmvs_conv2d_desc {
     float post_scale;
 } dmvs_conv2d_desc;
 
+/* Size limits (DMVS_EINVAL beyond them; the kernels address one batch item with 32-bit element offsets):
+ *   (c0 + c1) * Hin * Win < 2^31,  max(cout, out_cstride) * Hout * Wout < 2^31,  Hout * Wout < 2^24,  out_cstride < 2^24. */
 int dmvs_conv2d_f32(const dmvs_conv2d_desc* d, void* stream);
 
 /* FeatureNet stem in one kernel: relu(bn1(conv3x3(relu(bn0(conv3x3(x)))))) with 3 -> 8 -> 8 channels, padding 1, at full
@@ -131,6 +133,8 @@ typedef struct dmvs_conv3d_desc {
     int32_t act;
 } dmvs_conv3d_desc;
 
+/* Size limit of the stride-1 layers (DMVS_EINVAL beyond): cin * Din*Hin*Win < 2^31 and cout * Dout*Hout*Wout < 2^31
+ * (one batch item is addressed with 32-bit element offsets). */
 int dmvs_conv3d_f32(const dmvs_conv3d_desc* d, void* stream);
 
 /* Weight (and bias) gradient of the (non-transposed, stride 1|2) 3x3x3 convolution described by `d`:

@@ -52,3 +52,57 @@ def test_descriptor_structs_match_header_field_order():
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(_lib.DmvsError):
         _lib.Lib(str(tmp_path / "nope.so"))
+
+
+def test_invalid_descriptors_are_rejected_before_any_launch():
+    """Argument validation happens on the host before the first HIP call, so it can be exercised without a GPU: NULL
+    operands, unsupported shapes and sizes beyond the kernels' 32-bit addressing all return DMVS_EINVAL (-22).  The
+    pointers below are never dereferenced."""
+    from diffmvs_amd.build import build_hip
+    lib = _lib.Lib(build_hip())
+    p = ctypes.c_void_p(4096)
+
+    def conv2d(**kw):
+        d = _lib.Conv2dDesc(in0=p, weight=p, out=p, B=1, c0=16, c1=0, Hin=64, Win=64, Hout=64, Wout=64, cout=16, cout_pad=16,
+                            kh=3, kw=3, stride=1, pad_h=1, pad_w=1, in_mode=0, act=0, res_mode=0, res_after_act=0,
+                            out_layout=0, out_cstride=16, out_coffset=0, gn_groups=0, post_scale=1.0)
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return lib.dll.dmvs_conv2d_f32(ctypes.byref(d), None)
+
+    assert conv2d(in0=None) == -22
+    assert conv2d(out=None) == -22
+    assert conv2d(cout_pad=12) == -22                              # not a multiple of 8
+    assert conv2d(Hout=63) == -22                                  # inconsistent with Hin / pad / stride
+    assert conv2d(c1=8) == -22                                     # concat without a second tensor
+    assert conv2d(kh=4, kw=4, pad_h=1, pad_w=1, Hout=63, Wout=63) == -22      # no 4x4 instantiation
+    assert conv2d(Hin=8192, Win=8192, Hout=8192, Wout=8192) == -22            # plane >= 2^24 pixels
+    assert conv2d(c0=4096, Hin=1024, Win=1024, Hout=1024, Wout=1024) == -22   # item >= 2^31 elements
+
+    def conv3d(**kw):
+        d = _lib.Conv3dDesc(in_=p, weight=p, out=p, B=1, cin=8, cout=8, cout_pad=8, Din=8, Hin=8, Win=8, Dout=8, Hout=8, Wout=8,
+                            stride=1, transposed=0, act=0)
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return lib.dll.dmvs_conv3d_f32(ctypes.byref(d), None)
+
+    assert conv3d(weight=None) == -22
+    assert conv3d(stride=3) == -22
+    assert conv3d(Dout=7) == -22
+    assert conv3d(transposed=1, stride=1) == -22
+    assert conv3d(cin=64, Din=512, Hin=512, Win=512, Dout=512, Hout=512, Wout=512) == -22     # item >= 2^31 elements
+
+    def getcost(**kw):
+        d = _lib.GetCostDesc(ref=p, src=p, rt=p, inv_depth=p, view_w=p, disp_min=p, disp_max=p, out_cost=p, out_samples=p,
+                             worklist=p, B=1, S=2, C=32, G=4, n=6, H=32, W=32, vw_shift=1, cost_cstride=24, cost_coffset=0,
+                             samp_cstride=6, samp_coffset=0, interval=0.04, min_radius=0.125, max_radius=8.0)
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return lib.dll.dmvs_getcost_f32(ctypes.byref(d), None)
+
+    assert getcost(n=5) == -22                                     # the reference uses 4 or 6 hypotheses
+    assert getcost(C=24) == -22
+    assert getcost(G=3) == -22
+    assert getcost(ref=None) == -22
+    assert getcost(B=64, S=16, H=1024, W=1024) == -22              # source stack >= 4 GiB: 32-bit byte offsets
+    assert lib.dll.dmvs_conv2d_f32(None, None) == -22 and lib.dll.dmvs_conv3d_f32(None, None) == -22
