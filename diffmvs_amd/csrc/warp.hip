@@ -409,7 +409,7 @@ extern "C" int dmvs_getcost_f32(const dmvs_getcost_desc* dp, void* stream) {
     if (!dp) return DMVS_EINVAL;
     const dmvs_getcost_desc& d = *dp;
     if (int rc = getcost_check(d)) return rc;
-    if ((d.C != 32 && d.C != 16) || !d.worklist) return dmvs_getcost_gather_f32(dp, stream);
+    if ((d.C != 32 && d.C != 16) || !d.worklist || d.S > DMVS_GETCOST_MAX_WINDOW_VIEWS) return dmvs_getcost_gather_f32(dp, stream);
     hipStream_t st = (hipStream_t)stream;
     if (int rc = dmvs_getcost_win_dispatch(d, st)) return rc;          // pre-pass + tiles whose source windows fit LDS
     // the rest, one launch: the listed tiles, or (pre-pass: most tiles do not fit) every pixel in plain order

@@ -296,7 +296,7 @@ extern "C" int dmvs_getcost_bwd_f32(const dmvs_getcost_desc* dp, const float* gc
     dmvs_getcost_desc d = *dp;
     if (d.G != 4 || !d.ref || !d.src || !d.rt || !d.inv_depth || !d.view_w || (d.n != 4 && d.n != 6)) return DMVS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (d.worklist && (d.C == 32 || d.C == 16)) {
+    if (d.worklist && (d.C == 32 || d.C == 16) && d.S <= DMVS_GETCOST_MAX_WINDOW_VIEWS) {
         // LDS-window tiles first, then one launch for the rest: the listed tiles, or (pre-pass: mostly misfits) every pixel
         if (int rc = dmvs_getcost_bwd_win_dispatch(d, gcost, gref, gsrc, st)) return rc;
         return d.C == 32 ? launch_getcost_bwd_tiles<32, 4>(d, gcost, gref, gsrc, st)

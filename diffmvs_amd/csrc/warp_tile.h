@@ -146,7 +146,7 @@ __device__ __forceinline__ float hyp_depth(int k, float lo, float step, float dm
 // kernel takes every tile), [2..3] unused, flags[n] (1 = some view's footprint exceeds the window), list[n] (the
 // flagged tiles, ascending), boxes[n][MAXS][4] (x0, y0, ncols, nrows per view).  No atomics anywhere: same-address
 // device atomics from ~10^3 workgroups serialise at ~0.1 us each, more than the whole pre-pass costs.
-constexpr int MAXS = 16;
+constexpr int MAXS = DMVS_GETCOST_MAX_WINDOW_VIEWS;       // per-view footprint boxes kept per tile (entry points fall back to the gather kernels beyond)
 __device__ __forceinline__ int* ws_flags(int* ws) { return ws + 4; }
 __device__ __forceinline__ int* ws_list(int* ws, int ntiles) { return ws + 4 + ntiles; }
 __device__ __forceinline__ int* ws_boxes(int* ws, int ntiles) { return ws + 4 + 2 * ntiles; }

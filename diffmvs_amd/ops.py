@@ -106,6 +106,9 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+MAX_WINDOW_VIEWS = 16      # include/dmvs.h: DMVS_GETCOST_MAX_WINDOW_VIEWS
+
+
 class Ops:
     def __init__(self, lib: _lib.Lib, device):
         self.lib = lib
@@ -327,7 +330,7 @@ class Ops:
             st["last"] = (ntiles if bool(host[1]) else int(host[0]), ntiles)
             st["pending"] = None
         st["calls"] += 1
-        plain = gather or Cc == 48 or (st["gather"] and st["calls"] % 64 != 0)
+        plain = gather or Cc == 48 or S > MAX_WINDOW_VIEWS or (st["gather"] and st["calls"] % 64 != 0)
         wl = None if plain else torch.empty(4 + 66 * ntiles, dtype=torch.int32, device=self.device)
         d = _lib.GetCostDesc(ref=_ptr(ref), src=_ptr(src), rt=_ptr(rt), inv_depth=_ptr(inv_depth),
                              confidence=_ptr(confidence), view_w=_ptr(view_w), disp_min=_ptr(disp_min),
@@ -372,7 +375,7 @@ class Ops:
         if gsrc is None:
             gsrc = torch.zeros_like(src)
         ntiles = B * ((H + 15) // 16) * ((W + 15) // 16)
-        wl = None if (gather or Cc == 48) else torch.empty(4 + 66 * ntiles, dtype=torch.int32, device=self.device)
+        wl = None if (gather or Cc == 48 or S > MAX_WINDOW_VIEWS) else torch.empty(4 + 66 * ntiles, dtype=torch.int32, device=self.device)
         d = _lib.GetCostDesc(ref=_ptr(ref), src=_ptr(src), rt=_ptr(rt), inv_depth=_ptr(inv_depth),
                              confidence=_ptr(confidence), view_w=_ptr(view_w), disp_min=_ptr(disp_min),
                              disp_max=_ptr(disp_max), out_cost=None, out_samples=None, worklist=_ptr(wl), B=B, S=S, C=Cc, G=G, n=n,

@@ -200,6 +200,7 @@ int dmvs_warp_corr_init_gather_f32(const float* ref, const float* src, const flo
  * takes everything.  worklist == NULL, or C == 48: path (2) for everything.
  */
 #define DMVS_GETCOST_TILE 16
+#define DMVS_GETCOST_MAX_WINDOW_VIEWS 16      /* more source views than this: dmvs_getcost_f32 / _bwd_f32 take the per-pixel path */
 #define DMVS_GETCOST_WORKLIST_INTS(B, H, W) \
     (4 + 66 * (B) * (((H) + DMVS_GETCOST_TILE - 1) / DMVS_GETCOST_TILE) * (((W) + DMVS_GETCOST_TILE - 1) / DMVS_GETCOST_TILE))
 typedef struct dmvs_getcost_desc {

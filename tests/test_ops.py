@@ -293,6 +293,33 @@ def test_getcost_window_tiles(ops, C, n, interval, H, W):
     close(cost, cost_g.cpu(), 1e-5)
 
 
+@pytest.mark.parametrize("S", [16, 17])
+def test_getcost_many_source_views(ops, S):
+    """16 source views = the most the window kernels keep footprint boxes for; 17 must take the per-pixel kernels
+    (forward and backward) instead of overrunning them -- results identical either way."""
+    B, C, n, H, W = 1, 32, 6, 24, 40
+    pm = _cams(B, S + 1, H, W, 5)
+    feats = [rnd(B, C, H, W, seed=60 + v) for v in range(S + 1)]
+    inv = rnd(B, 1, H, W, seed=70, lo=0.3, hi=0.7)
+    vw = rnd(B, S, H // 2, W // 2, seed=72, lo=0.0, hi=1.0)
+    dv0, dv1 = torch.tensor([1 / 935.0]), torch.tensor([1 / 425.0])
+    dmax, dmin = (1 / dv0).view(-1, 1, 1, 1), (1 / dv1).view(-1, 1, 1, 1)
+    want_cost, want_s = O.get_cost(feats, pm, inv, 0.004, dmax, dmin, n, F.interpolate(vw, scale_factor=2, mode="nearest"),
+                                   None, 4, 0.25, 4.0)
+    rt = ops.compose_proj(dev(ops, pm))
+    args = (dev(ops, feats[0].permute(0, 2, 3, 1)), dev(ops, torch.stack([f.permute(0, 2, 3, 1) for f in feats[1:]])), rt,
+            dev(ops, inv), None, dev(ops, vw), dev(ops, 1 / (1 / dv0)), dev(ops, 1 / (1 / dv1)), n, 0.004, 0.25, 4.0)
+    cost, samp = ops.getcost(*args, vw_shift=1)
+    assert (ops.last_getcost_worklist is None) == (S > 16)
+    close(samp, want_s, 1e-6)
+    close(cost, want_cost, 1e-4)
+    gcost = dev(ops, rnd(B, 4 * n, H, W, seed=75))
+    gref, gsrc = ops.getcost_bwd(*args, vw_shift=1, gcost=gcost)
+    gref_g, gsrc_g = ops.getcost_bwd(*args, vw_shift=1, gcost=gcost, gather=True)
+    close(gref, gref_g.cpu(), 1e-5)
+    close(gsrc, gsrc_g.cpu(), 1e-5)
+
+
 def test_getcost_extreme_geometry(ops, golden):
     """per-pixel depth maps + the reference's own warping edge cases (OOB, negative z)."""
     g = golden("warp_edge.npz")
