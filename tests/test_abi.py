@@ -106,3 +106,13 @@ def test_invalid_descriptors_are_rejected_before_any_launch():
     assert getcost(ref=None) == -22
     assert getcost(B=64, S=16, H=1024, W=1024) == -22              # source stack >= 4 GiB: 32-bit byte offsets
     assert lib.dll.dmvs_conv2d_f32(None, None) == -22 and lib.dll.dmvs_conv3d_f32(None, None) == -22
+
+
+def test_integration_md_stub_matches_the_binding():
+    """the ctypes stub INTEGRATION.md shows a maintainer must describe the same struct as diffmvs_amd/_lib.py"""
+    src = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"class GetCostDesc\(C.Structure\):.*?\n\n", src, flags=re.S).group(0)
+    ns = {"C": ctypes}
+    exec(code, ns)
+    assert [n for n, _ in ns["GetCostDesc"]._fields_] == [n for n, _ in _lib.GetCostDesc._fields_]
+    assert ctypes.sizeof(ns["GetCostDesc"]) == ctypes.sizeof(_lib.GetCostDesc)
