@@ -416,10 +416,14 @@ int launch_conv2d(const dmvs_conv2d_desc& d, hipStream_t st) {
     // pixel tile = 16 x (4*MT).  Tall tiles amortise the halo and the weight slab; small images take
     // 16x4 tiles so that the 256 CUs still see a few workgroups each; stride-2 / many-tap / wide-N
     // shapes stop at MT=2 to keep the staging registers + accumulators inside the VGPR file.
+    // Thresholds from tools/conv_bench.py with the tile height forced (B = 16, us for MT = 1 / 2 / 4):
+    //   64->32 at 64x80 (320 16x16 tiles) 44.8 / 47.4 / 54.3;  32->32 at 64x80 28.1 / 28.6 / 32.0;
+    //   32->32 at 128x160 (1280 tiles: 1.25 rounds of the ~1024 resident 16x16 workgroups) 86.9 / 80.5 / 85.3;
+    //   24->32 at 128x160 70.1 / 65.0 / 67.7;  16->16 at 128x160 (one n-tile) 38.0 / 30.7 / 29.3.
     constexpr bool heavy = (S == 2) || (KH * KW >= 25);
     const long wg16 = (long)((d.Wout + 15) / 16) * ((d.Hout + 15) / 16) * d.B * ngroups;
-    if (wg16 * 4 < 1024) return launch_conv2d_mt<KH, KW, S, 1, false>(d, st, nt, ngroups);
-    if (heavy || nt == 4 || wg16 * 2 < 1024) return launch_conv2d_mt<KH, KW, S, 2, false>(d, st, nt, ngroups);
+    if (wg16 * 2 < 1024) return launch_conv2d_mt<KH, KW, S, 1, false>(d, st, nt, ngroups);
+    if (heavy || nt == 4 || (nt >= 2 && wg16 < 2048)) return launch_conv2d_mt<KH, KW, S, 2, false>(d, st, nt, ngroups);
     if constexpr (!heavy) return launch_conv2d_mt<KH, KW, S, 4, false>(d, st, nt, ngroups);
     return DMVS_EINVAL;
 }

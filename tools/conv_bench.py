@@ -15,6 +15,8 @@ SHAPES = [  # name, N, cin, cout, k, stride, H, W
     ("feat conv2.0 16->32 5x5s2", 96, 16, 32, 5, 2, 256, 320), ("feat conv3.0 32->64 5x5s2", 96, 32, 64, 5, 2, 128, 160),
     ("unet init 64->16 7x7 1/4", 16, 64, 16, 7, 1, 128, 160), ("enc 24->32 3x3 1/4", 16, 24, 32, 3, 1, 128, 160),
     ("unet 32->32 3x3 1/8", 16, 32, 32, 3, 1, 64, 80), ("ctx 16->16 1/2", 16, 16, 16, 3, 1, 256, 320),
+    ("cond 32->32 3x3 1/4 B16", 16, 32, 32, 3, 1, 128, 160), ("unet 16->16 3x3 1/4 B16", 16, 16, 16, 3, 1, 128, 160),
+    ("unet 64->32 3x3 1/8 B16", 16, 64, 32, 3, 1, 64, 80),
 ]
 
 
