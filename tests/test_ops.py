@@ -690,6 +690,18 @@ def test_conv3d_streamed_tiles(ops, cin, cout, with_res):
     close(out, ref, 2e-5)
 
 
+@pytest.mark.parametrize("cin,cout,D,H,W", [(4, 8, 1, 1, 1), (8, 8, 2, 3, 17), (8, 1, 1, 2, 33), (16, 16, 5, 4, 16), (3, 1, 4, 8, 32)])
+def test_conv3d_volumes_smaller_than_a_tile(ops, cin, cout, D, H, W):
+    """degenerate volumes: every staged halo element is border or padding in at least one axis (packed border test),
+    tiles exactly one voxel / exactly one tile wide"""
+    x = rnd(2, cin, D, H, W, seed=1)
+    w = rnd(cout, cin, 3, 3, 3, seed=2) * 0.3
+    bias = rnd(cout, seed=3)
+    ref = F.relu(F.conv3d(x, w, bias, 1, 1))
+    out = ops.conv3d(K.pack_conv3d(dev(ops, w), dev(ops, bias)), dev(ops, x), act=K.ACT_RELU)
+    close(out, ref, 2e-5)
+
+
 @pytest.mark.parametrize("W,act", [(72, "sigmoid"), (36, "none"), (30, "none")])
 def test_conv3d_single_output_channel(ops, W, act):
     """cout = 1 (PixelViewWeight conv1 with its sigmoid, CostRegNet's prob head): rows that are 16-byte multiples take the
