@@ -162,6 +162,10 @@ struct TileEpi {
     }
 };
 
+// resident workgroups per CU of the streamed kernel (28 KB LDS, 80 VGPRs each).  3 / 4 / 5 / 6 measured 898 / 881 / 880 / 891 us
+// on the 80-volume 4->8 layer: the kernel is not occupancy-limited.
+constexpr int kStreamWgsPerCu = 5;
+
 // cin <= 4 (PixelViewWeight conv0 and CostReg conv0: 4 -> 8 on the full S-view / aggregated cost volumes): the whole
 // K dimension is one LDS chunk, so a workgroup of the generic kernel is load -> wait -> 108 MFMAs -> store with nothing
 // to overlap.  This variant keeps workgroups resident and walks 16x4x4 voxel tiles: the next tile's halo streams into
@@ -587,8 +591,8 @@ extern "C" int dmvs_conv3d_f32(const dmvs_conv3d_desc* dp, void* stream) {
         const int ntiles = (d.cout_pad + 15) / 16;
         dim3 g((unsigned)(tiles_x * tiles_y * tiles_d * d.B), (unsigned)((ntiles + 1) / 2));
         const long vtiles = (long)tiles_x * tiles_y * tiles_d * d.B;
-        if (d.cin <= 4 && ntiles == 1 && vtiles >= 256 * 5) {      // one K chunk, many tiles: resident workgroups, pipelined tiles
-            dim3 gs((unsigned)(256 * 5), 1);
+        if (d.cin <= 4 && ntiles == 1 && vtiles >= 256 * kStreamWgsPerCu) {      // one K chunk, many tiles: resident workgroups, pipelined tiles
+            dim3 gs((unsigned)(256 * kStreamWgsPerCu), 1);
             hipLaunchKernelGGL((conv3d_mfma_stream_kernel<1>), gs, block, 0, st, d, tiles_x, tiles_y, tiles_d);
             return dmvs_launch_status();
         }
