@@ -1,9 +1,10 @@
 """Training-step plumbing: torch.autograd Functions whose forward AND backward are libdmvs_hip.so kernels.
 
-Status (round 1): convolution (forward, input gradient = the forward kernel on flipped weights, weight
-gradient = MFMA reduction over pixels) and the fused warp / correlation / aggregation kernels.  The
-normalisation layers and element-wise glue of the training graph still go through ATen; the train branch of
-the update block and the DDP harness are the next round's work."""
+Nodes: convolution (forward, input gradient = the forward kernel on flipped weights, weight gradient = MFMA
+reduction over pixels), the fused warp / correlation / aggregation kernels, training-mode BatchNorm(+ReLU) and
+GroupNorm + scale/shift + SiLU (norm.hip).  The remaining element-wise glue of the training graph (head
+activations, softmax regression, convex upsampling, concatenations, weight standardisation) is ATen device ops.
+The train branch of the update block is diffmvs_amd/train.py, the data-parallel step diffmvs_amd/trainer.py."""
 from __future__ import annotations
 
 import torch
@@ -100,30 +101,30 @@ def conv3d(ops: Ops, x, weight, bias=None, stride=1, transposed=False):
 
 class _WarpCorrInitFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ref, src, rt, disp_min, disp_max, ops: Ops, D):
+    def forward(ctx, ref, src, rt, disp_min, disp_max, ops: Ops, D, G):
         ctx.save_for_backward(ref, src, rt, disp_min, disp_max)
         ctx.ops = ops
-        return ops.warp_corr_init(ref, src, rt, disp_min, disp_max, D)
+        return ops.warp_corr_init(ref, src, rt, disp_min, disp_max, D, G)
 
     @staticmethod
     def backward(ctx, g):
         ref, src, rt, disp_min, disp_max = ctx.saved_tensors
         gref, gsrc = ctx.ops.warp_corr_init_bwd(ref, src, rt, disp_min, disp_max, g.contiguous())
-        return gref, gsrc, None, None, None, None, None
+        return gref, gsrc, None, None, None, None, None, None
 
 
-def warp_corr_init(ops: Ops, ref, src, rt, disp_min, disp_max, D):
+def warp_corr_init(ops: Ops, ref, src, rt, disp_min, disp_max, D, G=4):
     """ref [B,H,W,C], src [S,B,Hs,Ws,C] (NHWC, both may require grad) -> cor [B,S,G,D,H,W]"""
-    return _WarpCorrInitFn.apply(ref.contiguous(), src.contiguous(), rt, disp_min, disp_max, ops, D)
+    return _WarpCorrInitFn.apply(ref.contiguous(), src.contiguous(), rt, disp_min, disp_max, ops, D, G)
 
 
 class _GetCostFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, ops: Ops, n, interval, rmin, rmax, shift, key):
+    def forward(ctx, ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, ops: Ops, n, interval, rmin, rmax, shift, key, G):
         cost, samples = ops.getcost(ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, rmin, rmax, shift,
-                                    policy_key=key)
+                                    G=G, policy_key=key)
         ctx.save_for_backward(ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max)
-        ctx.ops, ctx.meta = ops, (n, interval, rmin, rmax, shift)
+        ctx.ops, ctx.meta = ops, (n, interval, rmin, rmax, shift, G)
         ctx.plain = ops.last_getcost_plain      # same geometry in the backward: same device path
         ctx.mark_non_differentiable(samples)
         return cost, samples
@@ -131,17 +132,17 @@ class _GetCostFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _gs):
         ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max = ctx.saved_tensors
-        n, interval, rmin, rmax, shift = ctx.meta
+        n, interval, rmin, rmax, shift, G = ctx.meta
         gref, gsrc = ctx.ops.getcost_bwd(ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, rmin,
-                                         rmax, shift, g.contiguous(), gather=ctx.plain)
-        return (gref, gsrc) + (None,) * 13
+                                         rmax, shift, g.contiguous(), G=G, gather=ctx.plain)
+        return (gref, gsrc) + (None,) * 14
 
 
 def getcost(ops: Ops, ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, rmin, rmax, vw_shift,
-            policy_key=None):
+            policy_key=None, G=4):
     """GetCost with gradients to the image features only (hypotheses / view weights are detached in the reference)."""
     return _GetCostFn.apply(ref.contiguous(), src.contiguous(), rt, inv_depth, confidence, view_w, disp_min, disp_max, ops, n,
-                            interval, rmin, rmax, vw_shift, policy_key)
+                            interval, rmin, rmax, vw_shift, policy_key, G)
 
 
 class _ViewAggregateFn(torch.autograd.Function):

@@ -429,8 +429,10 @@ class Engine:
 
     # ------------------------------------------------------------------ whole forward
     @torch.no_grad()
-    def forward(self, imgs, proj_matrices, depth_values, noise_fn: Optional[Callable] = None):
-        """CasDiffMVS.forward with test=True in eval mode (models/diffusion.py:139-295)."""
+    def forward(self, imgs, proj_matrices, depth_values, noise_fn: Optional[Callable] = None, test: bool = True):
+        """CasDiffMVS.forward in eval mode (models/diffusion.py:139-295).  test=True: the final iterate of each
+        refinement stage and its confidence at full resolution (test.py); test=False: every iterate in "depth" and
+        the Unet confidences in "conf" (diffusion.py:264-270, what train.py's validation loop feeds the loss)."""
         o, a = self.ops, self.args
         if noise_fn is None:
             noise_fn = lambda shape, device: torch.randn(shape, device=device)  # noqa: E731
@@ -445,7 +447,7 @@ class Engine:
         x = torch.cat([im.to(o.device).float() for im in imgs], 0).contiguous()                  # [V*B,3,H,W], view-major
         feats = run_feature(o, self.feat, x)
         trunk = run_context_trunk(o, self.ctx, x[:B])
-        depths, confs_full = [], []
+        depths, confs_full, confs_seq = [], [], []
         view_w = None
         for s in range(3):
             if a.stage_iters[s] == 0:
@@ -478,8 +480,13 @@ class Engine:
                 mask, hidden, inv_seq, conf_seq = self.update_block(
                     ub, ref, src, rt, inv_cur, hidden, X, view_w, s, disp_min, disp_max,
                     interval * _RATIOS[s], noise_fn)
-                depths.append(o.depth_convert(inv_seq[-1], disp_min, disp_max, K._lib.EW_DISP_TO_DEPTH).view(B, h, w))
-                confs_full.append(o.upsample_nearest(conf_seq[-1], 2 ** (3 - s)))
+                if test:
+                    depths.append(o.depth_convert(inv_seq[-1], disp_min, disp_max, K._lib.EW_DISP_TO_DEPTH).view(B, h, w))
+                    confs_full.append(o.upsample_nearest(conf_seq[-1], 2 ** (3 - s)))
+                else:
+                    for inv_i in inv_seq:
+                        depths.append(o.depth_convert(inv_i, disp_min, disp_max, K._lib.EW_DISP_TO_DEPTH).view(B, h, w))
+                    confs_seq.extend(conf_seq)
                 _, depth_up = o.convex_upsample(inv_seq[-1], mask, disp_min, disp_max, self.up_ratio, want_inv=False)
                 depths.append(depth_up)
-        return {"depth": depths, "conf": [], "photometric_confidence": confs_full}
+        return {"depth": depths, "conf": confs_seq, "photometric_confidence": confs_full}

@@ -108,6 +108,19 @@ def _ptr(t: Optional[torch.Tensor]):
 
 MAX_WINDOW_VIEWS = 16      # include/dmvs.h: DMVS_GETCOST_MAX_WINDOW_VIEWS
 
+# Kernels that write parameters / buffers through raw pointers (dmvs_adamw_step_f32, the running statistics of
+# dmvs_batchnorm_train_fwd_f32) do not bump torch's per-tensor version counters, so every cache of packed weights
+# (models.module.HipModule.packed, CasDiffMVS.engine) also keys on this process-wide generation.
+_weights_generation = [0]
+
+
+def weights_generation() -> int:
+    return _weights_generation[0]
+
+
+def bump_weights_generation() -> None:
+    _weights_generation[0] += 1
+
 
 class Ops:
     def __init__(self, lib: _lib.Lib, device):
@@ -531,6 +544,7 @@ class Ops:
         y = torch.empty_like(x)
         mean, rstd = self.empty(views, Cc), self.empty(views, Cc)
         ws, nb = self._bn_ws(B, Cc, S, views)
+        bump_weights_generation()         # running_mean / running_var are rewritten in place
         self._call("dmvs_batchnorm_train_fwd_f32", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(y),
                    _ptr(mean), _ptr(rstd), _ptr(ws), nb, B, Cc, S, views, int(view_major), momentum, eps, act, self.stream())
         return y, mean, rstd
@@ -557,5 +571,6 @@ class Ops:
 
     def adamw_step(self, p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, sumsq=None, max_norm=0.0):
         self._chk(p, g, m, v)
+        bump_weights_generation()         # parameters are rewritten in place
         self._call("dmvs_adamw_step_f32", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, wd, step,
                    grad_scale, _ptr(sumsq), max_norm, self.stream())

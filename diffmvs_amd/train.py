@@ -3,9 +3,9 @@ train branches of InitialCost (module.py:539-541) and DiffusionUpdateBlockDepth 
 
 Built as a torch.autograd graph whose heavy nodes are libdmvs_hip.so kernels, forward AND backward
 (diffmvs_amd/autograd.py): every 2-D / 3-D convolution (MFMA implicit GEMM, MFMA weight gradient), the fused
-homography-warp + group-correlation volumes, GetCost, the view aggregation.  Round-1 status: BatchNorm /
-GroupNorm (batch statistics) and the element-wise glue (activations, softmax regression, convex upsampling,
-concatenations) are ATen device ops for now; their HIP kernels are next-round work.
+homography-warp + group-correlation volumes, GetCost, the view aggregation, training-mode BatchNorm(+ReLU) with
+per-view statistics and GroupNorm + scale/shift + SiLU (norm.hip).  The element-wise glue (head activations,
+softmax regression, convex upsampling, concatenations, weight standardisation) is ATen device ops.
 
 Semantics that matter for parity with the reference's gradients:
   * FeatureNet is applied per view (diffusion.py:156-157) -> BatchNorm batch statistics per view, running stats
@@ -134,7 +134,7 @@ def initial_cost(n: _Net, feat, B, context, rt, disp_min, disp_max, dmin, dmax, 
     _, H, W, _ = ref.shape
     S = src.shape[0]
     mask = mask_head(n, context, p + ".mask")
-    cor = A.warp_corr_init(o, ref, src, rt, disp_min, disp_max, D)             # [B,S,G,D,H,W]
+    cor = A.warp_corr_init(o, ref, src, rt, disp_min, disp_max, D, G)           # [B,S,G,D,H,W]
     # PixelViewWeight on all source views at once (rows b*S+s: view-minor); BatchNorm statistics per view as in the
     # reference's per-view calls (module.py:533)
     x = n.cbr3(cor.view(B * S, G, D, H, W), p + ".pixel_view_weight.conv.0", views=S, view_major=False)
@@ -315,7 +315,7 @@ def forward_train(model, imgs, proj_matrices, depth_values, depth_gt_ms, ops: Op
             calls[0] += 1
             return A.getcost(o, ref, src, rt, inv.contiguous(), None if confidence is None else confidence.contiguous(), vw,
                              kmin, kmax, nsamp, interval * _RATIOS[s], a.min_radius, a.max_radius, s,
-                             policy_key=("train", s, calls[0]))
+                             policy_key=("train", s, calls[0]), G=a.cost_dim_stage[1])
 
         ub = f"update_block_depth{s + 1}"
         t = t_source(B, a.timesteps[s], dev)

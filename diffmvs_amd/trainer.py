@@ -7,7 +7,9 @@ One process per GPU.  All trainable parameters live in ONE flat fp32 bucket (Fla
               ->  dmvs_sumsq_f32 (global grad norm)  ->  dmvs_adamw_step_f32 (clip + 1/world average + AdamW)
 i.e. three launches that read each array once, instead of ~600 per-tensor optimizer launches.
 The LR schedule is the reference's OneCycle (linear anneal, pct_start 0.05, no momentum cycling); checkpoints use
-the reference's layout {'epoch', 'model', 'optimizer'} with a torch.optim.AdamW-compatible optimizer state."""
+the reference's layout {'epoch', 'model', 'optimizer'} with a torch.optim.AdamW-compatible optimizer state.
+The reference's default `--lr_sche mslr` (MultiStepLR) has no counterpart here: every training script of the reference
+passes `--lr_sche onecycle`, which is what is reproduced; a constant lr is the other option (total_steps=None)."""
 from __future__ import annotations
 
 import torch
@@ -132,6 +134,10 @@ class Trainer:
                  "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "amsgrad": False, "maximize": False,
                  "foreach": None, "capturable": False, "differentiable": False, "fused": None,
                  "params": list(range(len(self.flat.params)))}
+        if self.total_steps is not None:
+            # what torch's OneCycleLR(last_epoch != -1) reads on resume (reference train.py:372-376; div_factor 25,
+            # final_div_factor 1e4, cycle_momentum=False)
+            group.update(initial_lr=self.lr / 25.0, max_lr=self.lr, min_lr=self.lr / 25.0 / 1e4)
         return {"state": state if self.step_count else {}, "param_groups": [group]}
 
     def load_optimizer_state_dict(self, sd):

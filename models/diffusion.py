@@ -73,8 +73,21 @@ class CasDiffMVS(nn.Module):
 
     # ------------------------------------------------------------------ engine cache
     def _weights_key(self, device):
-        return (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters()) + \
-            tuple((b.data_ptr(), b._version) for b in self.buffers())
+        # the tensor list is cached (walking the module tree costs more than a batch-1 forward's launches); _apply()
+        # (.to / .cuda / .float) and load_state_dict(assign=True) are the calls that can replace tensors
+        ts = self.__dict__.get("_key_tensors")
+        if ts is None:
+            ts = self.__dict__["_key_tensors"] = list(self.parameters()) + list(self.buffers())
+        from diffmvs_amd.ops import weights_generation
+        return (str(device), weights_generation()) + tuple((t.data_ptr(), t._version) for t in ts)
+
+    def _apply(self, fn, *a, **k):
+        self.__dict__.pop("_key_tensors", None)
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self.__dict__.pop("_key_tensors", None)
+        return super().load_state_dict(*a, **k)
 
     def engine(self, ops: Ops | None = None) -> Engine:
         """The packed inference engine for the current weights (rebuilt when they change)."""
@@ -98,4 +111,4 @@ class CasDiffMVS(nn.Module):
             if ops is None:
                 ops = Ops.for_device(next(self.parameters()).device)
             return forward_train(self, imgs, proj_matrices, depth_values, depth_gt_ms, ops)
-        return self.engine().forward(imgs, proj_matrices, depth_values, noise_fn=self.noise_source)
+        return self.engine().forward(imgs, proj_matrices, depth_values, noise_fn=self.noise_source, test=self.test)

@@ -32,7 +32,7 @@ class HipModule(nn.Module):
         return Ops.for_device(t.device)
 
     def packed(self, builder):
-        key = tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        key = (K.weights_generation(),) + tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
         cache = self.__dict__.setdefault("_pack_cache", {})
         if cache.get("key") != key:
             dev = self.ops().device
@@ -42,8 +42,9 @@ class HipModule(nn.Module):
 
     def _eval_only(self):
         if self.training:
-            raise NotImplementedError(f"{type(self).__name__}: the training forward/backward is not built yet "
-                                      "in this MI355X implementation; call .eval()")
+            raise NotImplementedError(f"{type(self).__name__}.forward() stand-alone is the eval path (folded BatchNorm, packed "
+                                      "weights); training runs through CasDiffMVS.forward in train mode "
+                                      "(diffmvs_amd/train.py builds the autograd graph over the whole model); call .eval()")
 
 
 def _dev(o: Ops, t):

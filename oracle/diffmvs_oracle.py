@@ -422,8 +422,9 @@ def upsample_depth(depth, mask, ratio):
 
 
 # ------------------------------------------------------------------ a14 whole forward
-def forward(sd, args, imgs, proj_matrices, depth_values, noise_fn=None):
-    """CasDiffMVS.forward with test=True, eval mode (models/diffusion.py:139-295)."""
+def forward(sd, args, imgs, proj_matrices, depth_values, noise_fn=None, test=True):
+    """CasDiffMVS.forward, eval mode (models/diffusion.py:139-295); test=False keeps every iterate and the Unet
+    confidences (diffusion.py:264-270)."""
     if noise_fn is None:
         noise_fn = lambda shape: torch.randn(shape)  # noqa: E731
     cas = args.stage_iters[2] != 0
@@ -437,7 +438,7 @@ def forward(sd, args, imgs, proj_matrices, depth_values, noise_fn=None):
 
     feats = [feature_net(sd, im) for im in imgs]
     ctx = context_net(sd, imgs[0])
-    depths, confs_full = [], []
+    depths, confs_full, confs_seq = [], [], []
     view_weights = None
     for s in range(3):
         if args.stage_iters[s] == 0:
@@ -479,9 +480,13 @@ def forward(sd, args, imgs, proj_matrices, depth_values, noise_fn=None):
                 dim=args.unet_dim[s], n_levels=len(mults[s]), timesteps=args.timesteps[s],
                 sampling_timesteps=args.sampling_timesteps[s], eta=args.ddim_eta[s],
                 scale=args.scale[s], noise_fn=noise_fn)
-            depths.append(disp_to_depth(inv_seq[-1], dmin, dmax)[1].squeeze(1))
-            confs_full.append(F.interpolate(conf_seq[-1].unsqueeze(1), scale_factor=2 ** (3 - s),
-                                            mode="nearest").squeeze(1))
+            if test:
+                depths.append(disp_to_depth(inv_seq[-1], dmin, dmax)[1].squeeze(1))
+                confs_full.append(F.interpolate(conf_seq[-1].unsqueeze(1), scale_factor=2 ** (3 - s),
+                                                mode="nearest").squeeze(1))
+            else:
+                depths.extend(disp_to_depth(i, dmin, dmax)[1].squeeze(1) for i in inv_seq)
+                confs_seq.extend(conf_seq)
             up = upsample_depth(inv_seq[-1], mask, up_ratio).unsqueeze(1)
             depths.append(disp_to_depth(up, dmin, dmax)[1].squeeze(1))
-    return {"depth": depths, "conf": [], "photometric_confidence": confs_full}
+    return {"depth": depths, "conf": confs_seq, "photometric_confidence": confs_full}

@@ -16,6 +16,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A plain `pytest` in a container without a HIP device skips the gpu-marked tests instead of erroring."""
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="needs a HIP device (MI355X)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 class Golden:
     """npz fixture with '@key' aliases resolved (see tests/golden/make_golden.py:dedupe)."""
 
@@ -57,6 +67,15 @@ def golden():
 def state_keys(variant):
     with open(os.path.join(GOLDEN, f"state_keys_{variant}.json")) as f:
         return json.load(f)
+
+
+def conf_close(a, b, tol=1e-4, flips=0.01):
+    """photometric confidence of stage 1 = 4 neighbouring probabilities gathered at floor(index) (reference
+    module.py:569-571): discontinuous where the regressed index crosses an integer, so a small fraction of pixels may
+    land in the neighbouring bin; everywhere else the maps must agree."""
+    a, b = a.double().cpu(), b.double().cpu()
+    assert a.shape == b.shape
+    return float(((a - b).abs() > tol).double().mean()) < flips
 
 
 def rel_l1(a, b):

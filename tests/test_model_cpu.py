@@ -4,7 +4,7 @@ reference-generated goldens."""
 import pytest
 import torch
 
-from conftest import emu_ops, rel_l1, state_keys
+from conftest import conf_close, emu_ops, rel_l1, state_keys
 from diffmvs_amd import synth
 from diffmvs_amd._lib import DmvsError
 
@@ -65,5 +65,51 @@ def test_end_to_end_emulated(golden, variant):
     assert len(out["photometric_confidence"]) == len(refc)
     for a, b in zip(out["photometric_confidence"], refc):
         assert a.shape == b.shape
+    assert conf_close(out["photometric_confidence"][0], refc[0])      # stage 1: floor(index) bin flips allowed
     for a, b in zip(out["photometric_confidence"][1:], refc[1:]):
         assert rel_l1(a, b) < 1e-3
+
+
+@pytest.mark.parametrize("variant,tag", [("diffmvs", "ms2"), ("casdiffmvs", "evalall")])
+def test_multistep_and_all_iterates_emulated(golden, variant, tag):
+    """ms2: two DDIM steps per refinement stage (reference update.py:504-519); evalall: a test=False model in eval mode
+    returns every iterate + the Unet confidences (diffusion.py:264-270).  Through CasDiffMVS.forward's own dispatch."""
+    from models import CasDiffMVS
+    e = golden(f"e2e_{variant}_b2_{tag}.npz")
+    meta = e.meta()
+    args = synth.make_args(variant, numdepth_initial=meta["nd_init"], sampling_timesteps=meta["sampling_timesteps"])
+    model = CasDiffMVS(args, test=meta["test"]).eval()
+    model.load_state_dict(synth.synth_state_dict(model.state_dict(), meta["weight_seed"]), strict=True)
+    imgs, proj, dv = synth.synth_inputs(meta["H"], meta["W"], meta["n_src"], B=meta["B"], seed=meta["scene_seed"])
+    model.engine(emu_ops())
+    model.noise_source = synth.NoiseSource(meta["noise_seed"])
+    out = model(imgs, proj, dv)
+    ref = e.seq("out.depth")
+    assert len(out["depth"]) == len(ref)
+    for i, (a, b) in enumerate(zip(out["depth"], ref)):
+        assert a.shape == b.shape
+        assert rel_l1(a, b) < 1e-4, (i, rel_l1(a, b))
+    refc = e.seq("out.conf") if "out.conf.len" in e else []
+    assert len(out["conf"]) == len(refc)
+    for a, b in zip(out["conf"], refc):
+        assert a.shape == b.shape and rel_l1(a, b) < 1e-3
+    refp = e.seq("out.photometric_confidence")
+    assert len(out["photometric_confidence"]) == len(refp)
+    assert conf_close(out["photometric_confidence"][0], refp[0])
+    for a, b in zip(out["photometric_confidence"][1:], refp[1:]):
+        assert rel_l1(a, b) < 1e-3
+
+
+def test_validation_loss_on_eval_outputs(golden):
+    """the reference's validation loop (train.py test_sample_depth) feeds a test=False model's eval outputs to
+    compute_inverse_loss, which asserts one depth map per supervised iterate and indexes conf[-1]"""
+    from models import CasDiffMVS, compute_inverse_loss
+    args = synth.make_args("diffmvs", numdepth_initial=8)
+    model = CasDiffMVS(args, test=False).eval()
+    model.load_state_dict(synth.synth_state_dict(model.state_dict(), 5), strict=True)
+    imgs, proj, dv, gt, mask = synth.synth_inputs(32, 64, 2, B=1, seed=0, with_gt=True)
+    model.engine(emu_ops())
+    model.noise_source = synth.NoiseSource(1)
+    out = model(imgs, proj, dv)
+    loss, parts = compute_inverse_loss(args, out["depth"], out["conf"], gt, mask, dv, loss_rate=0.9, iters=args.stage_iters)
+    assert torch.isfinite(loss)

@@ -4,7 +4,7 @@ BASELINE.json full size.  Tolerance: 1e-3 relative L1 on depth (north star), fp3
 import pytest
 import torch
 
-from conftest import rel_l1
+from conftest import conf_close, rel_l1
 from diffmvs_amd import synth
 from oracle import diffmvs_oracle as O
 
@@ -12,10 +12,10 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 
 
-def make_model(variant, nd_init, weight_seed=123):
+def make_model(variant, nd_init, weight_seed=123, test=True, **overrides):
     from models import CasDiffMVS
-    args = synth.make_args(variant, numdepth_initial=nd_init)
-    model = CasDiffMVS(args, test=True).eval()
+    args = synth.make_args(variant, numdepth_initial=nd_init, **overrides)
+    model = CasDiffMVS(args, test=test).eval()
     sd = synth.synth_state_dict(model.state_dict(), weight_seed)
     model.load_state_dict(sd, strict=True)
     return model.to("cuda:0"), sd, args
@@ -55,7 +55,36 @@ def test_golden_end_to_end(golden, variant, cfg):
     assert max(errs) < TOL, errs
     refc = e.seq("out.photometric_confidence")
     assert len(out["photometric_confidence"]) == len(refc)
+    assert conf_close(out["photometric_confidence"][0], refc[0])      # stage 1: floor(index) bin flips allowed
     for a, b in zip(out["photometric_confidence"][1:], refc[1:]):
+        assert rel_l1(a.cpu(), b) < 5e-3
+
+
+@pytest.mark.parametrize("variant", ["diffmvs", "casdiffmvs"])
+@pytest.mark.parametrize("tag", ["ms2", "evalall"])
+def test_golden_multistep_and_all_iterates(golden, variant, tag):
+    """ms2: sampling_timesteps = 2, the multi-step DDIM tail (reference update.py:504-519, second noise draw per stage);
+    evalall: test=False in eval mode, every iterate + the Unet confidences (diffusion.py:264-270).  Both against
+    outputs recorded from the imported reference (tests/golden/make_golden_extra.py)."""
+    e = golden(f"e2e_{variant}_b2_{tag}.npz")
+    meta = e.meta()
+    model, _, _ = make_model(variant, meta["nd_init"], meta["weight_seed"], test=meta["test"],
+                             sampling_timesteps=meta["sampling_timesteps"])
+    imgs, proj, dv = synth.synth_inputs(meta["H"], meta["W"], meta["n_src"], B=meta["B"], seed=meta["scene_seed"])
+    out = run(model, imgs, proj, dv, meta["noise_seed"])
+    ref = e.seq("out.depth")
+    assert len(out["depth"]) == len(ref)
+    errs = [rel_l1(a.cpu(), b) for a, b in zip(out["depth"], ref)]
+    print(variant, tag, "depth rel-L1 per output:", ["%.2e" % x for x in errs])
+    assert max(errs) < TOL, errs
+    refc = e.seq("out.conf") if "out.conf.len" in e else []
+    assert len(out["conf"]) == len(refc)
+    for a, b in zip(out["conf"], refc):
+        assert a.shape == b.shape and rel_l1(a.cpu(), b) < 5e-3
+    refp = e.seq("out.photometric_confidence")
+    assert len(out["photometric_confidence"]) == len(refp)
+    assert conf_close(out["photometric_confidence"][0], refp[0])
+    for a, b in zip(out["photometric_confidence"][1:], refp[1:]):
         assert rel_l1(a.cpu(), b) < 5e-3
 
 

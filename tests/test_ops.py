@@ -321,28 +321,37 @@ def test_getcost_many_source_views(ops, S):
 
 
 def test_getcost_extreme_geometry(ops, golden):
-    """per-pixel depth maps + the reference's own warping edge cases (OOB, negative z)."""
+    """per-pixel depth maps + the reference's own warping edge cases pushed through the fused GetCost kernels (window
+    path with its per-pixel fallback, and the plain per-pixel kernel): case 0 mild, 1 large rotation (big out-of-bounds
+    regions), 2 camera looking backwards (negative z), 3 source grid != hypothesis grid.  (Case 4, exact z == 0 on
+    constant planes, goes through the stage-1 kernel in test_warp_golden_edge_cases.)  The kernels' contract is one
+    H x W grid for reference and source, so case 3 embeds both in a common canvas: zero texels beyond the source ARE
+    grid_sample's zero padding, and the extra reference pixels are not compared."""
     g = golden("warp_edge.npz")
-    for ci in (1, 2):
+    for ci in (0, 1, 2, 3):
         src, depth, want = g.t(f"c{ci}.src"), g.t(f"c{ci}.depth"), g.t(f"c{ci}.out")
         B, Cc, Hs, Ws = src.shape
         D, H, W = depth.shape[1:]
-        if (Hs, Ws) != (H, W):
-            continue
-        # choose disp range so that inv=0.5 with zero radius reproduces depth plane d exactly enough
-        srcp = torch.cat([src, torch.zeros(B, 16 - Cc, Hs, Ws)], 1)
+        Hc, Wc = max(H, Hs), max(W, Ws)
+        srcp = torch.zeros(B, 16, Hc, Wc)
+        srcp[:, :Cc, :Hs, :Ws] = src
         P = torch.matmul(g.t(f"c{ci}.src_proj"), torch.inverse(g.t(f"c{ci}.ref_proj")))
         rt = torch.cat([P[:, :3, :3].reshape(B, 9), P[:, :3, 3]], 1).view(B, 1, 12)
         lo, hi = torch.full((B,), 1 / 2000.0), torch.full((B,), 1 / 100.0)
         for d in range(D):
-            inv = ((1 / depth[:, d:d + 1]) - lo.view(-1, 1, 1, 1)) / (hi - lo).view(-1, 1, 1, 1)
-            cost, samp = ops.getcost(dev(ops, torch.ones(B, H, W, 16)), dev(ops, srcp.permute(0, 2, 3, 1).unsqueeze(0)),
-                                     dev(ops, rt), dev(ops, inv.contiguous()), None, dev(ops, torch.ones(B, 1, H, W)),
-                                     dev(ops, lo), dev(ops, hi), 4, 0.0, 1.0, 1.0, vw_shift=0)
-            got = cost.cpu()[:, 0] * 4.0        # group 0, hypothesis 0 (all 4 identical: zero radius)
+            dpl = torch.full((B, 1, Hc, Wc), 500.0)
+            dpl[:, :, :H, :W] = depth[:, d:d + 1]
+            # zero radius: all 4 hypotheses sit on the recorded depth (up to the inverse-depth round trip)
+            inv = ((1 / dpl) - lo.view(-1, 1, 1, 1)) / (hi - lo).view(-1, 1, 1, 1)
             w = want[:, :, d].sum(1)
-            # inverse-depth round trip perturbs depth by ~1e-4 relative; compare loosely but everywhere
-            assert float((got - w).abs().mean()) <= 2e-3 * max(1.0, float(w.abs().mean())), (ci, d)
+            for gather in (False, True):
+                cost, samp = ops.getcost(dev(ops, torch.ones(B, Hc, Wc, 16)), dev(ops, srcp.permute(0, 2, 3, 1).unsqueeze(0)),
+                                         dev(ops, rt), dev(ops, inv.contiguous()), None, dev(ops, torch.ones(B, 1, Hc, Wc)),
+                                         dev(ops, lo), dev(ops, hi), 4, 0.0, 1.0, 1.0, vw_shift=0, gather=gather)
+                cost = cost.cpu()
+                got = (cost[:, 0] + cost[:, 4] + cost[:, 8] + cost[:, 12])[:, :H, :W] * 4.0     # hypothesis 0 of the 4 groups: mean -> sum
+                # inverse-depth round trip perturbs depth by ~1e-4 relative; compare loosely but everywhere
+                assert float((got - w).abs().mean()) <= 2e-3 * max(1.0, float(w.abs().mean())), (ci, d, gather)
 
 
 def test_misc_kernels(ops):

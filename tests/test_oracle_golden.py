@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_l1, state_keys
+from conftest import conf_close, rel_l1, state_keys
 from diffmvs_amd import synth
 from oracle import diffmvs_oracle as O
 
@@ -157,7 +157,42 @@ def test_end_to_end(golden, variant, cfg):
         assert rel_l1(a, b) < 1e-5, rel_l1(a, b)
     refc = e.seq("out.photometric_confidence")
     assert len(out["photometric_confidence"]) == len(refc)
+    assert conf_close(out["photometric_confidence"][0], refc[0])       # stage 1: floor(index) bin flips allowed
     for a, b in zip(out["photometric_confidence"][1:], refc[1:]):
         assert rel_l1(a, b) < 1e-4
     for i, n in enumerate(e.seq("noise")):
         assert torch.equal(n, synth.synth_noise(n.shape, meta["noise_seed"], i))
+
+
+@pytest.mark.parametrize("variant", ["diffmvs", "casdiffmvs"])
+@pytest.mark.parametrize("tag", ["ms2", "evalall"])
+def test_end_to_end_multistep_and_all_iterates(golden, variant, tag):
+    """ms2: two DDIM sampling steps per refinement stage (reference update.py:504-519, second noise draw);
+    evalall: test=False in eval mode -- every iterate and the Unet confidences (diffusion.py:264-270)."""
+    e = golden(f"e2e_{variant}_b2_{tag}.npz")
+    meta = e.meta()
+    sd = make_sd(variant, meta["weight_seed"])
+    args = synth.make_args(variant, numdepth_initial=meta["nd_init"], sampling_timesteps=meta["sampling_timesteps"])
+    imgs, proj, dv = synth.synth_inputs(meta["H"], meta["W"], meta["n_src"], B=meta["B"], seed=meta["scene_seed"])
+    src = synth.NoiseSource(meta["noise_seed"])
+    with torch.no_grad():
+        out = O.forward(sd, args, imgs, proj, dv, noise_fn=lambda shape: src(shape, "cpu"), test=meta["test"])
+    check_outputs(out, e, 1e-5, 1e-4)
+
+
+def check_outputs(out, e, tol_depth, tol_conf):
+    ref = e.seq("out.depth")
+    assert len(out["depth"]) == len(ref)
+    for a, b in zip(out["depth"], ref):
+        assert a.shape == b.shape
+        assert rel_l1(a, b) < tol_depth, rel_l1(a, b)
+    refc = e.seq("out.conf") if "out.conf.len" in e else []
+    assert len(out["conf"]) == len(refc)
+    for a, b in zip(out["conf"], refc):
+        assert a.shape == b.shape
+        assert rel_l1(a, b) < tol_conf, rel_l1(a, b)
+    refp = e.seq("out.photometric_confidence")
+    assert len(out["photometric_confidence"]) == len(refp)
+    assert conf_close(out["photometric_confidence"][0], refp[0])
+    for a, b in zip(out["photometric_confidence"][1:], refp[1:]):
+        assert rel_l1(a, b) < tol_conf

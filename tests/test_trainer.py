@@ -246,3 +246,101 @@ def test_data_parallel_step_gloo(tmp_path):
     assert abs(r0["loss"] - r0["loss_serial"]) < 1e-5 * abs(r0["loss_serial"])
     assert abs(r0["gnorm"] - r0["serial_norm"]) < 1e-3 * r0["serial_norm"]
     assert r0["mean_diff"] < 0.02 * r0["mean_move"], r0          # first Adam step: |move| ~ lr everywhere
+
+
+def test_onecycle_resume_roundtrip():
+    """the reference's resume path (train.py:372-376) builds OneCycleLR(last_epoch = k) on the loaded optimizer, which
+    reads initial_lr / max_lr / min_lr from the checkpoint's param group"""
+    from models import CasDiffMVS
+    args = synth.make_args("diffmvs", numdepth_initial=8)
+    model = CasDiffMVS(args, test=False)
+    flat = FlatParams(model)
+    tr = Trainer.__new__(Trainer)
+    tr.flat, tr.step_count, tr.total_steps = flat, 40, 500
+    tr.lr, tr.wd, tr.betas, tr.eps = 1e-3, 1e-3, (0.9, 0.999), 1e-8
+    tr.exp_avg, tr.exp_avg_sq = torch.zeros(flat.numel), torch.zeros(flat.numel)
+    tr.model = model
+    ck = tr.checkpoint(3)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-3, eps=1e-8)
+    opt.load_state_dict(ck["optimizer"])
+    sch = torch.optim.lr_scheduler.OneCycleLR(opt, 1e-3, 500, pct_start=0.05, cycle_momentum=False, anneal_strategy="linear",
+                                              last_epoch=tr.step_count - 1)
+    # the scheduler resumes on the same curve the Trainer is on
+    assert abs(opt.param_groups[0]["lr"] - one_cycle_lr(tr.step_count, 1e-3, 500)) < 1e-9
+    opt.step()
+    sch.step()
+    assert abs(opt.param_groups[0]["lr"] - one_cycle_lr(tr.step_count + 1, 1e-3, 500)) < 1e-9
+
+
+def test_submodule_eval_after_train_step(golden, ops):
+    """packed-weight caches must notice parameters rewritten through raw pointers (dmvs_adamw_step_f32 does not bump
+    torch's version counters): a sub-module forward and the whole-model engine after a training step use the NEW weights"""
+    import models.module as M
+    variant = "diffmvs"
+    g = golden(f"train_{variant}.npz")
+    tr, model, sample = _golden_trainer(variant, g, ops)
+    enc = model.update_block_depth2.encoder
+    B, H, W = 1, 8, 12
+    dev = ops.device
+    depth, samples, cost = (torch.rand(B, 1, H, W).to(dev), torch.rand(B, 6, H, W).to(dev), torch.rand(B, 24, H, W).to(dev))
+    M.HipModule._ops = ops
+    try:
+        model.eval()
+        y0 = enc(depth, samples, cost).clone()
+        e0 = model.engine(ops)
+        tr.train_sample(sample)
+        model.eval()
+        y1 = enc(depth, samples, cost).clone()
+        assert model.engine(ops) is not e0                       # whole-model engine re-packed too
+        # fresh module with the post-step weights = what a cold pack gives
+        from models import CasDiffMVS
+        fresh = CasDiffMVS(tr.args, test=False).eval()
+        fresh.load_state_dict({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, strict=True)
+        fresh.to(dev)
+        y2 = fresh.update_block_depth2.encoder(depth, samples, cost)
+    finally:
+        M.HipModule._ops = None
+    assert float((y1 - y0).abs().max()) > 0                      # the step moved the encoder
+    assert torch.allclose(y1, y2, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_cfg4_full_size_training_step():
+    """BASELINE.json configs[3] at its stated size on one GPU's share: CasDiffMVS, 768x576, 9 views (8 source), batch 4,
+    fp32 -- forward(train) -> compute_inverse_loss -> backward -> clip(2.0) -> AdamW through Trainer.train_sample.
+    Too large for the CPU oracle; size-independent properties: finite loss, every parameter receives a gradient, the
+    global gradient norm is reproducible from identical weights + draws (the only atomics are the fp32 scatter-adds of
+    the warp backward), the step moves the weights, the 10 + 6 outputs have the reference's shapes."""
+    from models import CasDiffMVS
+    dev = torch.device("cuda:0")
+    H, W, S, B = 576, 768, 8, 4
+    imgs, proj, dv, gt, mask = synth.synth_inputs(H, W, S, B=B, seed=3, with_gt=True)
+    sample = {"imgs": [i.to(dev) for i in imgs], "proj_matrices": {k: v.to(dev) for k, v in proj.items()},
+              "depth_values": dv.to(dev), "depth": {k: v.to(dev) for k, v in gt.items()},
+              "mask": {k: v.to(dev) for k, v in mask.items()}}
+    runs = []
+    for _ in range(2):
+        args = synth.make_args("casdiffmvs", numdepth_initial=48)
+        model = CasDiffMVS(args, test=False)
+        model.load_state_dict(synth.synth_state_dict(model.state_dict(), 123), strict=True)
+        model.to(dev)
+        model.noise_source = synth.NoiseSource(21)
+        model.t_source = _t_source()
+        tr = Trainer(model, args, lr=1e-3, wd=1e-3, total_steps=1000)
+        before = tr.flat.data.clone()
+        torch.cuda.reset_peak_memory_stats()
+        loss, parts, gnorm, out = tr.train_sample(sample)
+        torch.cuda.synchronize()
+        assert torch.isfinite(loss) and torch.isfinite(gnorm) and float(gnorm) > 0
+        assert len(out["depth"]) == 10 and len(out["conf"]) == 6
+        assert out["depth"][-1].shape == (B, H, W) and out["depth"][0].shape == (B, H // 8, W // 8)
+        dead = [n for n, p in zip(tr.flat.names, tr.flat.params) if not bool((p.grad != 0).any())]
+        assert not dead, dead
+        assert torch.isfinite(tr.flat.grad).all()
+        moved = (tr.flat.data - before).abs()
+        assert 0 < float(moved.mean()) and float(moved.max()) <= 1e-3      # first Adam step: |move| ~ lr (OneCycle start lr/25)
+        runs.append((float(loss), float(gnorm)))
+        print(f"cfg4 step: loss {float(loss):.6f} grad-norm {float(gnorm):.5f} peak memory "
+              f"{torch.cuda.max_memory_allocated() / 2 ** 30:.2f} GiB")
+    assert abs(runs[0][0] - runs[1][0]) <= 1e-5 * abs(runs[0][0])
+    assert abs(runs[0][1] - runs[1][1]) <= 1e-3 * runs[0][1]
