@@ -73,7 +73,9 @@ def scene_geometry_getcost(ops, B, H, W, S, n, iters=20):
             traffic = ti["traffic_bytes_per_launch"]
     return {"kernel": "getcost_win_kernel<32,6> incl. its pre-pass (hypotheses around the scene's true depth, sigma 0.01)",
             "bound": "hbm", "achieved": round(alg / out[False] / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(alg / out[False] / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": alg,
+            "frac": round(alg / out[False] / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_source": "profiles/r1b_getcost_traffic.json (rocprofv3 PMC passes of an earlier run; not measured by this process)" if traffic else None,
+            "algorithmic_bytes_per_launch": alg,
             "avg_launch_us": round(out[False] * 1e6, 2), "tiles_on_gather_path": (o.getcost_tiles or (None, None))[0],
             "gather_kernel_same_inputs_us": round(out[True] * 1e6, 2), "gather_kernel_frac": round(alg / out[True] / 1e9 / HBM_PEAK_GBS, 4)}
 
@@ -82,7 +84,8 @@ def cpu_baseline(a):
     """oracle/diffmvs_oracle.py (the CPU restatement pinned to the reference) on the host cores."""
     from oracle import diffmvs_oracle as O
     from models import CasDiffMVS
-    cores = max(1, min(len(os.sched_getaffinity(0)), 32))
+    O.use_grid_sample_warp(True)       # the warp through F.grid_sample like the reference (the spelled-out checker is 1.3x slower)
+    cores = max(1, min(len(os.sched_getaffinity(0)), a.cpu_threads))
     torch.set_num_threads(cores)
     args = synth.make_args("diffmvs", numdepth_initial=48)
     sd = synth.synth_state_dict(CasDiffMVS(args, test=True).state_dict(), 123)
@@ -97,8 +100,67 @@ def cpu_baseline(a):
             n += 1
         ct = time.perf_counter() - t0
     print(json.dumps({"value": round(n / ct, 4), "unit": "depth-maps/s", "cores": cores, "kind": "port",
-                      "sample": f"{n} forwards of the same workload at batch 1 after 1 warm-up, "
-                                f"torch CPU backend with {cores} threads"}), flush=True)
+                      "sample": f"{n} forwards of the same workload at batch 1 after 1 warm-up, torch CPU backend (mkldnn convs, "
+                                f"F.grid_sample warp as in the reference) with {cores} of the box's "
+                                f"{len(os.sched_getaffinity(0))} hardware threads; measured in the build container on 8 threads: "
+                                f"the imported reference 0.86 s/map, this port 0.94 s/map (9 % slower)"}), flush=True)
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: one worker process per GPU (LOCAL_RANK = GPU index), the same
+    environment contract torch.distributed.run provides, rendezvous on 127.0.0.1.  Rank 0's JSON line is this process'
+    output; any failing rank fails the run."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=(None if r == 0 else subprocess.DEVNULL)))
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        raise SystemExit(f"bench.py: worker exit codes {rcs}")
+
+
+def timed_steps(step, steps, warmup, barrier):
+    """W untimed + exactly K timed steps bracketed by barrier + device sync on both sides -> elapsed seconds"""
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def stub_main(a):
+    """The N-rank plumbing of this file (env contract, process group, barrier-bracketed timing, max over ranks, one JSON
+    line from rank 0) with a stand-in for the model: used by the CPU test over gloo, never a measurement."""
+    from diffmvs_amd import shard
+    rank, world, local = shard.env_rank_world()
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    td = shard.init_distributed(a.backend) if world > 1 else None
+    x = torch.randn(64, 64)
+
+    def step():
+        time.sleep(0.002 * (rank + 1))          # rank-dependent duration: the slowest rank must set the time
+        return x @ x
+
+    elapsed = timed_steps(step, a.steps, a.warmup, (lambda: td.barrier()) if td else (lambda: None))
+    whole = shard.barrier_and_max(elapsed)
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": round(a.batch * a.steps * world / whole, 3), "n_gpus": world,
+                          "world_size_seen": td.get_world_size() if td else 1, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": round(whole / a.steps * 1e3, 4), "rank0_ms_per_step": round(elapsed / a.steps * 1e3, 4)}),
+              flush=True)
+    if td:
+        td.destroy_process_group()
 
 
 def main():
@@ -113,18 +175,27 @@ def main():
     ap.add_argument("--src-views", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-forwards", type=int, default=8)
+    ap.add_argument("--cpu-threads", type=int, default=32, help="threads of the CPU baseline leg (more than ~32 is slower at batch 1)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)        # "gloo" + --stub-model: the CPU test of the N>1 plumbing
+    ap.add_argument("--stub-model", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.cpu_baseline_only:
         return cpu_baseline(a)
+    if a.gpus > 1 and "RANK" not in os.environ:
+        return spawn_ranks(a.gpus)              # plain `python bench.py --gpus N`: start the N ranks ourselves
+    if a.stub_model:
+        return stub_main(a)
 
     from diffmvs_amd import shard
     rank, world, local = shard.env_rank_world()
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     dist = world > 1
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if dist:
-        td = shard.init_distributed("nccl", dev)       # RCCL: rendezvous, barrier and one 8-byte max-reduce only
+        td = shard.init_distributed(a.backend, dev)       # RCCL: rendezvous, barrier and one 8-byte max-reduce only
 
     from models import CasDiffMVS
     args = synth.make_args("diffmvs", numdepth_initial=48)
@@ -148,12 +219,7 @@ def main():
         for _ in range(a.warmup):
             model(imgs, proj, dv)
         eng.ops.timers = {"dmvs_getcost_f32": [], "dmvs_getcost_gather_f32": [], "dmvs_warp_corr_init_f32": []}
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            model(imgs, proj, dv)
-        barrier()
-        elapsed = time.perf_counter() - t0
+        elapsed = timed_steps(lambda: model(imgs, proj, dv), a.steps, 0, barrier)
     timers, eng.ops.timers = eng.ops.timers, None
     elapsed = shard.barrier_and_max(elapsed, dev)      # whole-job time = slowest rank
     # one extra, untimed step with an event pair around every conv2d launch (kept out of the timed region: ~200 launches)
@@ -195,7 +261,7 @@ def main():
 
     result = {
         "metric": "depth-maps/sec (640x512, 5 src views)", "value": round(value, 3), "unit": "depth-maps/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4),
+        "n_gpus": world, "rccl_world_size": (td.get_world_size() if dist else 1), "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"DiffMVS DTU eval {W}x{H}, {S} src views, numdepth_initial=48, 1 DDIM step, fp32",
                    "ref_views_per_gpu_per_step": B, "parallelism": f"ref-view sharding x{world}, no collective",
@@ -203,6 +269,7 @@ def main():
         "roofline": {"kernel": "GetCost: getcost_win_kernel<32,6> (LDS-staged source windows) / getcost_kernel<32,4,6> (per-pixel gather), picked per launch",
                      "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "traffic_source": "profiles/r1_getcost_traffic.json (rocprofv3 PMC passes of an earlier run; not measured by this process)" if traffic else None,
                      "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(gc_avg_s * 1e6, 2),
                      "launches_timed": len(gc_ms),
                      "launches_hybrid": n_hybrid, "launches_plain_gather": n_plain,
@@ -228,7 +295,7 @@ def main():
         try:
             cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only",
                                  "--height", str(H), "--width", str(W), "--src-views", str(S),
-                                 "--cpu-forwards", str(a.cpu_forwards)],
+                                 "--cpu-forwards", str(a.cpu_forwards), "--cpu-threads", str(a.cpu_threads)],
                                 capture_output=True, text=True, timeout=150)
             line = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
             result["cpu_baseline"] = json.loads(line[-1]) if line else {

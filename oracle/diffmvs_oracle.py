@@ -144,6 +144,37 @@ def warp(src_fea, src_proj, ref_proj, depth_values):
     return out.view(B, C, D, H, W)
 
 
+def warp_grid_sample(src_fea, src_proj, ref_proj, depth_values):
+    """differentiable_warping (models/module.py:181-218) through the same ATen operator the reference calls
+    (F.grid_sample: bilinear, zeros, align_corners=True) instead of the spelled-out gathers of warp().  Same results
+    (tests/test_oracle_golden.py::test_warp_impls_agree); ~1.3x faster on CPU, so this is the variant bench.py times as
+    the CPU baseline -- the spelled-out one stays the default checker because it states the tap arithmetic explicitly."""
+    B, C, Hs, Ws = src_fea.shape
+    D, H, W = depth_values.shape[1:]
+    proj = torch.matmul(src_proj, torch.inverse(ref_proj))
+    rot, trans = proj[:, :3, :3], proj[:, :3, 3:4]
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    xyz = torch.stack((xx.reshape(-1), yy.reshape(-1), torch.ones(H * W)))
+    p = torch.matmul(rot, xyz.unsqueeze(0).expand(B, 3, H * W)).unsqueeze(2) * depth_values.reshape(B, 1, D, H * W) \
+        + trans.view(B, 3, 1, 1)
+    z = p[:, 2]
+    z = torch.where(z == 0, z + 1e-8, z)
+    grid = torch.stack(((p[:, 0] / z) / ((Ws - 1) / 2) - 1, (p[:, 1] / z) / ((Hs - 1) / 2) - 1), dim=3)
+    out = F.grid_sample(src_fea, grid.view(B, D * H, W, 2), mode="bilinear", padding_mode="zeros", align_corners=True)
+    return out.view(B, C, D, H, W)
+
+
+_WARP_IMPL = [None]      # None = warp() (spelled-out taps); bench.py's cpu_baseline leg switches to warp_grid_sample
+
+
+def use_grid_sample_warp(flag=True):
+    _WARP_IMPL[0] = warp_grid_sample if flag else None
+
+
+def _warp(*a):
+    return (_WARP_IMPL[0] or warp)(*a)
+
+
 def group_corr(warped, ref_fea, G):
     """mean over the channels of each group of warped*ref (models/module.py:529-531, :644-646)."""
     B, C, D, H, W = warped.shape
@@ -213,7 +244,7 @@ def initial_cost(sd, feats, context, proj, depth_values, dmin, dmax, G, p="depth
     mask = mask_head(sd, context, p + ".mask")
     wsum, acc, weights = 1e-8, 0, []
     for v in range(1, len(feats)):
-        cor = group_corr(warp(feats[v], compose_proj(proj[:, v]), ref_proj, depth_values), ref, G)
+        cor = group_corr(_warp(feats[v], compose_proj(proj[:, v]), ref_proj, depth_values), ref, G)
         w = pixel_view_weight(sd, cor, p + ".pixel_view_weight")
         if debug is not None:
             debug.setdefault("cor", []).append(cor)
@@ -245,7 +276,7 @@ def get_cost(feats, proj, inv_depth, interval, dmax, dmin, n, view_weights, conf
     ref_proj = compose_proj(proj[:, 0])
     wsum, acc = 1e-8, 0
     for v in range(1, len(feats)):
-        cor = group_corr(warp(feats[v], compose_proj(proj[:, v]), ref_proj, depth), ref, G)
+        cor = group_corr(_warp(feats[v], compose_proj(proj[:, v]), ref_proj, depth), ref, G)
         w = view_weights[:, v - 1].unsqueeze(1).unsqueeze(1)
         wsum = wsum + w
         acc = acc + w * cor

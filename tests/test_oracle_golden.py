@@ -45,6 +45,29 @@ def test_warp_edge_cases(golden):
         close(out, ref, 1e-4)
 
 
+def test_warp_impls_agree(golden):
+    """the grid_sample-based warp that bench.py times as the CPU baseline == the spelled-out checker == the reference"""
+    g = golden("warp_edge.npz")
+    for ci in range(int(g.np("n_cases"))):
+        a = (g.t(f"c{ci}.src"), g.t(f"c{ci}.src_proj"), g.t(f"c{ci}.ref_proj"), g.t(f"c{ci}.depth"))
+        close(O.warp_grid_sample(*a), g.t(f"c{ci}.out"), 1e-5)
+        close(O.warp_grid_sample(*a), O.warp(*a), 1e-4)
+    e = golden("e2e_diffmvs_b2.npz")
+    meta = e.meta()
+    sd = make_sd("diffmvs", meta["weight_seed"])
+    args = synth.make_args("diffmvs", numdepth_initial=meta["nd_init"])
+    imgs, proj, dv = synth.synth_inputs(meta["H"], meta["W"], meta["n_src"], B=meta["B"], seed=meta["scene_seed"])
+    src = synth.NoiseSource(meta["noise_seed"])
+    O.use_grid_sample_warp(True)
+    try:
+        with torch.no_grad():
+            out = O.forward(sd, args, imgs, proj, dv, noise_fn=lambda shape: src(shape, "cpu"))
+    finally:
+        O.use_grid_sample_warp(False)
+    for a, b in zip(out["depth"], e.seq("out.depth")):
+        assert rel_l1(a, b) < 1e-5
+
+
 @pytest.mark.parametrize("variant", ["diffmvs", "casdiffmvs"])
 def test_feature_context(golden, variant):
     g = golden(f"ops_{variant}.npz")

@@ -59,3 +59,26 @@ def test_world_size_two_gloo(tmp_path):
     outs = [p.communicate(timeout=120)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "OK" in outs[0]
+
+
+def test_bench_spawns_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher starts 2 worker processes itself (env contract of torch.distributed.run,
+    rendezvous on 127.0.0.1), times K steps between barriers, takes the max over ranks and prints ONE JSON line from rank 0.
+    Here over gloo with a stand-in model (--stub-model); on the GPU box the same code path runs the real model over RCCL."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1",
+                         "--backend", "gloo", "--stub-model", "--batch", "3"], env=env, capture_output=True, text=True, timeout=180)
+    assert cp.returncode == 0, cp.stderr[-2000:]
+    lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, cp.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["world_size_seen"] == 2 and r["steps"] == 5
+    # the slowest rank (rank 1 sleeps twice as long) sets the time, value = all ranks' units / that time
+    assert r["ms_per_step"] >= 3.9 and r["ms_per_step"] >= r["rank0_ms_per_step"] * 0.999
+    assert abs(r["value"] - 3 * 5 * 2 / (r["ms_per_step"] * 5e-3)) < 1e-2 * r["value"]
+    # under a launcher (RANK set) the same file does not spawn again; a mismatching --gpus is refused
+    env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    cp2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub-model", "--backend", "gloo"],
+                         env=env2, capture_output=True, text=True, timeout=120)
+    assert cp2.returncode != 0 and "WORLD_SIZE=1" in cp2.stderr
