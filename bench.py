@@ -218,7 +218,8 @@ def main():
     with torch.no_grad():
         for _ in range(a.warmup):
             model(imgs, proj, dv)
-        eng.ops.timers = {"dmvs_getcost_f32": [], "dmvs_getcost_gather_f32": [], "dmvs_warp_corr_init_f32": []}
+        eng.ops.timers = {"dmvs_getcost_f32": [], "dmvs_getcost_gather_f32": [], "dmvs_getcost_quad_f32": [],
+                          "dmvs_warp_corr_init_f32": [], "dmvs_warp_corr_init_quad_f32": []}
         elapsed = timed_steps(lambda: model(imgs, proj, dv), a.steps, 0, barrier)
     timers, eng.ops.timers = eng.ops.timers, None
     elapsed = shard.barrier_and_max(elapsed, dev)      # whole-job time = slowest rank
@@ -236,9 +237,9 @@ def main():
 
     maps = B * a.steps * world
     value = maps / elapsed
-    gc_ms = [s.elapsed_time(e) for s, e in timers["dmvs_getcost_f32"] + timers["dmvs_getcost_gather_f32"]]
-    n_hybrid, n_plain = len(timers["dmvs_getcost_f32"]), len(timers["dmvs_getcost_gather_f32"])
-    wi_ms = [s.elapsed_time(e) for s, e in timers["dmvs_warp_corr_init_f32"]]
+    gc_ms = [s.elapsed_time(e) for s, e in timers["dmvs_getcost_f32"] + timers["dmvs_getcost_gather_f32"] + timers["dmvs_getcost_quad_f32"]]
+    n_hybrid, n_plain, n_quad = len(timers["dmvs_getcost_f32"]), len(timers["dmvs_getcost_gather_f32"]), len(timers["dmvs_getcost_quad_f32"])
+    wi_ms = [s.elapsed_time(e) for s, e in timers["dmvs_warp_corr_init_f32"] + timers["dmvs_warp_corr_init_quad_f32"]]
     gc_avg_s = sum(gc_ms) / max(1, len(gc_ms)) * 1e-3
     h2, w2 = H // 4, W // 4
     alg = getcost_algorithmic_bytes(B, 32, S, args.CostNum[1], 4, h2, w2)
@@ -266,15 +267,17 @@ def main():
         "config": {"workload": f"DiffMVS DTU eval {W}x{H}, {S} src views, numdepth_initial=48, 1 DDIM step, fp32",
                    "ref_views_per_gpu_per_step": B, "parallelism": f"ref-view sharding x{world}, no collective",
                    "weights": "seeded random init (no checkpoint offline)"},
-        "roofline": {"kernel": "GetCost: getcost_win_kernel<32,6> (LDS-staged source windows) / getcost_kernel<32,4,6> (per-pixel gather), picked per launch",
+        "roofline": {"kernel": ("GetCost: getcost_quad_kernel<32,6> (quad per pixel, one launch for any geometry)" if eng.quad else
+                                "GetCost: getcost_win_kernel<32,6> (LDS-staged source windows) / getcost_kernel<32,4,6> (per-pixel gather), picked per launch"),
                      "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "traffic_source": "profiles/r1_getcost_traffic.json (rocprofv3 PMC passes of an earlier run; not measured by this process)" if traffic else None,
                      "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(gc_avg_s * 1e6, 2),
                      "launches_timed": len(gc_ms),
-                     "launches_hybrid": n_hybrid, "launches_plain_gather": n_plain,
+                     "launches_quad": n_quad, "launches_hybrid": n_hybrid, "launches_plain_gather": n_plain,
                      "tiles_on_gather_path": gather_tiles[0], "tiles_total": gather_tiles[1]},
-        "roofline_warp_init": {"kernel": "warp_init_win_kernel<48> (stage-1 plane sweep, LDS-staged source windows)", "bound": "hbm",
+        "roofline_warp_init": {"kernel": ("warp_init_quad_kernel<48> (stage-1 plane sweep, quad per pixel)" if eng.quad else
+                                          "warp_init_win_kernel<48> (stage-1 plane sweep, LDS-staged source windows)"), "bound": "hbm",
                                "achieved": round(alg_init / wi_avg_s / 1e9, 2) if wi_avg_s > 0 else 0.0,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(alg_init / wi_avg_s / 1e9 / HBM_PEAK_GBS, 4) if wi_avg_s > 0 else 0.0,

@@ -69,6 +69,8 @@ SIGNATURES = {
     "dmvs_warp_volume_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dmvs_getcost_f32": [C.POINTER(GetCostDesc), _P],
     "dmvs_getcost_gather_f32": [C.POINTER(GetCostDesc), _P],
+    "dmvs_getcost_quad_f32": [C.POINTER(GetCostDesc), _P],
+    "dmvs_warp_corr_init_quad_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "dmvs_warp_corr_init_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "dmvs_getcost_bwd_f32": [C.POINTER(GetCostDesc), _P, _P, _P, _P],
     "dmvs_view_aggregate_bwd_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -1,0 +1,360 @@
+// Homography warp + group-wise correlation, "quad per pixel" kernels: GetCost (reference models/module.py:583-667) and the
+// stage-1 plane sweep (module.py:514-531, differentiable_warping :181-218) for ANY geometry -- no tile windows, no pre-pass,
+// no worklists, no LDS, no barriers.
+//
+// Mapping.  A reference pixel is owned by the 4 adjacent lanes of a quad; lane q owns correlation group q.  Features are read
+// in the GROUP-INTERLEAVED channel-last layout ("NHWC-g4", see dmvs.h): a texel is C/16 units of 64 bytes, unit j =
+// [4 channels of group 0 | group 1 | group 2 | group 3], so the quad fetches one unit with ONE fully coalesced 64-byte request
+// (lane q: bytes 16q..16q+15) and every lane receives channels of its own group only -- the group dot needs no cross-lane
+// reduction at all.
+//
+// Per (pixel, view) the work is organised by distinct source TEXEL, not by hypothesis:
+//   1. the NH hypotheses of the pixel are projected ONCE, split over the quad's lanes (lane q: hypotheses q and q+4);
+//   2. the texels their 2x2 footprints touch are collected in a per-pixel bitmask over an 8x8 texel grid anchored at the
+//      minimum footprint corner (quad-wide min / or through DPP quad_perm, no LDS); consecutive hypotheses walk the epipolar
+//      line in sub-texel steps, so 6 hypotheses touch ~4-7 distinct texels instead of 24 taps;
+//   3. each set bit = one texel: fetched once (C/16 loads per lane), dotted with the lane's reference channels once
+//      (C/4 FMAs), then scattered to ALL hypotheses with the bilinear "hat" weight  max(0,1-|u-x|) * max(0,1-|v-y|)
+//      (identical to the 2x2 tap weights, and exactly zero for hypotheses the texel does not belong to): each lane
+//      evaluates the weights of its own two hypotheses, the others arrive by DPP broadcast fused into the FMA.
+//   The texel loop is a plain per-lane `while (mask)` (exec-masked, so a pixel with fewer texels issues no requests) unrolled
+//   by two so that two texels' loads are in flight per trip.
+// A pixel whose hypotheses spread over more than 8 texels along an axis (very low confidence next to a wide baseline) falls
+// back to one chunk per hypothesis: same code, NH times.
+//
+// Semantics kept from the reference: per-tap zero padding with align_corners=True pixel coordinates, NO behind-camera
+// mask, z == 0 -> z + 1e-8, non-finite coordinates sample 0.
+#include <utility>
+
+#include "dmvs_common.h"
+
+#ifndef DMVS_QUAD_PERM      // (the host emulation predefines it)
+#define DMVS_QUAD_PERM(v, ctrl) __builtin_amdgcn_mov_dpp((v), (ctrl), 0xf, 0xf, true)
+#endif
+
+namespace {
+
+constexpr int QP_XOR1 = 0xB1;      // quad_perm:[1,0,3,2]
+constexpr int QP_XOR2 = 0x4E;      // quad_perm:[2,3,0,1]
+constexpr int BIG = 0x3fffffff;
+
+template <int CTRL> __device__ __forceinline__ int qperm(int v) { return DMVS_QUAD_PERM(v, CTRL); }
+template <int CTRL> __device__ __forceinline__ float qperm(float v) { return __int_as_float(DMVS_QUAD_PERM(__float_as_int(v), CTRL)); }
+__device__ __forceinline__ int quad_min(int v) {
+    v = min(v, qperm<QP_XOR1>(v));
+    return min(v, qperm<QP_XOR2>(v));
+}
+__device__ __forceinline__ int quad_max(int v) {
+    v = max(v, qperm<QP_XOR1>(v));
+    return max(v, qperm<QP_XOR2>(v));
+}
+__device__ __forceinline__ unsigned quad_or(unsigned v) {
+    v |= (unsigned)qperm<QP_XOR1>((int)v);
+    return v | (unsigned)qperm<QP_XOR2>((int)v);
+}
+
+struct RayQ {   // p(depth) = rot * (x, y, 1) * depth + trans   (reference module.py:199-205)
+    float rx, ry, rz, tx, ty, tz;
+    __device__ __forceinline__ void init(const float* m, float x, float y) {
+        rx = m[0] * x + m[1] * y + m[2];
+        ry = m[3] * x + m[4] * y + m[5];
+        rz = m[6] * x + m[7] * y + m[8];
+        tx = m[9]; ty = m[10]; tz = m[11];
+    }
+};
+
+// one hypothesis of this lane: source coordinates, top-left texel of its footprint, whether it can touch the image at all
+struct HypQ {
+    float u, v;
+    int x0, y0;
+    bool valid;
+};
+
+__device__ __forceinline__ HypQ project_q(const RayQ& r, float depth, bool exists, int Hs, int Ws) {
+    const float px = r.rx * depth + r.tx, py = r.ry * depth + r.ty;
+    float pz = r.rz * depth + r.tz;
+    if (pz == 0.0f) pz += 1e-8f;
+    // one reciprocal (hardware estimate + one Newton step: within an ulp of the IEEE quotient) shared by u and v
+    float inv = __builtin_amdgcn_rcpf(pz);
+    inv = fmaf(fmaf(-pz, inv, 1.0f), inv, inv);
+    HypQ h;
+    h.u = px * inv;
+    h.v = py * inv;
+    const float fx = floorf(h.u), fy = floorf(h.v);
+    // false for NaN / inf; a footprint with both columns (rows) outside the image only has padding taps
+    h.valid = exists && fx >= -1.0f && fx <= (float)(Ws - 1) && fy >= -1.0f && fy <= (float)(Hs - 1);
+    h.x0 = h.valid ? (int)fx : BIG;
+    h.y0 = h.valid ? (int)fy : BIG;
+    return h;
+}
+
+// this lane's 4*U channels of one texel
+template <int U> struct TexQ { float4 v[U]; };
+
+template <int U>
+__device__ __forceinline__ void load_texel(const char* base, unsigned byte_off, TexQ<U>& t) {
+#pragma unroll
+    for (int j = 0; j < U; ++j) t.v[j] = *reinterpret_cast<const float4*>(base + byte_off + j * 64);
+}
+
+template <int U>
+__device__ __forceinline__ float dot_texel(const TexQ<U>& t, const float4 (&ref)[U]) {
+    float a = 0.0f;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        a = fmaf(t.v[j].x, ref[j].x, a);
+        a = fmaf(t.v[j].y, ref[j].y, a);
+        a = fmaf(t.v[j].z, ref[j].z, a);
+        a = fmaf(t.v[j].w, ref[j].w, a);
+    }
+    return a;
+}
+
+__device__ __forceinline__ float hat(float rel, float pos) {      // bilinear weight of integer position `pos` for coordinate `rel`
+    return fminf(fmaxf(1.0f - fabsf(rel - pos), 0.0f), 1.0f);
+}
+
+template <int K> struct Bcast {     // weight of hypothesis K: computed by lane K & 3 as its (K >> 2)-th, broadcast over the quad
+    template <int HPL>
+    static __device__ __forceinline__ float get(const float (&w)[HPL]) { return qperm<(K & 3) * 0x55>(w[K >> 2]); }
+};
+
+// acc[k] += W[k] * d for every hypothesis k, W[k] taken from lane k & 3 of the quad
+template <int NH, int HPL, int... K>
+__device__ __forceinline__ void scatter_hyps(float (&acc)[NH], const float (&w)[HPL], float d, std::integer_sequence<int, K...>) {
+    ((acc[K] = fmaf(Bcast<K>::template get<HPL>(w), d, acc[K])), ...);
+}
+
+// acc[k] += wscale * (bilinear sample of the lane's group dot at hypothesis k), k < NH, for one (pixel, view).
+// own[h] = hypothesis q + 4h of the pixel (q = lane & 3).  base + view_off = the view's [Hs,Ws,C] NHWC-g4 image (+ 16q bytes).
+template <int U, int NH>
+__device__ __forceinline__ void quad_accumulate(const char* base, unsigned view_off, const HypQ (&own)[(NH + 3) / 4], int Hs, int Ws,
+                                                const float4 (&ref)[U], float wscale, float (&acc)[NH]) {
+    constexpr int HPL = (NH + 3) / 4, C = 16 * U;
+    const int q = threadIdx.x & 3;
+    // do all hypotheses of the pixel fit one 8x8 texel grid?
+    int xlo = BIG, ylo = BIG, xhi = -BIG, yhi = -BIG;
+#pragma unroll
+    for (int h = 0; h < HPL; ++h) {
+        xlo = min(xlo, own[h].x0); ylo = min(ylo, own[h].y0);
+        xhi = max(xhi, own[h].valid ? own[h].x0 : -BIG); yhi = max(yhi, own[h].valid ? own[h].y0 : -BIG);
+    }
+    xlo = quad_min(xlo); ylo = quad_min(ylo); xhi = quad_max(xhi); yhi = quad_max(yhi);
+    if (xlo == BIG) return;                                   // no hypothesis of this pixel touches the image (quad-uniform)
+    const bool fits = xhi - xlo <= 6 && yhi - ylo <= 6;
+    const int nchunks = fits ? 1 : NH;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        bool act[HPL];
+        int ax = BIG, ay = BIG;
+#pragma unroll
+        for (int h = 0; h < HPL; ++h) {
+            act[h] = own[h].valid && (fits || q + 4 * h == ch);
+            ax = min(ax, act[h] ? own[h].x0 : BIG);
+            ay = min(ay, act[h] ? own[h].y0 : BIG);
+        }
+        const int xmin = quad_min(ax), ymin = quad_min(ay);
+        if (xmin == BIG) continue;                            // this chunk's hypothesis is invalid (quad-uniform)
+        unsigned mlo = 0, mhi = 0;
+        float ur[HPL], vr[HPL];
+#pragma unroll
+        for (int h = 0; h < HPL; ++h) {
+            const int cx = act[h] ? own[h].x0 - xmin : 0, cy = act[h] ? own[h].y0 - ymin : 0;
+            const unsigned long long bits = act[h] ? (0x0303ull << (cy * 8 + cx)) : 0ull;
+            mlo |= (unsigned)bits;
+            mhi |= (unsigned)(bits >> 32);
+            ur[h] = act[h] ? own[h].u - (float)xmin : -4.0f;     // -4: every hat weight of an inactive hypothesis is 0
+            vr[h] = act[h] ? own[h].v - (float)ymin : -4.0f;
+        }
+        mlo = quad_or(mlo);
+        mhi = quad_or(mhi);
+        unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
+        while (m != 0ull) {
+            // two texels per trip; a pixel with an odd count repeats its last texel with weight 0
+            const int b0 = __ffsll((long long)m) - 1;
+            m &= m - 1ull;
+            const bool two = m != 0ull;
+            const int b1 = two ? __ffsll((long long)m) - 1 : b0;
+            m &= m - 1ull;
+            const int c0 = b0 & 7, r0 = b0 >> 3, c1 = b1 & 7, r1 = b1 >> 3;
+            const int tx0 = xmin + c0, ty0 = ymin + r0, tx1 = xmin + c1, ty1 = ymin + r1;
+            const bool in0 = (unsigned)tx0 < (unsigned)Ws && (unsigned)ty0 < (unsigned)Hs;
+            const bool in1 = two && (unsigned)tx1 < (unsigned)Ws && (unsigned)ty1 < (unsigned)Hs;
+            const unsigned o0 = view_off + (unsigned)(min(max(ty0, 0), Hs - 1) * Ws + min(max(tx0, 0), Ws - 1)) * (unsigned)(C * 4);
+            const unsigned o1 = view_off + (unsigned)(min(max(ty1, 0), Hs - 1) * Ws + min(max(tx1, 0), Ws - 1)) * (unsigned)(C * 4);
+            TexQ<U> t0, t1;
+            load_texel<U>(base, o0, t0);
+            load_texel<U>(base, o1, t1);
+            const float d0 = dot_texel<U>(t0, ref) * (in0 ? wscale : 0.0f);      // zero padding: a texel outside contributes 0
+            const float d1 = dot_texel<U>(t1, ref) * (in1 ? wscale : 0.0f);
+            float w0[HPL], w1[HPL];
+            const float fc0 = (float)c0, fr0 = (float)r0, fc1 = (float)c1, fr1 = (float)r1;
+#pragma unroll
+            for (int h = 0; h < HPL; ++h) {
+                w0[h] = hat(ur[h], fc0) * hat(vr[h], fr0);
+                w1[h] = hat(ur[h], fc1) * hat(vr[h], fr1);
+            }
+            scatter_hyps<NH, HPL>(acc, w0, d0, std::make_integer_sequence<int, NH>{});
+            scatter_hyps<NH, HPL>(acc, w1, d1, std::make_integer_sequence<int, NH>{});
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ GetCost
+template <int C, int N>
+__global__ void __launch_bounds__(DMVS_BLOCK) getcost_quad_kernel(const dmvs_getcost_desc d) {
+    constexpr int U = C / 16, HPL = (N + 3) / 4, PPB = DMVS_BLOCK / 4;
+    const int q = threadIdx.x & 3;
+    const int H = d.H, W = d.W;
+    const long hw = (long)H * W, npix = (long)d.B * hw;
+    const long pix = (long)dmvs_xcd_contiguous_block(blockIdx.x, gridDim.x) * PPB + (threadIdx.x >> 2);
+    const bool live = pix < npix;
+    const long pq = live ? pix : npix - 1;
+    const int x = (int)(pq % W), y = (int)((pq / W) % H), b = (int)(pq / hw);
+    const long yx = (long)y * W + x, pc = (long)b * hw + yx;
+
+    // hypotheses in normalised inverse depth (reference :259-276); this lane projects hypotheses q and q + 4
+    const float cur_inv = d.inv_depth[pc];
+    float radius = (float)(N / 2) * d.interval;
+    if (d.confidence) {
+        const float r0 = d.min_radius * radius, r1 = d.max_radius * radius;
+        radius = r0 + (1.0f - d.confidence[pc]) * (r1 - r0);
+    }
+    const float lo = cur_inv - radius, hi = cur_inv + radius;
+    const float step = (hi - lo) / (float)(N - 1);
+    const float dmin = d.disp_min[b], dmax = d.disp_max[b];
+    float own_depth[HPL];
+    bool exists[HPL];
+#pragma unroll
+    for (int h = 0; h < HPL; ++h) {
+        const int k = q + 4 * h;
+        exists[h] = k < N;
+        float sk = (float)(exists[h] ? k : 0) * step;
+        sk += lo;
+        sk = fminf(fmaxf(sk, 0.0f), 1.0f);
+        own_depth[h] = dmvs_disp_to_depth(sk, dmin, dmax);
+        if (live && exists[h]) d.out_samples[((long)b * d.samp_cstride + d.samp_coffset + k) * hw + yx] = sk;
+    }
+
+    float4 ref[U];
+    {
+        const float inv_cg = 1.0f / (float)(C / 4);       // mean over the channels of a group
+        const float4* rp = reinterpret_cast<const float4*>(d.ref + pc * C + q * 4);
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const float4 v = rp[j * 4];
+            ref[j] = make_float4(v.x * inv_cg, v.y * inv_cg, v.z * inv_cg, v.w * inv_cg);
+        }
+    }
+
+    float acc[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc[k] = 0.0f;
+    float wsum = 1e-8f;
+    const int Hv = H >> d.vw_shift, Wv = W >> d.vw_shift;
+    const long vwi = (long)(y >> d.vw_shift) * Wv + (x >> d.vw_shift);
+    const char* base = reinterpret_cast<const char*>(d.src);
+    for (int s = 0; s < d.S; ++s) {
+        const float w = d.view_w[((long)b * d.S + s) * Hv * Wv + vwi];
+        wsum += w;
+        RayQ ray;
+        ray.init(d.rt + ((long)b * d.S + s) * 12, (float)x, (float)y);
+        HypQ own[HPL];
+#pragma unroll
+        for (int h = 0; h < HPL; ++h) own[h] = project_q(ray, own_depth[h], exists[h], H, W);
+        const unsigned view_off = (unsigned)((((long)s * d.B + b) * hw * C + q * 4) * 4);
+        quad_accumulate<U, N>(base, view_off, own, H, W, ref, w, acc);
+    }
+    if (live) {
+        const float inv_w = 1.0f / wsum;
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            d.out_cost[((long)b * d.cost_cstride + d.cost_coffset + q * N + k) * hw + yx] = acc[k] * inv_w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ stage-1 plane sweep
+// grid = (pixel blocks, S); planes in chunks of 8 (lane q projects planes d0 + q and d0 + q + 4).  out [B,S,4,D,H,W].
+template <int C>
+__global__ void __launch_bounds__(DMVS_BLOCK)
+warp_init_quad_kernel(const float* __restrict__ ref_f, const float* __restrict__ src, const float* __restrict__ rt,
+                      const float* __restrict__ disp_min, const float* __restrict__ disp_max, float* __restrict__ out, int B, int S,
+                      int D, int H, int W, int Hs, int Ws) {
+    constexpr int U = C / 16, NB = 8, HPL = 2, PPB = DMVS_BLOCK / 4;
+    const int q = threadIdx.x & 3;
+    const long hw = (long)H * W, npix = (long)B * hw;
+    const long pix = (long)dmvs_xcd_contiguous_block(blockIdx.x, gridDim.x) * PPB + (threadIdx.x >> 2);
+    const bool live = pix < npix;
+    const long pq = live ? pix : npix - 1;
+    const int x = (int)(pq % W), y = (int)((pq / W) % H), b = (int)(pq / hw);
+    const int s = blockIdx.y;
+
+    float4 ref[U];
+    {
+        const float inv_cg = 1.0f / (float)(C / 4);
+        const float4* rp = reinterpret_cast<const float4*>(ref_f + pq * C + q * 4);
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const float4 v = rp[j * 4];
+            ref[j] = make_float4(v.x * inv_cg, v.y * inv_cg, v.z * inv_cg, v.w * inv_cg);
+        }
+    }
+    RayQ ray;
+    ray.init(rt + ((long)b * S + s) * 12, (float)x, (float)y);
+    const char* base = reinterpret_cast<const char*>(src);
+    const unsigned view_off = (unsigned)((((long)s * B + b) * (long)Hs * Ws * C + q * 4) * 4);
+    const float dmin = disp_min[b], dmax = disp_max[b];
+    const float dm1 = (float)(D - 1);
+    float* op = out + ((((long)b * S + s) * 4 + q) * D) * hw + (long)y * W + x;
+    for (int d0 = 0; d0 < D; d0 += NB) {
+        HypQ own[HPL];
+#pragma unroll
+        for (int h = 0; h < HPL; ++h) {
+            const int dk = d0 + q + 4 * h;
+            own[h] = project_q(ray, dmvs_disp_to_depth((float)min(dk, D - 1) / dm1, dmin, dmax), dk < D, Hs, Ws);
+        }
+        float acc[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) acc[k] = 0.0f;
+        quad_accumulate<U, NB>(base, view_off, own, Hs, Ws, ref, 1.0f, acc);
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k)
+                if (d0 + k < D) op[(long)(d0 + k) * hw] = acc[k];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int dmvs_getcost_quad_f32(const dmvs_getcost_desc* dp, void* stream) {
+    if (!dp) return DMVS_EINVAL;
+    const dmvs_getcost_desc& d = *dp;
+    if (d.G != 4 || !d.ref || !d.src || !d.rt || !d.inv_depth || !d.view_w || !d.out_cost || !d.out_samples) return DMVS_EINVAL;
+    if ((long)d.S * d.B * d.H * d.W * d.C * 4 >= (1L << 32)) return DMVS_EINVAL;   // 32-bit byte offsets over the source stack
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(dmvs_ceil_div((long)d.B * d.H * d.W, DMVS_BLOCK / 4)), block(DMVS_BLOCK);
+#define DMVS_GCQ(CC, NN) hipLaunchKernelGGL((getcost_quad_kernel<CC, NN>), grid, block, 0, st, d)
+    if (d.C == 32 && d.n == 6) DMVS_GCQ(32, 6);
+    else if (d.C == 32 && d.n == 4) DMVS_GCQ(32, 4);
+    else if (d.C == 16 && d.n == 4) DMVS_GCQ(16, 4);
+    else if (d.C == 16 && d.n == 6) DMVS_GCQ(16, 6);
+    else if (d.C == 48 && d.n == 4) DMVS_GCQ(48, 4);
+    else if (d.C == 48 && d.n == 6) DMVS_GCQ(48, 6);
+    else return DMVS_EINVAL;
+#undef DMVS_GCQ
+    return dmvs_launch_status();
+}
+
+extern "C" int dmvs_warp_corr_init_quad_f32(const float* ref, const float* src, const float* rt, const float* disp_min,
+                                            const float* disp_max, float* out, int32_t B, int32_t S, int32_t C, int32_t G,
+                                            int32_t D, int32_t H, int32_t W, int32_t Hs, int32_t Ws, void* stream) {
+    if (G != 4 || D < 2 || !ref || !src || !rt || !out) return DMVS_EINVAL;
+    if ((long)S * B * Hs * Ws * C * 4 >= (1L << 32)) return DMVS_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(dmvs_ceil_div((long)B * H * W, DMVS_BLOCK / 4), S), block(DMVS_BLOCK);
+    if (C == 48) hipLaunchKernelGGL((warp_init_quad_kernel<48>), grid, block, 0, st, ref, src, rt, disp_min, disp_max, out, B, S, D, H, W, Hs, Ws);
+    else if (C == 32) hipLaunchKernelGGL((warp_init_quad_kernel<32>), grid, block, 0, st, ref, src, rt, disp_min, disp_max, out, B, S, D, H, W, Hs, Ws);
+    else if (C == 16) hipLaunchKernelGGL((warp_init_quad_kernel<16>), grid, block, 0, st, ref, src, rt, disp_min, disp_max, out, B, S, D, H, W, Hs, Ws);
+    else return DMVS_EINVAL;
+    return dmvs_launch_status();
+}

@@ -14,6 +14,7 @@ Reference call graph followed (models/diffusion.py:139-295):
 from __future__ import annotations
 
 import math
+import os
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -36,18 +37,21 @@ def _cw(sd, p, **kw):
                        bn=_bn(sd, p + ".bn") if (p + ".bn.weight") in sd else None, **kw)
 
 
-def pack_feature(sd, p="feature"):
-    """FeatureNet weights (models/module.py:357-420)."""
+def pack_feature(sd, p="feature", g4=False):
+    """FeatureNet weights (models/module.py:357-420).  g4: the output convolutions emit their channels in the
+    group-interleaved NHWC-g4 order the quad-per-pixel warp kernels read (an output-channel permutation of the weights:
+    free at run time)."""
+    order = (lambda w: w[K.g4_channels(w.shape[0]).to(w.device)].contiguous()) if g4 else (lambda w: w)
     f = {"conv0.0": _cw(sd, p + ".conv0.0", pad=1), "conv0.1": _cw(sd, p + ".conv0.1", pad=1)}
     for i in (1, 2, 3):
         f[f"conv{i}.0"] = _cw(sd, f"{p}.conv{i}.0", stride=2, pad=2)
         f[f"conv{i}.1"], f[f"conv{i}.2"] = _cw(sd, f"{p}.conv{i}.1", pad=1), _cw(sd, f"{p}.conv{i}.2", pad=1)
-    f["out1"] = pack_conv2d(sd[p + ".out1.weight"])
+    f["out1"] = pack_conv2d(order(sd[p + ".out1.weight"]))
     f["inner1"] = pack_conv2d(sd[p + ".inner1.weight"], sd[p + ".inner1.bias"])
-    f["out2"] = pack_conv2d(sd[p + ".out2.weight"], pad=1)
+    f["out2"] = pack_conv2d(order(sd[p + ".out2.weight"]), pad=1)
     if (p + ".out3.weight") in sd:
         f["inner2"] = pack_conv2d(sd[p + ".inner2.weight"], sd[p + ".inner2.bias"])
-        f["out3"] = pack_conv2d(sd[p + ".out3.weight"], pad=1)
+        f["out3"] = pack_conv2d(order(sd[p + ".out3.weight"]), pad=1)
     return f
 
 
@@ -330,7 +334,10 @@ class Engine:
         self.up_ratio = 2 if self.cas else 4
         self.G = args.cost_dim_stage[0]
         self.G_cost = args.cost_dim_stage[1]
-        self.feat = pack_feature(sd, "feature")
+        # warp kernels: "quad" = quad-per-pixel kernels on NHWC-g4 features (warp_quad.hip, one launch for any geometry);
+        # "legacy" = the LDS-window / per-pixel-gather pair of round 1 on plain NHWC features (kept for A/B runs)
+        self.quad = os.environ.get("DMVS_WARP", "quad") != "legacy"
+        self.feat = pack_feature(sd, "feature", g4=self.quad)
         self.ctx = pack_context_trunk(sd, "context")
         # ContextNet output heads split into their hidden | context halves (diffusion.py:223-231): the
         # context half is written straight into the Unet input buffer, the hidden half feeds hidden_init
@@ -374,7 +381,8 @@ class Engine:
         o = self.ops
         B, H, W, _ = ref.shape
         S = src.shape[0]
-        cor = o.warp_corr_init(ref, src, rt, disp_min, disp_max, D, self.G)            # [B,S,G,D,H,W]
+        warp_init = o.warp_corr_init_quad if self.quad else o.warp_corr_init
+        cor = warp_init(ref, src, rt, disp_min, disp_max, D, self.G)                    # [B,S,G,D,H,W]
         vw = run_pvw(o, self.pvw, cor.view(B * S, self.G, D, H, W)).view(B, S, H, W)
         agg = o.view_aggregate(cor, vw)
         logits = run_costreg(o, self.reg, agg)                                          # [B,1,D,H,W]
@@ -406,9 +414,13 @@ class Engine:
             img, img_scale = delta, 1.0
             cur_hidden, confidence = hidden, None
             for it in range(ub.iters):
-                cost, samples = o.getcost(feats_ref, feats_src, rt, new, confidence, view_w, disp_min, disp_max, n,
-                                          interval, a.min_radius, a.max_radius, vw_shift, G=self.G_cost,
-                                          policy_key=(vw_shift, it))
+                if self.quad:
+                    cost, samples = o.getcost_quad(feats_ref, feats_src, rt, new, confidence, view_w, disp_min, disp_max, n,
+                                                   interval, a.min_radius, a.max_radius, vw_shift, G=self.G_cost)
+                else:
+                    cost, samples = o.getcost(feats_ref, feats_src, rt, new, confidence, view_w, disp_min, disp_max, n,
+                                              interval, a.min_radius, a.max_radius, vw_shift, G=self.G_cost,
+                                              policy_key=(vw_shift, it))
                 run_encoder(o, ub.enc, cost, samples, out=X, out_cstride=2 * cd, out_coffset=cd)
                 cur_hidden, upd, conf = run_unet(o, self.arena, ub, X, cur_hidden, ss_of)
                 confidence = conf.view(B, H, W)

@@ -102,6 +102,15 @@ def pack_conv3d(w: torch.Tensor, bias=None, bn: Optional[dict] = None, stride=1,
                       transposed)
 
 
+def g4_channels(C: int) -> torch.Tensor:
+    """Channel order of the GROUP-INTERLEAVED channel-last feature layout "NHWC-g4" the quad-per-pixel warp kernels read
+    (include/dmvs.h): position p of a texel holds channel  c(p) = ((p // 4) % 4) * (C // 4) + (p // 16) * 4 + p % 4,
+    i.e. x_g4 = x_nhwc[..., g4_channels(C)].  The engine folds this permutation into the weights of FeatureNet's output
+    convolutions; tests and the module-level GetCost use it on plain tensors."""
+    p = torch.arange(C)
+    return ((p // 4) % 4) * (C // 4) + (p // 16) * 4 + p % 4
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -302,6 +311,38 @@ class Ops:
         self._call("dmvs_warp_corr_init_gather_f32" if gather else "dmvs_warp_corr_init_f32", _ptr(ref), _ptr(src), _ptr(rt),
                    _ptr(disp_min), _ptr(disp_max), _ptr(out), B, S, Cc, G, D, H, W, Hs, Ws, self.stream())
         return out
+
+    def warp_corr_init_quad(self, ref, src, rt, disp_min, disp_max, D, G=4):
+        """quad-per-pixel plane sweep: ref [B,H,W,C], src [S,B,Hs,Ws,C] in the NHWC-g4 channel order -> [B,S,G,D,H,W]"""
+        self._chk(ref, src, rt, disp_min, disp_max)
+        B, H, W, Cc = ref.shape
+        S, _, Hs, Ws, _ = src.shape
+        out = self.empty(B, S, G, D, H, W)
+        self._call("dmvs_warp_corr_init_quad_f32", _ptr(ref), _ptr(src), _ptr(rt), _ptr(disp_min), _ptr(disp_max), _ptr(out),
+                   B, S, Cc, G, D, H, W, Hs, Ws, self.stream())
+        return out
+
+    def getcost_quad(self, ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, min_radius,
+                     max_radius, vw_shift, out_cost=None, cost_cstride=None, cost_coffset=0, out_samples=None,
+                     samp_cstride=None, samp_coffset=0, G=4):
+        """quad-per-pixel GetCost, one launch for any geometry; ref / src in the NHWC-g4 channel order"""
+        self._chk(ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, out_cost, out_samples)
+        B, H, W, Cc = ref.shape
+        S = src.shape[0]
+        if out_cost is None:
+            cost_cstride = G * n
+            out_cost = self.empty(B, G * n, H, W)
+        if out_samples is None:
+            samp_cstride = n
+            out_samples = self.empty(B, n, H, W)
+        d = _lib.GetCostDesc(ref=_ptr(ref), src=_ptr(src), rt=_ptr(rt), inv_depth=_ptr(inv_depth),
+                             confidence=_ptr(confidence), view_w=_ptr(view_w), disp_min=_ptr(disp_min),
+                             disp_max=_ptr(disp_max), out_cost=_ptr(out_cost), out_samples=_ptr(out_samples),
+                             worklist=None, B=B, S=S, C=Cc, G=G, n=n, H=H, W=W, vw_shift=vw_shift, cost_cstride=cost_cstride,
+                             cost_coffset=cost_coffset, samp_cstride=samp_cstride, samp_coffset=samp_coffset,
+                             interval=interval, min_radius=min_radius, max_radius=max_radius)
+        self._call("dmvs_getcost_quad_f32", C.byref(d), self.stream())
+        return out_cost, out_samples
 
     def warp_volume(self, src, rt, depth):
         """differentiable_warping: src [B,C,Hs,Ws], rt [B,12], depth [B,D,H,W] -> [B,C,D,H,W]."""

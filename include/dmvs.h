@@ -225,6 +225,22 @@ int dmvs_getcost_f32(const dmvs_getcost_desc* d, void* stream);
 /* Same contract, everything on path (2) regardless of `worklist`.  Kept public for A/B measurements. */
 int dmvs_getcost_gather_f32(const dmvs_getcost_desc* d, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * "Quad per pixel" variants of the two fused warp kernels (warp_quad.hip): same arithmetic contracts as
+ * dmvs_getcost_f32 / dmvs_warp_corr_init_f32, any geometry in ONE launch (no LDS windows, no pre-pass, `worklist`
+ * ignored), C in {16,32,48}.  The feature tensors `ref` / `src` are read in the GROUP-INTERLEAVED channel-last layout
+ * "NHWC-g4": a texel is C/16 units of 16 floats, unit j = [ch 4j..4j+3 of group 0 | of group 1 | of group 2 | of group 3]
+ * (group g = channels g*C/4 .. (g+1)*C/4 - 1 of the reference's NCHW tensor), i.e.
+ *     position p of a texel holds channel  c(p) = ((p / 4) % 4) * (C / 4) + (p / 16) * 4 + p % 4,
+ * so that the 4 lanes of a pixel fetch 64 contiguous bytes and each receives channels of its own correlation group.
+ * The inference engine has FeatureNet's output convolutions emit this layout directly (output-channel permutation of
+ * their weights); diffmvs_amd.ops.g4_channels(C) is the permutation for callers that hold plain NHWC tensors. */
+int dmvs_getcost_quad_f32(const dmvs_getcost_desc* d, void* stream);
+int dmvs_warp_corr_init_quad_f32(const float* ref, const float* src, const float* rt,
+                                 const float* disp_min, const float* disp_max, float* out,
+                                 int32_t B, int32_t S, int32_t C, int32_t G, int32_t D,
+                                 int32_t H, int32_t W, int32_t Hs, int32_t Ws, void* stream);
+
 /* Stand-alone differentiable_warping (models/module.py:181-218) in the reference's layouts:
  * src [B,C,Hs,Ws] NCHW, rt [B,12] (rot row-major, trans) = src_proj * inverse(ref_proj),
  * depth [B,D,H,W] metric -> out [B,C,D,H,W].  Not used by the model's fused path. */

@@ -308,5 +308,14 @@ static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline int __mul24(int a, int b) { return a * b; }
 // only ever applied to wave-uniform values (the wave index): identity under one-fiber-per-thread emulation
 static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }
+// DPP quad_perm: lane l of every quad reads lane (ctrl >> 2*(l&3)) & 3 of the same quad
+static inline int hipemu_quad_perm(int v, int ctrl) {
+    const int t = hipemu::linear_tid(), lane = t & 63;
+    return hipemu::shfl_from(v, (t & ~63) + ((lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3)));
+}
+#define DMVS_QUAD_PERM(v, ctrl) hipemu_quad_perm((v), (ctrl))
+static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+static inline float __int_as_float(int v) { float f; memcpy(&f, &v, 4); return f; }
+static inline int __float_as_int(float f) { int v; memcpy(&v, &f, 4); return v; }
 #define DMVS_ORDER_AFTER(var, dep) ((void)0)
 #define DMVS_LDS_BARRIER() __syncthreads()

@@ -753,3 +753,109 @@ def test_groupnorm_silu_autograd(ops, B, C_, H, W, with_ss):
     close(bd.grad, beta.grad, 1e-4)
     if with_ss:
         close(sd.grad, ss.grad, 1e-4)
+
+
+# ------------------------------------------------------------------------------------------ quad-per-pixel warp kernels
+def _g4(x_nhwc):
+    from diffmvs_amd.ops import g4_channels
+    return x_nhwc[..., g4_channels(x_nhwc.shape[-1])].contiguous()
+
+
+def test_g4_channel_order():
+    from diffmvs_amd.ops import g4_channels
+    for C in (16, 32, 48):
+        p = g4_channels(C)
+        assert sorted(p.tolist()) == list(range(C))
+        # lane q of a quad reads positions 16j + 4q .. 16j + 4q + 3: all channels of group q, in order
+        for q in range(4):
+            got = torch.cat([p[16 * j + 4 * q: 16 * j + 4 * q + 4] for j in range(C // 16)])
+            assert got.tolist() == list(range(q * C // 4, (q + 1) * C // 4))
+
+
+@pytest.mark.parametrize("C,n,interval,H,W,with_conf", [(32, 6, 2.0 / 384, 20, 28, True), (16, 4, 1.0 / 384, 18, 25, True),
+                                                        (32, 6, 0.15, 12, 20, True), (16, 4, 0.3, 10, 18, False),
+                                                        (48, 4, 2.0 / 384, 9, 13, False), (32, 4, 0.0, 8, 8, False)])
+def test_getcost_quad(ops, C, n, interval, H, W, with_conf):
+    """quad-per-pixel GetCost (any geometry in one launch): small intervals = the 8x8 texel grid path, the large ones spread
+    a pixel's hypotheses over more than 8 texels (per-hypothesis chunks); hypotheses clamped at both ends; interval 0 =
+    all hypotheses identical.  Against the oracle and the per-pixel gather kernel."""
+    B, S = 2, 3
+    pm = _cams(B, S + 1, H, W, 2)
+    feats = [rnd(B, C, H, W, seed=40 + v) for v in range(S + 1)]
+    inv = rnd(B, 1, H, W, seed=50, lo=-0.05, hi=1.05)
+    conf = rnd(B, H, W, seed=51, lo=0.0, hi=1.0) if with_conf else None
+    vw = rnd(B, S, H // 2, W // 2, seed=52, lo=0.0, hi=1.0)
+    dv0, dv1 = torch.tensor([1 / 935.0, 1 / 700.0]), torch.tensor([1 / 425.0, 1 / 450.0])
+    dmax, dmin = (1 / dv0).view(-1, 1, 1, 1), (1 / dv1).view(-1, 1, 1, 1)
+    Hv, Wv = (H // 2) * 2, (W // 2) * 2
+    want_cost, want_s = O.get_cost([f[:, :, :Hv, :Wv] for f in feats], pm, inv[:, :, :Hv, :Wv], interval, dmax, dmin, n,
+                                   F.interpolate(vw, scale_factor=2, mode="nearest"),
+                                   None if conf is None else conf[:, :Hv, :Wv], 4, 0.25, 4.0) if (Hv, Wv) == (H, W) else (None, None)
+    rt = ops.compose_proj(dev(ops, pm))
+    ref = feats[0].permute(0, 2, 3, 1)
+    src = torch.stack([f.permute(0, 2, 3, 1) for f in feats[1:]])
+    tail = (rt, dev(ops, inv), None if conf is None else dev(ops, conf), dev(ops, vw), dev(ops, 1 / (1 / dv0)), dev(ops, 1 / (1 / dv1)),
+            n, interval, 0.25, 4.0)
+    cost, samp = ops.getcost_quad(dev(ops, _g4(ref)), dev(ops, _g4(src)), *tail, vw_shift=1)
+    cost_g, samp_g = ops.getcost(dev(ops, ref), dev(ops, src), *tail, vw_shift=1, gather=True)
+    if want_cost is not None:
+        close(samp, want_s, 1e-6)
+        close(cost, want_cost, 1e-4)
+    close(samp, samp_g.cpu(), 1e-7)
+    close(cost, cost_g.cpu(), 2e-5)
+
+
+def test_getcost_quad_extreme_geometry(ops, golden):
+    """the reference's own warping edge cases (mild, large rotation, camera looking backwards, source grid != hypothesis
+    grid) through the quad-per-pixel GetCost kernel; same construction as test_getcost_extreme_geometry"""
+    g = golden("warp_edge.npz")
+    for ci in (0, 1, 2, 3):
+        src, depth, want = g.t(f"c{ci}.src"), g.t(f"c{ci}.depth"), g.t(f"c{ci}.out")
+        B, Cc, Hs, Ws = src.shape
+        D, H, W = depth.shape[1:]
+        Hc, Wc = max(H, Hs), max(W, Ws)
+        srcp = torch.zeros(B, 16, Hc, Wc)
+        srcp[:, :Cc, :Hs, :Ws] = src
+        P = torch.matmul(g.t(f"c{ci}.src_proj"), torch.inverse(g.t(f"c{ci}.ref_proj")))
+        rt = torch.cat([P[:, :3, :3].reshape(B, 9), P[:, :3, 3]], 1).view(B, 1, 12)
+        lo, hi = torch.full((B,), 1 / 2000.0), torch.full((B,), 1 / 100.0)
+        for d in range(D):
+            dpl = torch.full((B, 1, Hc, Wc), 500.0)
+            dpl[:, :, :H, :W] = depth[:, d:d + 1]
+            inv = ((1 / dpl) - lo.view(-1, 1, 1, 1)) / (hi - lo).view(-1, 1, 1, 1)
+            w = want[:, :, d].sum(1)
+            cost, samp = ops.getcost_quad(dev(ops, torch.ones(B, Hc, Wc, 16)), dev(ops, _g4(srcp.permute(0, 2, 3, 1)).unsqueeze(0)),
+                                          dev(ops, rt), dev(ops, inv.contiguous()), None, dev(ops, torch.ones(B, 1, Hc, Wc)),
+                                          dev(ops, lo), dev(ops, hi), 4, 0.0, 1.0, 1.0, vw_shift=0)
+            cost = cost.cpu()
+            got = (cost[:, 0] + cost[:, 4] + cost[:, 8] + cost[:, 12])[:, :H, :W] * 4.0
+            assert float((got - w).abs().mean()) <= 2e-3 * max(1.0, float(w.abs().mean())), (ci, d)
+
+
+@pytest.mark.parametrize("C,H,W,D,scene", [(48, 20, 28, 16, True), (48, 18, 15, 48, True), (48, 12, 20, 9, False), (32, 11, 14, 7, False),
+                                           (16, 11, 14, 10, False)])
+def test_warp_corr_init_quad(ops, C, H, W, D, scene):
+    """quad-per-pixel plane sweep: planes in chunks of 8 (ragged last chunk), synthetic cameras and strongly rotated ones
+    (chunks whose planes spread over more than 8 texels take the per-plane path).  Against the oracle and the per-pixel kernel."""
+    B, S = 2, 3
+    feats = [rnd(B, C, H, W, seed=80 + v) for v in range(S + 1)]
+    if scene:
+        _, proj, dvs = synth.synth_inputs(H * 8, W * 8, S, B=B, seed=7)
+        pm = proj["stage1"]
+        dv = torch.stack([dvs[:, 0], dvs[:, -1]], 1)
+    else:
+        pm = _cams(B, S + 1, H, W, 9)
+        dv = torch.tensor([[1 / 935.0, 1 / 425.0], [1 / 800.0, 1 / 500.0]])
+    disp_min, disp_max = dv[:, 0].contiguous(), dv[:, 1].contiguous()
+    hyp = (torch.arange(D).view(1, -1, 1, 1) / (D - 1.0)).repeat(B, 1, H, W)
+    hyp = O.disp_to_depth(hyp, (1 / dv[:, 1]).view(-1, 1, 1, 1), (1 / dv[:, 0]).view(-1, 1, 1, 1))[1]
+    ref_proj = O.compose_proj(pm[:, 0])
+    want = torch.stack([O.group_corr(O.warp(feats[v], O.compose_proj(pm[:, v]), ref_proj, hyp), feats[0], 4)
+                        for v in range(1, S + 1)], 1)
+    rt = ops.compose_proj(dev(ops, pm))
+    ref_nhwc = feats[0].permute(0, 2, 3, 1)
+    src_nhwc = torch.stack([f.permute(0, 2, 3, 1) for f in feats[1:]])
+    out = ops.warp_corr_init_quad(dev(ops, _g4(ref_nhwc)), dev(ops, _g4(src_nhwc)), rt, dev(ops, disp_min), dev(ops, disp_max), D)
+    out_g = ops.warp_corr_init(dev(ops, ref_nhwc), dev(ops, src_nhwc), rt, dev(ops, disp_min), dev(ops, disp_max), D, gather=True)
+    close(out, want, 1e-4)
+    close(out, out_g.cpu(), 2e-5)
