@@ -114,16 +114,51 @@ __device__ __forceinline__ float hat(float rel, float pos) {      // bilinear we
     return fminf(fmaxf(1.0f - fabsf(rel - pos), 0.0f), 1.0f);
 }
 
-template <int K> struct Bcast {     // weight of hypothesis K: computed by lane K & 3 as its (K >> 2)-th, broadcast over the quad
-    template <int HPL>
-    static __device__ __forceinline__ float get(const float (&w)[HPL]) { return qperm<(K & 3) * 0x55>(w[K >> 2]); }
-};
-
-// acc[k] += W[k] * d for every hypothesis k, W[k] taken from lane k & 3 of the quad
+// acc[k] += W0[k] * d0 + W1[k] * d1 for every hypothesis k of the pixel: W.[k] lives in lane k & 3 of the quad as that lane's
+// (k >> 2)-th weight and is read through DPP quad_perm inside the FMA itself (v_fmac_f32_dpp: no broadcast moves).  One asm
+// block per texel pair; the leading s_nop covers the VALU-write -> DPP-read hazard of the weights computed just before.
+#ifdef DMVS_HOST_EMULATION
+template <int K, int HPL>
+__device__ __forceinline__ float bcast_w(const float (&w)[HPL]) { return qperm<(K & 3) * 0x55>(w[K >> 2]); }
 template <int NH, int HPL, int... K>
-__device__ __forceinline__ void scatter_hyps(float (&acc)[NH], const float (&w)[HPL], float d, std::integer_sequence<int, K...>) {
-    ((acc[K] = fmaf(Bcast<K>::template get<HPL>(w), d, acc[K])), ...);
+__device__ __forceinline__ void scatter_seq(float (&acc)[NH], const float (&w0)[HPL], float d0, const float (&w1)[HPL], float d1,
+                                            std::integer_sequence<int, K...>) {
+    ((acc[K] = fmaf(bcast_w<K, HPL>(w0), d0, acc[K])), ...);
+    ((acc[K] = fmaf(bcast_w<K, HPL>(w1), d1, acc[K])), ...);
 }
+template <int NH, int HPL>
+__device__ __forceinline__ void scatter_pair(float (&acc)[NH], const float (&w0)[HPL], float d0, const float (&w1)[HPL], float d1) {
+    scatter_seq<NH, HPL>(acc, w0, d0, w1, d1, std::make_integer_sequence<int, NH>{});
+}
+#else
+#define DMVS_QF(A, W, D, L) "v_fmac_f32_dpp %" #A ", %" #W ", %" #D " quad_perm:[" #L "," #L "," #L "," #L "] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+template <int NH, int HPL>
+__device__ __forceinline__ void scatter_pair(float (&acc)[NH], const float (&w0)[HPL], float d0, const float (&w1)[HPL], float d1) {
+    if constexpr (NH == 4) {
+        asm("s_nop 1\n\t"
+            DMVS_QF(0, 4, 6, 0) DMVS_QF(1, 4, 6, 1) DMVS_QF(2, 4, 6, 2) DMVS_QF(3, 4, 6, 3)
+            DMVS_QF(0, 5, 7, 0) DMVS_QF(1, 5, 7, 1) DMVS_QF(2, 5, 7, 2) DMVS_QF(3, 5, 7, 3)
+            : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+            : "v"(w0[0]), "v"(w1[0]), "v"(d0), "v"(d1));
+    } else if constexpr (NH == 6) {
+        asm("s_nop 1\n\t"
+            DMVS_QF(0, 6, 10, 0) DMVS_QF(1, 6, 10, 1) DMVS_QF(2, 6, 10, 2) DMVS_QF(3, 6, 10, 3) DMVS_QF(4, 7, 10, 0) DMVS_QF(5, 7, 10, 1)
+            DMVS_QF(0, 8, 11, 0) DMVS_QF(1, 8, 11, 1) DMVS_QF(2, 8, 11, 2) DMVS_QF(3, 8, 11, 3) DMVS_QF(4, 9, 11, 0) DMVS_QF(5, 9, 11, 1)
+            : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5])
+            : "v"(w0[0]), "v"(w0[1]), "v"(w1[0]), "v"(w1[1]), "v"(d0), "v"(d1));
+    } else {
+        static_assert(NH == 8, "scatter_pair: 4, 6 or 8 hypotheses");
+        asm("s_nop 1\n\t"
+            DMVS_QF(0, 8, 12, 0) DMVS_QF(1, 8, 12, 1) DMVS_QF(2, 8, 12, 2) DMVS_QF(3, 8, 12, 3)
+            DMVS_QF(4, 9, 12, 0) DMVS_QF(5, 9, 12, 1) DMVS_QF(6, 9, 12, 2) DMVS_QF(7, 9, 12, 3)
+            DMVS_QF(0, 10, 13, 0) DMVS_QF(1, 10, 13, 1) DMVS_QF(2, 10, 13, 2) DMVS_QF(3, 10, 13, 3)
+            DMVS_QF(4, 11, 13, 0) DMVS_QF(5, 11, 13, 1) DMVS_QF(6, 11, 13, 2) DMVS_QF(7, 11, 13, 3)
+            : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+            : "v"(w0[0]), "v"(w0[1]), "v"(w1[0]), "v"(w1[1]), "v"(d0), "v"(d1));
+    }
+}
+#undef DMVS_QF
+#endif
 
 // acc[k] += wscale * (bilinear sample of the lane's group dot at hypothesis k), k < NH, for one (pixel, view).
 // own[h] = hypothesis q + 4h of the pixel (q = lane & 3).  base + view_off = the view's [Hs,Ws,C] NHWC-g4 image (+ 16q bytes).
@@ -168,6 +203,16 @@ __device__ __forceinline__ void quad_accumulate(const char* base, unsigned view_
         mlo = quad_or(mlo);
         mhi = quad_or(mhi);
         unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
+        {
+            // texels outside the image are grid_sample's zero padding: drop their bits here, so that the loop below needs
+            // neither bounds tests nor clamped addresses.  xmin, ymin >= -1 (footprints with both columns / rows outside are
+            // invalid hypotheses) and <= size - 1, so at most the first column / row and a trailing run fall outside.
+            const int clo = xmin < 0 ? 1 : 0, chi = min(8, Ws - xmin), rlo = ymin < 0 ? 1 : 0, rhi = min(8, Hs - ymin);
+            const unsigned colbits = (0xffu >> (8 - chi)) & (0xffu << clo) & 0xffu;
+            const unsigned long long rowmask = (~0ull >> (64 - 8 * rhi)) & (~0ull << (8 * rlo));
+            m &= rowmask & ((unsigned long long)colbits * 0x0101010101010101ull);
+        }
+        const unsigned texel_off = view_off + (unsigned)(__mul24(ymin, Ws) + xmin) * (unsigned)(C * 4);    // of grid cell (0, 0)
         while (m != 0ull) {
             // two texels per trip; a pixel with an odd count repeats its last texel with weight 0
             const int b0 = __ffsll((long long)m) - 1;
@@ -176,16 +221,13 @@ __device__ __forceinline__ void quad_accumulate(const char* base, unsigned view_
             const int b1 = two ? __ffsll((long long)m) - 1 : b0;
             m &= m - 1ull;
             const int c0 = b0 & 7, r0 = b0 >> 3, c1 = b1 & 7, r1 = b1 >> 3;
-            const int tx0 = xmin + c0, ty0 = ymin + r0, tx1 = xmin + c1, ty1 = ymin + r1;
-            const bool in0 = (unsigned)tx0 < (unsigned)Ws && (unsigned)ty0 < (unsigned)Hs;
-            const bool in1 = two && (unsigned)tx1 < (unsigned)Ws && (unsigned)ty1 < (unsigned)Hs;
-            const unsigned o0 = view_off + (unsigned)(min(max(ty0, 0), Hs - 1) * Ws + min(max(tx0, 0), Ws - 1)) * (unsigned)(C * 4);
-            const unsigned o1 = view_off + (unsigned)(min(max(ty1, 0), Hs - 1) * Ws + min(max(tx1, 0), Ws - 1)) * (unsigned)(C * 4);
+            const unsigned o0 = texel_off + (unsigned)(__mul24(r0, Ws) + c0) * (unsigned)(C * 4);
+            const unsigned o1 = texel_off + (unsigned)(__mul24(r1, Ws) + c1) * (unsigned)(C * 4);
             TexQ<U> t0, t1;
             load_texel<U>(base, o0, t0);
             load_texel<U>(base, o1, t1);
-            const float d0 = dot_texel<U>(t0, ref) * (in0 ? wscale : 0.0f);      // zero padding: a texel outside contributes 0
-            const float d1 = dot_texel<U>(t1, ref) * (in1 ? wscale : 0.0f);
+            const float d0 = dot_texel<U>(t0, ref) * wscale;
+            const float d1 = dot_texel<U>(t1, ref) * (two ? wscale : 0.0f);
             float w0[HPL], w1[HPL];
             const float fc0 = (float)c0, fr0 = (float)r0, fc1 = (float)c1, fr1 = (float)r1;
 #pragma unroll
@@ -193,8 +235,7 @@ __device__ __forceinline__ void quad_accumulate(const char* base, unsigned view_
                 w0[h] = hat(ur[h], fc0) * hat(vr[h], fr0);
                 w1[h] = hat(ur[h], fc1) * hat(vr[h], fr1);
             }
-            scatter_hyps<NH, HPL>(acc, w0, d0, std::make_integer_sequence<int, NH>{});
-            scatter_hyps<NH, HPL>(acc, w1, d1, std::make_integer_sequence<int, NH>{});
+            scatter_pair<NH, HPL>(acc, w0, d0, w1, d1);
         }
     }
 }
@@ -205,12 +246,15 @@ __global__ void __launch_bounds__(DMVS_BLOCK) getcost_quad_kernel(const dmvs_get
     constexpr int U = C / 16, HPL = (N + 3) / 4, PPB = DMVS_BLOCK / 4;
     const int q = threadIdx.x & 3;
     const int H = d.H, W = d.W;
-    const long hw = (long)H * W, npix = (long)d.B * hw;
-    const long pix = (long)dmvs_xcd_contiguous_block(blockIdx.x, gridDim.x) * PPB + (threadIdx.x >> 2);
-    const bool live = pix < npix;
-    const long pq = live ? pix : npix - 1;
-    const int x = (int)(pq % W), y = (int)((pq / W) % H), b = (int)(pq / hw);
-    const long yx = (long)y * W + x, pc = (long)b * hw + yx;
+    const int hw = H * W;
+    // grid = (64-pixel blocks of one image, B): the batch item is workgroup-uniform, so cameras, depth range and every
+    // tensor base are scalar registers / scalar loads
+    const int b = blockIdx.y;
+    const int pix = (int)dmvs_xcd_contiguous_block(blockIdx.x, gridDim.x) * PPB + (threadIdx.x >> 2);
+    const bool live = pix < hw;
+    const int yx = live ? pix : hw - 1;
+    const int y = yx / W, x = yx - y * W;
+    const long pc = (long)b * hw + yx;
 
     // hypotheses in normalised inverse depth (reference :259-276); this lane projects hypotheses q and q + 4
     const float cur_inv = d.inv_depth[pc];
@@ -232,7 +276,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) getcost_quad_kernel(const dmvs_get
         sk += lo;
         sk = fminf(fmaxf(sk, 0.0f), 1.0f);
         own_depth[h] = dmvs_disp_to_depth(sk, dmin, dmax);
-        if (live && exists[h]) d.out_samples[((long)b * d.samp_cstride + d.samp_coffset + k) * hw + yx] = sk;
+        if (live && exists[h]) d.out_samples[((long)b * d.samp_cstride + d.samp_coffset + k) * (long)hw + yx] = sk;
     }
 
     float4 ref[U];
@@ -251,24 +295,24 @@ __global__ void __launch_bounds__(DMVS_BLOCK) getcost_quad_kernel(const dmvs_get
     for (int k = 0; k < N; ++k) acc[k] = 0.0f;
     float wsum = 1e-8f;
     const int Hv = H >> d.vw_shift, Wv = W >> d.vw_shift;
-    const long vwi = (long)(y >> d.vw_shift) * Wv + (x >> d.vw_shift);
+    const int vwi = (y >> d.vw_shift) * Wv + (x >> d.vw_shift);
     const char* base = reinterpret_cast<const char*>(d.src);
     for (int s = 0; s < d.S; ++s) {
-        const float w = d.view_w[((long)b * d.S + s) * Hv * Wv + vwi];
+        const float w = d.view_w[((long)b * d.S + s) * (long)(Hv * Wv) + vwi];
         wsum += w;
         RayQ ray;
         ray.init(d.rt + ((long)b * d.S + s) * 12, (float)x, (float)y);
         HypQ own[HPL];
 #pragma unroll
         for (int h = 0; h < HPL; ++h) own[h] = project_q(ray, own_depth[h], exists[h], H, W);
-        const unsigned view_off = (unsigned)((((long)s * d.B + b) * hw * C + q * 4) * 4);
+        const unsigned view_off = (unsigned)((((long)s * d.B + b) * (long)hw * C + q * 4) * 4);
         quad_accumulate<U, N>(base, view_off, own, H, W, ref, w, acc);
     }
     if (live) {
         const float inv_w = 1.0f / wsum;
 #pragma unroll
         for (int k = 0; k < N; ++k)
-            d.out_cost[((long)b * d.cost_cstride + d.cost_coffset + q * N + k) * hw + yx] = acc[k] * inv_w;
+            d.out_cost[((long)b * d.cost_cstride + d.cost_coffset + q * N + k) * (long)hw + yx] = acc[k] * inv_w;
     }
 }
 
@@ -281,12 +325,13 @@ warp_init_quad_kernel(const float* __restrict__ ref_f, const float* __restrict__
                       int D, int H, int W, int Hs, int Ws) {
     constexpr int U = C / 16, NB = 8, HPL = 2, PPB = DMVS_BLOCK / 4;
     const int q = threadIdx.x & 3;
-    const long hw = (long)H * W, npix = (long)B * hw;
-    const long pix = (long)dmvs_xcd_contiguous_block(blockIdx.x, gridDim.x) * PPB + (threadIdx.x >> 2);
-    const bool live = pix < npix;
-    const long pq = live ? pix : npix - 1;
-    const int x = (int)(pq % W), y = (int)((pq / W) % H), b = (int)(pq / hw);
-    const int s = blockIdx.y;
+    const int hw = H * W;
+    const int b = blockIdx.y / S, s = blockIdx.y - b * S;        // (batch item, view): workgroup-uniform
+    const int pix = (int)dmvs_xcd_contiguous_block(blockIdx.x, gridDim.x) * PPB + (threadIdx.x >> 2);
+    const bool live = pix < hw;
+    const int yx = live ? pix : hw - 1;
+    const int y = yx / W, x = yx - y * W;
+    const long pq = (long)b * hw + yx;
 
     float4 ref[U];
     {
@@ -304,13 +349,14 @@ warp_init_quad_kernel(const float* __restrict__ ref_f, const float* __restrict__
     const unsigned view_off = (unsigned)((((long)s * B + b) * (long)Hs * Ws * C + q * 4) * 4);
     const float dmin = disp_min[b], dmax = disp_max[b];
     const float dm1 = (float)(D - 1);
-    float* op = out + ((((long)b * S + s) * 4 + q) * D) * hw + (long)y * W + x;
+    float* op = out + ((((long)b * S + s) * 4 + q) * D) * (long)hw + yx;
+    const float inv_dm1 = 1.0f / dm1;
     for (int d0 = 0; d0 < D; d0 += NB) {
         HypQ own[HPL];
 #pragma unroll
         for (int h = 0; h < HPL; ++h) {
             const int dk = d0 + q + 4 * h;
-            own[h] = project_q(ray, dmvs_disp_to_depth((float)min(dk, D - 1) / dm1, dmin, dmax), dk < D, Hs, Ws);
+            own[h] = project_q(ray, dmvs_disp_to_depth((float)min(dk, D - 1) * inv_dm1, dmin, dmax), dk < D, Hs, Ws);
         }
         float acc[NB];
 #pragma unroll
@@ -319,7 +365,7 @@ warp_init_quad_kernel(const float* __restrict__ ref_f, const float* __restrict__
         if (live) {
 #pragma unroll
             for (int k = 0; k < NB; ++k)
-                if (d0 + k < D) op[(long)(d0 + k) * hw] = acc[k];
+                if (d0 + k < D) op[(long)(d0 + k) * (long)hw] = acc[k];
         }
     }
 }
@@ -332,7 +378,8 @@ extern "C" int dmvs_getcost_quad_f32(const dmvs_getcost_desc* dp, void* stream) 
     if (d.G != 4 || !d.ref || !d.src || !d.rt || !d.inv_depth || !d.view_w || !d.out_cost || !d.out_samples) return DMVS_EINVAL;
     if ((long)d.S * d.B * d.H * d.W * d.C * 4 >= (1L << 32)) return DMVS_EINVAL;   // 32-bit byte offsets over the source stack
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(dmvs_ceil_div((long)d.B * d.H * d.W, DMVS_BLOCK / 4)), block(DMVS_BLOCK);
+    if ((long)d.H * d.W >= (1L << 24) || d.B > 65535) return DMVS_EINVAL;          // 24-bit row multiplies, grid.y
+    dim3 grid(dmvs_ceil_div((long)d.H * d.W, DMVS_BLOCK / 4), (unsigned)d.B), block(DMVS_BLOCK);
 #define DMVS_GCQ(CC, NN) hipLaunchKernelGGL((getcost_quad_kernel<CC, NN>), grid, block, 0, st, d)
     if (d.C == 32 && d.n == 6) DMVS_GCQ(32, 6);
     else if (d.C == 32 && d.n == 4) DMVS_GCQ(32, 4);
@@ -351,7 +398,8 @@ extern "C" int dmvs_warp_corr_init_quad_f32(const float* ref, const float* src, 
     if (G != 4 || D < 2 || !ref || !src || !rt || !out) return DMVS_EINVAL;
     if ((long)S * B * Hs * Ws * C * 4 >= (1L << 32)) return DMVS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(dmvs_ceil_div((long)B * H * W, DMVS_BLOCK / 4), S), block(DMVS_BLOCK);
+    if ((long)H * W >= (1L << 24) || (long)Hs * Ws >= (1L << 24) || (long)B * S > 65535) return DMVS_EINVAL;
+    dim3 grid(dmvs_ceil_div((long)H * W, DMVS_BLOCK / 4), (unsigned)(B * S)), block(DMVS_BLOCK);
     if (C == 48) hipLaunchKernelGGL((warp_init_quad_kernel<48>), grid, block, 0, st, ref, src, rt, disp_min, disp_max, out, B, S, D, H, W, Hs, Ws);
     else if (C == 32) hipLaunchKernelGGL((warp_init_quad_kernel<32>), grid, block, 0, st, ref, src, rt, disp_min, disp_max, out, B, S, D, H, W, Hs, Ws);
     else if (C == 16) hipLaunchKernelGGL((warp_init_quad_kernel<16>), grid, block, 0, st, ref, src, rt, disp_min, disp_max, out, B, S, D, H, W, Hs, Ws);
