@@ -253,7 +253,7 @@ def main():
     # HBM traffic per getcost launch from the PMC passes (rocprofv3 cannot run inside the timed process); only
     # quoted when the committed measurement was taken at this batch size
     traffic = None
-    tj = os.path.join(ROOT, "profiles", "r1_getcost_traffic.json")      # the per-pixel gather kernel, which runs in the timed steps
+    tj = os.path.join(ROOT, "profiles", "r2_getcost_traffic.json" if eng.quad else "r1_getcost_traffic.json")   # the kernel of the timed steps
     if os.path.exists(tj):
         with open(tj) as f:
             tinfo = json.load(f)
@@ -271,7 +271,7 @@ def main():
                                 "GetCost: getcost_win_kernel<32,6> (LDS-staged source windows) / getcost_kernel<32,4,6> (per-pixel gather), picked per launch"),
                      "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "traffic_source": "profiles/r1_getcost_traffic.json (rocprofv3 PMC passes of an earlier run; not measured by this process)" if traffic else None,
+                     "traffic_source": (os.path.relpath(tj, ROOT) + " (rocprofv3 PMC passes of an earlier run of this command; not measured by this process)") if traffic else None,
                      "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(gc_avg_s * 1e6, 2),
                      "launches_timed": len(gc_ms),
                      "launches_quad": n_quad, "launches_hybrid": n_hybrid, "launches_plain_gather": n_plain,

@@ -24,6 +24,8 @@
 //
 // Semantics kept from the reference: per-tap zero padding with align_corners=True pixel coordinates, NO behind-camera
 // mask, z == 0 -> z + 1e-8, non-finite coordinates sample 0.
+#include <stdlib.h>
+
 #include <utility>
 
 #include "dmvs_common.h"
@@ -70,22 +72,33 @@ struct HypQ {
     bool valid;
 };
 
-__device__ __forceinline__ HypQ project_q(const RayQ& r, float depth, bool exists, int Hs, int Ws) {
+__device__ __forceinline__ void project_uv_q(const RayQ& r, float depth, float& u, float& v) {
     const float px = r.rx * depth + r.tx, py = r.ry * depth + r.ty;
     float pz = r.rz * depth + r.tz;
     if (pz == 0.0f) pz += 1e-8f;
     // one reciprocal (hardware estimate + one Newton step: within an ulp of the IEEE quotient) shared by u and v
     float inv = __builtin_amdgcn_rcpf(pz);
     inv = fmaf(fmaf(-pz, inv, 1.0f), inv, inv);
+    u = px * inv;
+    v = py * inv;
+}
+
+__device__ __forceinline__ HypQ footprint_q(float u, float v, bool exists, int Hs, int Ws) {
     HypQ h;
-    h.u = px * inv;
-    h.v = py * inv;
+    h.u = u;
+    h.v = v;
     const float fx = floorf(h.u), fy = floorf(h.v);
     // false for NaN / inf; a footprint with both columns (rows) outside the image only has padding taps
     h.valid = exists && fx >= -1.0f && fx <= (float)(Ws - 1) && fy >= -1.0f && fy <= (float)(Hs - 1);
     h.x0 = h.valid ? (int)fx : BIG;
     h.y0 = h.valid ? (int)fy : BIG;
     return h;
+}
+
+__device__ __forceinline__ HypQ project_q(const RayQ& r, float depth, bool exists, int Hs, int Ws) {
+    float u, v;
+    project_uv_q(r, depth, u, v);
+    return footprint_q(u, v, exists, Hs, Ws);
 }
 
 // this lane's 4*U channels of one texel
@@ -97,17 +110,18 @@ __device__ __forceinline__ void load_texel(const char* base, unsigned byte_off, 
     for (int j = 0; j < U; ++j) t.v[j] = *reinterpret_cast<const float4*>(base + byte_off + j * 64);
 }
 
+typedef float f2q __attribute__((vector_size(8)));
+
+// two partial sums in one register pair: packed fp32 FMAs (v_pk_fma_f32) retire two products per issue slot
 template <int U>
 __device__ __forceinline__ float dot_texel(const TexQ<U>& t, const float4 (&ref)[U]) {
-    float a = 0.0f;
+    f2q a = {0.0f, 0.0f};
 #pragma unroll
     for (int j = 0; j < U; ++j) {
-        a = fmaf(t.v[j].x, ref[j].x, a);
-        a = fmaf(t.v[j].y, ref[j].y, a);
-        a = fmaf(t.v[j].z, ref[j].z, a);
-        a = fmaf(t.v[j].w, ref[j].w, a);
+        a = f2q{t.v[j].x, t.v[j].y} * f2q{ref[j].x, ref[j].y} + a;
+        a = f2q{t.v[j].z, t.v[j].w} * f2q{ref[j].z, ref[j].w} + a;
     }
-    return a;
+    return a[0] + a[1];
 }
 
 __device__ __forceinline__ float hat(float rel, float pos) {      // bilinear weight of integer position `pos` for coordinate `rel`
@@ -162,32 +176,41 @@ __device__ __forceinline__ void scatter_pair(float (&acc)[NH], const float (&w0)
 
 // acc[k] += wscale * (bilinear sample of the lane's group dot at hypothesis k), k < NH, for one (pixel, view).
 // own[h] = hypothesis q + 4h of the pixel (q = lane & 3).  base + view_off = the view's [Hs,Ws,C] NHWC-g4 image (+ 16q bytes).
-template <int U, int NH>
+template <int U, int NH, int TPT>
 __device__ __forceinline__ void quad_accumulate(const char* base, unsigned view_off, const HypQ (&own)[(NH + 3) / 4], int Hs, int Ws,
                                                 const float4 (&ref)[U], float wscale, float (&acc)[NH]) {
     constexpr int HPL = (NH + 3) / 4, C = 16 * U;
     const int q = threadIdx.x & 3;
-    // do all hypotheses of the pixel fit one 8x8 texel grid?
-    int xlo = BIG, ylo = BIG, xhi = -BIG, yhi = -BIG;
+    // do all hypotheses of the pixel fit one 8x8 texel grid anchored at the minimum footprint corner?
+    int xlo = BIG, ylo = BIG;
 #pragma unroll
     for (int h = 0; h < HPL; ++h) {
-        xlo = min(xlo, own[h].x0); ylo = min(ylo, own[h].y0);
-        xhi = max(xhi, own[h].valid ? own[h].x0 : -BIG); yhi = max(yhi, own[h].valid ? own[h].y0 : -BIG);
+        xlo = min(xlo, own[h].x0);       // invalid hypotheses carry BIG
+        ylo = min(ylo, own[h].y0);
     }
-    xlo = quad_min(xlo); ylo = quad_min(ylo); xhi = quad_max(xhi); yhi = quad_max(yhi);
+    xlo = quad_min(xlo);
+    ylo = quad_min(ylo);
     if (xlo == BIG) return;                                   // no hypothesis of this pixel touches the image (quad-uniform)
-    const bool fits = xhi - xlo <= 6 && yhi - ylo <= 6;
+    unsigned wide = 0;
+#pragma unroll
+    for (int h = 0; h < HPL; ++h) wide |= (own[h].valid && (own[h].x0 - xlo > 6 || own[h].y0 - ylo > 6)) ? 1u : 0u;
+    const bool fits = quad_or(wide) == 0u;
     const int nchunks = fits ? 1 : NH;
     for (int ch = 0; ch < nchunks; ++ch) {
         bool act[HPL];
-        int ax = BIG, ay = BIG;
 #pragma unroll
-        for (int h = 0; h < HPL; ++h) {
-            act[h] = own[h].valid && (fits || q + 4 * h == ch);
-            ax = min(ax, act[h] ? own[h].x0 : BIG);
-            ay = min(ay, act[h] ? own[h].y0 : BIG);
+        for (int h = 0; h < HPL; ++h) act[h] = own[h].valid && (fits || q + 4 * h == ch);
+        int xmin = xlo, ymin = ylo;
+        if (!fits) {                                          // rare: one hypothesis per chunk, anchored at its own footprint
+            int ax = BIG, ay = BIG;
+#pragma unroll
+            for (int h = 0; h < HPL; ++h) {
+                ax = min(ax, act[h] ? own[h].x0 : BIG);
+                ay = min(ay, act[h] ? own[h].y0 : BIG);
+            }
+            xmin = quad_min(ax);
+            ymin = quad_min(ay);
         }
-        const int xmin = quad_min(ax), ymin = quad_min(ay);
         if (xmin == BIG) continue;                            // this chunk's hypothesis is invalid (quad-uniform)
         unsigned mlo = 0, mhi = 0;
         float ur[HPL], vr[HPL];
@@ -202,46 +225,60 @@ __device__ __forceinline__ void quad_accumulate(const char* base, unsigned view_
         }
         mlo = quad_or(mlo);
         mhi = quad_or(mhi);
-        unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
-        {
+        if (xmin < 0 || ymin < 0 || xmin + 8 > Ws || ymin + 8 > Hs) {
             // texels outside the image are grid_sample's zero padding: drop their bits here, so that the loop below needs
             // neither bounds tests nor clamped addresses.  xmin, ymin >= -1 (footprints with both columns / rows outside are
             // invalid hypotheses) and <= size - 1, so at most the first column / row and a trailing run fall outside.
             const int clo = xmin < 0 ? 1 : 0, chi = min(8, Ws - xmin), rlo = ymin < 0 ? 1 : 0, rhi = min(8, Hs - ymin);
-            const unsigned colbits = (0xffu >> (8 - chi)) & (0xffu << clo) & 0xffu;
+            const unsigned colbits = ((0xffu >> (8 - chi)) & (0xffu << clo) & 0xffu) * 0x01010101u;
             const unsigned long long rowmask = (~0ull >> (64 - 8 * rhi)) & (~0ull << (8 * rlo));
-            m &= rowmask & ((unsigned long long)colbits * 0x0101010101010101ull);
+            mlo &= (unsigned)rowmask & colbits;
+            mhi &= (unsigned)(rowmask >> 32) & colbits;
         }
         const unsigned texel_off = view_off + (unsigned)(__mul24(ymin, Ws) + xmin) * (unsigned)(C * 4);    // of grid cell (0, 0)
-        while (m != 0ull) {
-            // two texels per trip; a pixel with an odd count repeats its last texel with weight 0
-            const int b0 = __ffsll((long long)m) - 1;
-            m &= m - 1ull;
-            const bool two = m != 0ull;
-            const int b1 = two ? __ffsll((long long)m) - 1 : b0;
-            m &= m - 1ull;
-            const int c0 = b0 & 7, r0 = b0 >> 3, c1 = b1 & 7, r1 = b1 >> 3;
-            const unsigned o0 = texel_off + (unsigned)(__mul24(r0, Ws) + c0) * (unsigned)(C * 4);
-            const unsigned o1 = texel_off + (unsigned)(__mul24(r1, Ws) + c1) * (unsigned)(C * 4);
-            TexQ<U> t0, t1;
-            load_texel<U>(base, o0, t0);
-            load_texel<U>(base, o1, t1);
-            const float d0 = dot_texel<U>(t0, ref) * wscale;
-            const float d1 = dot_texel<U>(t1, ref) * (two ? wscale : 0.0f);
-            float w0[HPL], w1[HPL];
-            const float fc0 = (float)c0, fr0 = (float)r0, fc1 = (float)c1, fr1 = (float)r1;
+        // rows 0..3 of the grid (mlo), then -- rarely non-empty -- rows 4..7 (mhi): 32-bit bit scans
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+        unsigned m = half ? mhi : mlo;
+        const int rbase = half * 4;
+        while (m != 0u) {
+            // TPT texels per trip (their loads in flight together); a pixel that runs out repeats its last texel with weight 0
+            int bit[TPT];
+            bool has[TPT];
 #pragma unroll
-            for (int h = 0; h < HPL; ++h) {
-                w0[h] = hat(ur[h], fc0) * hat(vr[h], fr0);
-                w1[h] = hat(ur[h], fc1) * hat(vr[h], fr1);
+            for (int i = 0; i < TPT; ++i) {
+                has[i] = m != 0u;
+                bit[i] = (i == 0 || has[i]) ? __ffs((int)m) - 1 : bit[i > 0 ? i - 1 : 0];
+                m &= m - 1u;
             }
-            scatter_pair<NH, HPL>(acc, w0, d0, w1, d1);
+            TexQ<U> t[TPT];
+            float fc[TPT], fr[TPT];
+#pragma unroll
+            for (int i = 0; i < TPT; ++i) {
+                const int c = bit[i] & 7, r = (bit[i] >> 3) + rbase;
+                load_texel<U>(base, texel_off + (unsigned)(__mul24(r, Ws) + c) * (unsigned)(C * 4), t[i]);
+                fc[i] = (float)c;
+                fr[i] = (float)r;
+            }
+            // every load of the trip is issued before anything waits on one: without this fence the scheduler, chasing one
+            // more wave of occupancy, re-uses one texel's registers and serialises load -> wait -> FMAs per texel
+            __builtin_amdgcn_sched_barrier(0);
+            float dd[TPT], w[TPT][HPL];
+#pragma unroll
+            for (int i = 0; i < TPT; ++i) {
+                dd[i] = dot_texel<U>(t[i], ref) * ((i == 0 || has[i]) ? wscale : 0.0f);
+#pragma unroll
+                for (int h = 0; h < HPL; ++h) w[i][h] = hat(ur[h], fc[i]) * hat(vr[h], fr[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < TPT; i += 2) scatter_pair<NH, HPL>(acc, w[i], dd[i], w[i + 1], dd[i + 1]);
+        }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------ GetCost
-template <int C, int N>
+template <int C, int N, int TPT>
 __global__ void __launch_bounds__(DMVS_BLOCK) getcost_quad_kernel(const dmvs_getcost_desc d) {
     constexpr int U = C / 16, HPL = (N + 3) / 4, PPB = DMVS_BLOCK / 4;
     const int q = threadIdx.x & 3;
@@ -306,7 +343,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) getcost_quad_kernel(const dmvs_get
 #pragma unroll
         for (int h = 0; h < HPL; ++h) own[h] = project_q(ray, own_depth[h], exists[h], H, W);
         const unsigned view_off = (unsigned)((((long)s * d.B + b) * (long)hw * C + q * 4) * 4);
-        quad_accumulate<U, N>(base, view_off, own, H, W, ref, w, acc);
+        quad_accumulate<U, N, TPT>(base, view_off, own, H, W, ref, w, acc);
     }
     if (live) {
         const float inv_w = 1.0f / wsum;
@@ -318,7 +355,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) getcost_quad_kernel(const dmvs_get
 
 // ------------------------------------------------------------------------------------------ stage-1 plane sweep
 // grid = (pixel blocks, S); planes in chunks of 8 (lane q projects planes d0 + q and d0 + q + 4).  out [B,S,4,D,H,W].
-template <int C>
+template <int C, int TPT>
 __global__ void __launch_bounds__(DMVS_BLOCK)
 warp_init_quad_kernel(const float* __restrict__ ref_f, const float* __restrict__ src, const float* __restrict__ rt,
                       const float* __restrict__ disp_min, const float* __restrict__ disp_max, float* __restrict__ out, int B, int S,
@@ -349,19 +386,26 @@ warp_init_quad_kernel(const float* __restrict__ ref_f, const float* __restrict__
     const unsigned view_off = (unsigned)((((long)s * B + b) * (long)Hs * Ws * C + q * 4) * 4);
     const float dmin = disp_min[b], dmax = disp_max[b];
     const float dm1 = (float)(D - 1);
+    // the plane depths are the same for every pixel of the batch item: one table per workgroup instead of a division chain
+    // per (pixel, plane)
+    constexpr int TAB = 256;
+    __shared__ float depth_tab[TAB];
+    if ((int)threadIdx.x < min(D, TAB)) depth_tab[threadIdx.x] = dmvs_disp_to_depth((float)threadIdx.x / dm1, dmin, dmax);
+    __syncthreads();
     float* op = out + ((((long)b * S + s) * 4 + q) * D) * (long)hw + yx;
-    const float inv_dm1 = 1.0f / dm1;
     for (int d0 = 0; d0 < D; d0 += NB) {
         HypQ own[HPL];
 #pragma unroll
         for (int h = 0; h < HPL; ++h) {
             const int dk = d0 + q + 4 * h;
-            own[h] = project_q(ray, dmvs_disp_to_depth((float)min(dk, D - 1) * inv_dm1, dmin, dmax), dk < D, Hs, Ws);
+            const int dc = min(dk, D - 1);
+            const float depth = dc < TAB ? depth_tab[dc] : dmvs_disp_to_depth((float)dc / dm1, dmin, dmax);
+            own[h] = project_q(ray, depth, dk < D, Hs, Ws);
         }
         float acc[NB];
 #pragma unroll
         for (int k = 0; k < NB; ++k) acc[k] = 0.0f;
-        quad_accumulate<U, NB>(base, view_off, own, Hs, Ws, ref, 1.0f, acc);
+        quad_accumulate<U, NB, TPT>(base, view_off, own, Hs, Ws, ref, 1.0f, acc);
         if (live) {
 #pragma unroll
             for (int k = 0; k < NB; ++k)
@@ -372,6 +416,15 @@ warp_init_quad_kernel(const float* __restrict__ ref_f, const float* __restrict__
 
 }  // namespace
 
+// texels per trip of the texel loop (kernel experiments: DMVS_QUAD_TPT=4 in the environment; default 2)
+static int quad_tpt() {
+    static const int v = [] {
+        const char* e = getenv("DMVS_QUAD_TPT");
+        return (e && e[0] == '4') ? 4 : 2;
+    }();
+    return v;
+}
+
 extern "C" int dmvs_getcost_quad_f32(const dmvs_getcost_desc* dp, void* stream) {
     if (!dp) return DMVS_EINVAL;
     const dmvs_getcost_desc& d = *dp;
@@ -380,7 +433,12 @@ extern "C" int dmvs_getcost_quad_f32(const dmvs_getcost_desc* dp, void* stream) 
     hipStream_t st = (hipStream_t)stream;
     if ((long)d.H * d.W >= (1L << 24) || d.B > 65535) return DMVS_EINVAL;          // 24-bit row multiplies, grid.y
     dim3 grid(dmvs_ceil_div((long)d.H * d.W, DMVS_BLOCK / 4), (unsigned)d.B), block(DMVS_BLOCK);
-#define DMVS_GCQ(CC, NN) hipLaunchKernelGGL((getcost_quad_kernel<CC, NN>), grid, block, 0, st, d)
+    const int tpt = quad_tpt();
+#define DMVS_GCQ(CC, NN)                                                                                 \
+    do {                                                                                                 \
+        if (tpt == 4) hipLaunchKernelGGL((getcost_quad_kernel<CC, NN, 4>), grid, block, 0, st, d);      \
+        else hipLaunchKernelGGL((getcost_quad_kernel<CC, NN, 2>), grid, block, 0, st, d);               \
+    } while (0)
     if (d.C == 32 && d.n == 6) DMVS_GCQ(32, 6);
     else if (d.C == 32 && d.n == 4) DMVS_GCQ(32, 4);
     else if (d.C == 16 && d.n == 4) DMVS_GCQ(16, 4);
@@ -400,9 +458,16 @@ extern "C" int dmvs_warp_corr_init_quad_f32(const float* ref, const float* src, 
     hipStream_t st = (hipStream_t)stream;
     if ((long)H * W >= (1L << 24) || (long)Hs * Ws >= (1L << 24) || (long)B * S > 65535) return DMVS_EINVAL;
     dim3 grid(dmvs_ceil_div((long)H * W, DMVS_BLOCK / 4), (unsigned)(B * S)), block(DMVS_BLOCK);
-    if (C == 48) hipLaunchKernelGGL((warp_init_quad_kernel<48>), grid, block, 0, st, ref, src, rt, disp_min, disp_max, out, B, S, D, H, W, Hs, Ws);
-    else if (C == 32) hipLaunchKernelGGL((warp_init_quad_kernel<32>), grid, block, 0, st, ref, src, rt, disp_min, disp_max, out, B, S, D, H, W, Hs, Ws);
-    else if (C == 16) hipLaunchKernelGGL((warp_init_quad_kernel<16>), grid, block, 0, st, ref, src, rt, disp_min, disp_max, out, B, S, D, H, W, Hs, Ws);
+    const int tpt = quad_tpt();
+#define DMVS_WIQ(CC)                                                                                                                             \
+    do {                                                                                                                                         \
+        if (tpt == 4) hipLaunchKernelGGL((warp_init_quad_kernel<CC, 4>), grid, block, 0, st, ref, src, rt, disp_min, disp_max, out, B, S, D, H, W, Hs, Ws); \
+        else hipLaunchKernelGGL((warp_init_quad_kernel<CC, 2>), grid, block, 0, st, ref, src, rt, disp_min, disp_max, out, B, S, D, H, W, Hs, Ws);         \
+    } while (0)
+    if (C == 48) DMVS_WIQ(48);
+    else if (C == 32) DMVS_WIQ(32);
+    else if (C == 16) DMVS_WIQ(16);
     else return DMVS_EINVAL;
+#undef DMVS_WIQ
     return dmvs_launch_status();
 }

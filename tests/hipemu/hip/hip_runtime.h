@@ -316,6 +316,7 @@ static inline int hipemu_quad_perm(int v, int ctrl) {
 #define DMVS_QUAD_PERM(v, ctrl) hipemu_quad_perm((v), (ctrl))
 #define DMVS_HOST_EMULATION 1
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+static inline int __ffs(int v) { return __builtin_ffs(v); }
 static inline float __int_as_float(int v) { float f; memcpy(&f, &v, 4); return f; }
 static inline int __float_as_int(float f) { int v; memcpy(&v, &f, 4); return v; }
 #define DMVS_ORDER_AFTER(var, dep) ((void)0)

@@ -1,7 +1,7 @@
 """Fold the two rocprofv3 PMC passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE; each with --kernel-trace, CSV output) into
 profiles/<round>_pmc_hbm_traffic_per_kernel.csv and profiles/<round>_getcost_traffic.json.
 
-    python tools/pmc_traffic.py <fetch_dir> <write_dir> <round-tag> <batch>
+    python tools/pmc_traffic.py <fetch_dir> <write_dir> <round-tag> <batch> [<kernel name prefix>]
 
 Counter unit: KiB per dispatch (hbm_bytes = counter * 1024).  gfx950 correction (MI355X_MICROARCH.md, HBM section):
 FETCH_SIZE reports half of a wide coalesced read, so corrected_fetch = 2 x raw."""
@@ -31,6 +31,7 @@ def short(name):
 
 def main():
     fetch_dir, write_dir, tag, batch = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+    kname = sys.argv[5] if len(sys.argv) > 5 else "getcost_quad_kernel<32, 6>"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     fe, wr = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
     rows = []
@@ -45,11 +46,11 @@ def main():
         f.write("kernel,grid,dispatches,fetch_raw_MiB,write_MiB\n")
         for r in rows[:60]:
             f.write(f"\"{r[0]}\",{r[1]},{r[2]},{r[3]:.2f},{r[4]:.2f}\n")
-    gc = [r for r in rows if r[0].startswith("getcost_win_kernel<32, 6>")]
+    gc = [r for r in rows if r[0].startswith(kname)]
     if gc:
         r = max(gc, key=lambda r: r[1])
         fetch_raw, write = r[3] * 2 ** 20, r[4] * 2 ** 20
-        info = {"batch": batch, "kernel": "getcost_win_kernel<32,6>", "fetch_size_raw_bytes": int(fetch_raw), "fetch_correction": 2.0,
+        info = {"batch": batch, "kernel": kname.replace(", ", ","), "fetch_size_raw_bytes": int(fetch_raw), "fetch_correction": 2.0,
                 "write_size_bytes": int(write), "traffic_bytes_per_launch": int(2 * fetch_raw + write),
                 "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, profiles/{tag}_pmc_hbm_traffic_per_kernel.csv"}
         with open(os.path.join(root, "profiles", f"{tag}_getcost_traffic.json"), "w") as f:
