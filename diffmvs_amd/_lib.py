@@ -90,6 +90,7 @@ SIGNATURES = {
     "dmvs_batchnorm_workspace_f32": [_I, _I, _I, _I, C.POINTER(C.c_int64)],
     "dmvs_batchnorm_train_fwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _I, _I, _I, _I, _I, _F, _F, _I, _P],
     "dmvs_batchnorm_train_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _I, _I, _I, _I, _I, _I, _P],
+    "dmvs_geo_consistency_f32": [_P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _P, _I, _I, _I, _I, _I, _P],
     "dmvs_sumsq_f32": [_P, C.c_int64, _P, _P],
     "dmvs_adamw_step_f32": [_P, _P, _P, _P, C.c_int64, _F, _F, _F, _F, _F, _I, _F, _P, _F, _P],
 }

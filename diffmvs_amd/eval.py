@@ -1,0 +1,122 @@
+"""Evaluation driver: the counterpart of the reference's test.py:92-205 (save_scene_depth) on the MI355X path.
+
+    python -m diffmvs_amd.eval --testpath <root> --dataset dtu --testlist lists/dtu/test.txt --loadckpt model.ckpt \\
+        --outdir outputs --method casdiffmvs --num_view 5 [--filter]
+
+For every reference view of every scene: build the sample (diffmvs_amd.formats.MVSDataset, the reference's dataset
+contract), run CasDiffMVS.forward timed between device synchronisations exactly like test.py:122-127, and write
+depth_est/*.pfm, conf{i}/*.pfm, cams/*_cam.txt, images/*.jpg in the reference's output layout, so that the reference's
+filter.py -- or this package's GPU consistency filter (--filter, diffmvs_amd.fusion) -- can fuse them.  Scenes shard over
+ranks (one process per GPU, RANK / WORLD_SIZE from the launcher) with no communication.
+If <testpath>/<scan>/depth_gt/%08d.pfm (+ optional mask/%08d.png) exist, the absolute and relative depth errors of
+utils.py:178-187 / BASELINE.json ("DTU abs-rel") are reported per scene."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import formats as IO
+from . import shard, synth
+
+
+def build_args(a) -> object:
+    """the constructor namespace of CasDiffMVS from the command line (reference test.py:20-78 flag names)"""
+    over = {}
+    for k in ("stage_iters", "cost_dim_stage", "CostNum", "hidden_dim", "context_dim", "unet_dim", "scale", "sampling_timesteps", "ddim_eta"):
+        v = getattr(a, k)
+        if v is not None:
+            over[k] = list(v)
+    for k in ("min_radius", "max_radius"):
+        if getattr(a, k) is not None:
+            over[k] = getattr(a, k)
+    return synth.make_args("casdiffmvs" if a.method == "casdiffmvs" else "diffmvs", numdepth_initial=a.numdepth_initial,
+                           numdepth=a.numdepth, **over)
+
+
+def run_scenes(model, a, scenes, device):
+    times, report = [], {}
+    for scene in scenes:
+        ds = IO.MVSDataset(a.testpath, a.num_view, a.numdepth, dataset=a.dataset, scan=[scene], max_h=a.max_h, max_w=a.max_w)
+        errs = []
+        for i0 in range(0, len(ds), a.batch_size):
+            sample = IO.collate([ds[i] for i in range(i0, min(i0 + a.batch_size, len(ds)))])
+            imgs = [t.to(device) for t in sample["imgs"]]
+            proj = {k: v.to(device) for k, v in sample["proj_matrices"].items()}
+            dv = sample["depth_values"].to(device)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            with torch.no_grad():
+                out = model(imgs, proj, dv)
+            torch.cuda.synchronize()
+            times.append(time.time() - t0)
+            IO.save_outputs(a.outdir, sample, out)
+            for b, pattern in enumerate(sample["filename"]):
+                gt_file = os.path.join(a.testpath, pattern.format("depth_gt", ".pfm"))
+                if os.path.exists(gt_file):
+                    gt = torch.from_numpy(np.ascontiguousarray(IO.read_pfm(gt_file)[0]))[None]
+                    est = out["depth"][-1][b:b + 1].float().cpu()
+                    m = (gt > 1.0 / float(dv[b, -1])) & (gt < 1.0 / float(dv[b, 0])) if gt.shape == est.shape else None
+                    if m is not None and bool(m.any()):
+                        errs.append((float(IO.abs_depth_error(est, gt, m)), float(IO.abs_rel_error(est, gt, m))))
+        if errs:
+            report[scene] = {"abs_err": float(np.mean([e[0] for e in errs])), "abs_rel": float(np.mean([e[1] for e in errs])), "views": len(errs)}
+    return times, report
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--testpath", required=True)
+    ap.add_argument("--dataset", default="dtu", choices=["dtu", "tank", "eth3d", "general"])
+    ap.add_argument("--testlist", default=None, help="file with one scene per line (default: the single scene '' of a general dataset)")
+    ap.add_argument("--loadckpt", default=None, help="reference checkpoint ({'model': state_dict}); default: seeded random weights")
+    ap.add_argument("--outdir", default="./outputs")
+    ap.add_argument("--method", default="casdiffmvs", choices=["casdiffmvs", "diffmvs"])
+    ap.add_argument("--batch_size", type=int, default=1)
+    ap.add_argument("--num_view", type=int, default=5, help="images per sample: 1 reference + num_view-1 sources")
+    ap.add_argument("--numdepth", type=int, default=384)
+    ap.add_argument("--numdepth_initial", type=int, default=48)
+    ap.add_argument("--max_h", type=int, default=4800)
+    ap.add_argument("--max_w", type=int, default=6400)
+    for k, t in (("stage_iters", int), ("cost_dim_stage", int), ("CostNum", int), ("hidden_dim", int), ("context_dim", int),
+                 ("unet_dim", int), ("scale", float), ("sampling_timesteps", int), ("ddim_eta", float)):
+        ap.add_argument("--" + k, type=t, nargs=3, default=None)
+    ap.add_argument("--min_radius", type=float, default=None)
+    ap.add_argument("--max_radius", type=float, default=None)
+    ap.add_argument("--filter", action="store_true", help="fuse the written depth maps with the GPU consistency filter afterwards")
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args(argv)
+
+    rank, world, local = shard.env_rank_world()
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    torch.manual_seed(a.seed + rank)
+    from models import CasDiffMVS
+    model = CasDiffMVS(build_args(a), test=True).eval()
+    if a.loadckpt:
+        sd = torch.load(a.loadckpt, map_location="cpu")
+        model.load_state_dict(sd["model"], strict=False)                     # test.py:108-109
+    else:
+        model.load_state_dict(synth.synth_state_dict(model.state_dict(), 123))
+    model.to(device)
+    scenes = [ln.strip() for ln in open(a.testlist)] if a.testlist else [""]
+    mine = shard.shard_scenes(scenes, rank, world)
+    times, report = run_scenes(model, a, mine, device)
+    res = {"rank": rank, "scenes": mine, "views": len(times), "avg_time_s": float(np.mean(times)) if times else None, "errors": report}
+    if a.filter:
+        from . import fusion
+        for scene in mine:
+            out_folder = os.path.join(a.outdir, scene)
+            n = fusion.filter_depth(os.path.join(a.testpath, scene), out_folder, os.path.join(a.outdir, (scene or "scene") + ".ply"),
+                                    method=a.method, dataset=a.dataset, device=device)
+            res.setdefault("fused_points", {})[scene] = n
+    print(json.dumps(res), flush=True)
+    return res
+
+
+if __name__ == "__main__":
+    main()

@@ -237,3 +237,24 @@ def getcost_scene_inputs(H, W, n_src, B, stage=2, C=32, noise=0.01, conf=0.5, se
     interval = (1.0 / dv.shape[1]) * (2 if stage == 2 else 1)
     return {"ref": ref, "src": src, "proj": proj[name], "inv": inv, "conf": cf, "view_w": vw, "disp_min": kmin, "disp_max": kmax,
             "interval": interval, "vw_shift": vshift}
+
+
+def synth_view_depths(H: int, W: int, n_views: int, seed: int = 0, b: int = 0) -> np.ndarray:
+    """depth map [V,H,W] (z in each camera's own frame) of the scene plane of synth_inputs(seed)[batch item b] for every
+    view: the input of the fusion tests (a depth map per view, as the reference's test.py leaves them on disk)"""
+    K = np.array([[1.2 * W, 0, W / 2.0], [0, 1.2 * W, H / 2.0], [0, 0, 1.0]], np.float64)
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    rays = np.linalg.inv(K) @ np.stack([xs.ravel(), ys.ravel(), np.ones(H * W)])
+    rs = np.random.RandomState(1000003 * seed + 7919 * b + 17)
+    d0 = rs.uniform(560.0, 760.0)
+    a, c = rs.uniform(-0.25, 0.25, 2)
+    n = np.array([-a, -c, 1.0])
+    out = np.zeros((n_views, H, W), np.float32)
+    for v in range(n_views):
+        ang = 0.05 * v * (1.0 + 0.1 * b)
+        R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+        t = np.array([-30.0 * v, 4.0 * v * ((-1) ** v), 0.0])
+        o = -R.T @ t
+        d = R.T @ rays
+        out[v] = ((d0 - n @ o) / (n @ d)).reshape(H, W).astype(np.float32)       # ray parameter = camera-frame depth (ray z = 1)
+    return out

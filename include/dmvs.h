@@ -359,6 +359,27 @@ int dmvs_batchnorm_train_bwd_f32(const float* x, const float* dy, const float* g
                                  int32_t view_major, int32_t act, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Depth-map fusion: geometric consistency of one reference depth map against S source depth maps (reference
+ * filter.py:8-93 reproject_with_depth + check_geometric_consistency, :230-259 the dynamic variant).  Per reference pixel and
+ * source view: reference depth -> source pixel -> source depth sampled like cv2.remap(INTER_LINEAR, constant 0 border,
+ * 1/32-pixel coordinate quantisation) -> back into the reference view; level l accepts the pair when
+ *     reprojection distance < pix_thres[l]  and  |depth_reproj - depth_ref| / depth_ref < rel_thres[l]
+ *     (and, if use_range, range_min < depth_ref < range_max -- filter.py:89).
+ *   depth_ref [H,W], depth_src [S,Hs,Ws] fp32
+ *   mats [S][DMVS_GEO_MATS_FLOATS] fp32, per source view row-major: inv(K_ref) 3x3 | (E_src inv(E_ref))[:3,:4] |
+ *        K_src 3x3 | inv(K_src) 3x3 | (E_ref inv(E_src))[:3,:4] | K_ref 3x3, composed by the caller in fp32 as the
+ *        reference's np.linalg.inv / np.matmul on its fp32 camera files do
+ *   level_counts [L,H,W] int32: number of source views accepted at level l;  depth_sum [H,W]: sum over the views accepted
+ *        at the LAST level of the reprojected depth (filter.py:91, :257), accumulated in view order in fp32.
+ * L = 1 is filter_depth (DTU / ETH3D), L = 11 - dh_view_num the Tanks&Temples dynamic check. */
+#define DMVS_GEO_MATS_FLOATS 60
+#define DMVS_GEO_MAX_LEVELS 12
+int dmvs_geo_consistency_f32(const float* depth_ref, const float* depth_src, const float* mats, const double* pix_thres,
+                             const float* rel_thres, int32_t L, int32_t use_range, float range_min, float range_max,
+                             int32_t* level_counts, float* depth_sum, int32_t S, int32_t H, int32_t W, int32_t Hs, int32_t Ws,
+                             void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Training-step tail on one flat fp32 parameter bucket (the buffer RCCL all-reduces).  Replaces
  * torch.nn.utils.clip_grad_norm_(model.parameters(), 2.0) + AdamW.step()   train.py:200-203, :321-326.
  * dmvs_sumsq_f32: *out (a device double) = sum g[i]^2;  `g` must be 16-byte aligned.
