@@ -112,7 +112,7 @@ def main(argv=None):
         for scene in mine:
             out_folder = os.path.join(a.outdir, scene)
             n = fusion.filter_depth(os.path.join(a.testpath, scene), out_folder, os.path.join(a.outdir, (scene or "scene") + ".ply"),
-                                    method=a.method, dataset=a.dataset, device=device)
+                                    method=a.method, dataset=a.dataset, scan=scene, device=device)
             res.setdefault("fused_points", {})[scene] = n
     print(json.dumps(res), flush=True)
     return res
