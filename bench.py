@@ -80,6 +80,33 @@ def scene_geometry_getcost(ops, B, H, W, S, n, iters=20):
             "gather_kernel_same_inputs_us": round(out[True] * 1e6, 2), "gather_kernel_frac": round(alg / out[True] / 1e9 / HBM_PEAK_GBS, 4)}
 
 
+def batch_sweep(model, H, W, S, dev, batches=(1, 2, 4, 8), iters=10):
+    """Untimed side measurement: ms per depth map at small batches, eager launch sequence vs the captured HIP graph of the same
+    forward (the reference's harness runs batch 1, test.py:101-127; there the ~350 launches of a forward are host-bound)."""
+    out = {}
+    was = model.hip_graphs
+    for B in batches:
+        imgs, proj, dv = synth.synth_inputs(H, W, S, B=B, seed=300 + B)
+        imgs = [i.to(dev) for i in imgs]
+        proj = {k: v.to(dev) for k, v in proj.items()}
+        dv = dv.to(dev)
+        row = {}
+        for graphs in (False, True):
+            model.hip_graphs = graphs
+            with torch.no_grad():
+                for _ in range(3):
+                    model(imgs, proj, dv)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    model(imgs, proj, dv)
+                torch.cuda.synchronize()
+            row["graph_ms_per_map" if graphs else "eager_ms_per_map"] = round((time.perf_counter() - t0) / iters / B * 1e3, 4)
+        out[str(B)] = row
+    model.hip_graphs = was
+    return out
+
+
 def cpu_baseline(a):
     """oracle/diffmvs_oracle.py (the CPU restatement pinned to the reference) on the host cores."""
     from oracle import diffmvs_oracle as O
@@ -173,6 +200,8 @@ def main():
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--src-views", type=int, default=5)
+    ap.add_argument("--graphs", action="store_true", help="run the timed steps through the captured HIP graph of the forward")
+    ap.add_argument("--no-batch-sweep", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-forwards", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=32, help="threads of the CPU baseline leg (more than ~32 is slower at batch 1)")
@@ -209,6 +238,7 @@ def main():
     proj = {k: v.to(dev) for k, v in proj.items()}
     dv = dv.to(dev)
     eng = model.engine()
+    model.hip_graphs = bool(a.graphs)
 
     def barrier():
         if dist:
@@ -223,6 +253,13 @@ def main():
         elapsed = timed_steps(lambda: model(imgs, proj, dv), a.steps, 0, barrier)
     timers, eng.ops.timers = eng.ops.timers, None
     elapsed = shard.barrier_and_max(elapsed, dev)      # whole-job time = slowest rank
+    model.hip_graphs = False                           # the per-kernel event legs below need the eager launch sequence
+    if a.graphs:      # no per-launch events inside a graph replay: one extra eager step for the roofline legs
+        with torch.no_grad():
+            eng.ops.timers = {k: [] for k in timers}
+            model(imgs, proj, dv)
+            torch.cuda.synchronize()
+        timers, eng.ops.timers = eng.ops.timers, None
     # one extra, untimed step with an event pair around every conv2d launch (kept out of the timed region: ~200 launches)
     with torch.no_grad():
         eng.ops.timers = {"dmvs_conv2d_f32": []}
@@ -235,6 +272,7 @@ def main():
     gather_tiles = eng.ops.getcost_tiles or (None, None)      # last lazily read-back probe of the hybrid launch
     scene = scene_geometry_getcost(eng.ops, B, H, W, S, args.CostNum[1]) if rank == 0 else None
 
+    sweep = batch_sweep(model, H, W, S, dev) if (rank == 0 and world == 1 and not a.no_batch_sweep) else None
     maps = B * a.steps * world
     value = maps / elapsed
     gc_ms = [s.elapsed_time(e) for s, e in timers["dmvs_getcost_f32"] + timers["dmvs_getcost_gather_f32"] + timers["dmvs_getcost_quad_f32"]]
@@ -266,7 +304,9 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"DiffMVS DTU eval {W}x{H}, {S} src views, numdepth_initial=48, 1 DDIM step, fp32",
                    "ref_views_per_gpu_per_step": B, "parallelism": f"ref-view sharding x{world}, no collective",
-                   "weights": "seeded random init (no checkpoint offline)"},
+                   "weights": "seeded random init (no checkpoint offline)",
+                   "launch": "captured HIP graph of the forward" if a.graphs else "eager launch sequence (~350 kernels per step)"},
+        "batch_sweep_ms_per_map": sweep,
         "roofline": {"kernel": ("GetCost: getcost_quad_kernel<32,6> (quad per pixel, one launch for any geometry)" if eng.quad else
                                 "GetCost: getcost_win_kernel<32,6> (LDS-staged source windows) / getcost_kernel<32,4,6> (per-pixel gather), picked per launch"),
                      "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -7,6 +7,8 @@ error on a non-HIP device or a missing libdmvs_hip.so).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
@@ -66,6 +68,9 @@ class CasDiffMVS(nn.Module):
         # the HIP device), the counterpart of torch.randn_like at reference update.py:472.  Parity tests
         # inject the oracle's noise stream here.
         self.noise_source = None
+        # eval forward through a captured HIP graph (diffmvs_amd.engine.GraphedForward): worth it for small batches, where
+        # ~350 launches per forward are host-bound; the returned tensors are then overwritten by the next call
+        self.hip_graphs = os.environ.get("DMVS_GRAPHS", "0") == "1"
         self.t_source = None          # train mode: callable (B, timesteps, device) -> int64 [B]; None = torch.randint
         self._train_ops = None        # tests pin the host-emulated library here
         self._engine = None
@@ -111,4 +116,7 @@ class CasDiffMVS(nn.Module):
             if ops is None:
                 ops = Ops.for_device(next(self.parameters()).device)
             return forward_train(self, imgs, proj_matrices, depth_values, depth_gt_ms, ops)
-        return self.engine().forward(imgs, proj_matrices, depth_values, noise_fn=self.noise_source, test=self.test)
+        eng = self.engine()
+        if self.hip_graphs:
+            return eng.forward_graphed(imgs, proj_matrices, depth_values, noise_fn=self.noise_source, test=self.test)
+        return eng.forward(imgs, proj_matrices, depth_values, noise_fn=self.noise_source, test=self.test)

@@ -179,3 +179,44 @@ def test_sizes_not_multiple_of_tile(H, W):
         ref = O.forward(sd, args, imgs, proj, dv, noise_fn=lambda shape: src(shape, "cpu"))
     errs = [rel_l1(a.cpu(), b) for a, b in zip(out["depth"], ref["depth"])]
     assert max(errs) < TOL, errs
+
+
+class _FixedNoise:
+    """device-resident noise tensors returned in order, the same tensors every forward: graph-capturable and comparable
+    with an eager run"""
+
+    def __init__(self, seed):
+        self.seed, self.bufs, self.i = seed, [], 0
+
+    def rewind(self):
+        self.i = 0
+
+    def __call__(self, shape, device):
+        if self.i == len(self.bufs):
+            self.bufs.append(synth.synth_noise(shape, self.seed, self.i).to(device))
+        t = self.bufs[self.i]
+        self.i += 1
+        return t
+
+
+@pytest.mark.parametrize("variant,B", [("diffmvs", 1), ("casdiffmvs", 2)])
+def test_hip_graph_forward_matches_eager(variant, B):
+    """the captured-graph forward (batch-1 operating point of the reference's harness) replays to the same depth maps as the
+    eager launch sequence, also after the inputs change"""
+    model, _, _ = make_model(variant, 16)
+    noise = _FixedNoise(5)
+    outs = {}
+    for graphs in (False, True):
+        model.hip_graphs = graphs
+        for seed in (21, 22, 21):                       # new inputs, then the first ones again
+            imgs, proj, dv = synth.synth_inputs(96, 160, 3, B=B, seed=seed)
+            noise.rewind()
+            model.noise_source = noise
+            with torch.no_grad():
+                o = model([i.cuda() for i in imgs], {k: v.cuda() for k, v in proj.items()}, dv.cuda())
+            torch.cuda.synchronize()
+            outs[(graphs, seed)] = [d.clone() for d in o["depth"]] + [c.clone() for c in o["photometric_confidence"]]
+    for seed in (21, 22):
+        for a, b in zip(outs[(True, seed)], outs[(False, seed)]):
+            assert a.shape == b.shape and rel_l1(a.cpu(), b.cpu()) < 1e-6
+    assert rel_l1(outs[(False, 21)][-3].cpu(), outs[(False, 22)][-3].cpu()) > 1e-4      # the two inputs do differ
