@@ -41,6 +41,19 @@ __device__ __forceinline__ float dmvs_act(float v, int act) {
     }
 }
 
+// GroupNorm statistics (per-(batch item, group) sum and sum of squares) are accumulated from many workgroups.  Floating-point
+// atomics would make the result depend on the arrival order; the 8-byte slots therefore hold FIXED-POINT integers (2^-16
+// units): integer addition is associative, so the statistics -- and with them the whole forward -- are bit-reproducible
+// run to run.  Range +-1.4e14, resolution 1.5e-5 per contribution (a workgroup's partial sum, magnitude 1e2..1e6).
+// Callers keep treating the buffer as opaque zero-initialised 8-byte slots (all-zero bits = 0 in either reading).
+#define DMVS_GN_FIX 65536.0
+__device__ __forceinline__ void dmvs_gn_accumulate(double* slot, double v) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)(long long)llrint(v * DMVS_GN_FIX));
+}
+__device__ __forceinline__ double dmvs_gn_read(const double* slot) {
+    return (double)(*reinterpret_cast<const long long*>(slot)) * (1.0 / DMVS_GN_FIX);
+}
+
 // disp_to_depth (reference models/module.py:220-227): normalised inverse depth -> metric depth
 __device__ __forceinline__ float dmvs_disp_to_depth(float nd, float disp_min, float disp_max) {
     float scaled = disp_min + (disp_max - disp_min) * nd;

@@ -192,8 +192,8 @@ extern "C" int dmvs_convex_upsample_f32(const float* inv, const float* mask, con
 }
 
 // ------------------------------------------------------------------------------------------
-// GroupNorm: pass 1 = per-(b,group) sum / sum of squares (block tree + one fp64 atomic pair
-// per block), pass 2 = normalise + scale/shift + SiLU (+ residual), one (b,c) row per
+// GroupNorm: pass 1 = per-(b,group) sum / sum of squares (block tree + one order-independent fixed-point
+// atomic pair per block, see dmvs_gn_accumulate), pass 2 = normalise + scale/shift + SiLU (+ residual), one (b,c) row per
 // blockIdx.y so the statistics are block-uniform scalars.
 __global__ void __launch_bounds__(DMVS_BLOCK)
 gn_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, long per_group, int chunk) {
@@ -225,8 +225,8 @@ gn_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, long pe
             a += (double)red[0][w];
             c += (double)red[1][w];
         }
-        atomicAdd(&stats[2 * bg], a);
-        atomicAdd(&stats[2 * bg + 1], c);
+        dmvs_gn_accumulate(&stats[2 * bg], a);
+        dmvs_gn_accumulate(&stats[2 * bg + 1], c);
     }
 }
 
@@ -239,8 +239,8 @@ gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma, co
     const int cg = C / groups;
     const int g = c / cg;
     const double n = (double)cg * HW;
-    const double mean = stats[2 * (b * groups + g)] / n;
-    double var = stats[2 * (b * groups + g) + 1] / n - mean * mean;
+    const double mean = dmvs_gn_read(&stats[2 * (b * groups + g)]) / n;
+    double var = dmvs_gn_read(&stats[2 * (b * groups + g) + 1]) / n - mean * mean;
     var = var < 0.0 ? 0.0 : var;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     // y = ((x - mean) * rstd * gamma + beta) * (scale + 1) + shift  ==  x * A + Bc

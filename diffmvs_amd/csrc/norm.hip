@@ -298,8 +298,8 @@ __device__ __forceinline__ void gn_row_consts(const double* stats, int b, int c,
                                               float& rstd) {
     const int cg = C / groups, g = c / cg;
     const double n = (double)cg * HW;
-    const double m = stats[2 * (b * groups + g)] / n;
-    double var = stats[2 * (b * groups + g) + 1] / n - m * m;
+    const double m = dmvs_gn_read(&stats[2 * (b * groups + g)]) / n;
+    double var = dmvs_gn_read(&stats[2 * (b * groups + g) + 1]) / n - m * m;
     var = var < 0.0 ? 0.0 : var;
     mean = (float)m;
     rstd = (float)(1.0 / sqrt(var + (double)eps));

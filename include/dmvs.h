@@ -68,7 +68,9 @@ typedef struct dmvs_conv2d_desc {
     const float* gru_z;     /* [B,cout,Hout,Wout] or NULL                                   */
     const float* gru_h;
     float* out;
-    double* gn_stats;       /* [B,gn_groups,2] or NULL: += per-(b,group) sum and sum of squares of y
+    double* gn_stats;       /* [B,gn_groups,2] 8-byte slots or NULL (opaque: fixed-point integers, so that the accumulation
+                               order of the workgroups cannot change the result -- zero-initialise, hand to
+                               dmvs_groupnorm_apply_f32): += per-(b,group) sum and sum of squares of y
                                BEFORE the activation (GroupNorm statistics of the conv output, so
                                that Block.forward needs no separate reduction pass; the caller
                                zeroes the buffer).  gn_groups must be 4 and divide cout.       */
@@ -294,7 +296,7 @@ int dmvs_convex_upsample_f32(const float* inv, const float* mask, const float* d
 /* GroupNorm statistics + fused apply of Block.forward (models/update.py:124-133):
  *   y = silu( gn(x) * (scale+1) + shift ) [+ residual]
  * x [B,C,HW]; gamma,beta [C]; scale_shift [B,2C] (scale then shift) or NULL; residual or NULL.
- * stats: caller-provided scratch of B*groups*2 doubles.  In-place (y == x) is allowed. */
+ * stats: caller-provided scratch of B*groups*2 8-byte slots (opaque, see gn_stats above).  In-place (y == x) is allowed. */
 int dmvs_groupnorm_silu_f32(const float* x, const float* gamma, const float* beta,
                             const float* scale_shift, const float* residual, float* y,
                             double* stats, int32_t B, int32_t C, int32_t HW, int32_t groups,

@@ -268,6 +268,7 @@ static inline T hipemu_atomic_add(T* addr, T val) {
 static inline float atomicAdd(float* a, float v) { return hipemu_atomic_add(a, v); }
 static inline double atomicAdd(double* a, double v) { return hipemu_atomic_add(a, v); }
 static inline int atomicAdd(int* a, int v) { return __atomic_fetch_add(a, v, __ATOMIC_RELAXED); }
+static inline unsigned long long atomicAdd(unsigned long long* a, unsigned long long v) { return __atomic_fetch_add(a, v, __ATOMIC_RELAXED); }
 
 // clang's ext_vector_type spelled for g++ (kernels only use 4 x float vectors)
 #define ext_vector_type(N) vector_size((N) * 4)

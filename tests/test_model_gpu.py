@@ -105,7 +105,7 @@ def test_against_oracle_fresh_inputs(variant, H, W, S, B, nd):
 def test_full_size_properties():
     """BASELINE.json configs[1] (640x512, 5 src, nd_init 48): too slow for the CPU oracle in a unit test, so
     check size-independent properties: batch items are independent (B=2 equals two B=1 runs bit-for-bit
-    modulo GroupNorm's atomic accumulation order), same noise => same output, depths inside the range."""
+    ), same noise => bit-identical output, depths inside the range."""
     model, _, _ = make_model("diffmvs", 48)
     imgs, proj, dv = synth.synth_inputs(512, 640, 5, B=2, seed=5)
     out2 = run(model, imgs, proj, dv, 1)
@@ -114,9 +114,10 @@ def test_full_size_properties():
     assert d2.shape == (2, 512, 640)
     assert torch.isfinite(d2).all()
     assert float(d2.min()) >= 424.9 and float(d2.max()) <= 935.1
-    assert rel_l1(out2b["depth"][-1].cpu(), d2.cpu()) < 1e-6
-    # first stage has no atomics: bit-identical across runs
-    assert torch.equal(out2["depth"][0], out2b["depth"][0])
+    # no floating-point atomics anywhere in the eval forward (GroupNorm statistics accumulate in fixed point): same
+    # inputs + same noise => bit-identical outputs, every stage
+    for x, yv in zip(out2["depth"], out2b["depth"]):
+        assert torch.equal(x, yv)
     for b in range(2):
         sub_i = [i[b:b + 1] for i in imgs]
         sub_p = {k: v[b:b + 1] for k, v in proj.items()}
@@ -147,8 +148,8 @@ def test_casdiffmvs_cfg3_size_properties():
     for d in out["depth"]:
         assert torch.isfinite(d).all() and float(d.min()) >= 424.9 and float(d.max()) <= 935.1
     again = run(model, imgs, proj, dv, 2)
-    assert torch.equal(again["depth"][0], out["depth"][0])
-    assert rel_l1(again["depth"][-1].cpu(), out["depth"][-1].cpu()) < 1e-6
+    for x, yv in zip(again["depth"], out["depth"]):
+        assert torch.equal(x, yv)
 
 
 def test_casdiffmvs_cfg5_size_properties():
@@ -164,8 +165,8 @@ def test_casdiffmvs_cfg5_size_properties():
     for d in out["depth"]:
         assert torch.isfinite(d).all() and float(d.min()) >= 424.9 and float(d.max()) <= 935.1
     again = run(model, imgs, proj, dv, 5)
-    assert torch.equal(again["depth"][0], out["depth"][0])
-    assert rel_l1(again["depth"][-1].cpu(), out["depth"][-1].cpu()) < 1e-6
+    for x, yv in zip(again["depth"], out["depth"]):
+        assert torch.equal(x, yv)
 
 
 @pytest.mark.parametrize("H,W", [(96, 160), (160, 224)])

@@ -430,7 +430,7 @@ def test_conv_fused_groupnorm_stats(ops, cin, cout, HW):
     h = ops.conv2d(pc, dev(ops, x), gn_stats=stats)
     close(h, y, 2e-5)
     n = (cout // 4) * HW[0] * HW[1]
-    st = stats.cpu().view(B, 4, 2)
+    st = (stats.cpu().view(torch.int64).double() / 65536.0).view(B, 4, 2)      # opaque slots: 2^-16 fixed point (dmvs_common.h)
     yg = y.view(B, 4, -1).double()
     assert torch.allclose(st[..., 0] / n, yg.mean(-1), atol=1e-5)
     assert torch.allclose(st[..., 1] / n, (yg * yg).mean(-1), rtol=1e-5, atol=1e-6)
