@@ -38,46 +38,39 @@ def getcost_algorithmic_bytes(B, C, S, n, G, H, W):
 
 
 def scene_geometry_getcost(ops, B, H, W, S, n, iters=20):
-    """The GetCost kernels on the geometry a TRAINED network produces: hypotheses centred on the synthetic scene's true
-    depth (sigma 0.01 of the normalised inverse-depth range).  The timed model above runs random-init weights, whose
-    depth maps are noise: there every 16x16 tile's source footprint exceeds the LDS window and the per-pixel gather
-    kernel does the work; on surfaces the window kernel does.  Untimed side measurement, same stage-2 shapes."""
-    from diffmvs_amd.ops import Ops
-    o = Ops(ops.lib, ops.device)                     # fresh adaptive state
+    """The GetCost kernel on the geometry a TRAINED network produces from its second GRU iteration on: hypotheses centred on the
+    synthetic scene's true depth (sigma 0.01 of the normalised inverse-depth range), confidence 0.5.  The timed model above runs
+    random-init weights, whose depth maps are noise (as is the first iteration of every diffusion stage of any network:
+    scale * randn, update.py:472).  Untimed side measurement, same stage-2 shapes; the round-1 per-pixel gather kernel on the
+    same inputs beside it."""
+    from diffmvs_amd.ops import Ops, g4_channels
+    o = Ops(ops.lib, ops.device)
     dev = ops.device
     gi = synth.getcost_scene_inputs(H, W, S, B, stage=2, C=32, noise=0.01, conf=0.5)
     t = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in gi.items()}
     rt = o.compose_proj(t["proj"].float().contiguous())
-    call = (t["ref"], t["src"], rt, t["inv"], t["conf"], t["view_w"], t["disp_min"], t["disp_max"], n, t["interval"], 0.2, 2.0,
-            t["vw_shift"])
+    perm = g4_channels(32).to(dev)
+    ref4, src4 = t["ref"][..., perm].contiguous(), t["src"][..., perm].contiguous()
+    tail = (rt, t["inv"], t["conf"], t["view_w"], t["disp_min"], t["disp_max"], n, t["interval"], 0.25, 4.0, t["vw_shift"])
     out = {}
-    for gather in (False, True):
+    for name, fn in (("quad", lambda: o.getcost_quad(ref4, src4, *tail)), ("gather", lambda: o.getcost(t["ref"], t["src"], *tail, gather=True))):
         for _ in range(5):
-            o.getcost(*call, gather=gather)
+            fn()
         torch.cuda.synchronize()
         st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         st.record()
         for _ in range(iters):
-            o.getcost(*call, gather=gather)
+            fn()
         en.record()
         torch.cuda.synchronize()
-        out[gather] = st.elapsed_time(en) * 1e-3 / iters
+        out[name] = st.elapsed_time(en) * 1e-3 / iters
     h2, w2 = H // 4, W // 4
     alg = getcost_algorithmic_bytes(B, 32, S, n, 4, h2, w2)
-    traffic = None
-    tj = os.path.join(ROOT, "profiles", "r1b_getcost_traffic.json")
-    if os.path.exists(tj):
-        with open(tj) as f:
-            ti = json.load(f)
-        if ti.get("batch") == B and (H, W, S) == (512, 640, 5):
-            traffic = ti["traffic_bytes_per_launch"]
-    return {"kernel": "getcost_win_kernel<32,6> incl. its pre-pass (hypotheses around the scene's true depth, sigma 0.01)",
-            "bound": "hbm", "achieved": round(alg / out[False] / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(alg / out[False] / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "traffic_source": "profiles/r1b_getcost_traffic.json (rocprofv3 PMC passes of an earlier run; not measured by this process)" if traffic else None,
-            "algorithmic_bytes_per_launch": alg,
-            "avg_launch_us": round(out[False] * 1e6, 2), "tiles_on_gather_path": (o.getcost_tiles or (None, None))[0],
-            "gather_kernel_same_inputs_us": round(out[True] * 1e6, 2), "gather_kernel_frac": round(alg / out[True] / 1e9 / HBM_PEAK_GBS, 4)}
+    return {"kernel": "getcost_quad_kernel<32,6> (hypotheses around the scene's true depth, sigma 0.01, confidence 0.5)",
+            "bound": "hbm", "achieved": round(alg / out["quad"] / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(alg / out["quad"] / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": alg,
+            "avg_launch_us": round(out["quad"] * 1e6, 2), "round1_gather_kernel_same_inputs_us": round(out["gather"] * 1e6, 2),
+            "round1_gather_kernel_frac": round(alg / out["gather"] / 1e9 / HBM_PEAK_GBS, 4)}
 
 
 def batch_sweep(model, H, W, S, dev, batches=(1, 2, 4, 8), iters=10):
@@ -200,6 +193,10 @@ def main():
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--src-views", type=int, default=5)
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3"],
+                    help="cfg2 = BASELINE.json configs[1] (the metric's configuration, default); cfg3 = configs[2]: CasDiffMVS 1152x864, "
+                         "7 source views, bf16 feature storage (a second line, not the headline)")
+    ap.add_argument("--precision", default=None, choices=["fp32", "bf16", "fp16"], help="feature storage precision (default: the config's)")
     ap.add_argument("--graphs", action="store_true", help="run the timed steps through the captured HIP graph of the forward")
     ap.add_argument("--no-batch-sweep", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -227,7 +224,15 @@ def main():
         td = shard.init_distributed(a.backend, dev)       # RCCL: rendezvous, barrier and one 8-byte max-reduce only
 
     from models import CasDiffMVS
-    args = synth.make_args("diffmvs", numdepth_initial=48)
+    variant = "diffmvs"
+    if a.config == "cfg3":
+        variant = "casdiffmvs"
+        a.height, a.width, a.src_views = 864, 1152, 7
+        if "DMVS_BENCH_BATCH" not in os.environ and "--batch" not in sys.argv:
+            a.batch = 4
+        a.precision = a.precision or "bf16"
+    prec = a.precision or "fp32"
+    args = synth.make_args(variant, numdepth_initial=48, precision=prec)
     model = CasDiffMVS(args, test=True).eval()
     sd = synth.synth_state_dict(model.state_dict(), 123)
     model.load_state_dict(sd)
@@ -270,9 +275,9 @@ def main():
     timers.update(eng.ops.timers)
     eng.ops.timers = None
     gather_tiles = eng.ops.getcost_tiles or (None, None)      # last lazily read-back probe of the hybrid launch
-    scene = scene_geometry_getcost(eng.ops, B, H, W, S, args.CostNum[1]) if rank == 0 else None
+    scene = scene_geometry_getcost(eng.ops, B, H, W, S, args.CostNum[1]) if (rank == 0 and a.config == "cfg2" and eng.quad) else None
 
-    sweep = batch_sweep(model, H, W, S, dev) if (rank == 0 and world == 1 and not a.no_batch_sweep) else None
+    sweep = batch_sweep(model, H, W, S, dev) if (rank == 0 and world == 1 and not a.no_batch_sweep and a.config == "cfg2") else None
     maps = B * a.steps * world
     value = maps / elapsed
     gc_ms = [s.elapsed_time(e) for s, e in timers["dmvs_getcost_f32"] + timers["dmvs_getcost_gather_f32"] + timers["dmvs_getcost_quad_f32"]]
@@ -281,9 +286,13 @@ def main():
     gc_avg_s = sum(gc_ms) / max(1, len(gc_ms)) * 1e-3
     h2, w2 = H // 4, W // 4
     alg = getcost_algorithmic_bytes(B, 32, S, args.CostNum[1], 4, h2, w2)
-    achieved = alg / gc_avg_s / 1e9 if gc_avg_s > 0 else 0.0
     h1, w1 = H // 8, W // 8
     alg_init = 4 * B * h1 * w1 * (48 + S * 48 + S * 4 * 48)      # ref + src + per-view volumes out
+    if timers.get("_getcost_bytes"):          # quad kernels: bytes recorded per launch (stage-2 and stage-3 shapes, feature element size)
+        alg = sum(timers["_getcost_bytes"]) / len(timers["_getcost_bytes"])
+    if timers.get("_warp_init_bytes"):
+        alg_init = sum(timers["_warp_init_bytes"]) / len(timers["_warp_init_bytes"])
+    achieved = alg / gc_avg_s / 1e9 if gc_avg_s > 0 else 0.0
     wi_avg_s = sum(wi_ms) / max(1, len(wi_ms)) * 1e-3
     cv_s = sum(s.elapsed_time(e) for s, e in timers["dmvs_conv2d_f32"]) * 1e-3
     cv_flops = sum(timers.get("_conv2d_flops", []))
@@ -331,7 +340,14 @@ def main():
                             "share_of_step_time": round(cv_s / conv_step_s, 4)},
     }
 
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if a.config != "cfg2":
+        result["metric"] = f"depth-maps/sec ({W}x{H}, {S} src views)"
+        result["config"]["workload"] = (f"CasDiffMVS DTU eval {W}x{H}, {S} src views, numdepth_initial=48, sampling_timesteps 0/1/1, "
+                                        f"{prec} feature storage + fp32 arithmetic (BASELINE.json configs[2]; not the headline configuration)")
+        result["roofline"]["kernel"] = "GetCost: getcost_quad_kernel<32,4> + <16,4> (stage 2 and stage 3 launches, bytes averaged per launch)"
+        result["roofline_conv2d"] = None
+    result["config"]["feature_storage"] = prec
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.config == "cfg2":
         # the CPU leg runs in a child process with a hard time limit so that an oversubscribed or slow
         # host can never stall the GPU measurement
         import subprocess

@@ -14,7 +14,8 @@ HIP_LIB_PATH = os.path.join(PKG, "libdmvs_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_SILU = range(5)
 IN_PLAIN, IN_UPSAMPLE2, IN_UNSHUFFLE2, IN_ZEROINSERT2 = range(4)
-LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
+LAYOUT_NCHW, LAYOUT_NHWC, LAYOUT_NHWC_BF16, LAYOUT_NHWC_F16 = 0, 1, 2, 3
+DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
 EW_DEPTH_TO_DISP, EW_DISP_TO_DEPTH = 0, 1
 
 _P = C.c_void_p
@@ -48,7 +49,7 @@ class GetCostDesc(C.Structure):
         ("disp_min", _P), ("disp_max", _P), ("out_cost", _P), ("out_samples", _P), ("worklist", _P),
         ("B", _I), ("S", _I), ("C", _I), ("G", _I), ("n", _I), ("H", _I), ("W", _I), ("vw_shift", _I),
         ("cost_cstride", _I), ("cost_coffset", _I), ("samp_cstride", _I), ("samp_coffset", _I),
-        ("interval", _F), ("min_radius", _F), ("max_radius", _F),
+        ("interval", _F), ("min_radius", _F), ("max_radius", _F), ("feat_dtype", _I),
     ]
 
 
@@ -70,7 +71,7 @@ SIGNATURES = {
     "dmvs_getcost_f32": [C.POINTER(GetCostDesc), _P],
     "dmvs_getcost_gather_f32": [C.POINTER(GetCostDesc), _P],
     "dmvs_getcost_quad_f32": [C.POINTER(GetCostDesc), _P],
-    "dmvs_warp_corr_init_quad_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "dmvs_warp_corr_init_quad_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "dmvs_warp_corr_init_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "dmvs_getcost_bwd_f32": [C.POINTER(GetCostDesc), _P, _P, _P, _P],
     "dmvs_view_aggregate_bwd_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

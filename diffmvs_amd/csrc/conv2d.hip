@@ -63,7 +63,9 @@ struct ConvCfg {
 // shapes otherwise settle at 160 / 212 VGPRs = 3 / 2 waves, too few to cover the per-chunk barrier + DMA latency
 constexpr int conv_min_waves(int nt, int mt) { return (nt == 2 && mt == 4) ? 4 : ((nt == 4 && mt == 2) ? 3 : 1); }
 
-template <int KH, int KW, int S, int NT, int MT, bool ZI>
+// OT = element type of a channel-last output (DMVS_DTYPE_*): 16-bit feature storage is its own instantiation so that the
+// fp32 kernels keep their register allocation.
+template <int KH, int KW, int S, int NT, int MT, bool ZI, int OT = DMVS_DTYPE_F32>
 __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfma_kernel(const dmvs_conv2d_desc d, int tiles_x, int tiles_y) {
     using Cfg = ConvCfg<KH, KW, S, NT, MT>;
     constexpr int T = Cfg::T, TW = Cfg::TW, TH = Cfg::TH, PLANE = Cfg::PLANE, NW = Cfg::NW, WPAD = Cfg::WPAD;
@@ -345,7 +347,16 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
                     y[nt][r] = (1.0f - z) * ghb[gi] + z * y[nt][r];
                 }
         }
-        if (d.out_layout == DMVS_LAYOUT_NCHW) {
+        if constexpr (OT != DMVS_DTYPE_F32) {      // channel-last, 16-bit elements
+            uint16_t* const ob16 = reinterpret_cast<uint16_t*>(d.out) + (size_t)b * oplane * d.out_cstride + d.out_coffset;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int cg = nbase + nt * 16 + kq * 4 + r;
+                    if (okp && cg < d.cout) ob16[(unsigned)(__mul24(opix, d.out_cstride) + cg)] = dmvs_to_x16<OT>(y[nt][r]);
+                }
+        } else if (d.out_layout == DMVS_LAYOUT_NCHW) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -389,8 +400,29 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     }
 }
 
+// 16-bit channel-last outputs (FeatureNet's out1 / out2 / out3 in the reduced-precision configurations): 1x1 and 3x3 stride 1
+template <int KH, int KW, int MT, int OT>
+int launch_conv2d_x16(const dmvs_conv2d_desc& d, hipStream_t st, int nt, int ngroups) {
+    const int tiles_x = (d.Wout + 15) / 16, tiles_y = (d.Hout + 4 * MT - 1) / (4 * MT);
+    dim3 grid((unsigned)(tiles_x * tiles_y * d.B), (unsigned)ngroups), block(DMVS_BLOCK);
+    switch (nt) {
+        case 1: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, 1, 1, MT, false, OT>), grid, block, 0, st, d, tiles_x, tiles_y); break;
+        case 2: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, 1, 2, MT, false, OT>), grid, block, 0, st, d, tiles_x, tiles_y); break;
+        case 3: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, 1, 3, MT, false, OT>), grid, block, 0, st, d, tiles_x, tiles_y); break;
+        default: return DMVS_EINVAL;
+    }
+    return dmvs_launch_status();
+}
+
 template <int KH, int KW, int S, int MT, bool ZI>
 int launch_conv2d_mt(const dmvs_conv2d_desc& d, hipStream_t st, int nt, int ngroups) {
+    if (d.out_layout == DMVS_LAYOUT_NHWC_BF16 || d.out_layout == DMVS_LAYOUT_NHWC_F16) {
+        if constexpr (!ZI && S == 1 && ((KH == 1 && KW == 1) || (KH == 3 && KW == 3)) && MT == 2) {
+            return d.out_layout == DMVS_LAYOUT_NHWC_BF16 ? launch_conv2d_x16<KH, KW, MT, DMVS_DTYPE_BF16>(d, st, nt, ngroups)
+                                                         : launch_conv2d_x16<KH, KW, MT, DMVS_DTYPE_F16>(d, st, nt, ngroups);
+        }
+        return DMVS_EINVAL;
+    }
     const int tiles_x = (d.Wout + 15) / 16, tiles_y = (d.Hout + 4 * MT - 1) / (4 * MT);
     dim3 grid((unsigned)(tiles_x * tiles_y * d.B), (unsigned)ngroups), block(DMVS_BLOCK);
     switch (nt) {
@@ -421,6 +453,8 @@ int launch_conv2d(const dmvs_conv2d_desc& d, hipStream_t st) {
     //   32->32 at 128x160 (1280 tiles: 1.25 rounds of the ~1024 resident 16x16 workgroups) 86.9 / 80.5 / 85.3;
     //   24->32 at 128x160 70.1 / 65.0 / 67.7;  16->16 at 128x160 (one n-tile) 38.0 / 30.7 / 29.3.
     constexpr bool heavy = (S == 2) || (KH * KW >= 25);
+    if (d.out_layout == DMVS_LAYOUT_NHWC_BF16 || d.out_layout == DMVS_LAYOUT_NHWC_F16)      // one tile shape (16x8) for the 16-bit outputs
+        return launch_conv2d_mt<KH, KW, S, 2, false>(d, st, nt, ngroups);
     const long wg16 = (long)((d.Wout + 15) / 16) * ((d.Hout + 15) / 16) * d.B * ngroups;
     if (wg16 * 2 < 1024) return launch_conv2d_mt<KH, KW, S, 1, false>(d, st, nt, ngroups);
     if (heavy || nt == 4 || (nt >= 2 && wg16 < 2048)) return launch_conv2d_mt<KH, KW, S, 2, false>(d, st, nt, ngroups);
@@ -668,6 +702,8 @@ extern "C" int dmvs_conv2d_f32(const dmvs_conv2d_desc* dp, void* stream) {
     // 32-bit element offsets inside one batch item
     if ((long)(d.c0 + d.c1) * d.Hin * d.Win * (d.in_mode == DMVS_IN_UNSHUFFLE2 ? 4 : 1) >= (1L << 31)) return DMVS_EINVAL;
     // epilogue: channel * plane + pixel in 24-bit x 24-bit multiplies and 32-bit sums
+    if (d.out_layout < DMVS_LAYOUT_NCHW || d.out_layout > DMVS_LAYOUT_NHWC_F16) return DMVS_EINVAL;
+    if (d.out_layout >= DMVS_LAYOUT_NHWC_BF16 && (d.gru_z || d.gn_stats)) return DMVS_EINVAL;
     const int ocs = d.out_cstride > d.cout ? d.out_cstride : d.cout;
     if ((long)d.Hout * d.Wout >= (1L << 24) || ocs >= (1 << 24) || (long)ocs * d.Hout * d.Wout >= (1L << 31)) return DMVS_EINVAL;
     const int key = d.kh * 100 + d.kw * 10 + d.stride;

@@ -54,6 +54,24 @@ __device__ __forceinline__ double dmvs_gn_read(const double* slot) {
     return (double)(*reinterpret_cast<const long long*>(slot)) * (1.0 / DMVS_GN_FIX);
 }
 
+// 16-bit feature storage (DMVS_DTYPE_BF16 / DMVS_DTYPE_F16): round-to-nearest-even conversions; arithmetic stays fp32.
+__device__ __forceinline__ uint16_t dmvs_f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);      // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float dmvs_bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+#ifdef DMVS_HOST_EMULATION
+__device__ __forceinline__ uint16_t dmvs_f32_to_f16(float f) { return hipemu_f32_to_f16(f); }
+__device__ __forceinline__ float dmvs_f16_to_f32(uint16_t h) { return hipemu_f16_to_f32(h); }
+#else
+__device__ __forceinline__ uint16_t dmvs_f32_to_f16(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+__device__ __forceinline__ float dmvs_f16_to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+#endif
+template <int DT> __device__ __forceinline__ uint16_t dmvs_to_x16(float f) { return DT == DMVS_DTYPE_BF16 ? dmvs_f32_to_bf16(f) : dmvs_f32_to_f16(f); }
+template <int DT> __device__ __forceinline__ float dmvs_from_x16(uint16_t h) { return DT == DMVS_DTYPE_BF16 ? dmvs_bf16_to_f32(h) : dmvs_f16_to_f32(h); }
+
 // disp_to_depth (reference models/module.py:220-227): normalised inverse depth -> metric depth
 __device__ __forceinline__ float dmvs_disp_to_depth(float nd, float disp_min, float disp_max) {
     float scaled = disp_min + (disp_max - disp_min) * nd;

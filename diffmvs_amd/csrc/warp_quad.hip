@@ -24,8 +24,6 @@
 //
 // Semantics kept from the reference: per-tap zero padding with align_corners=True pixel coordinates, NO behind-camera
 // mask, z == 0 -> z + 1e-8, non-finite coordinates sample 0.
-#include <stdlib.h>
-
 #include <utility>
 
 #include "dmvs_common.h"
@@ -101,27 +99,64 @@ __device__ __forceinline__ HypQ project_q(const RayQ& r, float depth, bool exist
     return footprint_q(u, v, exists, Hs, Ws);
 }
 
-// this lane's 4*U channels of one texel
-template <int U> struct TexQ { float4 v[U]; };
-
-template <int U>
-__device__ __forceinline__ void load_texel(const char* base, unsigned byte_off, TexQ<U>& t) {
-#pragma unroll
-    for (int j = 0; j < U; ++j) t.v[j] = *reinterpret_cast<const float4*>(base + byte_off + j * 64);
-}
-
 typedef float f2q __attribute__((vector_size(8)));
 
-// two partial sums in one register pair: packed fp32 FMAs (v_pk_fma_f32) retire two products per issue slot
-template <int U>
-__device__ __forceinline__ float dot_texel(const TexQ<U>& t, const float4 (&ref)[U]) {
+// This lane's C/4 channels (= all channels of its correlation group) of one texel, for the three feature element types.
+//   fp32   : NHWC-g4, C/16 units of 64 bytes, the lane reads 16 bytes of each (4 channels)
+//   16-bit : plain NHWC -- a group's C/4 channels are already contiguous (8 / 16 / 24 bytes per lane), the quad still reads one
+//            contiguous run of 2*C bytes; converted to fp32 on arrival, all arithmetic stays fp32
+template <int C, int FT> struct Feat {
+    static constexpr int E = C / 4;                                          // channels per lane
+    static constexpr int ESIZE = FT == DMVS_DTYPE_F32 ? 4 : 2;
+    static constexpr int TEXEL_BYTES = C * ESIZE;
+    static constexpr int NW = FT == DMVS_DTYPE_F32 ? E : E / 2;              // 32-bit words per lane and texel
+    uint32_t w[NW];
+
+    static __device__ __forceinline__ unsigned lane_bytes(int q) { return FT == DMVS_DTYPE_F32 ? (unsigned)q * 16u : (unsigned)q * (E * 2); }
+
+    __device__ __forceinline__ void load(const char* p) {
+        if constexpr (FT == DMVS_DTYPE_F32) {
+#pragma unroll
+            for (int j = 0; j < C / 16; ++j) {
+                const uint4 v = *reinterpret_cast<const uint4*>(p + j * 64);
+                w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
+            }
+        } else {
+            if constexpr (NW >= 4) {
+                const uint4 v = *reinterpret_cast<const uint4*>(p);
+                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+            }
+            if constexpr (NW == 2 || NW == 6) {
+                const uint2 v = *reinterpret_cast<const uint2*>(p + (NW == 6 ? 16 : 0));
+                w[NW - 2] = v.x; w[NW - 1] = v.y;
+            }
+        }
+    }
+    __device__ __forceinline__ float get(int i) const {      // channel i of the lane's group
+        if constexpr (FT == DMVS_DTYPE_F32) return __uint_as_float(w[i]);
+        else if constexpr (FT == DMVS_DTYPE_BF16) return __uint_as_float((i & 1) ? (w[i >> 1] & 0xffff0000u) : (w[i >> 1] << 16));
+        else return dmvs_f16_to_f32((uint16_t)((i & 1) ? (w[i >> 1] >> 16) : (w[i >> 1] & 0xffffu)));
+    }
+};
+
+// group dot with the lane's (pre-scaled, fp32) reference channels: two partial sums in one register pair, so that packed fp32
+// FMAs (v_pk_fma_f32) retire two products per issue slot
+template <int C, int FT>
+__device__ __forceinline__ float dot_texel(const Feat<C, FT>& t, const float (&ref)[C / 4]) {
     f2q a = {0.0f, 0.0f};
 #pragma unroll
-    for (int j = 0; j < U; ++j) {
-        a = f2q{t.v[j].x, t.v[j].y} * f2q{ref[j].x, ref[j].y} + a;
-        a = f2q{t.v[j].z, t.v[j].w} * f2q{ref[j].z, ref[j].w} + a;
-    }
+    for (int i = 0; i < C / 4; i += 2) a = f2q{t.get(i), t.get(i + 1)} * f2q{ref[i], ref[i + 1]} + a;
     return a[0] + a[1];
+}
+
+// the lane's reference channels, scaled by 1 / (channels per group): cor = MEAN over the group (module.py:529-531)
+template <int C, int FT>
+__device__ __forceinline__ void load_ref(const void* ref_base, long pixel, int q, float (&ref)[C / 4]) {
+    Feat<C, FT> r;
+    r.load(reinterpret_cast<const char*>(ref_base) + pixel * Feat<C, FT>::TEXEL_BYTES + Feat<C, FT>::lane_bytes(q));
+    const float inv_cg = 1.0f / (float)(C / 4);
+#pragma unroll
+    for (int i = 0; i < C / 4; ++i) ref[i] = r.get(i) * inv_cg;
 }
 
 __device__ __forceinline__ float hat(float rel, float pos) {      // bilinear weight of integer position `pos` for coordinate `rel`
@@ -176,10 +211,10 @@ __device__ __forceinline__ void scatter_pair(float (&acc)[NH], const float (&w0)
 
 // acc[k] += wscale * (bilinear sample of the lane's group dot at hypothesis k), k < NH, for one (pixel, view).
 // own[h] = hypothesis q + 4h of the pixel (q = lane & 3).  base + view_off = the view's [Hs,Ws,C] NHWC-g4 image (+ 16q bytes).
-template <int U, int NH, int TPT>
+template <int C, int FT, int NH, int TPT>
 __device__ __forceinline__ void quad_accumulate(const char* base, unsigned view_off, const HypQ (&own)[(NH + 3) / 4], int Hs, int Ws,
-                                                const float4 (&ref)[U], float wscale, float (&acc)[NH]) {
-    constexpr int HPL = (NH + 3) / 4, C = 16 * U;
+                                                const float (&ref)[C / 4], float wscale, float (&acc)[NH]) {
+    constexpr int HPL = (NH + 3) / 4, TB = Feat<C, FT>::TEXEL_BYTES;
     const int q = threadIdx.x & 3;
     // do all hypotheses of the pixel fit one 8x8 texel grid anchored at the minimum footprint corner?
     int xlo = BIG, ylo = BIG;
@@ -235,7 +270,7 @@ __device__ __forceinline__ void quad_accumulate(const char* base, unsigned view_
             mlo &= (unsigned)rowmask & colbits;
             mhi &= (unsigned)(rowmask >> 32) & colbits;
         }
-        const unsigned texel_off = view_off + (unsigned)(__mul24(ymin, Ws) + xmin) * (unsigned)(C * 4);    // of grid cell (0, 0)
+        const unsigned texel_off = view_off + (unsigned)(__mul24(ymin, Ws) + xmin) * (unsigned)TB;    // of grid cell (0, 0)
         // rows 0..3 of the grid (mlo), then -- rarely non-empty -- rows 4..7 (mhi): 32-bit bit scans
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
@@ -251,12 +286,12 @@ __device__ __forceinline__ void quad_accumulate(const char* base, unsigned view_
                 bit[i] = (i == 0 || has[i]) ? __ffs((int)m) - 1 : bit[i > 0 ? i - 1 : 0];
                 m &= m - 1u;
             }
-            TexQ<U> t[TPT];
+            Feat<C, FT> t[TPT];
             float fc[TPT], fr[TPT];
 #pragma unroll
             for (int i = 0; i < TPT; ++i) {
                 const int c = bit[i] & 7, r = (bit[i] >> 3) + rbase;
-                load_texel<U>(base, texel_off + (unsigned)(__mul24(r, Ws) + c) * (unsigned)(C * 4), t[i]);
+                t[i].load(base + (texel_off + (unsigned)(__mul24(r, Ws) + c) * (unsigned)TB));
                 fc[i] = (float)c;
                 fr[i] = (float)r;
             }
@@ -266,7 +301,7 @@ __device__ __forceinline__ void quad_accumulate(const char* base, unsigned view_
             float dd[TPT], w[TPT][HPL];
 #pragma unroll
             for (int i = 0; i < TPT; ++i) {
-                dd[i] = dot_texel<U>(t[i], ref) * ((i == 0 || has[i]) ? wscale : 0.0f);
+                dd[i] = dot_texel<C, FT>(t[i], ref) * ((i == 0 || has[i]) ? wscale : 0.0f);
 #pragma unroll
                 for (int h = 0; h < HPL; ++h) w[i][h] = hat(ur[h], fc[i]) * hat(vr[h], fr[i]);
             }
@@ -278,9 +313,9 @@ __device__ __forceinline__ void quad_accumulate(const char* base, unsigned view_
 }
 
 // ------------------------------------------------------------------------------------------ GetCost
-template <int C, int N, int TPT>
+template <int C, int N, int TPT, int FT>
 __global__ void __launch_bounds__(DMVS_BLOCK) getcost_quad_kernel(const dmvs_getcost_desc d) {
-    constexpr int U = C / 16, HPL = (N + 3) / 4, PPB = DMVS_BLOCK / 4;
+    constexpr int HPL = (N + 3) / 4, PPB = DMVS_BLOCK / 4;
     const int q = threadIdx.x & 3;
     const int H = d.H, W = d.W;
     const int hw = H * W;
@@ -316,16 +351,8 @@ __global__ void __launch_bounds__(DMVS_BLOCK) getcost_quad_kernel(const dmvs_get
         if (live && exists[h]) d.out_samples[((long)b * d.samp_cstride + d.samp_coffset + k) * (long)hw + yx] = sk;
     }
 
-    float4 ref[U];
-    {
-        const float inv_cg = 1.0f / (float)(C / 4);       // mean over the channels of a group
-        const float4* rp = reinterpret_cast<const float4*>(d.ref + pc * C + q * 4);
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const float4 v = rp[j * 4];
-            ref[j] = make_float4(v.x * inv_cg, v.y * inv_cg, v.z * inv_cg, v.w * inv_cg);
-        }
-    }
+    float ref[C / 4];
+    load_ref<C, FT>(d.ref, pc, q, ref);
 
     float acc[N];
 #pragma unroll
@@ -342,8 +369,8 @@ __global__ void __launch_bounds__(DMVS_BLOCK) getcost_quad_kernel(const dmvs_get
         HypQ own[HPL];
 #pragma unroll
         for (int h = 0; h < HPL; ++h) own[h] = project_q(ray, own_depth[h], exists[h], H, W);
-        const unsigned view_off = (unsigned)((((long)s * d.B + b) * (long)hw * C + q * 4) * 4);
-        quad_accumulate<U, N, TPT>(base, view_off, own, H, W, ref, w, acc);
+        const unsigned view_off = (unsigned)(((long)s * d.B + b) * (long)hw * Feat<C, FT>::TEXEL_BYTES) + Feat<C, FT>::lane_bytes(q);
+        quad_accumulate<C, FT, N, TPT>(base, view_off, own, H, W, ref, w, acc);
     }
     if (live) {
         const float inv_w = 1.0f / wsum;
@@ -355,12 +382,12 @@ __global__ void __launch_bounds__(DMVS_BLOCK) getcost_quad_kernel(const dmvs_get
 
 // ------------------------------------------------------------------------------------------ stage-1 plane sweep
 // grid = (pixel blocks, S); planes in chunks of 8 (lane q projects planes d0 + q and d0 + q + 4).  out [B,S,4,D,H,W].
-template <int C, int TPT>
+template <int C, int TPT, int FT>
 __global__ void __launch_bounds__(DMVS_BLOCK)
-warp_init_quad_kernel(const float* __restrict__ ref_f, const float* __restrict__ src, const float* __restrict__ rt,
+warp_init_quad_kernel(const void* __restrict__ ref_f, const void* __restrict__ src, const float* __restrict__ rt,
                       const float* __restrict__ disp_min, const float* __restrict__ disp_max, float* __restrict__ out, int B, int S,
                       int D, int H, int W, int Hs, int Ws) {
-    constexpr int U = C / 16, NB = 8, HPL = 2, PPB = DMVS_BLOCK / 4;
+    constexpr int NB = 8, HPL = 2, PPB = DMVS_BLOCK / 4;
     const int q = threadIdx.x & 3;
     const int hw = H * W;
     const int b = blockIdx.y / S, s = blockIdx.y - b * S;        // (batch item, view): workgroup-uniform
@@ -370,20 +397,12 @@ warp_init_quad_kernel(const float* __restrict__ ref_f, const float* __restrict__
     const int y = yx / W, x = yx - y * W;
     const long pq = (long)b * hw + yx;
 
-    float4 ref[U];
-    {
-        const float inv_cg = 1.0f / (float)(C / 4);
-        const float4* rp = reinterpret_cast<const float4*>(ref_f + pq * C + q * 4);
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const float4 v = rp[j * 4];
-            ref[j] = make_float4(v.x * inv_cg, v.y * inv_cg, v.z * inv_cg, v.w * inv_cg);
-        }
-    }
+    float ref[C / 4];
+    load_ref<C, FT>(ref_f, pq, q, ref);
     RayQ ray;
     ray.init(rt + ((long)b * S + s) * 12, (float)x, (float)y);
     const char* base = reinterpret_cast<const char*>(src);
-    const unsigned view_off = (unsigned)((((long)s * B + b) * (long)Hs * Ws * C + q * 4) * 4);
+    const unsigned view_off = (unsigned)(((long)s * B + b) * (long)Hs * Ws * Feat<C, FT>::TEXEL_BYTES) + Feat<C, FT>::lane_bytes(q);
     const float dmin = disp_min[b], dmax = disp_max[b];
     const float dm1 = (float)(D - 1);
     // the plane depths are the same for every pixel of the batch item: one table per workgroup instead of a division chain
@@ -405,7 +424,7 @@ warp_init_quad_kernel(const float* __restrict__ ref_f, const float* __restrict__
         float acc[NB];
 #pragma unroll
         for (int k = 0; k < NB; ++k) acc[k] = 0.0f;
-        quad_accumulate<U, NB, TPT>(base, view_off, own, Hs, Ws, ref, 1.0f, acc);
+        quad_accumulate<C, FT, NB, TPT>(base, view_off, own, Hs, Ws, ref, 1.0f, acc);
         if (live) {
 #pragma unroll
             for (int k = 0; k < NB; ++k)
@@ -416,29 +435,13 @@ warp_init_quad_kernel(const float* __restrict__ ref_f, const float* __restrict__
 
 }  // namespace
 
-// texels per trip of the texel loop (kernel experiments: DMVS_QUAD_TPT=4 in the environment; default 2)
-static int quad_tpt() {
-    static const int v = [] {
-        const char* e = getenv("DMVS_QUAD_TPT");
-        return (e && e[0] == '4') ? 4 : 2;
-    }();
-    return v;
-}
+// texels per trip of the texel loop: 2 (4 measured 8-10 % slower on the MI355X: one wave per SIMD less, more idle slots when a
+// pixel's texel count is not a multiple of the trip)
+constexpr int QUAD_TPT = 2;
 
-extern "C" int dmvs_getcost_quad_f32(const dmvs_getcost_desc* dp, void* stream) {
-    if (!dp) return DMVS_EINVAL;
-    const dmvs_getcost_desc& d = *dp;
-    if (d.G != 4 || !d.ref || !d.src || !d.rt || !d.inv_depth || !d.view_w || !d.out_cost || !d.out_samples) return DMVS_EINVAL;
-    if ((long)d.S * d.B * d.H * d.W * d.C * 4 >= (1L << 32)) return DMVS_EINVAL;   // 32-bit byte offsets over the source stack
-    hipStream_t st = (hipStream_t)stream;
-    if ((long)d.H * d.W >= (1L << 24) || d.B > 65535) return DMVS_EINVAL;          // 24-bit row multiplies, grid.y
-    dim3 grid(dmvs_ceil_div((long)d.H * d.W, DMVS_BLOCK / 4), (unsigned)d.B), block(DMVS_BLOCK);
-    const int tpt = quad_tpt();
-#define DMVS_GCQ(CC, NN)                                                                                 \
-    do {                                                                                                 \
-        if (tpt == 4) hipLaunchKernelGGL((getcost_quad_kernel<CC, NN, 4>), grid, block, 0, st, d);      \
-        else hipLaunchKernelGGL((getcost_quad_kernel<CC, NN, 2>), grid, block, 0, st, d);               \
-    } while (0)
+template <int FT>
+static int launch_getcost_quad(const dmvs_getcost_desc& d, dim3 grid, dim3 block, hipStream_t st) {
+#define DMVS_GCQ(CC, NN) hipLaunchKernelGGL((getcost_quad_kernel<CC, NN, QUAD_TPT, FT>), grid, block, 0, st, d)
     if (d.C == 32 && d.n == 6) DMVS_GCQ(32, 6);
     else if (d.C == 32 && d.n == 4) DMVS_GCQ(32, 4);
     else if (d.C == 16 && d.n == 4) DMVS_GCQ(16, 4);
@@ -450,24 +453,43 @@ extern "C" int dmvs_getcost_quad_f32(const dmvs_getcost_desc* dp, void* stream) 
     return dmvs_launch_status();
 }
 
-extern "C" int dmvs_warp_corr_init_quad_f32(const float* ref, const float* src, const float* rt, const float* disp_min,
-                                            const float* disp_max, float* out, int32_t B, int32_t S, int32_t C, int32_t G,
-                                            int32_t D, int32_t H, int32_t W, int32_t Hs, int32_t Ws, void* stream) {
-    if (G != 4 || D < 2 || !ref || !src || !rt || !out) return DMVS_EINVAL;
-    if ((long)S * B * Hs * Ws * C * 4 >= (1L << 32)) return DMVS_EINVAL;
+extern "C" int dmvs_getcost_quad_f32(const dmvs_getcost_desc* dp, void* stream) {
+    if (!dp) return DMVS_EINVAL;
+    const dmvs_getcost_desc& d = *dp;
+    if (d.G != 4 || !d.ref || !d.src || !d.rt || !d.inv_depth || !d.view_w || !d.out_cost || !d.out_samples) return DMVS_EINVAL;
+    if (d.feat_dtype < DMVS_DTYPE_F32 || d.feat_dtype > DMVS_DTYPE_F16) return DMVS_EINVAL;
+    const int esize = d.feat_dtype == DMVS_DTYPE_F32 ? 4 : 2;
+    if ((long)d.S * d.B * d.H * d.W * d.C * esize >= (1L << 32)) return DMVS_EINVAL;   // 32-bit byte offsets over the source stack
     hipStream_t st = (hipStream_t)stream;
-    if ((long)H * W >= (1L << 24) || (long)Hs * Ws >= (1L << 24) || (long)B * S > 65535) return DMVS_EINVAL;
-    dim3 grid(dmvs_ceil_div((long)H * W, DMVS_BLOCK / 4), (unsigned)(B * S)), block(DMVS_BLOCK);
-    const int tpt = quad_tpt();
-#define DMVS_WIQ(CC)                                                                                                                             \
-    do {                                                                                                                                         \
-        if (tpt == 4) hipLaunchKernelGGL((warp_init_quad_kernel<CC, 4>), grid, block, 0, st, ref, src, rt, disp_min, disp_max, out, B, S, D, H, W, Hs, Ws); \
-        else hipLaunchKernelGGL((warp_init_quad_kernel<CC, 2>), grid, block, 0, st, ref, src, rt, disp_min, disp_max, out, B, S, D, H, W, Hs, Ws);         \
-    } while (0)
+    if ((long)d.H * d.W >= (1L << 24) || d.B > 65535) return DMVS_EINVAL;          // 24-bit row multiplies, grid.y
+    dim3 grid(dmvs_ceil_div((long)d.H * d.W, DMVS_BLOCK / 4), (unsigned)d.B), block(DMVS_BLOCK);
+    if (d.feat_dtype == DMVS_DTYPE_BF16) return launch_getcost_quad<DMVS_DTYPE_BF16>(d, grid, block, st);
+    if (d.feat_dtype == DMVS_DTYPE_F16) return launch_getcost_quad<DMVS_DTYPE_F16>(d, grid, block, st);
+    return launch_getcost_quad<DMVS_DTYPE_F32>(d, grid, block, st);
+}
+
+template <int FT>
+static int launch_warp_init_quad(const void* ref, const void* src, const float* rt, const float* disp_min, const float* disp_max, float* out,
+                                 int B, int S, int C, int D, int H, int W, int Hs, int Ws, dim3 grid, dim3 block, hipStream_t st) {
+#define DMVS_WIQ(CC) hipLaunchKernelGGL((warp_init_quad_kernel<CC, QUAD_TPT, FT>), grid, block, 0, st, ref, src, rt, disp_min, disp_max, out, B, S, D, H, W, Hs, Ws)
     if (C == 48) DMVS_WIQ(48);
     else if (C == 32) DMVS_WIQ(32);
     else if (C == 16) DMVS_WIQ(16);
     else return DMVS_EINVAL;
 #undef DMVS_WIQ
     return dmvs_launch_status();
+}
+
+extern "C" int dmvs_warp_corr_init_quad_f32(const void* ref, const void* src, const float* rt, const float* disp_min,
+                                            const float* disp_max, float* out, int32_t B, int32_t S, int32_t C, int32_t G,
+                                            int32_t D, int32_t H, int32_t W, int32_t Hs, int32_t Ws, int32_t feat_dtype, void* stream) {
+    if (G != 4 || D < 2 || !ref || !src || !rt || !out) return DMVS_EINVAL;
+    if (feat_dtype < DMVS_DTYPE_F32 || feat_dtype > DMVS_DTYPE_F16) return DMVS_EINVAL;
+    if ((long)S * B * Hs * Ws * C * (feat_dtype == DMVS_DTYPE_F32 ? 4 : 2) >= (1L << 32)) return DMVS_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if ((long)H * W >= (1L << 24) || (long)Hs * Ws >= (1L << 24) || (long)B * S > 65535) return DMVS_EINVAL;
+    dim3 grid(dmvs_ceil_div((long)H * W, DMVS_BLOCK / 4), (unsigned)(B * S)), block(DMVS_BLOCK);
+    if (feat_dtype == DMVS_DTYPE_BF16) return launch_warp_init_quad<DMVS_DTYPE_BF16>(ref, src, rt, disp_min, disp_max, out, B, S, C, D, H, W, Hs, Ws, grid, block, st);
+    if (feat_dtype == DMVS_DTYPE_F16) return launch_warp_init_quad<DMVS_DTYPE_F16>(ref, src, rt, disp_min, disp_max, out, B, S, C, D, H, W, Hs, Ws, grid, block, st);
+    return launch_warp_init_quad<DMVS_DTYPE_F32>(ref, src, rt, disp_min, disp_max, out, B, S, C, D, H, W, Hs, Ws, grid, block, st);
 }

@@ -37,11 +37,11 @@ def _cw(sd, p, **kw):
                        bn=_bn(sd, p + ".bn") if (p + ".bn.weight") in sd else None, **kw)
 
 
-def pack_feature(sd, p="feature", g4=False):
+def pack_feature(sd, p="feature", g4=False, feat_dtype=torch.float32):
     """FeatureNet weights (models/module.py:357-420).  g4: the output convolutions emit their channels in the
     group-interleaved NHWC-g4 order the quad-per-pixel warp kernels read (an output-channel permutation of the weights:
-    free at run time)."""
-    order = (lambda w: w[K.g4_channels(w.shape[0]).to(w.device)].contiguous()) if g4 else (lambda w: w)
+    free at run time; identity for 16-bit feature storage)."""
+    order = (lambda w: w[K.g4_channels(w.shape[0], feat_dtype).to(w.device)].contiguous()) if g4 else (lambda w: w)
     f = {"conv0.0": _cw(sd, p + ".conv0.0", pad=1), "conv0.1": _cw(sd, p + ".conv0.1", pad=1)}
     for i in (1, 2, 3):
         f[f"conv{i}.0"] = _cw(sd, f"{p}.conv{i}.0", stride=2, pad=2)
@@ -55,20 +55,21 @@ def pack_feature(sd, p="feature", g4=False):
     return f
 
 
-def run_feature(o: Ops, f, x, layout=K.LAYOUT_NHWC):
+def run_feature(o: Ops, f, x, layout=K.LAYOUT_NHWC, feat_dtype=torch.float32):
     """x [N,3,H,W] -> {'stage1': [N,H/8,W/8,48], 'stage2': [N,H/4,W/4,32], ('stage3': [N,H/2,W/2,16])} (NHWC by
-    default: the layout the warp kernels read)."""
+    default: the layout the warp kernels read; feat_dtype bf16 / fp16 = reduced-precision feature storage, rounded in the
+    output convolutions' epilogue)."""
     R = K.ACT_RELU
     c0 = o.featurenet_stem(f["conv0.0"], f["conv0.1"], x)      # conv0.0 + conv0.1 fused: the 8-channel intermediate stays in LDS
     c1 = o.conv2d(f["conv1.2"], o.conv2d(f["conv1.1"], o.conv2d(f["conv1.0"], c0, act=R), act=R), act=R)
     c2 = o.conv2d(f["conv2.2"], o.conv2d(f["conv2.1"], o.conv2d(f["conv2.0"], c1, act=R), act=R), act=R)
     c3 = o.conv2d(f["conv3.2"], o.conv2d(f["conv3.1"], o.conv2d(f["conv3.0"], c2, act=R), act=R), act=R)
-    out = {"stage1": o.conv2d(f["out1"], c3, out_layout=layout)}
+    out = {"stage1": o.conv2d(f["out1"], c3, out_layout=layout, out_dtype=feat_dtype)}
     intra = o.conv2d(f["inner1"], c2, residual=c3, res_mode=K.IN_UPSAMPLE2)
-    out["stage2"] = o.conv2d(f["out2"], intra, out_layout=layout)
+    out["stage2"] = o.conv2d(f["out2"], intra, out_layout=layout, out_dtype=feat_dtype)
     if "out3" in f:
         intra = o.conv2d(f["inner2"], c1, residual=intra, res_mode=K.IN_UPSAMPLE2)
-        out["stage3"] = o.conv2d(f["out3"], intra, out_layout=layout)
+        out["stage3"] = o.conv2d(f["out3"], intra, out_layout=layout, out_dtype=feat_dtype)
     return out
 
 
@@ -382,7 +383,16 @@ class Engine:
         # warp kernels: "quad" = quad-per-pixel kernels on NHWC-g4 features (warp_quad.hip, one launch for any geometry);
         # "legacy" = the LDS-window / per-pixel-gather pair of round 1 on plain NHWC features (kept for A/B runs)
         self.quad = os.environ.get("DMVS_WARP", "quad") != "legacy"
-        self.feat = pack_feature(sd, "feature", g4=self.quad)
+        # feature storage precision: args.precision / DMVS_PRECISION in {"fp32", "bf16", "fp16"} (BASELINE.json configs[2] /
+        # [4]).  The image features FeatureNet hands to the warp kernels are stored in 16 bits (half the bytes of the path's
+        # dominant gather traffic); projection, hypotheses, correlation, every convolution and all accumulators stay fp32
+        prec = os.environ.get("DMVS_PRECISION") or getattr(args, "precision", "fp32") or "fp32"
+        if prec not in K.FEATURE_DTYPES:
+            raise K._lib.DmvsError(f"precision '{prec}': expected one of {sorted(K.FEATURE_DTYPES)}")
+        self.precision, self.feat_dtype = prec, K.FEATURE_DTYPES[prec]
+        if self.feat_dtype != torch.float32 and not self.quad:
+            raise K._lib.DmvsError("16-bit feature storage needs the quad-per-pixel warp kernels (unset DMVS_WARP=legacy)")
+        self.feat = pack_feature(sd, "feature", g4=self.quad, feat_dtype=self.feat_dtype)
         self.ctx = pack_context_trunk(sd, "context")
         # ContextNet output heads split into their hidden | context halves (diffusion.py:223-231): the
         # context half is written straight into the Unet input buffer, the hidden half feeds hidden_init
@@ -515,7 +525,7 @@ class Engine:
         interval = 1.0 / depth_values.size(1)
 
         x = torch.cat([im.to(o.device).float() for im in imgs], 0).contiguous()                  # [V*B,3,H,W], view-major
-        feats = run_feature(o, self.feat, x)
+        feats = run_feature(o, self.feat, x, feat_dtype=self.feat_dtype)
         trunk = run_context_trunk(o, self.ctx, x[:B])
         depths, confs_full, confs_seq = [], [], []
         view_w = None

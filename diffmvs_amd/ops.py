@@ -15,8 +15,13 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU, ACT_TANH, IN_PLAIN, IN_UNSHUFFLE2,  # noqa: F401
-                   IN_UPSAMPLE2, IN_ZEROINSERT2, LAYOUT_NCHW, LAYOUT_NHWC)
+from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU, ACT_TANH, DTYPE_BF16, DTYPE_F16, DTYPE_F32, IN_PLAIN,  # noqa: F401
+                   IN_UNSHUFFLE2, IN_UPSAMPLE2, IN_ZEROINSERT2, LAYOUT_NCHW, LAYOUT_NHWC, LAYOUT_NHWC_BF16, LAYOUT_NHWC_F16)
+
+# reduced-precision FEATURE storage (BASELINE.json's bf16 / fp16 configurations): torch dtype <-> C-ABI codes
+FEATURE_DTYPES = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
+_DTYPE_CODE = {torch.float32: DTYPE_F32, torch.bfloat16: DTYPE_BF16, torch.float16: DTYPE_F16}
+_NHWC_LAYOUT = {torch.float32: LAYOUT_NHWC, torch.bfloat16: LAYOUT_NHWC_BF16, torch.float16: LAYOUT_NHWC_F16}
 
 
 def _round_up(x: int, m: int) -> int:
@@ -102,12 +107,15 @@ def pack_conv3d(w: torch.Tensor, bias=None, bn: Optional[dict] = None, stride=1,
                       transposed)
 
 
-def g4_channels(C: int) -> torch.Tensor:
+def g4_channels(C: int, dtype=torch.float32) -> torch.Tensor:
     """Channel order of the GROUP-INTERLEAVED channel-last feature layout "NHWC-g4" the quad-per-pixel warp kernels read
     (include/dmvs.h): position p of a texel holds channel  c(p) = ((p // 4) % 4) * (C // 4) + (p // 16) * 4 + p % 4,
     i.e. x_g4 = x_nhwc[..., g4_channels(C)].  The engine folds this permutation into the weights of FeatureNet's output
-    convolutions; tests and the module-level GetCost use it on plain tensors."""
+    convolutions; tests and the module-level GetCost use it on plain tensors.  16-bit features are read in plain NHWC
+    order (a group's channels already form one 8 / 16 / 24-byte run per lane): identity."""
     p = torch.arange(C)
+    if dtype != torch.float32:
+        return p
     return ((p // 4) % 4) * (C // 4) + (p // 16) * 4 + p % 4
 
 
@@ -171,6 +179,14 @@ class Ops:
     def empty(self, *shape, dtype=torch.float32):
         return torch.empty(*shape, dtype=dtype, device=self.device)
 
+    def _chk_feat(self, *ts):
+        dt = ts[0].dtype
+        for t in ts:
+            if t.dtype not in _DTYPE_CODE or t.dtype != dt or not t.is_contiguous() or t.device != self.device:
+                raise _lib.DmvsError(f"expected contiguous fp32 / bf16 / fp16 feature tensors of one dtype on {self.device}, got "
+                                     f"{t.dtype} contiguous={t.is_contiguous()} on {t.device}")
+        return _DTYPE_CODE[dt]
+
     def _chk(self, *ts):
         for t in ts:
             if t is None:
@@ -182,10 +198,17 @@ class Ops:
     # ------------------------------------------------------------------ conv2d
     def conv2d(self, pc: PackedConv, x0, x1=None, *, mul0=None, in_mode=IN_PLAIN, act=ACT_NONE, residual=None,
                res_mode=IN_PLAIN, res_after_act=False, post_scale=1.0, gru_z=None, gru_h=None, out=None,
-               out_layout=LAYOUT_NCHW, out_cstride=None, out_coffset=0, gn_stats=None, gn_groups=4):
+               out_layout=LAYOUT_NCHW, out_cstride=None, out_coffset=0, gn_stats=None, gn_groups=4, out_dtype=torch.float32):
         """gn_stats: zeroed float64 [B*gn_groups*2] tensor that receives the GroupNorm statistics of
-        the (pre-activation) output, for a following groupnorm_apply()."""
-        self._chk(x0, x1, mul0, residual, gru_z, gru_h, out)
+        the (pre-activation) output, for a following groupnorm_apply().  out_dtype (channel-last outputs only): bf16 / fp16
+        feature storage, rounded to nearest even in the epilogue."""
+        self._chk(x0, x1, mul0, residual, gru_z, gru_h)
+        if out_dtype != torch.float32:
+            if out_layout != LAYOUT_NHWC or out is not None:
+                raise _lib.DmvsError("16-bit outputs are channel-last feature tensors allocated by conv2d")
+            out_layout = _NHWC_LAYOUT[out_dtype]
+        else:
+            self._chk(out)
         if gn_stats is not None and (gn_stats.dtype != torch.float64 or gn_stats.numel() < x0.shape[0] * gn_groups * 2):
             raise _lib.DmvsError("gn_stats must be float64 with B*groups*2 elements")
         B = x0.shape[0]
@@ -204,7 +227,7 @@ class Ops:
             out_cstride = pc.cout
         if out is None:
             shape = (B, out_cstride, Hout, Wout) if out_layout == LAYOUT_NCHW else (B, Hout, Wout, out_cstride)
-            out = self.empty(*shape)
+            out = self.empty(*shape, dtype=out_dtype)
         d = _lib.Conv2dDesc(
             in0=_ptr(x0), in1=_ptr(x1), mul0=_ptr(mul0), weight=_ptr(pc.weight), scale=_ptr(pc.scale),
             shift=_ptr(pc.shift), residual=_ptr(residual), gru_z=_ptr(gru_z), gru_h=_ptr(gru_h), out=_ptr(out),
@@ -313,20 +336,26 @@ class Ops:
         return out
 
     def warp_corr_init_quad(self, ref, src, rt, disp_min, disp_max, D, G=4):
-        """quad-per-pixel plane sweep: ref [B,H,W,C], src [S,B,Hs,Ws,C] in the NHWC-g4 channel order -> [B,S,G,D,H,W]"""
-        self._chk(ref, src, rt, disp_min, disp_max)
+        """quad-per-pixel plane sweep: ref [B,H,W,C], src [S,B,Hs,Ws,C] in the NHWC-g4 channel order (fp32) or plain NHWC
+        (bf16 / fp16 feature storage) -> [B,S,G,D,H,W] fp32"""
+        self._chk(rt, disp_min, disp_max)
+        fdt = self._chk_feat(ref, src)
         B, H, W, Cc = ref.shape
         S, _, Hs, Ws, _ = src.shape
         out = self.empty(B, S, G, D, H, W)
         self._call("dmvs_warp_corr_init_quad_f32", _ptr(ref), _ptr(src), _ptr(rt), _ptr(disp_min), _ptr(disp_max), _ptr(out),
-                   B, S, Cc, G, D, H, W, Hs, Ws, self.stream())
+                   B, S, Cc, G, D, H, W, Hs, Ws, fdt, self.stream())
+        if self.timers is not None and "dmvs_warp_corr_init_quad_f32" in self.timers:
+            self.timers.setdefault("_warp_init_bytes", []).append(B * H * W * (ref.element_size() * (Cc + S * Cc) + 4 * S * G * D))
         return out
 
     def getcost_quad(self, ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, min_radius,
                      max_radius, vw_shift, out_cost=None, cost_cstride=None, cost_coffset=0, out_samples=None,
                      samp_cstride=None, samp_coffset=0, G=4):
-        """quad-per-pixel GetCost, one launch for any geometry; ref / src in the NHWC-g4 channel order"""
-        self._chk(ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, out_cost, out_samples)
+        """quad-per-pixel GetCost, one launch for any geometry; ref / src in the NHWC-g4 channel order (fp32) or plain NHWC
+        (bf16 / fp16 feature storage)"""
+        self._chk(rt, inv_depth, confidence, view_w, disp_min, disp_max, out_cost, out_samples)
+        fdt = self._chk_feat(ref, src)
         B, H, W, Cc = ref.shape
         S = src.shape[0]
         if out_cost is None:
@@ -340,8 +369,11 @@ class Ops:
                              disp_max=_ptr(disp_max), out_cost=_ptr(out_cost), out_samples=_ptr(out_samples),
                              worklist=None, B=B, S=S, C=Cc, G=G, n=n, H=H, W=W, vw_shift=vw_shift, cost_cstride=cost_cstride,
                              cost_coffset=cost_coffset, samp_cstride=samp_cstride, samp_coffset=samp_coffset,
-                             interval=interval, min_radius=min_radius, max_radius=max_radius)
+                             interval=interval, min_radius=min_radius, max_radius=max_radius, feat_dtype=fdt)
         self._call("dmvs_getcost_quad_f32", C.byref(d), self.stream())
+        if self.timers is not None and "dmvs_getcost_quad_f32" in self.timers:      # bench: algorithmic bytes of this launch
+            es = ref.element_size()
+            self.timers.setdefault("_getcost_bytes", []).append(B * H * W * (es * (Cc + S * Cc) + 4 * (n + S + G * n)))
         return out_cost, out_samples
 
     def warp_volume(self, src, rt, depth):

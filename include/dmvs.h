@@ -32,7 +32,12 @@ enum { DMVS_ACT_NONE = 0, DMVS_ACT_RELU = 1, DMVS_ACT_SIGMOID = 2, DMVS_ACT_TANH
 /* how the logical input of a 2-D convolution is read from memory */
 enum { DMVS_IN_PLAIN = 0, DMVS_IN_UPSAMPLE2 = 1 /* nearest x2, F.interpolate */, DMVS_IN_UNSHUFFLE2 = 2 /* einops 'b c (h p1) (w p2) -> b (c p1 p2) h w' */,
        DMVS_IN_ZEROINSERT2 = 3 /* logical (2y,2x) = physical (y,x), zero elsewhere: the input-gradient of a stride-2 conv as a stride-1 conv */ };
-enum { DMVS_LAYOUT_NCHW = 0, DMVS_LAYOUT_NHWC = 1 };
+enum { DMVS_LAYOUT_NCHW = 0, DMVS_LAYOUT_NHWC = 1,
+       /* channel-last output stored as 16-bit elements (round to nearest even): the reduced-precision FEATURE storage of
+          BASELINE.json's bf16 / fp16 configurations; `out` then points at uint16 elements, strides / offsets count elements */
+       DMVS_LAYOUT_NHWC_BF16 = 2, DMVS_LAYOUT_NHWC_F16 = 3 };
+/* element type of the image-feature tensors handed to the quad warp kernels */
+enum { DMVS_DTYPE_F32 = 0, DMVS_DTYPE_BF16 = 1, DMVS_DTYPE_F16 = 2 };
 
 int dmvs_abi_version(void);
 
@@ -206,7 +211,7 @@ int dmvs_warp_corr_init_gather_f32(const float* ref, const float* src, const flo
 #define DMVS_GETCOST_WORKLIST_INTS(B, H, W) \
     (4 + 66 * (B) * (((H) + DMVS_GETCOST_TILE - 1) / DMVS_GETCOST_TILE) * (((W) + DMVS_GETCOST_TILE - 1) / DMVS_GETCOST_TILE))
 typedef struct dmvs_getcost_desc {
-    const float* ref;       /* [B,H,W,C] NHWC */
+    const float* ref;       /* [B,H,W,C] NHWC (16-bit elements behind the pointer for dmvs_getcost_quad_f32 with feat_dtype != 0) */
     const float* src;       /* [S][B,H,W,C] NHWC */
     const float* rt;        /* [B,S,12] */
     const float* inv_depth;
@@ -221,6 +226,7 @@ typedef struct dmvs_getcost_desc {
     int32_t vw_shift;
     int32_t cost_cstride, cost_coffset, samp_cstride, samp_coffset;
     float interval, min_radius, max_radius;
+    int32_t feat_dtype;     /* DMVS_DTYPE_*: element type of ref / src; honoured by dmvs_getcost_quad_f32 only (the others: fp32) */
 } dmvs_getcost_desc;
 
 int dmvs_getcost_f32(const dmvs_getcost_desc* d, void* stream);
@@ -236,12 +242,15 @@ int dmvs_getcost_gather_f32(const dmvs_getcost_desc* d, void* stream);
  *     position p of a texel holds channel  c(p) = ((p / 4) % 4) * (C / 4) + (p / 16) * 4 + p % 4,
  * so that the 4 lanes of a pixel fetch 64 contiguous bytes and each receives channels of its own correlation group.
  * The inference engine has FeatureNet's output convolutions emit this layout directly (output-channel permutation of
- * their weights); diffmvs_amd.ops.g4_channels(C) is the permutation for callers that hold plain NHWC tensors. */
+ * their weights); diffmvs_amd.ops.g4_channels(C) is the permutation for callers that hold plain NHWC tensors.
+ * Reduced-precision feature storage (BASELINE.json's bf16 / fp16 configurations): feat_dtype = DMVS_DTYPE_BF16 | _F16 reads ref /
+ * src as 16-bit elements in PLAIN NHWC order (a group's C/4 channels are then contiguous already: 8 / 16 / 24 bytes per lane);
+ * values are widened to fp32 on arrival, projection, hypotheses, correlation and accumulation stay fp32. */
 int dmvs_getcost_quad_f32(const dmvs_getcost_desc* d, void* stream);
-int dmvs_warp_corr_init_quad_f32(const float* ref, const float* src, const float* rt,
+int dmvs_warp_corr_init_quad_f32(const void* ref, const void* src, const float* rt,
                                  const float* disp_min, const float* disp_max, float* out,
                                  int32_t B, int32_t S, int32_t C, int32_t G, int32_t D,
-                                 int32_t H, int32_t W, int32_t Hs, int32_t Ws, void* stream);
+                                 int32_t H, int32_t W, int32_t Hs, int32_t Ws, int32_t feat_dtype, void* stream);
 
 /* Stand-alone differentiable_warping (models/module.py:181-218) in the reference's layouts:
  * src [B,C,Hs,Ws] NCHW, rt [B,12] (rot row-major, trans) = src_proj * inverse(ref_proj),

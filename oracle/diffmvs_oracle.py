@@ -453,7 +453,7 @@ def upsample_depth(depth, mask, ratio):
 
 
 # ------------------------------------------------------------------ a14 whole forward
-def forward(sd, args, imgs, proj_matrices, depth_values, noise_fn=None, test=True):
+def forward(sd, args, imgs, proj_matrices, depth_values, noise_fn=None, test=True, feature_dtype=None):
     """CasDiffMVS.forward, eval mode (models/diffusion.py:139-295); test=False keeps every iterate and the Unet
     confidences (diffusion.py:264-270)."""
     if noise_fn is None:
@@ -468,6 +468,8 @@ def forward(sd, args, imgs, proj_matrices, depth_values, noise_fn=None, test=Tru
     interval = 1.0 / depth_values.size(1)
 
     feats = [feature_net(sd, im) for im in imgs]
+    if feature_dtype is not None:      # reduced-precision FEATURE storage (not reference behaviour): round, compute in fp32
+        feats = [{k: v.to(feature_dtype).float() for k, v in f.items()} for f in feats]
     ctx = context_net(sd, imgs[0])
     depths, confs_full, confs_seq = [], [], []
     view_weights = None

@@ -35,6 +35,8 @@ struct dim3 {
 struct float2 { float x, y; };
 struct float3 { float x, y, z; };
 struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(8) uint2 { unsigned x, y; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline float3 make_float3(float x, float y, float z) { return float3{x, y, z}; }
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
@@ -318,6 +320,38 @@ static inline int hipemu_quad_perm(int v, int ctrl) {
 #define DMVS_HOST_EMULATION 1
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 static inline int __ffs(int v) { return __builtin_ffs(v); }
+static inline uint32_t __float_as_uint(float f) { uint32_t v; memcpy(&v, &f, 4); return v; }
+static inline float __uint_as_float(uint32_t v) { float f; memcpy(&f, &v, 4); return f; }
+// IEEE binary16 <-> binary32, round to nearest even (the hardware's v_cvt_f16_f32 / v_cvt_f32_f16)
+static inline uint16_t hipemu_f32_to_f16(float f) {
+    uint32_t x = __float_as_uint(f);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | (x > 0x7f800000u ? 0x7e00u : 0x7c00u));
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                     // rounds to >= 65520 -> inf
+    if (x < 0x38800000u) {                                                       // subnormal half (or zero)
+        if (x < 0x33000000u) return (uint16_t)sign;
+        const int e = (int)(x >> 23);
+        uint32_t m = (x & 0x7fffffu) | 0x800000u;
+        const int shift = 126 - e;                                               // 14 .. 24
+        const uint32_t half = m >> shift, rem = m & ((1u << shift) - 1u), mid = 1u << (shift - 1);
+        return (uint16_t)(sign | (half + ((rem > mid || (rem == mid && (half & 1u))) ? 1u : 0u)));
+    }
+    uint32_t h = ((x - 0x38000000u) >> 13);
+    const uint32_t rem = x & 0x1fffu;
+    h += (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ? 1u : 0u;
+    return (uint16_t)(sign | h);
+}
+static inline float hipemu_f16_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    if (e == 0) {
+        if (m == 0) return __uint_as_float(sign);
+        float v = (float)m * (1.0f / 16777216.0f);                                // m * 2^-24
+        return (h & 0x8000u) ? -v : v;
+    }
+    if (e == 31) return __uint_as_float(sign | 0x7f800000u | (m << 13));
+    return __uint_as_float(sign | ((e + 112u) << 23) | (m << 13));
+}
 static inline float __int_as_float(int v) { float f; memcpy(&f, &v, 4); return f; }
 static inline int __float_as_int(float f) { int v; memcpy(&v, &f, 4); return v; }
 #define DMVS_ORDER_AFTER(var, dep) ((void)0)

@@ -113,3 +113,32 @@ def test_validation_loss_on_eval_outputs(golden):
     out = model(imgs, proj, dv)
     loss, parts = compute_inverse_loss(args, out["depth"], out["conf"], gt, mask, dv, loss_rate=0.9, iters=args.stage_iters)
     assert torch.isfinite(loss)
+
+
+@pytest.mark.parametrize("variant,prec", [("casdiffmvs", "bf16"), ("diffmvs", "fp16")])
+def test_reduced_precision_feature_storage_emulated(golden, variant, prec):
+    """BASELINE.json configs[2] / [4] name bf16 / fp16, which the reference itself never runs.  The build's
+    reduced-precision mode stores the image FEATURES in 16 bits and keeps every computation fp32, so it must agree tightly
+    with the oracle run on the same rounded features, and loosely with the fp32 reference golden."""
+    import torch as _t
+    from models import CasDiffMVS
+    from oracle import diffmvs_oracle as O
+    e = golden(f"e2e_{variant}_b2.npz")
+    meta = e.meta()
+    args = synth.make_args(variant, numdepth_initial=meta["nd_init"], precision=prec)
+    model = CasDiffMVS(args, test=True).eval()
+    sd = synth.synth_state_dict(model.state_dict(), meta["weight_seed"])
+    model.load_state_dict(sd, strict=True)
+    imgs, proj, dv = synth.synth_inputs(meta["H"], meta["W"], meta["n_src"], B=meta["B"], seed=meta["scene_seed"])
+    eng = model.engine(emu_ops())
+    assert eng.precision == prec
+    out = eng.forward(imgs, proj, dv, noise_fn=synth.NoiseSource(meta["noise_seed"]))
+    src = synth.NoiseSource(meta["noise_seed"])
+    with _t.no_grad():
+        want = O.forward(sd, args, imgs, proj, dv, noise_fn=lambda shape: src(shape, "cpu"),
+                         feature_dtype={"bf16": _t.bfloat16, "fp16": _t.float16}[prec])
+    errs = [rel_l1(a, b) for a, b in zip(out["depth"], want["depth"])]
+    assert max(errs) < 1e-4, errs
+    loose = [rel_l1(a, b) for a, b in zip(out["depth"], e.seq("out.depth"))]
+    print(variant, prec, "vs fp32 reference:", ["%.2e" % x for x in loose])
+    assert max(loose) < (2e-3 if prec == "bf16" else 2e-4), loose

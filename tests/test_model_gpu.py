@@ -221,3 +221,48 @@ def test_hip_graph_forward_matches_eager(variant, B):
         for a, b in zip(outs[(True, seed)], outs[(False, seed)]):
             assert a.shape == b.shape and rel_l1(a.cpu(), b.cpu()) < 1e-6
     assert rel_l1(outs[(False, 21)][-3].cpu(), outs[(False, 22)][-3].cpu()) > 1e-4      # the two inputs do differ
+
+
+@pytest.mark.parametrize("variant,prec", [("casdiffmvs", "bf16"), ("diffmvs", "bf16"), ("casdiffmvs", "fp16")])
+def test_reduced_precision_feature_storage(golden, variant, prec):
+    """bf16 / fp16 FEATURE storage (BASELINE.json configs[2], [4]; the reference has no reduced-precision behaviour, SURVEY
+    F4): tight against the oracle run on the same rounded features, and still inside the fp32 reference's band"""
+    e = golden(f"e2e_{variant}_b2.npz")
+    meta = e.meta()
+    model, sd, args = make_model(variant, meta["nd_init"], meta["weight_seed"], precision=prec)
+    imgs, proj, dv = synth.synth_inputs(meta["H"], meta["W"], meta["n_src"], B=meta["B"], seed=meta["scene_seed"])
+    out = run(model, imgs, proj, dv, meta["noise_seed"])
+    assert model.engine().precision == prec
+    src = synth.NoiseSource(meta["noise_seed"])
+    with torch.no_grad():
+        want = O.forward(sd, args, imgs, proj, dv, noise_fn=lambda shape: src(shape, "cpu"),
+                         feature_dtype={"bf16": torch.bfloat16, "fp16": torch.float16}[prec])
+    errs = [rel_l1(a.cpu(), b) for a, b in zip(out["depth"], want["depth"])]
+    assert max(errs) < 1e-4, errs
+    loose = [rel_l1(a.cpu(), b) for a, b in zip(out["depth"], e.seq("out.depth"))]
+    print(variant, prec, "depth rel-L1 vs the fp32 reference:", ["%.2e" % x for x in loose])
+    assert max(loose) < (2e-3 if prec == "bf16" else 2e-4), loose
+
+
+@pytest.mark.parametrize("cfg,variant,H,W,S,nd,prec", [("cfg3", "casdiffmvs", 864, 1152, 7, 48, "bf16"), ("cfg5", "casdiffmvs", 1056, 1920, 11, 96, "fp16")])
+def test_reduced_precision_full_size(cfg, variant, H, W, S, nd, prec):
+    """BASELINE.json configs[2] (CasDiffMVS 1152x864, 7 source views, bf16) and configs[4] (1920x1056, 11 source views, fp16) at
+    their stated sizes in their stated storage precision: finite, in range, bit-reproducible, and within the reduced-precision
+    band of the SAME model run in fp32 (the fp32 path is what the oracle / reference goldens pin)."""
+    imgs, proj, dv = synth.synth_inputs(H, W, S, B=1, seed=9)
+    outs = {}
+    for p in ("fp32", prec):
+        model, _, _ = make_model(variant, nd, precision=p)
+        outs[p] = run(model, imgs, proj, dv, 2)
+        if p == prec:
+            again = run(model, imgs, proj, dv, 2)
+            for x, yv in zip(again["depth"], outs[p]["depth"]):
+                assert torch.equal(x, yv)
+        del model
+        torch.cuda.empty_cache()
+    for d in outs[prec]["depth"]:
+        assert torch.isfinite(d).all() and float(d.min()) >= 424.9 and float(d.max()) <= 935.1
+    assert outs[prec]["depth"][-1].shape == (1, H, W)
+    errs = [rel_l1(a.cpu(), b.cpu()) for a, b in zip(outs[prec]["depth"], outs["fp32"]["depth"])]
+    print(cfg, prec, "depth rel-L1 vs the fp32 run:", ["%.2e" % x for x in errs])
+    assert max(errs) < (1e-2 if prec == "bf16" else 1e-3), errs

@@ -859,3 +859,64 @@ def test_warp_corr_init_quad(ops, C, H, W, D, scene):
     out_g = ops.warp_corr_init(dev(ops, ref_nhwc), dev(ops, src_nhwc), rt, dev(ops, disp_min), dev(ops, disp_max), D, gather=True)
     close(out, want, 1e-4)
     close(out, out_g.cpu(), 2e-5)
+
+
+# ------------------------------------------------------------------------------------------ 16-bit feature storage
+_X16 = [torch.bfloat16, torch.float16]
+
+
+@pytest.mark.parametrize("dt", _X16)
+@pytest.mark.parametrize("cin,cout,k", [(64, 48, 1), (64, 32, 3), (24, 16, 3)])
+def test_conv2d_16bit_channel_last_output(ops, dt, cin, cout, k):
+    """FeatureNet's output convolutions storing bf16 / fp16 features: the fp32 result rounded to nearest even in the epilogue"""
+    B, H, W = 2, 19, 37
+    x, w = rnd(B, cin, H, W, seed=1), rnd(cout, cin, k, k, seed=2) * 0.2
+    pc = K.pack_conv2d(dev(ops, w), pad=k // 2)
+    full = ops.conv2d(pc, dev(ops, x), out_layout=K.LAYOUT_NHWC)
+    got = ops.conv2d(pc, dev(ops, x), out_layout=K.LAYOUT_NHWC, out_dtype=dt)
+    assert got.dtype == dt and got.shape == (B, H, W, cout)
+    assert torch.equal(got.cpu(), full.cpu().to(dt))
+    close(full.permute(0, 3, 1, 2), F.conv2d(x, w, None, 1, k // 2), 2e-5)
+
+
+@pytest.mark.parametrize("dt", _X16)
+@pytest.mark.parametrize("C,n", [(32, 6), (16, 4), (48, 4)])
+def test_getcost_quad_16bit_features(ops, dt, C, n):
+    """bf16 / fp16 feature storage: identical to the fp32 kernel (and the oracle) on the rounded feature values -- only the
+    storage is reduced, the arithmetic is fp32"""
+    B, S, H, W = 2, 3, 14, 22
+    pm = _cams(B, S + 1, H, W, 2)
+    feats = [rnd(B, C, H, W, seed=40 + v).to(dt).float() for v in range(S + 1)]
+    inv = rnd(B, 1, H, W, seed=50, lo=-0.05, hi=1.05)
+    conf = rnd(B, H, W, seed=51, lo=0.0, hi=1.0)
+    vw = rnd(B, S, H // 2, W // 2, seed=52, lo=0.0, hi=1.0)
+    dv0, dv1 = torch.tensor([1 / 935.0, 1 / 700.0]), torch.tensor([1 / 425.0, 1 / 450.0])
+    dmax, dmin = (1 / dv0).view(-1, 1, 1, 1), (1 / dv1).view(-1, 1, 1, 1)
+    want_cost, want_s = O.get_cost(feats, pm, inv, 2.0 / 384, dmax, dmin, n, F.interpolate(vw, scale_factor=2, mode="nearest"), conf, 4, 0.25, 4.0)
+    rt = ops.compose_proj(dev(ops, pm))
+    ref = feats[0].permute(0, 2, 3, 1).contiguous()
+    src = torch.stack([f.permute(0, 2, 3, 1) for f in feats[1:]]).contiguous()
+    tail = (rt, dev(ops, inv), dev(ops, conf), dev(ops, vw), dev(ops, 1 / (1 / dv0)), dev(ops, 1 / (1 / dv1)), n, 2.0 / 384, 0.25, 4.0)
+    cost, samp = ops.getcost_quad(ref.to(dt).to(ops.device), src.to(dt).to(ops.device), *tail, vw_shift=1)
+    cost32, _ = ops.getcost_quad(dev(ops, _g4(ref)), dev(ops, _g4(src)), *tail, vw_shift=1)
+    close(samp, want_s, 1e-6)
+    close(cost, want_cost, 1e-4)
+    close(cost, cost32.cpu(), 2e-6)
+
+
+@pytest.mark.parametrize("dt", _X16)
+def test_warp_corr_init_quad_16bit_features(ops, dt):
+    B, S, C, H, W, D = 2, 2, 48, 11, 17, 12
+    feats = [rnd(B, C, H, W, seed=80 + v).to(dt).float() for v in range(S + 1)]
+    _, proj, dvs = synth.synth_inputs(H * 8, W * 8, S, B=B, seed=7)
+    pm = proj["stage1"]
+    dv = torch.stack([dvs[:, 0], dvs[:, -1]], 1)
+    hyp = (torch.arange(D).view(1, -1, 1, 1) / (D - 1.0)).repeat(B, 1, H, W)
+    hyp = O.disp_to_depth(hyp, (1 / dv[:, 1]).view(-1, 1, 1, 1), (1 / dv[:, 0]).view(-1, 1, 1, 1))[1]
+    ref_proj = O.compose_proj(pm[:, 0])
+    want = torch.stack([O.group_corr(O.warp(feats[v], O.compose_proj(pm[:, v]), ref_proj, hyp), feats[0], 4) for v in range(1, S + 1)], 1)
+    rt = ops.compose_proj(dev(ops, pm))
+    ref = feats[0].permute(0, 2, 3, 1).contiguous().to(dt).to(ops.device)
+    src = torch.stack([f.permute(0, 2, 3, 1) for f in feats[1:]]).contiguous().to(dt).to(ops.device)
+    out = ops.warp_corr_init_quad(ref, src, rt, dev(ops, dv[:, 0].contiguous()), dev(ops, dv[:, 1].contiguous()), D)
+    close(out, want, 1e-4)
