@@ -524,9 +524,9 @@ class Engine:
         disp_min, disp_max = (1.0 / depth_max_).contiguous(), (1.0 / depth_min_).contiguous()   # module.py:222-223
         interval = 1.0 / depth_values.size(1)
 
-        x = torch.cat([im.to(o.device).float() for im in imgs], 0).contiguous()                  # [V*B,3,H,W], view-major
-        feats = run_feature(o, self.feat, x, feat_dtype=self.feat_dtype)
-        trunk = run_context_trunk(o, self.ctx, x[:B])
+        views = [im.to(o.device).float().contiguous() for im in imgs]       # V x [B,3,H,W]: FeatureNet's stem reads them in place
+        feats = run_feature(o, self.feat, views, feat_dtype=self.feat_dtype)
+        trunk = run_context_trunk(o, self.ctx, views[0])
         depths, confs_full, confs_seq = [], [], []
         view_w = None
         for s in range(3):

@@ -241,17 +241,30 @@ class Ops:
         return out
 
     def featurenet_stem(self, pc0: PackedConv, pc1: PackedConv, x):
-        """relu(bn(conv0.1(relu(bn(conv0.0(x)))))) of FeatureNet in one kernel: x [N,3,H,W] -> [N,8,H,W]"""
+        """relu(bn(conv0.1(relu(bn(conv0.0(x)))))) of FeatureNet in one kernel: x [N,3,H,W] -> [N,8,H,W].
+        x may be a LIST of V tensors [B,3,H,W] (the views of a batch): one launch per view into consecutive slices of one
+        [V*B,8,H,W] output -- the view stack is never concatenated"""
+        if isinstance(x, (list, tuple)):
+            self._chk(*x)
+            Bv, cin, H, W = x[0].shape
+            y = self.empty(len(x) * Bv, 8, H, W)
+            for v, xv in enumerate(x):
+                self._stem_launch(pc0, pc1, xv, y[v * Bv:(v + 1) * Bv])
+            return y
         self._chk(x)
+        N, cin, H, W = x.shape
+        y = self.empty(N, 8, H, W)
+        self._stem_launch(pc0, pc1, x, y)
+        return y
+
+    def _stem_launch(self, pc0: PackedConv, pc1: PackedConv, x, y):
         N, cin, H, W = x.shape
         if not (cin == 3 and pc0.cin == 3 and pc0.cout == 8 and pc1.cin == 8 and pc1.cout == 8 and pc0.k == (3, 3) and
                 pc1.k == (3, 3) and pc0.stride == 1 and pc1.stride == 1 and pc0.pad == (1, 1) and pc1.pad == (1, 1) and
                 pc0.cout_pad == 8 and pc1.cout_pad == 8):
             raise _lib.DmvsError("featurenet_stem: expects the 3->8->8 3x3 stem of FeatureNet")
-        y = self.empty(N, 8, H, W)
         self._call("dmvs_featurenet_stem_f32", _ptr(x), _ptr(pc0.weight), _ptr(pc0.scale), _ptr(pc0.shift), _ptr(pc1.weight),
                    _ptr(pc1.scale), _ptr(pc1.shift), _ptr(y), N, H, W, self.stream())
-        return y
 
     def conv2d_wgrad(self, pc: PackedConv, x0, grad_out, x1=None, *, mul0=None, in_mode=IN_PLAIN, want_bias=False):
         """Weight gradient of conv2d(pc, x0, x1, mul0=..., in_mode=...) in torch layout [cout, cin, kh, kw]
