@@ -73,17 +73,13 @@ def scene_geometry_getcost(ops, B, H, W, S, n, iters=20):
             "round1_gather_kernel_frac": round(alg / out["gather"] / 1e9 / HBM_PEAK_GBS, 4)}
 
 
-def batch_sweep(model, base, dev, batches=(1, 2, 4, 8, 16, 32, 64), iters=6):
+def batch_sweep(model, make_batch, batches=(1, 2, 4, 8, 16, 32, 64), iters=6):
     """Untimed side measurement: ms per depth map against the batch size (eager launch sequence; up to batch 8 also through the
-    captured HIP graph of the same forward -- the reference's harness runs batch 1, test.py:101-127).  `base` = the distinct
-    reference views already on the device, sliced / repeated to each batch size."""
-    imgs0, proj0, dv0 = base
-    uniq = dv0.shape[0]
+    captured HIP graph of the same forward -- the reference's harness runs batch 1, test.py:101-127)."""
     out = {}
     was = model.hip_graphs
     for B in batches:
-        rep = lambda t: torch.cat([t] * ((B + uniq - 1) // uniq), 0)[:B].contiguous()      # noqa: E731
-        imgs, proj, dv = [rep(i) for i in imgs0], {k: rep(v) for k, v in proj0.items()}, rep(dv0)
+        imgs, proj, dv = make_batch(B)
         row = {}
         for graphs in ((False, True) if B <= 8 else (False,)):
             model.hip_graphs = graphs
@@ -191,8 +187,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("DMVS_BENCH_BATCH", "96")),
                     help="reference views per GPU per step (576 images at the default 96: ~30 GB of the 288 GB; measured on the "
-                         "MI355X: 16 -> 870 maps/s with the warp kernel at 0.34 of the HBM roofline, 64 -> 976 / 0.57, 96 -> 986 / 0.67, "
-                         "128 -> 998 / 0.68 -- below ~64 the gather kernels do not have enough waves in flight to cover the memory latency)")
+                         "MI355X: 16 -> 870 depth-maps/s, 32 -> 930, 64 -> 968, 96 -> 975: larger tiles counts fill the 256 CUs' MFMA pipes better)")
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--src-views", type=int, default=5)
@@ -241,15 +236,27 @@ def main():
     model.load_state_dict(sd)
     model = model.to(dev)
     H, W, S, B = a.height, a.width, a.src_views, a.batch
-    # the synthetic scenes are rendered on the host (~1 s per reference view with its source views): at most 16 distinct
-    # reference views per rank, repeated along the batch axis (separate copies in HBM: nothing is shared between them)
+    # the synthetic scenes are rendered on the host (~1 s per reference view with its source views): at most 16 are rendered
+    # per rank; further batch items re-use those images shifted horizontally by a different amount each (so that no two items
+    # share content and hence depth maps / gather patterns) with the cameras of the scene they were derived from.  (The
+    # generator's cameras rotate further with the batch index -- meant for small test batches: beyond ~16 the source views look
+    # away from the scene, most samples fall outside the images and the warp kernels look faster than they are.)
     uniq = min(B, 16)
     imgs, proj, dv = synth.synth_inputs(H, W, S, B=uniq, seed=100 + rank)
     base = ([i.to(dev) for i in imgs], {k: v.to(dev) for k, v in proj.items()}, dv.to(dev))
-    rep = lambda t: torch.cat([t] * ((B + uniq - 1) // uniq), 0)[:B].contiguous()      # noqa: E731
-    imgs = [rep(i) for i in base[0]]
-    proj = {k: rep(v) for k, v in base[1].items()}
-    dv = rep(base[2])
+
+    def make_batch(nb):
+        idx = torch.arange(nb) % uniq
+        pj, dvs = {k: p[idx] for k, p in proj.items()}, dv[idx]
+        ims = []
+        for v in range(S + 1):
+            t = torch.cat([base[0][v]] * ((nb + uniq - 1) // uniq), 0)[:nb].contiguous()
+            for i in range(uniq, nb):
+                t[i] = torch.roll(t[i], shifts=37 * (i // uniq) + 3 * (i % uniq), dims=-1)
+            ims.append(t)
+        return ims, {k: p.to(dev) for k, p in pj.items()}, dvs.to(dev)
+
+    imgs, proj, dv = make_batch(B)
     eng = model.engine()
     model.hip_graphs = bool(a.graphs)
 
@@ -285,7 +292,7 @@ def main():
     gather_tiles = eng.ops.getcost_tiles or (None, None)      # last lazily read-back probe of the hybrid launch
     scene = scene_geometry_getcost(eng.ops, B, H, W, S, args.CostNum[1]) if (rank == 0 and a.config == "cfg2" and eng.quad) else None
 
-    sweep = batch_sweep(model, base, dev) if (rank == 0 and world == 1 and not a.no_batch_sweep and a.config == "cfg2") else None
+    sweep = batch_sweep(model, make_batch) if (rank == 0 and world == 1 and not a.no_batch_sweep and a.config == "cfg2") else None
     maps = B * a.steps * world
     value = maps / elapsed
     gc_ms = [s.elapsed_time(e) for s, e in timers["dmvs_getcost_f32"] + timers["dmvs_getcost_gather_f32"] + timers["dmvs_getcost_quad_f32"]]
@@ -318,7 +325,7 @@ def main():
     result = {
         "metric": "depth-maps/sec (640x512, 5 src views)", "value": round(value, 3), "unit": "depth-maps/s",
         "n_gpus": world, "rccl_world_size": (td.get_world_size() if dist else 1), "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic (rendered slanted-plane scenes; <= 16 distinct reference views per rank, repeated along the batch)",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic (rendered slanted-plane scenes; 16 rendered per rank, further batch items = horizontally shifted copies)",
         "config": {"workload": f"DiffMVS DTU eval {W}x{H}, {S} src views, numdepth_initial=48, 1 DDIM step, fp32",
                    "ref_views_per_gpu_per_step": B, "parallelism": f"ref-view sharding x{world}, no collective",
                    "weights": "seeded random init (no checkpoint offline)",

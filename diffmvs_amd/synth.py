@@ -258,3 +258,26 @@ def synth_view_depths(H: int, W: int, n_views: int, seed: int = 0, b: int = 0) -
         d = R.T @ rays
         out[v] = ((d0 - n @ o) / (n @ d)).reshape(H, W).astype(np.float32)       # ray parameter = camera-frame depth (ray z = 1)
     return out
+
+
+def synth_cameras(H: int, W: int, n_src: int, B: int = 1, numdepth: int = 384, depth_min: float = 425.0, depth_max: float = 935.0):
+    """the cameras and depth range of synth_inputs(H, W, n_src, B) without rendering the images (seed-independent):
+    -> proj {stage1..4: [B,V,2,4,4]}, depth_values [B,numdepth]"""
+    V = n_src + 1
+    proj = {s: np.zeros((B, V, 2, 4, 4), np.float32) for s in ("stage1", "stage2", "stage3", "stage4")}
+    scales = {"stage1": 0.125, "stage2": 0.25, "stage3": 0.5, "stage4": 1.0}
+    K = np.array([[1.2 * W, 0, W / 2.0], [0, 1.2 * W, H / 2.0], [0, 0, 1.0]], np.float64)
+    for b in range(B):
+        for v in range(V):
+            ang = 0.05 * v * (1.0 + 0.1 * b)
+            R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+            E = np.eye(4)
+            E[:3, :3] = R
+            E[:3, 3] = np.array([-30.0 * v, 4.0 * v * ((-1) ** v), 0.0])
+            for sname, sc in scales.items():
+                Ks = K.copy()
+                Ks[:2, :] *= sc
+                proj[sname][b, v, 0] = E.astype(np.float32)
+                proj[sname][b, v, 1, :3, :3] = Ks.astype(np.float32)
+    dv = np.tile(np.linspace(1.0 / depth_max, 1.0 / depth_min, numdepth, dtype=np.float32)[None], (B, 1))
+    return {k: torch.from_numpy(p) for k, p in proj.items()}, torch.from_numpy(dv)
