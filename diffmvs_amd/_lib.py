@@ -31,6 +31,7 @@ class Conv2dDesc(C.Structure):
         ("cout", _I), ("cout_pad", _I), ("kh", _I), ("kw", _I), ("stride", _I), ("pad_h", _I), ("pad_w", _I),
         ("in_mode", _I), ("act", _I), ("res_mode", _I), ("res_after_act", _I),
         ("out_layout", _I), ("out_cstride", _I), ("out_coffset", _I), ("gn_groups", _I), ("post_scale", _F),
+        ("gate_cstride", _I),
     ]
 
 

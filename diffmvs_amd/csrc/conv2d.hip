@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     const int plane0 = pH * pW, plane1 = d.Hin * d.Win;
     const int pc0 = mode == DMVS_IN_UNSHUFFLE2 ? (d.c0 >> 2) : d.c0;
     const float* in0b = d.in0 + (size_t)b * pc0 * plane0;
-    const float* mul0b = d.mul0 ? d.mul0 + (size_t)b * pc0 * plane0 : nullptr;
+    const float* mul0b = d.mul0 ? d.mul0 + (size_t)b * (d.gate_cstride ? d.gate_cstride : pc0) * plane0 : nullptr;
     const float* in1b = d.in1 ? d.in1 + (size_t)b * d.c1 * plane1 : d.in0;
 
     // element e of the padded LDS input image of chunk c0 -> global source (or nullptr for padding)
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     float* const outb = d.out_layout == DMVS_LAYOUT_NCHW ? d.out + ((size_t)b * d.out_cstride + d.out_coffset) * oplane
                                                          : d.out + (size_t)b * oplane * d.out_cstride + d.out_coffset;
     const float* const resb = d.residual ? d.residual + (size_t)b * d.cout * rplane : nullptr;
-    const float* const gzb = d.gru_z ? d.gru_z + (size_t)b * d.cout * oplane : nullptr;
+    const float* const gzb = d.gru_z ? d.gru_z + (size_t)b * (d.gate_cstride ? d.gate_cstride : d.cout) * oplane : nullptr;
     const float* const ghb = d.gru_z ? d.gru_h + (size_t)b * d.cout * oplane : nullptr;
     float sc[NT][4], sh[NT][4];
 #pragma unroll
@@ -538,7 +538,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_wgrad_kernel(const dmvs_con
         const int ox0 = tx * 16, oy0 = ty * 16;
         const int gy0 = oy0 * S - d.pad_h, gx0 = ox0 * S - d.pad_w;
         const float* in0b = d.in0 + (size_t)b * pc0 * plane0;
-        const float* mul0b = d.mul0 ? d.mul0 + (size_t)b * pc0 * plane0 : nullptr;
+        const float* mul0b = d.mul0 ? d.mul0 + (size_t)b * (d.gate_cstride ? d.gate_cstride : pc0) * plane0 : nullptr;
         const float* in1b = d.in1 ? d.in1 + (size_t)b * d.c1 * plane1 : d.in0;
         const float* gb = gout + (size_t)b * d.cout * oplane + (size_t)oy0 * d.Wout + ox0;
         __syncthreads();                              // previous tile fully consumed
@@ -696,6 +696,7 @@ extern "C" int dmvs_conv2d_f32(const dmvs_conv2d_desc* dp, void* stream) {
     if (d.in_mode == DMVS_IN_UNSHUFFLE2 && (d.c0 % 4)) return DMVS_EINVAL;
     if ((d.in_mode == DMVS_IN_UPSAMPLE2 || d.in_mode == DMVS_IN_ZEROINSERT2) && ((d.Hin | d.Win) & 1)) return DMVS_EINVAL;
     if (d.gru_z && (!d.gru_h || d.act != DMVS_ACT_TANH)) return DMVS_EINVAL;
+    if (d.gate_cstride < 0 || (d.gate_cstride && d.in_mode != DMVS_IN_PLAIN)) return DMVS_EINVAL;
     if (d.gn_stats && (d.gn_groups != 4 || d.cout % 4)) return DMVS_EINVAL;
     const int eh = (d.Hin + 2 * d.pad_h - d.kh) / d.stride + 1, ew = (d.Win + 2 * d.pad_w - d.kw) / d.stride + 1;
     if (eh != d.Hout || ew != d.Wout) return DMVS_EINVAL;

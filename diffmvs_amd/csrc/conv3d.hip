@@ -277,6 +277,134 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_kernel(const dm
     if (pb >= 0) store(pend, pb, ptd, pty, ptx);
 }
 
+// cin <= 4 AND cout <= 8 (PixelViewWeight conv0, CostReg conv0: 4 -> 8 on the largest volumes of the model): with 8 output
+// channels half of the 16 A rows of v_mfma_f32_16x16x4_f32 would be zero padding.  This variant gives the spare rows to a
+// SECOND OUTPUT DEPTH SLICE: a wave owns output slices 2w and 2w+1 of a 16(x) x 4(y) x 8(d) tile, and for input slice
+// j = -1 .. 2 (relative to 2w) and tap (ky, kx) the A operand is  rows 0-7 = W[kd = j+1] (output 2w), rows 8-15 = W[kd = j]
+// (output 2w+1), zero where kd falls outside 0..2 -- both outputs read the same B operand (the input slice).  4 x 9 x 4 = 144
+// MFMAs per wave produce two slices instead of 2 x 108: 1.5x fewer MFMAs for the same result, bit-identical per output
+// (each output still sums its 27 x cin products in (kd, ky, kx) order).  Same resident, tile-pipelined structure as
+// conv3d_mfma_stream_kernel.
+constexpr int kPairWgsPerCu = 3;       // 45 KB of LDS each
+__global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_pair_kernel(const dmvs_conv3d_desc d, int tiles_x, int tiles_y, int tiles_d) {
+    constexpr int TX = 16, TY = 4, TD = 8, CK = 4;
+    constexpr int IW = TX + 2, IH = TY + 2, ID = TD + 2;
+    constexpr int PLANE = pad16mod32_3d(ID * IH * IW);
+    constexpr int WP = pad16mod32_3d(36 * 16);             // paired weights of one input channel: [j 4][ky 3][kx 3][16 rows]
+    using Halo = HaloMap<ID, IH, IW, PLANE>;
+    __shared__ __attribute__((aligned(16))) float lds[2 * CK * PLANE + CK * WP];
+    float* const s_w = lds + 2 * CK * PLANE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, kq = lane >> 4;
+    const int vol = d.Din * d.Hin * d.Win, ovol = d.Dout * d.Hout * d.Wout;
+    const int ntiles = tiles_x * tiles_y * tiles_d * d.B;
+
+    Halo halo;
+    halo.init(tid, d.Hin, d.Win);
+    // paired weight slab, built once per workgroup from the [cin][27][cout_pad = 8] weights
+    for (int e = tid; e < CK * 36 * 16; e += DMVS_BLOCK) {
+        const int ci = e / (36 * 16), rem = e - ci * (36 * 16);
+        const int jt = rem >> 4, row = rem & 15;
+        const int j = jt / 9, t9 = jt - j * 9;
+        const int kd = row < 8 ? j : j - 1, co = row & 7;
+        float v = 0.0f;
+        if (ci < d.cin && kd >= 0 && kd <= 2 && co < d.cout) v = d.weight[(ci * 27 + kd * 9 + t9) * d.cout_pad + co];
+        s_w[ci * WP + jt * 16 + row] = v;
+    }
+    // epilogue constants: this lane holds output slice 2w + (kq >> 1), channels (kq & 1) * 4 + r
+    const int cg0 = (kq & 1) * 4, sl = kq >> 1;
+    float sc[4], sh[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const bool okc = cg0 + r < d.cout;
+        sc[r] = d.scale ? d.scale[okc ? cg0 + r : 0] : 1.0f;
+        sh[r] = d.shift ? d.shift[okc ? cg0 + r : 0] : 0.0f;
+    }
+
+    auto stage = [&](int b, int td, int ty, int tx, float* buf) {
+        const int gx0 = tx * TX - 1, gy0 = ty * TY - 1, gd0 = td * TD - 1;
+        unsigned lo, him1;
+        Halo::bounds(gd0, gy0, gx0, d.Din, d.Hin, d.Win, lo, him1);
+        const float* origin = d.in + (size_t)b * d.cin * vol + ((long)gd0 * d.Hin + gy0) * d.Win + gx0;
+#pragma unroll
+        for (int ci = 0; ci < CK; ++ci) halo.stage(origin + (long)ci * vol, ci < d.cin, lo, him1, buf + ci * PLANE, wave);
+    };
+    auto decode = [&](int tile, int& b, int& td, int& ty, int& tx) {
+        tx = tile % tiles_x; tile /= tiles_x;
+        ty = tile % tiles_y; tile /= tiles_y;
+        td = tile % tiles_d;
+        b = tile / tiles_d;
+    };
+    auto store = [&](const f32x4 (&a)[4], int sb, int std_, int sty, int stx) {
+        const int ox = stx * TX + m, od = std_ * TD + 2 * wave + sl;
+        if (ox >= d.Wout || od >= d.Dout) return;
+        float* outb = d.out + (size_t)sb * d.cout * ovol;
+        const float* resb = d.residual ? d.residual + (size_t)sb * d.cout * ovol : nullptr;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int oy = sty * TY + mt;
+            if (oy >= d.Hout) continue;
+            const int ovox = (od * d.Hout + oy) * d.Wout + ox;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (cg0 + r < d.cout) {
+                    float v = dmvs_act(a[mt][r] * sc[r] + sh[r], d.act);
+                    const int o = (cg0 + r) * ovol + ovox;
+                    if (resb) v += resb[o];
+                    outb[o] = v;
+                }
+            }
+        }
+    };
+
+    int tile = blockIdx.x, cur = 0;
+    int b = 0, td = 0, ty = 0, tx = 0;
+    f32x4 pend[4];                      // the previous tile's accumulators, stored one iteration late (after the barrier)
+    int pb = -1, ptd = 0, pty = 0, ptx = 0;
+    if (tile < ntiles) {
+        decode(tile, b, td, ty, tx);
+        stage(b, td, ty, tx, lds);
+    }
+    for (; tile < ntiles; tile += gridDim.x, cur ^= 1) {
+        __syncthreads();            // this tile's halo (and, first time, the paired weights) landed; the other buffer is free
+        int nb = 0, ntd = 0, nty = 0, ntx = 0;
+        if (tile + (int)gridDim.x < ntiles) {
+            decode(tile + gridDim.x, nb, ntd, nty, ntx);
+            stage(nb, ntd, nty, ntx, lds + (cur ^ 1) * (CK * PLANE));
+        }
+        if (pb >= 0) store(pend, pb, ptd, pty, ptx);
+        const float* s_in = lds + cur * (CK * PLANE);
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        {
+            const float* wp = s_w + kq * WP + m;                                   // k = input channel kq
+            const float* ipb = s_in + kq * PLANE + (2 * wave) * (IH * IW) + m;      // halo slice 2w = input slice (2w - 1)
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float av = wp[((j * 3 + ky) * 3 + kx) * 16];
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) {
+                            const float bv = ipb[(j * IH + ky + mt) * IW + kx];
+                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[mt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pend[i] = acc[i];
+        pb = b; ptd = td; pty = ty; ptx = tx;
+        b = nb; td = ntd; ty = nty; tx = ntx;
+    }
+    if (pb >= 0) store(pend, pb, ptd, pty, ptx);
+}
+
 template <int NT>
 __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_kernel(const dmvs_conv3d_desc d, int tiles_x, int tiles_y, int tiles_d) {
     constexpr int TX = 16, TY = 4, TD = 4;
@@ -591,6 +719,14 @@ extern "C" int dmvs_conv3d_f32(const dmvs_conv3d_desc* dp, void* stream) {
         const int ntiles = (d.cout_pad + 15) / 16;
         dim3 g((unsigned)(tiles_x * tiles_y * tiles_d * d.B), (unsigned)((ntiles + 1) / 2));
         const long vtiles = (long)tiles_x * tiles_y * tiles_d * d.B;
+        if (d.cin <= 4 && d.cout <= 8 && d.cout_pad == 8) {      // 4 -> 8 layers: two output depth slices share the 16 MFMA rows
+            const int tiles_d8 = (d.Dout + 7) / 8;
+            if ((long)tiles_x * tiles_y * tiles_d8 * d.B >= 512) {
+                dim3 gs((unsigned)(256 * kPairWgsPerCu), 1);
+                hipLaunchKernelGGL(conv3d_mfma_stream_pair_kernel, gs, block, 0, st, d, tiles_x, tiles_y, tiles_d8);
+                return dmvs_launch_status();
+            }
+        }
         if (d.cin <= 4 && ntiles == 1 && vtiles >= 256 * kStreamWgsPerCu) {      // one K chunk, many tiles: resident workgroups, pipelined tiles
             dim3 gs((unsigned)(256 * kStreamWgsPerCu), 1);
             hipLaunchKernelGGL((conv3d_mfma_stream_kernel<1>), gs, block, 0, st, d, tiles_x, tiles_y, tiles_d);

@@ -150,14 +150,23 @@ def pack_gru(sd, p):
     for n, pad in (("1", (0, 2)), ("2", (2, 0))):
         for gate in "zrq":
             g[gate + n] = pack_conv2d(sd[f"{p}.conv{gate}{n}.weight"], sd[f"{p}.conv{gate}{n}.bias"], pad=pad)
+        # z and r read the same input: ONE convolution with the two weight sets stacked along cout ([z | r])
+        g["zr" + n] = pack_conv2d(torch.cat([sd[f"{p}.convz{n}.weight"], sd[f"{p}.convr{n}.weight"]], 0),
+                                  torch.cat([sd[f"{p}.convz{n}.bias"], sd[f"{p}.convr{n}.bias"]], 0), pad=pad)
     return g
 
 
 def run_gru(o: Ops, g, h, x):
+    hd = h.shape[1]
+    merged = os.environ.get("DMVS_GRU_MERGE", "1") != "0"      # A/B knob: 0 = z and r as two launches
     for n in ("1", "2"):     # horizontal then vertical pass (module.py:164-177)
-        z = o.conv2d(g["z" + n], h, x, act=K.ACT_SIGMOID)
-        r = o.conv2d(g["r" + n], h, x, act=K.ACT_SIGMOID)
-        h = o.conv2d(g["q" + n], h, x, mul0=r, act=K.ACT_TANH, gru_z=z, gru_h=h)
+        if merged:
+            zr = o.conv2d(g["zr" + n], h, x, act=K.ACT_SIGMOID)               # [B, 2*hd, H, W] = sigmoid([convz | convr]([h, x]))
+            h = o.conv2d(g["q" + n], h, x, mul0=zr[:, hd:], act=K.ACT_TANH, gru_z=zr[:, :hd], gru_h=h, gate_cstride=2 * hd)
+        else:
+            z = o.conv2d(g["z" + n], h, x, act=K.ACT_SIGMOID)
+            r = o.conv2d(g["r" + n], h, x, act=K.ACT_SIGMOID)
+            h = o.conv2d(g["q" + n], h, x, mul0=r, act=K.ACT_TANH, gru_z=z, gru_h=h)
     return h
 
 

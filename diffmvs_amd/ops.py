@@ -198,11 +198,19 @@ class Ops:
     # ------------------------------------------------------------------ conv2d
     def conv2d(self, pc: PackedConv, x0, x1=None, *, mul0=None, in_mode=IN_PLAIN, act=ACT_NONE, residual=None,
                res_mode=IN_PLAIN, res_after_act=False, post_scale=1.0, gru_z=None, gru_h=None, out=None,
-               out_layout=LAYOUT_NCHW, out_cstride=None, out_coffset=0, gn_stats=None, gn_groups=4, out_dtype=torch.float32):
+               out_layout=LAYOUT_NCHW, out_cstride=None, out_coffset=0, gn_stats=None, gn_groups=4, out_dtype=torch.float32,
+               gate_cstride=0):
         """gn_stats: zeroed float64 [B*gn_groups*2] tensor that receives the GroupNorm statistics of
         the (pre-activation) output, for a following groupnorm_apply().  out_dtype (channel-last outputs only): bf16 / fp16
         feature storage, rounded to nearest even in the epilogue."""
-        self._chk(x0, x1, mul0, residual, gru_z, gru_h)
+        if gate_cstride:      # mul0 / gru_z are channel slices of one [B,gate_cstride,H,W] tensor (merged z|r gate convolution)
+            self._chk(x0, x1, residual, gru_h)
+            for t in (mul0, gru_z):
+                if t is not None and (t.dtype != torch.float32 or t.device != self.device or t.stride(1) != t.shape[2] * t.shape[3] or
+                                      t.stride(0) != gate_cstride * t.shape[2] * t.shape[3] or t.stride(3) != 1):
+                    raise _lib.DmvsError("gate_cstride: mul0 / gru_z must be channel slices of a contiguous [B,gate_cstride,H,W] tensor")
+        else:
+            self._chk(x0, x1, mul0, residual, gru_z, gru_h)
         if out_dtype != torch.float32:
             if out_layout != LAYOUT_NHWC or out is not None:
                 raise _lib.DmvsError("16-bit outputs are channel-last feature tensors allocated by conv2d")
@@ -234,7 +242,7 @@ class Ops:
             gn_stats=_ptr(gn_stats), gn_groups=(gn_groups if gn_stats is not None else 0), B=B, c0=c0, c1=c1, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, cout=pc.cout, cout_pad=pc.cout_pad,
             kh=kh, kw=kw, stride=pc.stride, pad_h=pc.pad[0], pad_w=pc.pad[1], in_mode=in_mode, act=act,
             res_mode=res_mode, res_after_act=int(res_after_act), out_layout=out_layout, out_cstride=out_cstride,
-            out_coffset=out_coffset, post_scale=post_scale)
+            out_coffset=out_coffset, post_scale=post_scale, gate_cstride=gate_cstride)
         self._call("dmvs_conv2d_f32", C.byref(d), self.stream())
         if self.timers is not None and "dmvs_conv2d_f32" in self.timers:      # bench: MFMA roofline over every conv launch
             self.timers.setdefault("_conv2d_flops", []).append(2.0 * B * Hout * Wout * pc.cout * pc.cin * kh * kw)

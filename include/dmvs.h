@@ -90,6 +90,9 @@ typedef struct dmvs_conv2d_desc {
     int32_t out_layout, out_cstride, out_coffset;
     int32_t gn_groups;
     float post_scale;
+    int32_t gate_cstride;   /* 0: mul0 / gru_z are dense [B,c0,..] / [B,cout,..] tensors.  > 0: both are channel slices (the pointers
+                               include the channel offset) of tensors with this many channels per batch item -- SepConvGRU's z and
+                               r gates computed by ONE convolution with 2x cout (models/module.py:164-177)              */
 } dmvs_conv2d_desc;
 
 /* Size limits (DMVS_EINVAL beyond them; the kernels address one batch item with 32-bit element offsets):
