@@ -685,6 +685,119 @@ __global__ void __launch_bounds__(DMVS_BLOCK) deconv3d_kernel(const dmvs_conv3d_
     conv3d_epilogue<CO>(d, acc, co0, b, ((size_t)od * d.Hout + oy) * d.Wout + ox);
 }
 
+// Transposed 3x3x3 convolution, stride 2, output_padding 1 (Deconv3d, module.py:110-144; CostRegNet conv7: 16 -> 8 onto the
+// full cost volume) on the matrix cores.  In gather form an output o = 2j + p reads, per axis,
+//     p = 0: tap k = 1 at input j            p = 1: tap k = 2 at input j  and  tap k = 0 at input j + 1,
+// so every input offset (dz, dy, dx) in {0,1}^3 of a 16(x) x 4(y) x 4(d) tile of INPUT positions j feeds a fixed set of
+// output parity classes.  With cout <= 8 the two x-parities share one MFMA: A rows 0-7 = W[.., kx] of class px = 0, rows 8-15 =
+// class px = 1 (dx = 0: kx = 1 | 2; dx = 1: zero | kx = 0), B = the input at that offset, 4 input channels per MFMA.  Per
+// axis pair (z, y) there are 3 x 3 (offset, parity, tap) combinations -> 18 A slabs per input channel, 18 x cin/4 x 4 rows =
+// 288 MFMAs per wave for 16 x 4 x 8 x cout outputs (the direct kernel issued 27 x cin FMAs per output LANE and ran at ~10
+// TFLOP/s).  Every output still sums its products in a fixed order (ci groups of 4, then the slab order).
+constexpr int kDeconvCin = 16;
+__global__ void __launch_bounds__(DMVS_BLOCK) deconv3d_mfma_kernel(const dmvs_conv3d_desc d, int tiles_x, int tiles_y, int tiles_d) {
+    constexpr int TX = 16, TY = 4, TD = 4, CK = kDeconvCin;
+    constexpr int IW = TX + 1, IH = TY + 1, ID = TD + 1;
+    constexpr int PLANE = pad16mod32_3d(ID * IH * IW);
+    constexpr int NS = 18;                                   // A slabs per input channel: (cz, cy, dx)
+    constexpr int WP = pad16mod32_3d(NS * 16);
+    using Halo = HaloMap<ID, IH, IW, PLANE>;
+    __shared__ __attribute__((aligned(16))) float lds[CK * PLANE + CK * WP];
+    float* const s_w = lds + CK * PLANE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, kq = lane >> 4;
+    int tile = blockIdx.x;
+    const int tx = tile % tiles_x; tile /= tiles_x;
+    const int ty = tile % tiles_y; tile /= tiles_y;
+    const int td = tile % tiles_d;
+    const int b = tile / tiles_d;
+    const int vol = d.Din * d.Hin * d.Win, ovol = d.Dout * d.Hout * d.Wout;
+    const int jx0 = tx * TX, jy0 = ty * TY, jd0 = td * TD;
+
+    Halo halo;
+    halo.init(tid, d.Hin, d.Win);
+    {
+        unsigned lo, him1;
+        Halo::bounds(jd0, jy0, jx0, d.Din, d.Hin, d.Win, lo, him1);
+        const float* origin = d.in + (size_t)b * d.cin * vol + ((long)jd0 * d.Hin + jy0) * d.Win + jx0;
+#pragma unroll 4
+        for (int ci = 0; ci < CK; ++ci) halo.stage(origin + (long)ci * vol, ci < d.cin, lo, him1, lds + ci * PLANE, wave);
+    }
+    // A slabs from the gather-form weights [cin][27][cout_pad = 8]: combination c of an axis = (offset, parity, tap):
+    // c = 0: (0, 0, k=1), c = 1: (0, 1, k=2), c = 2: (1, 1, k=0)
+    for (int e = tid; e < CK * NS * 16; e += DMVS_BLOCK) {
+        const int ci = e / (NS * 16), rem = e - ci * (NS * 16);
+        const int sidx = rem >> 4, row = rem & 15;
+        const int dx = sidx & 1, cy = (sidx >> 1) % 3, cz = (sidx >> 1) / 3;
+        const int kd = cz == 0 ? 1 : (cz == 1 ? 2 : 0), ky = cy == 0 ? 1 : (cy == 1 ? 2 : 0);
+        const int co = row & 7;
+        int kx = -1;
+        if (row < 8) kx = dx == 0 ? 1 : -1;
+        else kx = dx == 0 ? 2 : 0;
+        float v = 0.0f;
+        if (ci < d.cin && kx >= 0 && co < d.cout) v = d.weight[(ci * 27 + (kd * 3 + ky) * 3 + kx) * d.cout_pad + co];
+        s_w[ci * WP + sidx * 16 + row] = v;
+    }
+    f32x4 acc[4][4];                    // [pz * 2 + py][input row mt]
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[c][i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    __syncthreads();                    // halo (LDS-DMA) and slabs (ds_write) landed
+
+    const int ngroups = (d.cin + 3) >> 2;
+#pragma unroll 1
+    for (int g = 0; g < ngroups; ++g) {
+        const int ci = g * 4 + kq;
+        const float* wp = s_w + ci * WP + m;
+        const float* ipb = lds + ci * PLANE + wave * (IH * IW) + m;
+#pragma unroll
+        for (int cz = 0; cz < 3; ++cz) {
+            const int dz = cz == 2 ? 1 : 0, pz = cz == 0 ? 0 : 1;
+#pragma unroll
+            for (int cy = 0; cy < 3; ++cy) {
+                const int dy = cy == 2 ? 1 : 0, py = cy == 0 ? 0 : 1;
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const float av = wp[((cz * 3 + cy) * 2 + dx) * 16];
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        const float bv = ipb[(dz * IH + mt + dy) * IW + dx];
+                        acc[pz * 2 + py][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[pz * 2 + py][mt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // epilogue: this lane holds x-parity kq >> 1, channels (kq & 1) * 4 + r of input position (jd0 + wave, jy0 + mt, jx0 + m)
+    const int px = kq >> 1, cg0 = (kq & 1) * 4;
+    const int jx = jx0 + m, jd = jd0 + wave;
+    if (jx >= d.Win || jd >= d.Din) return;
+    float* outb = d.out + (size_t)b * d.cout * ovol;
+    const float* resb = d.residual ? d.residual + (size_t)b * d.cout * ovol : nullptr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int cg = cg0 + r;
+        if (cg >= d.cout) break;
+        const float sc = d.scale ? d.scale[cg] : 1.0f, sh = d.shift ? d.shift[cg] : 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int od = 2 * jd + (c >> 1);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int jy = jy0 + mt;
+                if (jy >= d.Hin) continue;
+                const int o = cg * ovol + (od * d.Hout + 2 * jy + (c & 1)) * d.Wout + 2 * jx + px;
+                float v = dmvs_act(acc[c][mt][r] * sc + sh, d.act);
+                if (resb) v += resb[o];
+                outb[o] = v;
+            }
+        }
+    }
+}
+
 extern "C" int dmvs_conv3d_f32(const dmvs_conv3d_desc* dp, void* stream) {
     if (!dp) return DMVS_EINVAL;
     const dmvs_conv3d_desc& d = *dp;
@@ -695,6 +808,13 @@ extern "C" int dmvs_conv3d_f32(const dmvs_conv3d_desc* dp, void* stream) {
     if (d.transposed) {
         if (d.stride != 2 || d.Dout != 2 * d.Din || d.Hout != 2 * d.Hin || d.Wout != 2 * d.Win) return DMVS_EINVAL;
         const long total = (long)d.B * d.Din * d.Hin * d.Win;
+        if (d.cout <= 8 && d.cout_pad == 8 && d.cin <= kDeconvCin && (long)d.cout * d.Dout * d.Hout * d.Wout < (1L << 31) &&
+            (long)d.cin * d.Din * d.Hin * d.Win < (1L << 31)) {      // matrix-core form (CostRegNet conv7)
+            const int tiles_x = (d.Win + 15) / 16, tiles_y = (d.Hin + 3) / 4, tiles_d = (d.Din + 3) / 4;
+            dim3 g((unsigned)(tiles_x * tiles_y * tiles_d * d.B));
+            hipLaunchKernelGGL(deconv3d_mfma_kernel, g, block, 0, st, d, tiles_x, tiles_y, tiles_d);
+            return dmvs_launch_status();
+        }
         dim3 grid(dmvs_ceil_div(total, DMVS_BLOCK), d.cout_pad / co, 8);
         if (co == 16) hipLaunchKernelGGL((deconv3d_kernel<16>), grid, block, 0, st, d);
         else hipLaunchKernelGGL((deconv3d_kernel<8>), grid, block, 0, st, d);

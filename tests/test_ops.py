@@ -920,3 +920,21 @@ def test_warp_corr_init_quad_16bit_features(ops, dt):
     src = torch.stack([f.permute(0, 2, 3, 1) for f in feats[1:]]).contiguous().to(dt).to(ops.device)
     out = ops.warp_corr_init_quad(ref, src, rt, dev(ops, dv[:, 0].contiguous()), dev(ops, dv[:, 1].contiguous()), D)
     close(out, want, 1e-4)
+
+
+@pytest.mark.parametrize("cin,cout,D,H,W,with_res", [(16, 8, 6, 9, 21, True), (8, 8, 5, 4, 16, False), (12, 6, 3, 5, 33, True), (4, 3, 2, 2, 2, False)])
+def test_deconv3d_matrix_core_form(ops, cin, cout, D, H, W, with_res):
+    """transposed conv, stride 2, output_padding 1 with cout <= 8 on the matrix cores (CostRegNet conv7): several tiles per
+    axis, ragged last tiles, channel counts that do not fill the 4-channel MFMA groups, both x-parities sharing the A rows"""
+    B = 2
+    x = rnd(B, cin, D, H, W, seed=1)
+    w = rnd(cin, cout, 3, 3, 3, seed=2) * 0.2
+    bn = {"weight": rnd(cout, seed=4, lo=0.5, hi=1.5), "bias": rnd(cout, seed=5),
+          "running_mean": rnd(cout, seed=6), "running_var": rnd(cout, seed=7, lo=0.5, hi=1.5)}
+    ref = F.relu(F.batch_norm(F.conv_transpose3d(x, w, None, 2, 1, 1), bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"], False, 0.0, 1e-5))
+    res = rnd(*ref.shape, seed=9) if with_res else None
+    if with_res:
+        ref = ref + res
+    pc = K.pack_conv3d(dev(ops, w), bn={k_: v.to(ops.device) for k_, v in bn.items()}, stride=2, transposed=True)
+    out = ops.conv3d(pc, dev(ops, x), act=K.ACT_RELU, residual=dev(ops, res))
+    close(out, ref, 2e-5)
