@@ -771,28 +771,40 @@ __global__ void __launch_bounds__(DMVS_BLOCK) deconv3d_mfma_kernel(const dmvs_co
         }
     }
 
-    // epilogue: this lane holds x-parity kq >> 1, channels (kq & 1) * 4 + r of input position (jd0 + wave, jy0 + mt, jx0 + m)
-    const int px = kq >> 1, cg0 = (kq & 1) * 4;
+    // epilogue: this lane holds x-parity kq >> 1, channels (kq & 1) * 4 + r of input position (jd0 + wave, jy0 + mt, jx0 + m).
+    // The two x-parities of a channel sit 32 lanes apart; stored as they are, every store instruction would write 4-byte
+    // elements at an 8-byte stride.  Lanes 0-31 therefore take the (pz, py) classes 0, 1 and lanes 32-63 the classes 2, 3 of
+    // BOTH parities (one cross-half exchange per value) and write / read 8-byte pairs: 128 contiguous bytes per 16 lanes.
+    const bool lowhalf = kq < 2;
+    const int cg0 = (kq & 1) * 4;
     const int jx = jx0 + m, jd = jd0 + wave;
-    if (jx >= d.Win || jd >= d.Din) return;
+    const bool live = jx < d.Win && jd < d.Din;
     float* outb = d.out + (size_t)b * d.cout * ovol;
     const float* resb = d.residual ? d.residual + (size_t)b * d.cout * ovol : nullptr;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int cg = cg0 + r;
-        if (cg >= d.cout) break;
-        const float sc = d.scale ? d.scale[cg] : 1.0f, sh = d.shift ? d.shift[cg] : 0.0f;
+        const bool okc = cg < d.cout;
+        const float sc = d.scale ? d.scale[okc ? cg : 0] : 1.0f, sh = d.shift ? d.shift[okc ? cg : 0] : 0.0f;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int od = 2 * jd + (c >> 1);
+        for (int c2 = 0; c2 < 2; ++c2) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
+                const float keep = lowhalf ? acc[c2][mt][r] : acc[c2 + 2][mt][r];
+                const float give = lowhalf ? acc[c2 + 2][mt][r] : acc[c2][mt][r];
+                const float got = __shfl_xor(give, 32, 64);
+                const int c = lowhalf ? c2 : c2 + 2;
                 const int jy = jy0 + mt;
-                if (jy >= d.Hin) continue;
-                const int o = cg * ovol + (od * d.Hout + 2 * jy + (c & 1)) * d.Wout + 2 * jx + px;
-                float v = dmvs_act(acc[c][mt][r] * sc + sh, d.act);
-                if (resb) v += resb[o];
-                outb[o] = v;
+                if (!live || !okc || jy >= d.Hin) continue;
+                const int o = cg * ovol + ((2 * jd + (c >> 1)) * d.Hout + 2 * jy + (c & 1)) * d.Wout + 2 * jx;      // even: 8-byte aligned
+                float v0 = dmvs_act((lowhalf ? keep : got) * sc + sh, d.act);       // x-parity 0
+                float v1 = dmvs_act((lowhalf ? got : keep) * sc + sh, d.act);       // x-parity 1
+                if (resb) {
+                    const float2 rv = *reinterpret_cast<const float2*>(resb + o);
+                    v0 += rv.x;
+                    v1 += rv.y;
+                }
+                *reinterpret_cast<float2*>(outb + o) = make_float2(v0, v1);
             }
         }
     }
