@@ -15,6 +15,7 @@
 #include "dmvs_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int pad16mod32_3d(int n) {
     int m = n;
@@ -496,19 +497,19 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_kernel(const dmvs_conv
 
 // ------------------------------------------------------------------------------------------
 // cout == 1 (PixelViewWeight's second conv, CostRegNet's prob head, reference :439,:456): a
-// 16-wide MFMA N-tile would be 94 % padding, so this is a direct form.  Workgroup = 32(x) x 8(y)
-// x 4(d) voxels, one lane = 4 consecutive x of one (y, d): per (ci, kd, ky) it reads a 6-float row
-// from the LDS halo tile (3 x ds_read_b64) and slides the 3 x-taps over it -- 12 FMAs per row.
-// The 27 weights of a channel sit in LDS and are read as wave-wide broadcasts.  Chunks of CK1 input channels are
-// double-buffered: chunk c+1 streams in by LDS-DMA while chunk c is being consumed.
-template <int CK1>
+// 16-wide MFMA N-tile would be 94 % padding, so this is a direct form, register-blocked so that the LDS is not the
+// limit: workgroup = 16(x) x 16(y) x 16(d) voxels, one lane = 4 consecutive x of 2 rows of 2 depth slices.  Per input
+// channel the lane walks the 4 x 4 (slice, row) halo rows it touches, reads each 6-float row ONCE (3 x ds_read_b64) and
+// slides the 3 x-taps of every (kd, ky) that maps it to one of its 2 x 2 output rows over it: 48 LDS reads per 432 FMAs
+// (the one-row-per-lane form needed 54 reads per 108).  The 27 weights of a channel are wave-uniform: scalar loads, used
+// as SGPR operands of the FMAs.  One channel per chunk, double-buffered: channel c+1 streams in by LDS-DMA while c is
+// consumed.  Each output's products are summed in (ci, kd, ky, kx = 2,1,0) order.
 __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_c1_kernel(const dmvs_conv3d_desc d, int tiles_x, int tiles_y, int tiles_d) {
-    constexpr int TX = 32, TY = 8, TD = 4;
-    constexpr int IW = TX + 4, IH = TY + 2, ID = TD + 2;      // row pitch 36: x halo 1 left, 3 right (8-byte aligned rows)
+    constexpr int TX = 16, TY = 16, TD = 16;
+    constexpr int IW = TX + 4, IH = TY + 2, ID = TD + 2;      // row pitch 20: x halo 1 left, 3 right (8-byte aligned rows)
     constexpr int PLANE = ID * IH * IW;
-    constexpr int BUF = CK1 * PLANE + 32 * CK1;               // halo planes + 27 weights per channel (padded to 32)
     using Halo = HaloMap<ID, IH, IW, PLANE>;
-    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+    __shared__ __attribute__((aligned(16))) float lds[2 * PLANE];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile = blockIdx.x;
     const int tx = tile % tiles_x; tile /= tiles_x;
@@ -517,63 +518,215 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_c1_kernel(const dmvs_conv3d
     const int b = tile / tiles_d;
     const int x0 = tx * TX, y0 = ty * TY, d0 = td * TD;
     const int vol = d.Din * d.Hin * d.Win;
-    const int lx = (tid & 7) * 4, ly = (tid >> 3) & 7, ld = tid >> 6;
+    const int lx = (tid & 3) * 4, ly = ((tid >> 2) & 7) * 2, ld = (tid >> 5) * 2;
 
     Halo halo;
     halo.init(tid, d.Hin, d.Win);
     unsigned lo, him1;
     Halo::bounds(d0 - 1, y0 - 1, x0 - 1, d.Din, d.Hin, d.Win, lo, him1);
     const float* origin = d.in + (size_t)b * d.cin * vol + ((long)(d0 - 1) * d.Hin + (y0 - 1)) * d.Win + (x0 - 1);
-    auto stage = [&](int c0, float* buf) {
-#pragma unroll
-        for (int ci = 0; ci < CK1; ++ci) halo.stage(origin + (long)(c0 + ci) * vol, c0 + ci < d.cin, lo, him1, buf + ci * PLANE, wave);
-        if (tid < 32 * CK1) {
-            const int ci = tid >> 5, t = tid & 31;
-            buf[CK1 * PLANE + tid] = (t < 27 && c0 + ci < d.cin) ? d.weight[((c0 + ci) * 27 + t) * d.cout_pad] : 0.0f;
-        }
-    };
 
-    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    stage(0, lds);
+    float acc[2][2][4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) (&acc[0][0][0])[i] = 0.0f;
+    halo.stage(origin, true, lo, him1, lds, wave);
     int cur = 0;
-    for (int c0 = 0; c0 < d.cin; c0 += CK1, cur ^= 1) {
-        const float* s_in = lds + cur * BUF;
-        const float* s_w = s_in + CK1 * PLANE;
-        __syncthreads();     // chunk c0 landed (DMA drained, weights written); the other buffer is free
-        if (c0 + CK1 < d.cin) stage(c0 + CK1, lds + (cur ^ 1) * BUF);
-        const int live_c = d.cin - c0 < CK1 ? d.cin - c0 : CK1;
-        for (int ci = 0; ci < live_c; ++ci) {
+    for (int ci = 0; ci < d.cin; ++ci, cur ^= 1) {
+        const float* s_in = lds + cur * PLANE + (ld * IH + ly) * IW + lx;
+        __syncthreads();     // channel ci landed (DMA drained); the other buffer is free
+        if (ci + 1 < d.cin) halo.stage(origin + (long)(ci + 1) * vol, true, lo, him1, lds + (cur ^ 1) * PLANE, wave);
+        // constant address space + wave-uniform index = s_load (lgkmcnt): a vector load here would put a vmcnt(0) -- and with it
+        // the wait for the NEXT channel's LDS-DMA -- in front of this channel's arithmetic
+        typedef const __attribute__((address_space(4))) float* cfloat_p;
+        cfloat_p wc = (cfloat_p)(uintptr_t)(d.weight + ci * 27 * d.cout_pad);
+        float w[27];
 #pragma unroll
-            for (int kd = 0; kd < 3; ++kd) {
+        for (int t = 0; t < 27; ++t) w[t] = wc[t * d.cout_pad];
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const float* row = s_in + ci * PLANE + ((ld + kd) * IH + ly + ky) * IW + lx;
-                    const float2 r01 = *reinterpret_cast<const float2*>(row);
-                    const float2 r23 = *reinterpret_cast<const float2*>(row + 2);
-                    const float2 r45 = *reinterpret_cast<const float2*>(row + 4);
-                    const float in6[6] = {r01.x, r01.y, r23.x, r23.y, r45.x, r45.y};
-                    const float* wr = s_w + ci * 32 + (kd * 3 + ky) * 3;
-                    const float w0 = wr[0], w1 = wr[1], w2 = wr[2];
+        for (int dz = 0; dz < 4; ++dz) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[j] = fmaf(in6[j], w0, fmaf(in6[j + 1], w1, fmaf(in6[j + 2], w2, acc[j])));
+            for (int yy = 0; yy < 4; ++yy) {
+                const float* row = s_in + (dz * IH + yy) * IW;
+                // (native vector type on purpose: its loads keep their TBAA tag, and hipcc waits out every LDS-DMA in flight --
+                // here the next channel's prefetch -- before an LDS read that carries no alias metadata at all, which is what
+                // the struct copy of a float2 compiles to)
+                const f32x2 r01 = *reinterpret_cast<const f32x2*>(row);
+                const f32x2 r23 = *reinterpret_cast<const f32x2*>(row + 2);
+                const f32x2 r45 = *reinterpret_cast<const f32x2*>(row + 4);
+                const float in6[6] = {r01[0], r01[1], r23[0], r23[1], r45[0], r45[1]};
+#pragma unroll
+                for (int od = 0; od < 2; ++od) {
+#pragma unroll
+                    for (int oy = 0; oy < 2; ++oy) {
+                        const int kd = dz - od, ky = yy - oy;
+                        if (kd < 0 || kd > 2 || ky < 0 || ky > 2) continue;
+                        const float w0 = w[(kd * 3 + ky) * 3], w1 = w[(kd * 3 + ky) * 3 + 1], w2 = w[(kd * 3 + ky) * 3 + 2];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[od][oy][j] = fmaf(in6[j], w0, fmaf(in6[j + 1], w1, fmaf(in6[j + 2], w2, acc[od][oy][j])));
+                    }
                 }
             }
         }
     }
-    const int od = d0 + ld, oy = y0 + ly;
-    if (od >= d.Dout || oy >= d.Hout) return;
     const int ovol = d.Dout * d.Hout * d.Wout;
     const float sc = d.scale ? d.scale[0] : 1.0f, sh = d.shift ? d.shift[0] : 0.0f;
     float* outb = d.out + (size_t)b * ovol;
     const float* resb = d.residual ? d.residual + (size_t)b * ovol : nullptr;
-    const int o0 = (od * d.Hout + oy) * d.Wout + x0 + lx;
+    const bool vec = (d.Wout & 3) == 0;       // x0 + lx is a multiple of 4: rows of 16-byte pieces
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (x0 + lx + j >= d.Wout) continue;
-        float y = dmvs_act(acc[j] * sc + sh, d.act);
-        if (resb) y += resb[o0 + j];
-        outb[o0 + j] = y;
+    for (int od = 0; od < 2; ++od) {
+#pragma unroll
+        for (int oy = 0; oy < 2; ++oy) {
+            const int gd = d0 + ld + od, gy = y0 + ly + oy;
+            if (gd >= d.Dout || gy >= d.Hout || x0 + lx >= d.Wout) continue;
+            const int o0 = (gd * d.Hout + gy) * d.Wout + x0 + lx;
+            float y[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = dmvs_act(acc[od][oy][j] * sc + sh, d.act);
+            if (vec) {
+                if (resb) {
+                    const float4 r = *reinterpret_cast<const float4*>(resb + o0);
+                    y[0] += r.x; y[1] += r.y; y[2] += r.z; y[3] += r.w;
+                }
+                *reinterpret_cast<float4*>(outb + o0) = make_float4(y[0], y[1], y[2], y[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (x0 + lx + j >= d.Wout) continue;
+                    outb[o0 + j] = resb ? y[j] + resb[o0 + j] : y[j];
+                }
+            }
+        }
     }
+}
+
+
+// cout == 1 on volumes whose rows are 16-byte multiples and at most 256 floats wide (every CostRegNet / PixelViewWeight
+// volume of the reference configurations): FULL-ROW tiles.  An LDS-DMA instruction costs the texture path the same
+// ~60 cycles whether its lanes move 4 or 16 bytes, and the 16-wide tiles above can only use 4-byte pieces (their halo
+// starts one column left of the tile): at 26 instructions per lane and channel that kernel is bound by DMA ISSUE, 4 B/clk/CU.
+// Here a tile spans the whole row, so the halo slab of a depth slice is one contiguous run of 16-byte pieces; the x padding
+// is a zero piece between consecutive rows (the right pad of row r is the left pad of row r + 1).  XT = W/4 lanes cover a
+// row, the 256/XT lane rows split into YT (y) x DT (d), every lane again on 2 x 2 x 4 outputs; the tile shape is chosen by the
+// host per volume (c1_rows_shape).  Arithmetic and summation order are those of conv3d_c1_kernel.
+constexpr int kC1RowsLds = 13448;          // floats: two channel buffers of (8 x 10 rows) x (80 + 4) + 4 -- three workgroups per CU
+constexpr int kC1RowsPieces = 8;           // 16-byte pieces per lane and channel
+
+__global__ void __launch_bounds__(DMVS_BLOCK) conv3d_c1_rows_kernel(const dmvs_conv3d_desc d, int XT, int YT, int DT, int tiles_y, int tiles_d) {
+    __shared__ __attribute__((aligned(16))) float lds[kC1RowsLds];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile = blockIdx.x;
+    const int ty = tile % tiles_y; tile /= tiles_y;
+    const int td = tile % tiles_d;
+    const int b = tile / tiles_d;
+    const int IH = 2 * YT + 2, ID = 2 * DT + 2, PW = d.Win + 4, NP = XT + 1;
+    const int plane = ID * IH * PW + 4, npieces = ID * IH * NP + 1;
+    const int y0 = ty * 2 * YT, d0 = td * 2 * DT;
+    const int vol = d.Din * d.Hin * d.Win;
+
+    // piece p of a channel buffer: p = 0 the leading zero piece; then per halo row XT data pieces and one zero piece
+    int off[kC1RowsPieces];               // float offset from the channel's first voxel; -1: zero piece; -2: beyond the buffer
+#pragma unroll
+    for (int it = 0; it < kC1RowsPieces; ++it) {
+        const int p = it * DMVS_BLOCK + tid;
+        const int q = p - 1, row = q / NP, xi = q - row * NP;
+        const int zz = row / IH, rr = row - zz * IH;
+        const int gd = d0 - 1 + zz, gy = y0 - 1 + rr;
+        const bool data = p >= 1 && xi < XT && gd >= 0 && gd < d.Din && gy >= 0 && gy < d.Hin;
+        off[it] = p >= npieces ? -2 : data ? (gd * d.Hin + gy) * d.Win + 4 * xi : -1;
+    }
+    const float* chan0 = d.in + (size_t)b * d.cin * vol;
+    auto stage = [&](int ci, float* buf) {
+        const float* base = chan0 + (long)ci * vol;
+#pragma unroll
+        for (int it = 0; it < kC1RowsPieces; ++it) {
+            if (off[it] != -2) {
+                const float* srcp = off[it] >= 0 ? base + off[it] : dmvs_zero16_3d;
+                float* dstp = buf + (it * DMVS_BLOCK + wave * 64) * 4;
+                __builtin_amdgcn_global_load_lds(srcp, DMVS_LDS(dstp), 16, 0, 0);
+            }
+        }
+    };
+
+    const int xr = tid / XT, lx = (tid - xr * XT) * 4;
+    const int rd = xr / YT, ry = xr - rd * YT;
+    const bool active = rd < DT;
+    const int lbase = 4 + ((2 * rd) * IH + 2 * ry) * PW + lx;      // this lane's (slice 0, row 0, column lx) of the halo slab
+    float acc[2][2][4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) (&acc[0][0][0])[i] = 0.0f;
+    stage(0, lds);
+    int cur = 0;
+    for (int ci = 0; ci < d.cin; ++ci, cur ^= 1) {
+        const float* s_in = lds + cur * plane + lbase;
+        __syncthreads();     // channel ci landed (DMA drained); the other buffer is free
+        if (ci + 1 < d.cin) stage(ci + 1, lds + (cur ^ 1) * plane);
+        if (!active) continue;
+        typedef const __attribute__((address_space(4))) float* cfloat_p;      // wave-uniform weights: scalar loads (see conv3d_c1_kernel)
+        cfloat_p wc = (cfloat_p)(uintptr_t)(d.weight + ci * 27 * d.cout_pad);
+        float w[27];
+#pragma unroll
+        for (int t = 0; t < 27; ++t) w[t] = wc[t * d.cout_pad];
+#pragma unroll
+        for (int dz = 0; dz < 4; ++dz) {
+#pragma unroll
+            for (int yy = 0; yy < 4; ++yy) {
+                const float* row = s_in + (dz * IH + yy) * PW;
+                const f32x4 mid = *reinterpret_cast<const f32x4*>(row);      // native vector type: keeps its TBAA tag (see conv3d_c1_kernel)
+                const float in6[6] = {row[-1], mid[0], mid[1], mid[2], mid[3], row[4]};
+#pragma unroll
+                for (int od = 0; od < 2; ++od) {
+#pragma unroll
+                    for (int oy = 0; oy < 2; ++oy) {
+                        const int kd = dz - od, ky = yy - oy;
+                        if (kd < 0 || kd > 2 || ky < 0 || ky > 2) continue;
+                        const float w0 = w[(kd * 3 + ky) * 3], w1 = w[(kd * 3 + ky) * 3 + 1], w2 = w[(kd * 3 + ky) * 3 + 2];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[od][oy][j] = fmaf(in6[j], w0, fmaf(in6[j + 1], w1, fmaf(in6[j + 2], w2, acc[od][oy][j])));
+                    }
+                }
+            }
+        }
+    }
+    if (!active) return;
+    const int ovol = d.Dout * d.Hout * d.Wout;
+    const float sc = d.scale ? d.scale[0] : 1.0f, sh = d.shift ? d.shift[0] : 0.0f;
+    float* outb = d.out + (size_t)b * ovol;
+    const float* resb = d.residual ? d.residual + (size_t)b * ovol : nullptr;
+#pragma unroll
+    for (int od = 0; od < 2; ++od) {
+#pragma unroll
+        for (int oy = 0; oy < 2; ++oy) {
+            const int gd = d0 + 2 * rd + od, gy = y0 + 2 * ry + oy;
+            if (gd >= d.Dout || gy >= d.Hout) continue;
+            const int o0 = (gd * d.Hout + gy) * d.Wout + lx;
+            f32x4 y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = dmvs_act(acc[od][oy][j] * sc + sh, d.act);
+            if (resb) y += *reinterpret_cast<const f32x4*>(resb + o0);
+            *reinterpret_cast<f32x4*>(outb + o0) = y;
+        }
+    }
+}
+
+// tile shape of conv3d_c1_rows_kernel for a volume: fewest tiles first, then fewest staged halo rows; false: not applicable
+static bool c1_rows_shape(const dmvs_conv3d_desc& d, int& XT, int& YT, int& DT) {
+    if (d.Win % 4 || d.Win < 16 || d.Win > 256) return false;
+    XT = d.Win / 4;
+    const int RT = DMVS_BLOCK / XT;
+    long best_tiles = -1, best_rows = 0;
+    for (int yt = 1; yt <= 4 && yt <= RT; ++yt)
+        for (int dt = 1; dt <= 4 && yt * dt <= RT; ++dt) {
+            const long rows = (long)(2 * yt + 2) * (2 * dt + 2);
+            if (2 * (rows * (d.Win + 4) + 4) > kC1RowsLds || rows * (XT + 1) + 1 > kC1RowsPieces * DMVS_BLOCK) continue;
+            const long tiles = (long)((d.Hout + 2 * yt - 1) / (2 * yt)) * ((d.Dout + 2 * dt - 1) / (2 * dt));
+            if (best_tiles < 0 || tiles < best_tiles || (tiles == best_tiles && tiles * rows < best_rows)) {
+                best_tiles = tiles; best_rows = tiles * rows; YT = yt; DT = dt;
+            }
+        }
+    return best_tiles > 0;
 }
 
 
@@ -841,9 +994,16 @@ extern "C" int dmvs_conv3d_f32(const dmvs_conv3d_desc* dp, void* stream) {
     if (d.stride == 1 && ((long)d.cin * d.Din * d.Hin * d.Win >= (1L << 31) || (long)d.cout * d.Dout * d.Hout * d.Wout >= (1L << 31)))
         return DMVS_EINVAL;
     if (d.stride == 1 && d.cout == 1) {
-        const int tiles_x = (d.Wout + 31) / 32, tiles_y = (d.Hout + 7) / 8, tiles_d = (d.Dout + 3) / 4;
+        int XT, YT, DT;
+        if (c1_rows_shape(d, XT, YT, DT)) {
+            const int tiles_y = (d.Hout + 2 * YT - 1) / (2 * YT), tiles_d = (d.Dout + 2 * DT - 1) / (2 * DT);
+            dim3 g((unsigned)(tiles_y * tiles_d * d.B));
+            hipLaunchKernelGGL(conv3d_c1_rows_kernel, g, block, 0, st, d, XT, YT, DT, tiles_y, tiles_d);
+            return dmvs_launch_status();
+        }
+        const int tiles_x = (d.Wout + 15) / 16, tiles_y = (d.Hout + 15) / 16, tiles_d = (d.Dout + 15) / 16;
         dim3 g((unsigned)(tiles_x * tiles_y * tiles_d * d.B));
-        hipLaunchKernelGGL((conv3d_c1_kernel<2>), g, block, 0, st, d, tiles_x, tiles_y, tiles_d);
+        hipLaunchKernelGGL(conv3d_c1_kernel, g, block, 0, st, d, tiles_x, tiles_y, tiles_d);
         return dmvs_launch_status();
     }
     if (d.stride == 1) {

@@ -7,7 +7,9 @@
 //   * conv0.0 on the 18x18 halo'd intermediate as an implicit GEMM with K = 27 (ci, tap) padded to 28:
 //     7 x v_mfma_f32_16x16x4_f32 per 16 pixels, B operand gathered from the LDS halo through per-lane k offsets;
 //     BN + ReLU, zeroed outside the image (it is conv0.1's zero padding), written to LDS [8][18x18];
-//   * conv0.1 from that LDS image exactly like conv2d_mfma_kernel<3,3,1,1,4>; BN + ReLU; NCHW store.
+//   * conv0.1 from that LDS image, with TWO OUTPUT ROWS per MFMA: cout = 8 would leave half of the 16 A rows as zero padding, so
+//     rows 0-7 carry W[ky = j] (output row y) and rows 8-15 W[ky = j-1] (output row y+1) for input row y+j, j = 0..3 -- both
+//     outputs read the same B operand: 24 instead of 36 MFMAs per row pair, every lane stores; BN + ReLU; NCHW store.
 // Exact-fp32 MFMA; conv0.0's 27 products are summed in (ci, tap) order here and in (tap, ci) order by the generic
 // kernel, so the two agree to the last bits, not bitwise.
 #include "dmvs_common.h"
@@ -22,7 +24,7 @@ constexpr int MW = TS + 2, MP = MW * MW;          // intermediate tile 18 x 18 =
 constexpr int IW = TS + 4, IP = IW * IW;          // input tile 20 x 20 = 400
 constexpr int MPLANE = 336;                        // 324 padded to 16 mod 32 (bank spread over the 4 k-groups)
 constexpr int IN_FLOATS = 3 * IP;                  // 1200
-constexpr int W1S = 9 * 16;                        // conv0.1 weight slab stride per input channel (144 = 16 mod 32)
+constexpr int W1S = 208;                           // conv0.1 paired weight slab [j 4][kx 3][16 rows] per input channel, padded (192 -> 16 mod 32)
 
 __device__ __attribute__((aligned(16))) const float stem_zero16[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
@@ -50,8 +52,10 @@ featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0
         s_w0[e] = (k < 27 && co < 8) ? w0[k * 8 + co] : 0.0f;
     }
     for (int e = tid; e < 8 * W1S; e += DMVS_BLOCK) {
-        const int ci = e / W1S, r = e - ci * W1S, t = r >> 4, co = r & 15;
-        s_w1[e] = co < 8 ? w1[(ci * 9 + t) * 8 + co] : 0.0f;
+        const int ci = e / W1S, r = e - ci * W1S, jt = r >> 4, row = r & 15;
+        const int j = jt / 3, kx = jt - j * 3;
+        const int ky = row < 8 ? j : j - 1;              // rows 0-7: output row y, rows 8-15: output row y + 1
+        s_w1[e] = (jt < 12 && ky >= 0 && ky <= 2) ? w1[(ci * 9 + ky * 3 + kx) * 8 + (row & 7)] : 0.0f;
     }
 
     // Input halo staging (3 x 20 x 20, zero padded): 4-byte LDS-DMA, 64 consecutive words per wave.  Which (channel,
@@ -113,23 +117,21 @@ featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0
 
     // BN + ReLU + NCHW store of a finished tile.  Issued one iteration LATE (after the next tile's barrier): the
     // barrier's vmcnt(0) -- needed for the LDS-DMA -- would otherwise also wait out stores issued just before it.
-    auto store_tile = [&](const f32x4 (&a)[4], int n, int ox0, int oy0) {
-        if (kq < 2) {
-            const int ox = ox0 + m;
+    auto store_tile = [&](const f32x4 (&a)[2], int n, int ox0, int oy0) {
+        const int ox = ox0 + m;
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int oy = oy0 + wave * 4 + mt;
-                if (ox < W && oy < H) {
+        for (int pr = 0; pr < 2; ++pr) {      // lanes kq < 2: first row of the pair, kq >= 2: second row; channels 4 * (kq & 1) + r
+            const int oy = oy0 + wave * 4 + 2 * pr + (kq >> 1);
+            if (ox < W && oy < H) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        y[((long)n * 8 + 4 * kq + r) * plane + (long)oy * W + ox] = fmaxf(fmaf(a[mt][r], sc1[r], sh1[r]), 0.0f);
-                }
+                for (int r = 0; r < 4; ++r)
+                    y[((long)n * 8 + 4 * (kq & 1) + r) * plane + (long)oy * W + ox] = fmaxf(fmaf(a[pr][r], sc1[r], sh1[r]), 0.0f);
             }
         }
     };
 
     int tile = blockIdx.x, cur = 0;
-    f32x4 pend[4];                       // conv0.1 accumulators of the previous tile, not stored yet
+    f32x4 pend[2];                       // conv0.1 accumulators of the previous tile (two row pairs), not stored yet
     int pn = -1, pox0 = 0, poy0 = 0;
     if (tile < ntiles) stage(tile, lds);
     for (; tile < ntiles; tile += gridDim.x, cur ^= 1) {
@@ -162,27 +164,27 @@ featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0
         }
         DMVS_LDS_BARRIER();     // s_mid complete (ds_writes only); the next tile's input DMA stays in flight
 
-        // ---- conv0.1 from s_mid: wave = 4 output rows, 2 k-groups x 9 taps
-        f32x4 acc[4];
+        // ---- conv0.1 from s_mid: wave = 4 output rows = 2 row pairs, 2 k-groups x 4 input rows x 3 kx
+        f32x4 acc[2];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int pr = 0; pr < 2; ++pr) acc[pr] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int c4 = 0; c4 < 2; ++c4) {
             const int ci = c4 * 4 + kq;
             const float* wp = s_w1 + ci * W1S + m;
             const float* mp = s_mid + ci * MPLANE + (wave * 4) * MW + m;
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const float av = wp[(ky * 3 + kx) * 16];
+                    const float av = wp[(j * 3 + kx) * 16];
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
-                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, mp[(mt + ky) * MW + kx], acc[mt], 0, 0, 0);
+                    for (int pr = 0; pr < 2; ++pr)
+                        acc[pr] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, mp[(2 * pr + j) * MW + kx], acc[pr], 0, 0, 0);
                 }
         }
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) pend[mt] = acc[mt];
+        for (int pr = 0; pr < 2; ++pr) pend[pr] = acc[pr];
         pn = n; pox0 = ox0; poy0 = oy0;
     }
     if (pn >= 0) store_tile(pend, pn, pox0, poy0);

@@ -63,6 +63,29 @@ def test_conv2d_basic(ops, cin, cout, k, stride, pad, act):
         close(out, ref, 2e-5)
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,pad", [(5, 8, (3, 3), 1, (1, 1)), (16, 48, (1, 1), 1, (0, 0)), (12, 31, (3, 3), 1, (1, 1)),
+                                                   (10, 16, (7, 7), 1, (3, 3)), (9, 20, (1, 5), 1, (0, 2)), (9, 20, (5, 1), 1, (2, 0)),
+                                                   (6, 36, (3, 3), 2, (1, 1)), (7, 16, (5, 5), 2, (2, 2)), (33, 64, (3, 3), 1, (1, 1))])
+@pytest.mark.parametrize("W,misalign", [(20, False), (36, False), (20, True)])
+def test_conv2d_row_alignment(ops, cin, cout, k, stride, pad, W, misalign):
+    """rows that are 16-byte multiples, on a 16-byte aligned tensor and on the same tensor at a 4-byte offset (no staging or
+    epilogue path may assume more than element alignment); tiles ragged in both axes, partial last channel chunk, image
+    narrower than a tile, every kernel shape of the model"""
+    B, H = 2, 21
+    x = rnd(B, cin, H, W, seed=1)
+    w = rnd(cout, cin, *k, seed=2) * 0.3
+    bias = rnd(cout, seed=3)
+    ref = F.relu(F.conv2d(x, w, bias, stride, pad))
+    xd = dev(ops, x)
+    if misalign:
+        store = torch.zeros(x.numel() + 1, device=ops.device)
+        store[1:] = xd.reshape(-1)
+        xd = store[1:].view(x.shape)
+        assert xd.data_ptr() % 16 == 4
+    out = ops.conv2d(K.pack_conv2d(*dev(ops, w, bias), stride=stride, pad=pad), xd, act=K.ACT_RELU)
+    close(out, ref, 2e-5)
+
+
 @pytest.mark.parametrize("cin,cout,stride,H,W", [(3, 8, 1, 250, 262), (8, 8, 1, 256, 256), (8, 16, 2, 260, 500), (8, 24, 1, 256, 258)])
 def test_conv2d_large_image_stem(ops, cin, cout, stride, H, W):
     """image sizes that select the 16x16-pixel tile (MT=4) instantiations of the FeatureNet / ContextNet stem layers"""
@@ -711,20 +734,26 @@ def test_conv3d_volumes_smaller_than_a_tile(ops, cin, cout, D, H, W):
     close(out, ref, 2e-5)
 
 
-@pytest.mark.parametrize("W,act", [(72, "sigmoid"), (36, "none"), (30, "none")])
-def test_conv3d_single_output_channel(ops, W, act):
-    """cout = 1 (PixelViewWeight conv1 with its sigmoid, CostRegNet's prob head): rows that are 16-byte multiples take the
-    16-byte LDS-DMA form with the halo starting 4 columns left of the tile, others the 4-byte form; several tiles per
-    axis with ragged last tiles, 8 input channels = 4 double-buffered chunks"""
-    B, cin, D, H = 2, 8, 6, 11
+@pytest.mark.parametrize("D,H,W,act,with_res", [(6, 11, 72, "sigmoid", False), (6, 11, 36, "none", False), (6, 11, 30, "none", True),
+                                                 (20, 19, 22, "none", False), (33, 17, 16, "sigmoid", True),
+                                                 (14, 20, 80, "none", True), (5, 7, 256, "none", False), (3, 4, 260, "none", False)])
+def test_conv3d_single_output_channel(ops, D, H, W, act, with_res):
+    """cout = 1 (PixelViewWeight conv1 with its sigmoid, CostRegNet's prob head), every lane on 2 x 2 x 4 outputs: full-row
+    tiles (16-byte LDS-DMA pieces, host-chosen tile shape) where rows are 16-byte multiples of 16..256 floats, 16 x 16 x 16
+    tiles otherwise; several tiles per axis with ragged last tiles (odd extents: a lane's second row / slice falls
+    outside), idle lane rows (256 not a multiple of W/4), 8 double-buffered input channels"""
+    B, cin = 2, 8
     x = rnd(B, cin, D, H, W, seed=1)
     w = rnd(1, cin, 3, 3, 3, seed=2) * 0.2
     bias = rnd(1, seed=3)
     ref = F.conv3d(x, w, bias, 1, 1)
     if act == "sigmoid":
         ref = torch.sigmoid(ref)
+    res = rnd(B, 1, D, H, W, seed=4) if with_res else None
+    if with_res:
+        ref = ref + res
     pc = K.pack_conv3d(dev(ops, w), dev(ops, bias))
-    out = ops.conv3d(pc, dev(ops, x), act=K.ACT_SIGMOID if act == "sigmoid" else K.ACT_NONE)
+    out = ops.conv3d(pc, dev(ops, x), act=K.ACT_SIGMOID if act == "sigmoid" else K.ACT_NONE, residual=dev(ops, res) if with_res else None)
     close(out, ref, 2e-5)
 
 

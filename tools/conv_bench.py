@@ -23,7 +23,8 @@ SHAPES = [  # name, N, cin, cout, k, stride, H, W
 SHAPES3D = [  # name, N, cin, cout, D, H, W, stride
     ("pvw conv0 4->8 (5 views)", 80, 4, 8, 48, 64, 80, 1), ("costreg conv0 4->8", 16, 4, 8, 48, 64, 80, 1),
     ("costreg conv1 8->8", 16, 8, 8, 48, 64, 80, 1), ("costreg conv3 16->16", 16, 16, 16, 24, 32, 40, 1),
-    ("costreg conv5 32->32", 16, 32, 32, 12, 16, 20, 1),
+    ("costreg conv5 32->32", 16, 32, 32, 12, 16, 20, 1), ("costreg prob 8->1 B96", 96, 8, 1, 48, 64, 80, 1),
+    ("costreg conv0 4->8 B96", 96, 4, 8, 48, 64, 80, 1), ("costreg conv1 8->8 B96", 96, 8, 8, 48, 64, 80, 1),
 ]
 
 
