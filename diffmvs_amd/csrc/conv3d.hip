@@ -714,6 +714,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_c1_rows_kernel(const dmvs_c
 // tile shape of conv3d_c1_rows_kernel for a volume: fewest tiles first, then fewest staged halo rows; false: not applicable
 static bool c1_rows_shape(const dmvs_conv3d_desc& d, int& XT, int& YT, int& DT) {
     if (d.Win % 4 || d.Win < 16 || d.Win > 256) return false;
+    if (((uintptr_t)d.in | (uintptr_t)d.out | (uintptr_t)d.residual) & 15) return false;       // 16-byte pieces, loads and stores
     XT = d.Win / 4;
     const int RT = DMVS_BLOCK / XT;
     long best_tiles = -1, best_rows = 0;

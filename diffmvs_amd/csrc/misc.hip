@@ -230,34 +230,79 @@ gn_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, long pe
     }
 }
 
+// y = silu(GroupNorm(x) * (scale + 1) + shift) (+ residual): one (batch item, channel) plane per blockIdx.y, 16 elements per
+// lane.  The per-plane constants need fp64 (var = E[x^2] - mean^2 from the fixed-point sums): ~150 instructions that every
+// wave of every workgroup used to repeat for 4 elements per lane -- more issue slots than the streaming itself.  One lane
+// computes them now, the workgroup reads them from LDS; VEC = 16-byte accesses (planes that are 16-byte multiples).
+constexpr int kGnPerLane = 16;
+
+template <bool VEC>
 __global__ void __launch_bounds__(DMVS_BLOCK)
 gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                 const float* __restrict__ scale_shift, const float* __restrict__ residual, float* __restrict__ y,
                 const double* __restrict__ stats, int C, int HW, int groups, float eps) {
+    __shared__ float s_ab[2];
     const int bc = blockIdx.y;
-    const int b = bc / C, c = bc % C;
-    const int cg = C / groups;
-    const int g = c / cg;
-    const double n = (double)cg * HW;
-    const double mean = dmvs_gn_read(&stats[2 * (b * groups + g)]) / n;
-    double var = dmvs_gn_read(&stats[2 * (b * groups + g) + 1]) / n - mean * mean;
-    var = var < 0.0 ? 0.0 : var;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    // y = ((x - mean) * rstd * gamma + beta) * (scale + 1) + shift  ==  x * A + Bc
-    float A = rstd * gamma[c];
-    float Bc = beta[c] - (float)mean * A;
-    if (scale_shift) {
-        const float sc = scale_shift[(long)b * 2 * C + c] + 1.0f, sh = scale_shift[(long)b * 2 * C + C + c];
-        A *= sc;
-        Bc = Bc * sc + sh;
+    if (threadIdx.x == 0) {
+        const int b = bc / C, c = bc % C;
+        const int cg = C / groups;
+        const int g = c / cg;
+        const double n = (double)cg * HW;
+        const double mean = dmvs_gn_read(&stats[2 * (b * groups + g)]) / n;
+        double var = dmvs_gn_read(&stats[2 * (b * groups + g) + 1]) / n - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        // y = ((x - mean) * rstd * gamma + beta) * (scale + 1) + shift  ==  x * A + Bc
+        float A = rstd * gamma[c];
+        float Bc = beta[c] - (float)mean * A;
+        if (scale_shift) {
+            const float sc = scale_shift[(long)b * 2 * C + c] + 1.0f, sh = scale_shift[(long)b * 2 * C + C + c];
+            A *= sc;
+            Bc = Bc * sc + sh;
+        }
+        s_ab[0] = A;
+        s_ab[1] = Bc;
     }
+    __syncthreads();
+    const float A = s_ab[0], Bc = s_ab[1];
     const long base = (long)bc * HW;
-    for (long i = (long)blockIdx.x * DMVS_BLOCK + threadIdx.x; i < HW; i += (long)gridDim.x * DMVS_BLOCK) {
-        float v = fmaf(x[base + i], A, Bc);
-        v = v * dmvs_sigmoid(v);
-        if (residual) v += residual[base + i];
-        y[base + i] = v;
+    const int i0 = blockIdx.x * (DMVS_BLOCK * kGnPerLane);
+    if constexpr (VEC) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int k = 0; k < kGnPerLane / 4; ++k) {
+            const int i = i0 + (k * DMVS_BLOCK + threadIdx.x) * 4;
+            if (i < HW) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(x + base + i);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float t = fmaf(v[j], A, Bc);
+                    v[j] = t * dmvs_sigmoid(t);
+                }
+                if (residual) v += *reinterpret_cast<const f32x4*>(residual + base + i);
+                *reinterpret_cast<f32x4*>(y + base + i) = v;
+            }
+        }
+    } else {
+#pragma unroll 4
+        for (int k = 0; k < kGnPerLane; ++k) {
+            const int i = i0 + k * DMVS_BLOCK + threadIdx.x;
+            if (i < HW) {
+                float v = fmaf(x[base + i], A, Bc);
+                v = v * dmvs_sigmoid(v);
+                if (residual) v += residual[base + i];
+                y[base + i] = v;
+            }
+        }
     }
+}
+
+static void launch_gn_apply(const float* x, const float* gamma, const float* beta, const float* scale_shift, const float* residual,
+                            float* y, const double* stats, int B, int C, int HW, int groups, float eps, hipStream_t st) {
+    const dim3 grid(dmvs_ceil_div(HW, DMVS_BLOCK * kGnPerLane), (unsigned)(B * C));
+    const bool vec = HW % 4 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0;
+    if (vec) hipLaunchKernelGGL((gn_apply_kernel<true>), grid, dim3(DMVS_BLOCK), 0, st, x, gamma, beta, scale_shift, residual, y, stats, C, HW, groups, eps);
+    else hipLaunchKernelGGL((gn_apply_kernel<false>), grid, dim3(DMVS_BLOCK), 0, st, x, gamma, beta, scale_shift, residual, y, stats, C, HW, groups, eps);
 }
 
 extern "C" int dmvs_groupnorm_silu_f32(const float* x, const float* gamma, const float* beta, const float* scale_shift,
@@ -271,9 +316,7 @@ extern "C" int dmvs_groupnorm_silu_f32(const float* x, const float* gamma, const
     const int chunk = 8192;
     hipLaunchKernelGGL(gn_stats_kernel, dim3(dmvs_ceil_div(per_group, chunk), B * groups), dim3(DMVS_BLOCK), 0, st, x,
                        stats, per_group, chunk);
-    unsigned gx = dmvs_ceil_div(HW, DMVS_BLOCK * 4);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(gx, B * C), dim3(DMVS_BLOCK), 0, st, x, gamma, beta, scale_shift, residual, y,
-                       stats, C, HW, groups, eps);
+    launch_gn_apply(x, gamma, beta, scale_shift, residual, y, stats, B, C, HW, groups, eps, st);
     return dmvs_launch_status();
 }
 
@@ -281,9 +324,7 @@ extern "C" int dmvs_groupnorm_apply_f32(const float* x, const float* gamma, cons
                                         const float* residual, float* y, const double* stats, int32_t B, int32_t C,
                                         int32_t HW, int32_t groups, float eps, void* stream) {
     if (!x || !y || !stats || groups <= 0 || C % groups) return DMVS_EINVAL;
-    unsigned gx = dmvs_ceil_div(HW, DMVS_BLOCK * 4);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(gx, B * C), dim3(DMVS_BLOCK), 0, (hipStream_t)stream, x, gamma, beta,
-                       scale_shift, residual, y, stats, C, HW, groups, eps);
+    launch_gn_apply(x, gamma, beta, scale_shift, residual, y, stats, B, C, HW, groups, eps, (hipStream_t)stream);
     return dmvs_launch_status();
 }
 

@@ -755,6 +755,11 @@ def test_conv3d_single_output_channel(ops, D, H, W, act, with_res):
     pc = K.pack_conv3d(dev(ops, w), dev(ops, bias))
     out = ops.conv3d(pc, dev(ops, x), act=K.ACT_SIGMOID if act == "sigmoid" else K.ACT_NONE, residual=dev(ops, res) if with_res else None)
     close(out, ref, 2e-5)
+    # the same volume at a 4-byte offset: the 16-byte forms do not apply, the values must not change
+    store = torch.zeros(x.numel() + 1, device=ops.device)
+    store[1:] = dev(ops, x).reshape(-1)
+    out2 = ops.conv3d(pc, store[1:].view(x.shape), act=K.ACT_SIGMOID if act == "sigmoid" else K.ACT_NONE, residual=dev(ops, res) if with_res else None)
+    assert torch.equal(out2, out)
 
 
 @pytest.mark.parametrize("B,C_,H,W,with_ss", [(2, 8, 9, 13, True), (3, 16, 20, 24, False), (1, 32, 100, 90, True)])
