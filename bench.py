@@ -197,6 +197,7 @@ def main():
     ap.add_argument("--precision", default=None, choices=["fp32", "bf16", "fp16"], help="feature storage precision (default: the config's)")
     ap.add_argument("--graphs", action="store_true", help="run the timed steps through the captured HIP graph of the forward")
     ap.add_argument("--no-batch-sweep", action="store_true")
+    ap.add_argument("--conv-table", action="store_true", help="print the per-shape table of the step's conv2d launches to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-forwards", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=32, help="threads of the CPU baseline leg (more than ~32 is slower at batch 1)")
@@ -289,6 +290,14 @@ def main():
         conv_step_s = time.perf_counter() - t1
     timers.update(eng.ops.timers)
     eng.ops.timers = None
+    if a.conv_table and rank == 0:      # per-shape table of the step's conv2d launches (stderr): where the 0.54 comes from
+        by = {}
+        for (st_, en_), fl, shp in zip(timers["dmvs_conv2d_f32"], timers["_conv2d_flops"], timers["_conv2d_shape"]):
+            e = by.setdefault(shp, [0, 0.0, 0.0])
+            e[0] += 1; e[1] += st_.elapsed_time(en_); e[2] += fl
+        print("B cin cout kh kw s Hout Wout mode gated | launches  ms/step  TFLOP/s  frac", file=sys.stderr)
+        for shp, (n, ms, fl) in sorted(by.items(), key=lambda kv: -kv[1][1]):
+            print(*shp, "|", n, round(ms, 3), round(fl / ms / 1e9, 1), round(fl / ms / 1e9 / FP32_MFMA_PEAK_TFS, 3), file=sys.stderr)
     gather_tiles = eng.ops.getcost_tiles or (None, None)      # last lazily read-back probe of the hybrid launch
     scene = scene_geometry_getcost(eng.ops, B, H, W, S, args.CostNum[1]) if (rank == 0 and a.config == "cfg2" and eng.quad) else None
 

@@ -65,7 +65,7 @@ constexpr int conv_min_waves(int nt, int mt) { return (nt == 2 && mt == 4) ? 4 :
 
 // OT = element type of a channel-last output (DMVS_DTYPE_*): 16-bit feature storage is its own instantiation so that the
 // fp32 kernels keep their register allocation.
-template <int KH, int KW, int S, int NT, int MT, bool ZI, int OT = DMVS_DTYPE_F32>
+template <int KH, int KW, int S, int NT, int MT, bool ZI, int OT = DMVS_DTYPE_F32, bool TR = false>
 __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfma_kernel(const dmvs_conv2d_desc d, int tiles_x, int tiles_y) {
     using Cfg = ConvCfg<KH, KW, S, NT, MT>;
     constexpr int T = Cfg::T, TW = Cfg::TW, TH = Cfg::TH, PLANE = Cfg::PLANE, NW = Cfg::NW, WPAD = Cfg::WPAD;
@@ -242,7 +242,8 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
                         const float bv = ip[(mt * S + ky) * TW + kx];
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[nt], bv, acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = TR ? __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av[nt], acc[mt][nt], 0, 0, 0)       // D[pixel][cout]
+                                             : __builtin_amdgcn_mfma_f32_16x16x4f32(av[nt], bv, acc[mt][nt], 0, 0, 0);     // D[cout][pixel]
                     }
                 }
             }
@@ -263,115 +264,212 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     const float* const resb = d.residual ? d.residual + (size_t)b * d.cout * rplane : nullptr;
     const float* const gzb = d.gru_z ? d.gru_z + (size_t)b * (d.gate_cstride ? d.gate_cstride : d.cout) * oplane : nullptr;
     const float* const ghb = d.gru_z ? d.gru_h + (size_t)b * d.cout * oplane : nullptr;
-    float sc[NT][4], sh[NT][4];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int cg = nbase + nt * 16 + kq * 4 + r;
-            const bool okc = cg < d.cout;
-            sc[nt][r] = d.scale ? d.scale[okc ? cg : 0] : 1.0f;
-            sh[nt][r] = d.shift ? d.shift[okc ? cg : 0] : 0.0f;
-        }
     // GroupNorm statistics of the pre-activation output (4 groups), reduced lane -> wave -> workgroup
     float gs[4] = {0.0f, 0.0f, 0.0f, 0.0f}, gq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const int gn_cg = d.gn_stats ? d.cout / d.gn_groups : 1;
+    if constexpr (TR) {
+        // Transposed accumulators (the MFMA was issued with the operands swapped): this lane holds cout nbase + nt*16 + m of
+        // the 4 CONSECUTIVE pixels ox0 + 4*kq + r of row oy0 + MT*wave + mt -- one 16-byte NCHW store (and one 16-byte
+        // residual / GRU-gate read) per (row, n-tile) instead of four 4-byte ones, one bounds predicate and one offset
+        // per four values.  NCHW fp32 outputs only; the values are those of the other form bit for bit.
+        const int oxb = ox0 + 4 * kq;
+        const bool vec = (d.Wout & 3) == 0 && (((uintptr_t)d.out | (uintptr_t)d.residual | (uintptr_t)d.gru_z | (uintptr_t)d.gru_h) & 15) == 0 &&
+                         ((oplane * d.out_coffset) & 3) == 0;
+        float sc[NT], sh[NT];
+        int cgs[NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int oy = oy0 + wave * MT + mt;
-        const bool okp = ox < d.Wout && oy < d.Hout;
-        const int opix = oy * d.Wout + ox;
-        const int rpix = rup ? (oy >> 1) * rW + (ox >> 1) : opix;
-        float y[NT][4];
+        for (int nt = 0; nt < NT; ++nt) {
+            cgs[nt] = nbase + nt * 16 + m;
+            const bool okc = cgs[nt] < d.cout;
+            sc[nt] = d.scale ? d.scale[okc ? cgs[nt] : 0] : 1.0f;
+            sh[nt] = d.shift ? d.shift[okc ? cgs[nt] : 0] : 0.0f;
+        }
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int mt = 0; mt < MT; ++mt) {
+            const int oy = oy0 + wave * MT + mt;
+            const int opix = oy * d.Wout + oxb;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) y[nt][r] = acc[mt][nt][r] * sc[nt][r] + sh[nt][r];
-        if (d.gn_stats) {
+            for (int nt = 0; nt < NT; ++nt) {
+                const int cg = cgs[nt];
+                const bool okl = oy < d.Hout && cg < d.cout;          // this lane's (row, channel) exists
+                bool ok[4];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+                for (int r = 0; r < 4; ++r) ok[r] = okl && oxb + r < d.Wout;
+                const bool fast = vec && ok[0];                        // rows of 16-byte multiples: the four pixels exist together
+                f32x4 y;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int cg = nbase + nt * 16 + kq * 4 + r;
-                    const float v = (okp && cg < d.cout) ? y[nt][r] : 0.0f;
+                for (int r = 0; r < 4; ++r) y[r] = acc[mt][nt][r] * sc[nt] + sh[nt];
+                if (d.gn_stats) {
                     const int g = cg / gn_cg;
+                    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = ok[r] ? y[r] : 0.0f;
+                        s1 += v;
+                        s2 += v * v;
+                    }
 #pragma unroll
                     for (int gi = 0; gi < 4; ++gi) {
-                        gs[gi] += g == gi ? v : 0.0f;
-                        gq[gi] += g == gi ? v * v : 0.0f;
+                        gs[gi] += g == gi ? s1 : 0.0f;
+                        gq[gi] += g == gi ? s2 : 0.0f;
                     }
                 }
-        }
-        float res[NT][4];
-        if (d.residual) {
+                const unsigned o0 = okl ? (unsigned)(__mul24(cg, oplane) + opix) : 0u;
+                f32x4 res = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (d.residual) {
+                    if (!rup && fast) {
+                        res = *reinterpret_cast<const f32x4*>(resb + o0);
+                    } else {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int cg = nbase + nt * 16 + kq * 4 + r;
-                    const bool okr = okp && cg < d.cout;
-                    const float rv = resb[okr ? (unsigned)(__mul24(cg, rplane) + rpix) : 0u];
-                    res[nt][r] = okr ? rv : 0.0f;
-                    if (!d.res_after_act) y[nt][r] += res[nt][r];
+                        for (int r = 0; r < 4; ++r) {
+                            const int rpix = rup ? (oy >> 1) * rW + ((oxb + r) >> 1) : opix + r;
+                            const float rv = resb[ok[r] ? (unsigned)(__mul24(cg, rplane) + rpix) : 0u];
+                            res[r] = ok[r] ? rv : 0.0f;
+                        }
+                    }
+                    if (!d.res_after_act) y += res;
                 }
+                if (d.act == DMVS_ACT_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[r] = fmaxf(y[r], 0.0f);
+                } else if (d.act != DMVS_ACT_NONE) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[r] = dmvs_act(y[r], d.act);
+                }
+                y *= d.post_scale;
+                if (d.residual && d.res_after_act) y += res;
+                if (d.gru_z) {
+                    f32x4 z, h;
+                    if (fast) {
+                        z = *reinterpret_cast<const f32x4*>(gzb + o0);
+                        h = *reinterpret_cast<const f32x4*>(ghb + o0);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            z[r] = gzb[ok[r] ? o0 + r : 0u];
+                            h[r] = ghb[ok[r] ? o0 + r : 0u];
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[r] = (1.0f - z[r]) * h[r] + z[r] * y[r];
+                }
+                if (fast) {
+                    *reinterpret_cast<f32x4*>(outb + o0) = y;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (ok[r]) outb[o0 + r] = y[r];
+                }
+            }
         }
-        if (d.act == DMVS_ACT_RELU) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) y[nt][r] = fmaxf(y[nt][r], 0.0f);
-        } else if (d.act != DMVS_ACT_NONE) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) y[nt][r] = dmvs_act(y[nt][r], d.act);
-        }
+    } else {
+        float sc[NT][4], sh[NT][4];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) y[nt][r] *= d.post_scale;
-        if (d.residual && d.res_after_act) {
+            for (int r = 0; r < 4; ++r) {
+                const int cg = nbase + nt * 16 + kq * 4 + r;
+                const bool okc = cg < d.cout;
+                sc[nt][r] = d.scale ? d.scale[okc ? cg : 0] : 1.0f;
+                sh[nt][r] = d.shift ? d.shift[okc ? cg : 0] : 0.0f;
+            }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int oy = oy0 + wave * MT + mt;
+            const bool okp = ox < d.Wout && oy < d.Hout;
+            const int opix = oy * d.Wout + ox;
+            const int rpix = rup ? (oy >> 1) * rW + (ox >> 1) : opix;
+            float y[NT][4];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) y[nt][r] += res[nt][r];
-        }
-        if (d.gru_z) {
+                for (int r = 0; r < 4; ++r) y[nt][r] = acc[mt][nt][r] * sc[nt][r] + sh[nt][r];
+            if (d.gn_stats) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int cg = nbase + nt * 16 + kq * 4 + r;
+                        const float v = (okp && cg < d.cout) ? y[nt][r] : 0.0f;
+                        const int g = cg / gn_cg;
+#pragma unroll
+                        for (int gi = 0; gi < 4; ++gi) {
+                            gs[gi] += g == gi ? v : 0.0f;
+                            gq[gi] += g == gi ? v * v : 0.0f;
+                        }
+                    }
+            }
+            float res[NT][4];
+            if (d.residual) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int cg = nbase + nt * 16 + kq * 4 + r;
+                        const bool okr = okp && cg < d.cout;
+                        const float rv = resb[okr ? (unsigned)(__mul24(cg, rplane) + rpix) : 0u];
+                        res[nt][r] = okr ? rv : 0.0f;
+                        if (!d.res_after_act) y[nt][r] += res[nt][r];
+                    }
+            }
+            if (d.act == DMVS_ACT_RELU) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[nt][r] = fmaxf(y[nt][r], 0.0f);
+            } else if (d.act != DMVS_ACT_NONE) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[nt][r] = dmvs_act(y[nt][r], d.act);
+            }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int cg = nbase + nt * 16 + kq * 4 + r;
-                    const unsigned gi = (okp && cg < d.cout) ? (unsigned)(__mul24(cg, oplane) + opix) : 0u;
-                    const float z = gzb[gi];
-                    y[nt][r] = (1.0f - z) * ghb[gi] + z * y[nt][r];
-                }
-        }
-        if constexpr (OT != DMVS_DTYPE_F32) {      // channel-last, 16-bit elements
-            uint16_t* const ob16 = reinterpret_cast<uint16_t*>(d.out) + (size_t)b * oplane * d.out_cstride + d.out_coffset;
+                for (int r = 0; r < 4; ++r) y[nt][r] *= d.post_scale;
+            if (d.residual && d.res_after_act) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int cg = nbase + nt * 16 + kq * 4 + r;
-                    if (okp && cg < d.cout) ob16[(unsigned)(__mul24(opix, d.out_cstride) + cg)] = dmvs_to_x16<OT>(y[nt][r]);
-                }
-        } else if (d.out_layout == DMVS_LAYOUT_NCHW) {
+                    for (int r = 0; r < 4; ++r) y[nt][r] += res[nt][r];
+            }
+            if (d.gru_z) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int cg = nbase + nt * 16 + kq * 4 + r;
-                    if (okp && cg < d.cout) outb[(unsigned)(__mul24(cg, oplane) + opix)] = y[nt][r];
-                }
-        } else {
+                    for (int r = 0; r < 4; ++r) {
+                        const int cg = nbase + nt * 16 + kq * 4 + r;
+                        const unsigned gi = (okp && cg < d.cout) ? (unsigned)(__mul24(cg, oplane) + opix) : 0u;
+                        const float z = gzb[gi];
+                        y[nt][r] = (1.0f - z) * ghb[gi] + z * y[nt][r];
+                    }
+            }
+            if constexpr (OT != DMVS_DTYPE_F32) {      // channel-last, 16-bit elements
+                uint16_t* const ob16 = reinterpret_cast<uint16_t*>(d.out) + (size_t)b * oplane * d.out_cstride + d.out_coffset;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int cg = nbase + nt * 16 + kq * 4 + r;
-                    if (okp && cg < d.cout) outb[(unsigned)(__mul24(opix, d.out_cstride) + cg)] = y[nt][r];
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const int cg = nbase + nt * 16 + kq * 4 + r;
+                        if (okp && cg < d.cout) ob16[(unsigned)(__mul24(opix, d.out_cstride) + cg)] = dmvs_to_x16<OT>(y[nt][r]);
+                    }
+            } else if (d.out_layout == DMVS_LAYOUT_NCHW) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int cg = nbase + nt * 16 + kq * 4 + r;
+                        if (okp && cg < d.cout) outb[(unsigned)(__mul24(cg, oplane) + opix)] = y[nt][r];
+                    }
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int cg = nbase + nt * 16 + kq * 4 + r;
+                        if (okp && cg < d.cout) outb[(unsigned)(__mul24(opix, d.out_cstride) + cg)] = y[nt][r];
+                    }
+            }
         }
     }
     if (d.gn_stats) {
@@ -425,6 +523,15 @@ int launch_conv2d_mt(const dmvs_conv2d_desc& d, hipStream_t st, int nt, int ngro
     }
     const int tiles_x = (d.Wout + 15) / 16, tiles_y = (d.Hout + 4 * MT - 1) / (4 * MT);
     dim3 grid((unsigned)(tiles_x * tiles_y * d.B), (unsigned)ngroups), block(DMVS_BLOCK);
+    if (d.out_layout == DMVS_LAYOUT_NCHW) {      // transposed accumulators: 16-byte NCHW stores
+        switch (nt) {
+            case 1: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 1, MT, ZI, DMVS_DTYPE_F32, true>), grid, block, 0, st, d, tiles_x, tiles_y); break;
+            case 2: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 2, MT, ZI, DMVS_DTYPE_F32, true>), grid, block, 0, st, d, tiles_x, tiles_y); break;
+            case 3: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 3, MT, ZI, DMVS_DTYPE_F32, true>), grid, block, 0, st, d, tiles_x, tiles_y); break;
+            default: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 4, MT, ZI, DMVS_DTYPE_F32, true>), grid, block, 0, st, d, tiles_x, tiles_y); break;
+        }
+        return dmvs_launch_status();
+    }
     switch (nt) {
         case 1: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 1, MT, ZI>), grid, block, 0, st, d, tiles_x, tiles_y); break;
         case 2: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 2, MT, ZI>), grid, block, 0, st, d, tiles_x, tiles_y); break;

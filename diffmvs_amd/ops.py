@@ -246,6 +246,7 @@ class Ops:
         self._call("dmvs_conv2d_f32", C.byref(d), self.stream())
         if self.timers is not None and "dmvs_conv2d_f32" in self.timers:      # bench: MFMA roofline over every conv launch
             self.timers.setdefault("_conv2d_flops", []).append(2.0 * B * Hout * Wout * pc.cout * pc.cin * kh * kw)
+            self.timers.setdefault("_conv2d_shape", []).append((B, pc.cin, pc.cout, kh, kw, pc.stride, Hout, Wout, in_mode, int(mul0 is not None)))
         return out
 
     def featurenet_stem(self, pc0: PackedConv, pc1: PackedConv, x):

@@ -17,6 +17,9 @@ SHAPES = [  # name, N, cin, cout, k, stride, H, W
     ("unet 32->32 3x3 1/8", 16, 32, 32, 3, 1, 64, 80), ("ctx 16->16 1/2", 16, 16, 16, 3, 1, 256, 320),
     ("cond 32->32 3x3 1/4 B16", 16, 32, 32, 3, 1, 128, 160), ("unet 16->16 3x3 1/4 B16", 16, 16, 16, 3, 1, 128, 160),
     ("unet 64->32 3x3 1/8 B16", 16, 64, 32, 3, 1, 64, 80),
+    ("unet 32->32 3x3 1/4 B96", 96, 32, 32, 3, 1, 128, 160), ("unet 16->16 3x3 1/4 B96", 96, 16, 16, 3, 1, 128, 160),
+    ("feat out 32->64 1x1 1/4", 576, 32, 64, 1, 1, 128, 160), ("1x1 64->144 1/4 B96", 96, 64, 144, 1, 1, 128, 160),
+    ("1x1 32->16 1/4 B96", 96, 32, 16, 1, 1, 128, 160), ("gru 64->64 1x5 1/8 B96", 96, 64, 64, (1, 5), 1, 64, 80),
 ]
 
 
@@ -62,8 +65,9 @@ def main():
         if only and only not in name:
             continue
         x = torch.randn(N, cin, H, W, generator=g).cuda()
-        w = torch.randn(cout, cin, k, k, generator=g).cuda() * 0.1
-        pc = K.pack_conv2d(w, None, stride=s, pad=k // 2)
+        kh, kw = k if isinstance(k, tuple) else (k, k)
+        w = torch.randn(cout, cin, kh, kw, generator=g).cuda() * 0.1
+        pc = K.pack_conv2d(w, None, stride=s, pad=(kh // 2, kw // 2))
         for _ in range(3):
             y = o.conv2d(pc, x, act=K.ACT_RELU)
         torch.cuda.synchronize()
@@ -74,7 +78,7 @@ def main():
         en.record()
         torch.cuda.synchronize()
         us = st.elapsed_time(en) * 100.0
-        flops = 2.0 * N * y.shape[2] * y.shape[3] * cout * cin * k * k
+        flops = 2.0 * N * y.shape[2] * y.shape[3] * cout * cin * kh * kw
         gb = 4.0 * (x.numel() + y.numel()) / 1e9
         print(json.dumps({"layer": name, "us": round(us, 1), "TFLOPs": round(flops / us / 1e6, 1), "frac_mfma": round(flops / us / 1e6 / 157.3, 3),
                           "GB": round(gb, 3), "TBs": round(gb / us * 1e3, 2)}))
