@@ -22,6 +22,7 @@
 // upsampling, pixel-unshuffle, r*h gating, zero padding) or into the epilogue (folded BN /
 // bias, residual adds, activations, post-scale, GRU blend, NHWC / channel-offset output);
 // see include/dmvs.h for the contract.
+#include <cstdlib>
 #include <type_traits>
 
 #include "dmvs_common.h"
@@ -319,6 +320,10 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
                 if (d.residual) {
                     if (!rup && fast) {
                         res = *reinterpret_cast<const f32x4*>(resb + o0);
+                    } else if (rup && fast) {      // nearest-x2 source: pixels 4*kq..4*kq+3 read source pixels 2*kq, 2*kq+1 (8 bytes)
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+                        const f32x2 rv = *reinterpret_cast<const f32x2*>(resb + (unsigned)(__mul24(cg, rplane) + (oy >> 1) * rW + (oxb >> 1)));
+                        res = f32x4{rv[0], rv[0], rv[1], rv[1]};
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -563,6 +568,12 @@ int launch_conv2d(const dmvs_conv2d_desc& d, hipStream_t st) {
     if (d.out_layout == DMVS_LAYOUT_NHWC_BF16 || d.out_layout == DMVS_LAYOUT_NHWC_F16)      // one tile shape (16x8) for the 16-bit outputs
         return launch_conv2d_mt<KH, KW, S, 2, false>(d, st, nt, ngroups);
     const long wg16 = (long)((d.Wout + 15) / 16) * ((d.Hout + 15) / 16) * d.B * ngroups;
+    static const int force_mt = getenv("DMVS_CONV_MT") ? atoi(getenv("DMVS_CONV_MT")) : 0;      // experiments: force the tile height
+    if constexpr (!heavy) {
+        if (force_mt == 4) return launch_conv2d_mt<KH, KW, S, 4, false>(d, st, nt, ngroups);
+    }
+    if (force_mt == 2) return launch_conv2d_mt<KH, KW, S, 2, false>(d, st, nt, ngroups);
+    if (force_mt == 1) return launch_conv2d_mt<KH, KW, S, 1, false>(d, st, nt, ngroups);
     if (wg16 * 2 < 1024) return launch_conv2d_mt<KH, KW, S, 1, false>(d, st, nt, ngroups);
     if (heavy || nt == 4 || (nt >= 2 && wg16 < 2048)) return launch_conv2d_mt<KH, KW, S, 2, false>(d, st, nt, ngroups);
     if constexpr (!heavy) return launch_conv2d_mt<KH, KW, S, 4, false>(d, st, nt, ngroups);

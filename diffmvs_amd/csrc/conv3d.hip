@@ -107,58 +107,55 @@ struct SlabMap {
 // shift sit in registers for the whole kernel (they were re-read from global memory, with a wait each, per VALUE).
 template <int NT>
 struct TileEpi {
-    float sc[NT][4], sh[NT][4];
-    int cg0[NT];
-    __device__ __forceinline__ void init(const dmvs_conv3d_desc& d, int nbase, int kq) {
+    // Transposed accumulators: the kernels issue the MFMA with the operands swapped (A = input pixels, B = weights), so a lane
+    // holds output channel nbase + nt*16 + m of the 4 CONSECUTIVE voxels x0 + 4*kq + r of a row: one 16-byte store (and
+    // residual read) per (row, n-tile) instead of four 4-byte ones.  Values are those of the other operand order bit for bit.
+    float sc[NT], sh[NT];
+    int cg[NT];
+    bool vec;
+    __device__ __forceinline__ void init(const dmvs_conv3d_desc& d, int nbase, int m) {
+        vec = (d.Wout & 3) == 0 && (((uintptr_t)d.out | (uintptr_t)d.residual) & 15) == 0;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            cg0[nt] = nbase + nt * 16 + kq * 4;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int cg = cg0[nt] + r;
-                const bool okc = cg < d.cout;
-                sc[nt][r] = d.scale ? d.scale[okc ? cg : 0] : 1.0f;
-                sh[nt][r] = d.shift ? d.shift[okc ? cg : 0] : 0.0f;
-            }
+            cg[nt] = nbase + nt * 16 + m;
+            const bool okc = cg[nt] < d.cout;
+            sc[nt] = d.scale ? d.scale[okc ? cg[nt] : 0] : 1.0f;
+            sh[nt] = d.shift ? d.shift[okc ? cg[nt] : 0] : 0.0f;
         }
     }
-    // rows y0 .. y0+3 of depth slice od at column ox; outb / resb = this batch item's [cout][Dout][Hout][Wout] block,
+    // rows y0 .. y0+3 of depth slice od, columns oxb .. oxb+3; outb / resb = this batch item's [cout][Dout][Hout][Wout] block,
     // addressed with 32-bit element offsets (the entry point rejects cout * volume >= 2^31)
-    __device__ __forceinline__ void store(const dmvs_conv3d_desc& d, const f32x4 (&acc)[4][NT], float* outb, const float* resb, int ox,
+    __device__ __forceinline__ void store(const dmvs_conv3d_desc& d, const f32x4 (&acc)[4][NT], float* outb, const float* resb, int oxb,
                                           int od, int y0, int ovol) const {
-        if (ox >= d.Wout || od >= d.Dout) return;
+        if (oxb >= d.Wout || od >= d.Dout) return;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const int oy = y0 + mt;
             if (oy >= d.Hout) continue;
-            const int ovox = (od * d.Hout + oy) * d.Wout + ox;
-            float y[NT][4];
+            const int ovox = (od * d.Hout + oy) * d.Wout + oxb;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NT; ++nt) {
+                if (cg[nt] >= d.cout) continue;
+                f32x4 y;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) y[nt][r] = acc[mt][nt][r] * sc[nt][r] + sh[nt][r];
-            if (d.act == DMVS_ACT_RELU) {
+                for (int r = 0; r < 4; ++r) y[r] = acc[mt][nt][r] * sc[nt] + sh[nt];
+                if (d.act == DMVS_ACT_RELU) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
+                    for (int r = 0; r < 4; ++r) y[r] = fmaxf(y[r], 0.0f);
+                } else if (d.act != DMVS_ACT_NONE) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) y[nt][r] = fmaxf(y[nt][r], 0.0f);
-            } else if (d.act != DMVS_ACT_NONE) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) y[nt][r] = dmvs_act(y[nt][r], d.act);
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (cg0[nt] + r < d.cout) {
-                        const int o = (cg0[nt] + r) * ovol + ovox;
-                        float v = y[nt][r];
-                        if (resb) v += resb[o];
-                        outb[o] = v;
-                    }
+                    for (int r = 0; r < 4; ++r) y[r] = dmvs_act(y[r], d.act);
                 }
+                const int o = cg[nt] * ovol + ovox;
+                if (vec) {
+                    if (resb) y += *reinterpret_cast<const f32x4*>(resb + o);
+                    *reinterpret_cast<f32x4*>(outb + o) = y;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (oxb + r < d.Wout) outb[o + r] = resb ? y[r] + resb[o + r] : y[r];
+                }
+            }
         }
     }
 };
@@ -195,7 +192,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_kernel(const dm
     Halo halo;
     halo.init(tid, d.Hin, d.Win);
     TileEpi<NT> epi;
-    epi.init(d, nbase, kq);
+    epi.init(d, nbase, m);
     {
         Slab slab;
         slab.init(tid, nbase, d.cout_pad);
@@ -219,7 +216,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_kernel(const dm
 
     auto store = [&](const f32x4 (&a)[4][NT], int sb, int std_, int sty, int stx) {
         const size_t ob = (size_t)sb * d.cout * ovol;
-        epi.store(d, a, d.out + ob, d.residual ? d.residual + ob : nullptr, stx * TX + m, std_ * TD + wave, sty * TY, ovol);
+        epi.store(d, a, d.out + ob, d.residual ? d.residual + ob : nullptr, stx * TX + 4 * kq, std_ * TD + wave, sty * TY, ovol);
     };
 
     int tile = blockIdx.x, cur = 0;
@@ -262,7 +259,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_kernel(const dm
                             const float bv = ipb[(kd * IH + ky + mt) * IW + kx];
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[nt], bv, acc[mt][nt], 0, 0, 0);
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av[nt], acc[mt][nt], 0, 0, 0);      // D[voxel][cout] (TileEpi)
                         }
                     }
                 }
@@ -313,15 +310,11 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_pair_kernel(con
         if (ci < d.cin && kd >= 0 && kd <= 2 && co < d.cout) v = d.weight[(ci * 27 + kd * 9 + t9) * d.cout_pad + co];
         s_w[ci * WP + jt * 16 + row] = v;
     }
-    // epilogue constants: this lane holds output slice 2w + (kq >> 1), channels (kq & 1) * 4 + r
-    const int cg0 = (kq & 1) * 4, sl = kq >> 1;
-    float sc[4], sh[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const bool okc = cg0 + r < d.cout;
-        sc[r] = d.scale ? d.scale[okc ? cg0 + r : 0] : 1.0f;
-        sh[r] = d.shift ? d.shift[okc ? cg0 + r : 0] : 0.0f;
-    }
+    // epilogue constants (transposed accumulators: A = input pixels, B = the paired weights): this lane holds output slice
+    // 2w + (m >> 3), channel m & 7, of the 4 consecutive voxels tx*16 + 4*kq + r of a row -- 16-byte stores
+    const int co = m & 7, sl = m >> 3;
+    const float sc = d.scale ? d.scale[co < d.cout ? co : 0] : 1.0f, sh = d.shift ? d.shift[co < d.cout ? co : 0] : 0.0f;
+    const bool vec = (d.Wout & 3) == 0 && (((uintptr_t)d.out | (uintptr_t)d.residual) & 15) == 0;
 
     auto stage = [&](int b, int td, int ty, int tx, float* buf) {
         const int gx0 = tx * TX - 1, gy0 = ty * TY - 1, gd0 = td * TD - 1;
@@ -338,23 +331,25 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_pair_kernel(con
         b = tile / tiles_d;
     };
     auto store = [&](const f32x4 (&a)[4], int sb, int std_, int sty, int stx) {
-        const int ox = stx * TX + m, od = std_ * TD + 2 * wave + sl;
-        if (ox >= d.Wout || od >= d.Dout) return;
+        const int oxb = stx * TX + 4 * kq, od = std_ * TD + 2 * wave + sl;
+        if (oxb >= d.Wout || od >= d.Dout || co >= d.cout) return;
         float* outb = d.out + (size_t)sb * d.cout * ovol;
         const float* resb = d.residual ? d.residual + (size_t)sb * d.cout * ovol : nullptr;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const int oy = sty * TY + mt;
             if (oy >= d.Hout) continue;
-            const int ovox = (od * d.Hout + oy) * d.Wout + ox;
+            const int o = co * ovol + (od * d.Hout + oy) * d.Wout + oxb;
+            f32x4 y;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (cg0 + r < d.cout) {
-                    float v = dmvs_act(a[mt][r] * sc[r] + sh[r], d.act);
-                    const int o = (cg0 + r) * ovol + ovox;
-                    if (resb) v += resb[o];
-                    outb[o] = v;
-                }
+            for (int r = 0; r < 4; ++r) y[r] = dmvs_act(a[mt][r] * sc + sh, d.act);
+            if (vec) {
+                if (resb) y += *reinterpret_cast<const f32x4*>(resb + o);
+                *reinterpret_cast<f32x4*>(outb + o) = y;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (oxb + r < d.Wout) outb[o + r] = resb ? y[r] + resb[o + r] : y[r];
             }
         }
     };
@@ -392,7 +387,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_pair_kernel(con
 #pragma unroll
                         for (int mt = 0; mt < 4; ++mt) {
                             const float bv = ipb[(j * IH + ky + mt) * IW + kx];
-                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[mt], 0, 0, 0);
+                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[mt], 0, 0, 0);      // D[voxel][(slice, cout)]
                         }
                     }
                 }
@@ -480,7 +475,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_kernel(const dmvs_conv
                             const float bv = ipb[(kd * IH + ky + mt) * IW + kx];
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[nt], bv, acc[mt][nt], 0, 0, 0);
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av[nt], acc[mt][nt], 0, 0, 0);      // D[voxel][cout] (TileEpi)
                         }
                     }
                 }
@@ -489,9 +484,9 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_kernel(const dmvs_conv
     }
 
     TileEpi<NT> epi;
-    epi.init(d, nbase, kq);
+    epi.init(d, nbase, m);
     const size_t ob = (size_t)b * d.cout * ovol;
-    epi.store(d, acc, d.out + ob, d.residual ? d.residual + ob : nullptr, x0 + m, d0 + wave, y0, ovol);
+    epi.store(d, acc, d.out + ob, d.residual ? d.residual + ob : nullptr, x0 + 4 * kq, d0 + wave, y0, ovol);
 }
 
 

@@ -20,6 +20,9 @@ SHAPES = [  # name, N, cin, cout, k, stride, H, W
     ("unet 32->32 3x3 1/4 B96", 96, 32, 32, 3, 1, 128, 160), ("unet 16->16 3x3 1/4 B96", 96, 16, 16, 3, 1, 128, 160),
     ("feat out 32->64 1x1 1/4", 576, 32, 64, 1, 1, 128, 160), ("1x1 64->144 1/4 B96", 96, 64, 144, 1, 1, 128, 160),
     ("1x1 32->16 1/4 B96", 96, 32, 16, 1, 1, 128, 160), ("gru 64->64 1x5 1/8 B96", 96, 64, 64, (1, 5), 1, 64, 80),
+    ("feat 64->64 3x3 1/8 N576", 576, 64, 64, 3, 1, 64, 80), ("unet 64->31 3x3 1/4 B96", 96, 64, 31, 3, 1, 128, 160),
+    ("unet 32->32 3x3 1/8 B96", 96, 32, 32, 3, 1, 64, 80), ("unet 32->16 3x3 1/4 B96", 96, 32, 16, 3, 1, 128, 160),
+    ("unet 48->32 3x3 1/8 B96", 96, 48, 32, 3, 1, 64, 80),
 ]
 
 
