@@ -9,7 +9,8 @@
 //     BN + ReLU, zeroed outside the image (it is conv0.1's zero padding), written to LDS [8][18x18];
 //   * conv0.1 from that LDS image, with TWO OUTPUT ROWS per MFMA: cout = 8 would leave half of the 16 A rows as zero padding, so
 //     rows 0-7 carry W[ky = j] (output row y) and rows 8-15 W[ky = j-1] (output row y+1) for input row y+j, j = 0..3 -- both
-//     outputs read the same B operand: 24 instead of 36 MFMAs per row pair, every lane stores; BN + ReLU; NCHW store.
+//     outputs read the same input operand: 24 instead of 36 MFMAs per row pair.  The pixels are the A operand and the paired
+//     weights B, so a lane ends up with 4 consecutive pixels of one (row, channel): BN + ReLU + one 16-byte NCHW store.
 // Exact-fp32 MFMA; conv0.0's 27 products are summed in (ci, tap) order here and in (tap, ci) order by the generic
 // kernel, so the two agree to the last bits, not bitwise.
 #include "dmvs_common.h"
@@ -105,27 +106,38 @@ featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0
         const int ci = kk / 9, t = kk - ci * 9;
         koff[j] = ci * IP + (t / 3) * IW + (t % 3);
     }
-    float sc0[4], sh0[4], sc1[4], sh1[4];       // this lane's output channels 4*kq + r (lanes with kq >= 2 hold padding)
+    float sc0[4], sh0[4];       // conv0.0: this lane's output channels 4*kq + r (lanes with kq >= 2 hold padding)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int co = (4 * kq + r) & 7;
         sc0[r] = scale0 ? scale0[co] : 1.0f;
         sh0[r] = shift0 ? shift0[co] : 0.0f;
-        sc1[r] = scale1 ? scale1[co] : 1.0f;
-        sh1[r] = shift1 ? shift1[co] : 0.0f;
     }
 
     // BN + ReLU + NCHW store of a finished tile.  Issued one iteration LATE (after the next tile's barrier): the
     // barrier's vmcnt(0) -- needed for the LDS-DMA -- would otherwise also wait out stores issued just before it.
+    // (transposed accumulators: conv0.1's MFMAs take the pixels as A and the paired weights as B, so a lane holds row
+    // (m >> 3) of the pair, channel m & 7, of the 4 consecutive pixels 4*kq + r: one 16-byte store per row pair)
+    const bool vec = (W & 3) == 0 && ((uintptr_t)y & 15) == 0;
+    const int co1 = m & 7;
+    const float sc1t = scale1 ? scale1[co1] : 1.0f, sh1t = shift1 ? shift1[co1] : 0.0f;
     auto store_tile = [&](const f32x4 (&a)[2], int n, int ox0, int oy0) {
-        const int ox = ox0 + m;
+        const int ox = ox0 + 4 * kq;
 #pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {      // lanes kq < 2: first row of the pair, kq >= 2: second row; channels 4 * (kq & 1) + r
-            const int oy = oy0 + wave * 4 + 2 * pr + (kq >> 1);
+        for (int pr = 0; pr < 2; ++pr) {
+            const int oy = oy0 + wave * 4 + 2 * pr + (m >> 3);
             if (ox < W && oy < H) {
+                f32x4 v;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    y[((long)n * 8 + 4 * (kq & 1) + r) * plane + (long)oy * W + ox] = fmaxf(fmaf(a[pr][r], sc1[r], sh1[r]), 0.0f);
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaf(a[pr][r], sc1t, sh1t), 0.0f);
+                float* dst = y + ((long)n * 8 + co1) * plane + (long)oy * W + ox;
+                if (vec) {
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (ox + r < W) dst[r] = v[r];
+                }
             }
         }
     };
@@ -180,7 +192,7 @@ featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0
                     const float av = wp[(j * 3 + kx) * 16];
 #pragma unroll
                     for (int pr = 0; pr < 2; ++pr)
-                        acc[pr] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, mp[(2 * pr + j) * MW + kx], acc[pr], 0, 0, 0);
+                        acc[pr] = __builtin_amdgcn_mfma_f32_16x16x4f32(mp[(2 * pr + j) * MW + kx], av, acc[pr], 0, 0, 0);      // D[pixel][(row, cout)]
                 }
         }
 #pragma unroll
