@@ -187,7 +187,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("DMVS_BENCH_BATCH", "96")),
                     help="reference views per GPU per step (576 images at the default 96: ~30 GB of the 288 GB; measured on the "
-                         "MI355X: 16 -> 923 depth-maps/s, 32 -> 990, 64 -> 1041, 96 -> 1051: larger tile counts fill the 256 CUs' MFMA pipes better)")
+                         "MI355X: 16 -> 981 depth-maps/s, 32 -> 1054, 64 -> 1109, 96 -> 1120: larger tile counts fill the 256 CUs' MFMA pipes better)")
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--src-views", type=int, default=5)
