@@ -582,6 +582,159 @@ int launch_conv2d(const dmvs_conv2d_desc& d, hipStream_t st) {
 
 
 // ------------------------------------------------------------------------------------------
+// 1x1 convolutions without the LDS input tile.  A 1x1 layer has no halo and no spatial structure: it is the GEMM
+// out[cout][p] = W[cout][ci] X[ci][p] over the flat pixel index p, and at 16..64 input channels it is bound by memory and by the
+// per-tile fixed costs of the tiled kernel (input DMA + barrier per 8 channels, 16 x 16 tiles of 64-byte rows), which ran
+// these layers at 0.12-0.27 of the MFMA peak and ~2 TB/s.  Here a wave owns MT x 16 consecutive pixels and every output
+// channel: the pixels are the A operand, loaded straight from global memory (lane = pixel m, channel 4c + kq: four 64-byte
+// segments per load), the weights the B operand from an LDS copy made once per workgroup; no barrier in the channel loop,
+// loads of the next channel groups in flight under the MFMAs.  Accumulators are in the transposed form (4 consecutive
+// pixels of one channel per lane): 16-byte stores and residual reads.  The k order equals the tiled kernel's, so the
+// values are identical bit for bit.  Covers plain / concatenated inputs, BN / bias, activation, post-scale, residual
+// (same size or nearest-x2), NCHW output with channel offset; anything else takes the tiled kernel.  Instantiated for
+// one 16-channel n-tile (the narrow layers, where it wins: see conv1x1_direct_ok).
+constexpr int kC11MaxCin = 64;
+
+template <int NT, int MT>
+__global__ void __launch_bounds__(DMVS_BLOCK) conv1x1_direct_kernel(const dmvs_conv2d_desc d, int tiles_per_item) {
+    constexpr int NW = NT * 16, WS = (NW % 32 == 0) ? NW + 16 : NW;      // weight row stride: the four k-groups on disjoint banks
+    __shared__ float s_w[kC11MaxCin * WS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int cin = d.c0 + d.c1, cin4 = (cin + 3) >> 2;
+    const int HW = d.Hout * d.Wout;
+    for (int e = tid; e < cin4 * 4 * NW; e += DMVS_BLOCK) {
+        const int k = e / NW, co = e - k * NW;
+        s_w[k * WS + co] = (k < cin && co < d.cout_pad) ? d.weight[k * d.cout_pad + co] : 0.0f;
+    }
+    const int b = blockIdx.x / tiles_per_item, t = blockIdx.x - b * tiles_per_item;
+    const int p0 = (t * 4 + wave) * (16 * MT);
+    const float* in0b = d.in0 + (size_t)b * d.c0 * HW;
+    const float* in1b = d.in1 ? d.in1 + (size_t)b * d.c1 * HW : d.in0;
+    __syncthreads();
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    // Two channel groups ahead: the loads of groups c+1, c+2 are in flight while group c goes through the matrix cores.  The
+    // loads are UNCONDITIONAL (channel and pixel clamped into the tensor, the value zeroed when it is consumed): predicated
+    // loads sit in their own basic blocks, and hipcc then waits vmcnt(0) -- i.e. also for the prefetch -- before the MFMAs.
+    int pc[MT];
+    bool pok[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int p = p0 + 16 * mt + m;
+        pok[mt] = p < HW;
+        pc[mt] = pok[mt] ? p : HW - 1;
+    }
+    auto load = [&](int c, float (&a)[MT]) {
+        int ci = 4 * c + kq;
+        ci = ci < cin ? ci : cin - 1;
+        const float* src = ci < d.c0 ? in0b + (size_t)ci * HW : in1b + (size_t)(ci - d.c0) * HW;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = src[pc[mt]];
+    };
+    auto mma = [&](int c, const float (&a)[MT]) {
+        const bool cok = 4 * c + kq < cin;
+        const float* wp = s_w + (4 * c + kq) * WS + m;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float bw = wp[nt * 16];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32((cok && pok[mt]) ? a[mt] : 0.0f, bw, acc[mt][nt], 0, 0, 0);
+        }
+    };
+    // three register sets in rotation (renamed, not moved: a move of the prefetched value would wait for it);
+    // the scheduling barrier keeps each prefetch in front of the current group's MFMAs (hipcc sinks it behind them otherwise)
+    float a0[MT], a1[MT], a2[MT];
+    load(0, a0);
+    load(1, a1);
+    for (int c = 0;;) {
+        load(c + 2, a2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(c, a0);
+        if (++c >= cin4) break;
+        load(c + 2, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(c, a1);
+        if (++c >= cin4) break;
+        load(c + 2, a1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(c, a2);
+        if (++c >= cin4) break;
+    }
+
+    // epilogue: this lane holds channel nt*16 + m of pixels p0 + 16*mt + 4*kq + r (HW and Wout are multiples of 4: the four
+    // pixels exist together and lie in one image row)
+    const bool rup = d.res_mode == DMVS_IN_UPSAMPLE2;
+    const int rW = rup ? (d.Wout >> 1) : d.Wout, rplane = rup ? (d.Hout >> 1) * rW : HW;
+    float* const outb = d.out + ((size_t)b * d.out_cstride + d.out_coffset) * HW;
+    const float* const resb = d.residual ? d.residual + (size_t)b * d.cout * rplane : nullptr;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int cg = nt * 16 + m;
+        if (cg >= d.cout) continue;
+        const float sc = d.scale ? d.scale[cg] : 1.0f, sh = d.shift ? d.shift[cg] : 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int p = p0 + 16 * mt + 4 * kq;
+            if (p >= HW) continue;
+            f32x4 y;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = acc[mt][nt][r] * sc + sh;
+            f32x4 res = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (resb) {
+                if (rup) {
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    const int oy = p / d.Wout, ox = p - oy * d.Wout;
+                    const f32x2 rv = *reinterpret_cast<const f32x2*>(resb + (size_t)cg * rplane + (oy >> 1) * rW + (ox >> 1));
+                    res = f32x4{rv[0], rv[0], rv[1], rv[1]};
+                } else {
+                    res = *reinterpret_cast<const f32x4*>(resb + (size_t)cg * HW + p);
+                }
+                if (!d.res_after_act) y += res;
+            }
+            if (d.act == DMVS_ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = fmaxf(y[r], 0.0f);
+            } else if (d.act != DMVS_ACT_NONE) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = dmvs_act(y[r], d.act);
+            }
+            y *= d.post_scale;
+            if (resb && d.res_after_act) y += res;
+            *reinterpret_cast<f32x4*>(outb + (size_t)cg * HW + p) = y;
+        }
+    }
+}
+
+// the direct form applies: plain 1x1, <= 64 input channels, <= 16 output channels, fp32 NCHW output, rows of 16-byte multiples
+// on 16-byte aligned tensors, none of the GRU / GroupNorm fusions.  (Measured at B=96, 128x160, against the tiled kernel with
+// transposed accumulators: 32->16 95 -> 75 us = 5.0 TB/s; with wider N tiles the template is no better -- 32->64 on 576 images
+// 1379 -> 1350 us, 64->144 856 -> 892 us -- so those layers stay on the tiled kernel.)
+static bool conv1x1_direct_ok(const dmvs_conv2d_desc& d) {
+    if (d.kh != 1 || d.kw != 1 || d.stride != 1 || d.pad_h || d.pad_w || d.in_mode != DMVS_IN_PLAIN) return false;
+    if (d.mul0 || d.gru_z || d.gn_stats || d.out_layout != DMVS_LAYOUT_NCHW) return false;
+    if (d.c0 + d.c1 > kC11MaxCin || d.cout_pad > 16 || (d.Wout & 3)) return false;
+    if (d.res_mode == DMVS_IN_UPSAMPLE2 && ((d.Hout | d.Wout) & 1)) return false;
+    if ((((uintptr_t)d.in0 | (uintptr_t)d.in1 | (uintptr_t)d.out | (uintptr_t)d.residual) & 15) != 0) return false;
+    return true;
+}
+
+template <int NT, int MT>
+static int launch_conv1x1_direct(const dmvs_conv2d_desc& d, hipStream_t st) {
+    const int HW = d.Hout * d.Wout;
+    const int tiles = (HW + 64 * MT - 1) / (64 * MT);
+    hipLaunchKernelGGL((conv1x1_direct_kernel<NT, MT>), dim3((unsigned)(tiles * d.B)), dim3(DMVS_BLOCK), 0, st, d, tiles);
+    return dmvs_launch_status();
+}
+
+static int conv1x1_direct(const dmvs_conv2d_desc& d, hipStream_t st) { return launch_conv1x1_direct<1, 4>(d, st); }
+
+// ------------------------------------------------------------------------------------------
 // Weight gradient:  gw[ci][t][co] += sum_pixels dY[co][p] * X[ci][p (+) tap t]   as an MFMA GEMM with the
 // reduction over pixels:  A = dY [co = lane&15][k = pixel], B = X [k = pixel][j = (ci,t) = lane&15].
 // Workgroup = (8 input channels) x (16 output channels), sweeping 16x16 pixel tiles in a grid-stride loop;
@@ -827,7 +980,7 @@ extern "C" int dmvs_conv2d_f32(const dmvs_conv2d_desc* dp, void* stream) {
     if ((long)d.Hout * d.Wout >= (1L << 24) || ocs >= (1 << 24) || (long)ocs * d.Hout * d.Wout >= (1L << 31)) return DMVS_EINVAL;
     const int key = d.kh * 100 + d.kw * 10 + d.stride;
     switch (key) {
-        case 111: return launch_conv2d<1, 1, 1>(d, st);
+        case 111: return conv1x1_direct_ok(d) ? conv1x1_direct(d, st) : launch_conv2d<1, 1, 1>(d, st);
         case 331: return launch_conv2d<3, 3, 1>(d, st);
         case 332: return launch_conv2d<3, 3, 2>(d, st);
         case 552: return launch_conv2d<5, 5, 2>(d, st);

@@ -86,6 +86,38 @@ def test_conv2d_row_alignment(ops, cin, cout, k, stride, pad, W, misalign):
     close(out, ref, 2e-5)
 
 
+@pytest.mark.parametrize("c0,c1,cout,H,W,res,act", [
+    (16, 0, 1, 9, 12, None, "sigmoid"), (32, 0, 16, 21, 20, None, "relu"), (32, 0, 64, 10, 16, "up", "none"), (64, 0, 144, 7, 8, None, "none"),
+    (48, 0, 13, 5, 44, "same", "relu"), (6, 0, 9, 33, 36, None, "tanh"), (20, 10, 16, 12, 28, "same", "none"), (64, 0, 16, 16, 64, "up", "relu"),
+    (3, 0, 8, 1, 4, None, "none"), (65, 0, 16, 6, 8, None, "none"), (20, 10, 31, 12, 28, "same", "none"), (30, 0, 12, 40, 52, "up", "none")])
+def test_conv2d_1x1_direct(ops, c0, c1, cout, H, W, res, act):
+    """1x1 layers with at most 16 output channels and rows of 16-byte multiples take the direct (no LDS input tile) kernel,
+    wider ones the tiled kernel with transposed accumulators: channel counts that are not multiples of 4, a concatenated
+    second input, same-size and nearest-x2 residuals before the activation, a ragged last pixel tile, output into a
+    channel slice, more than 64 input channels (tiled kernel again)"""
+    B = 2
+    x0 = rnd(B, c0, H, W, seed=1)
+    x1 = rnd(B, c1, H, W, seed=2) if c1 else None
+    w, bias = rnd(cout, c0 + c1, 1, 1, seed=3) * 0.3, rnd(cout, seed=4)
+    ref = F.conv2d(x0 if x1 is None else torch.cat([x0, x1], 1), w, bias)
+    r = None
+    if res == "same":
+        r = rnd(B, cout, H, W, seed=5)
+        ref = ref + r
+    elif res == "up":
+        r = rnd(B, cout, H // 2, W // 2, seed=5)
+        ref = ref + F.interpolate(r, scale_factor=2, mode="nearest")
+    ref = {"none": lambda t: t, "relu": F.relu, "sigmoid": torch.sigmoid, "tanh": torch.tanh}[act](ref) * 0.5
+    big = torch.full((B, cout + 5, H, W), 7.0)
+    bigd = dev(ops, big)
+    ops.conv2d(K.pack_conv2d(*dev(ops, w, bias)), dev(ops, x0), None if x1 is None else dev(ops, x1),
+               residual=None if r is None else dev(ops, r), res_mode=K.IN_UPSAMPLE2 if res == "up" else K.IN_PLAIN,
+               act={"none": K.ACT_NONE, "relu": K.ACT_RELU, "sigmoid": K.ACT_SIGMOID, "tanh": K.ACT_TANH}[act], post_scale=0.5,
+               out=bigd, out_cstride=cout + 5, out_coffset=3)
+    close(bigd[:, 3:3 + cout], ref, 2e-5)
+    assert float(bigd[:, :3].min()) == 7.0 and float(bigd[:, 3 + cout:].min()) == 7.0
+
+
 @pytest.mark.parametrize("cin,cout,stride,H,W", [(3, 8, 1, 250, 262), (8, 8, 1, 256, 256), (8, 16, 2, 260, 500), (8, 24, 1, 256, 258)])
 def test_conv2d_large_image_stem(ops, cin, cout, stride, H, W):
     """image sizes that select the 16x16-pixel tile (MT=4) instantiations of the FeatureNet / ContextNet stem layers"""
