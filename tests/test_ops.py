@@ -86,6 +86,46 @@ def test_conv2d_row_alignment(ops, cin, cout, k, stride, pad, W, misalign):
     close(out, ref, 2e-5)
 
 
+@pytest.mark.parametrize("W,misalign", [(13, False), (18, False), (16, True)])
+def test_conv2d_fusions_ragged_rows(ops, W, misalign):
+    """the fused epilogues (GRU blend with r*h gating, residual before / after the activation, nearest-x2 residual, GroupNorm
+    statistics) on rows that are not 16-byte multiples or on operands at a 4-byte offset: the 4-pixel groups of the
+    transposed accumulators take their element-wise form, partially outside the image in the last group of a row"""
+    B, H = 2, 10
+
+    def place(t):      # the tensor at a 4-byte offset from a 16-byte boundary
+        td = dev(ops, t)
+        if not misalign:
+            return td
+        store = torch.zeros(t.numel() + 1, device=ops.device)
+        store[1:] = td.reshape(-1)
+        return store[1:].view(t.shape)
+
+    h, x = rnd(B, 6, H, W, seed=1), rnd(B, 10, H, W, seed=2)
+    r, z = torch.sigmoid(rnd(B, 6, H, W, seed=3)), torch.sigmoid(rnd(B, 6, H, W, seed=4))
+    w, bias = rnd(6, 16, 3, 3, seed=5) * 0.3, rnd(6, seed=6)
+    q = torch.tanh(F.conv2d(torch.cat([r * h, x], 1), w, bias, 1, 1))
+    out = ops.conv2d(K.pack_conv2d(*dev(ops, w, bias), pad=1), place(h), place(x), mul0=place(r), act=K.ACT_TANH, gru_z=place(z), gru_h=place(h))
+    close(out, (1 - z) * h + z * q, 2e-5)
+    # residual before and after the activation
+    x8, res = rnd(B, 8, H, W, seed=7), rnd(B, 12, H, W, seed=8)
+    w3, b3 = rnd(12, 8, 3, 3, seed=9) * 0.3, rnd(12, seed=10)
+    pc = K.pack_conv2d(*dev(ops, w3, b3), pad=1)
+    close(ops.conv2d(pc, place(x8), residual=place(res), act=K.ACT_RELU), F.relu(F.conv2d(x8, w3, b3, 1, 1) + res), 2e-5)
+    close(ops.conv2d(pc, place(x8), residual=place(res), act=K.ACT_RELU, res_after_act=True), F.relu(F.conv2d(x8, w3, b3, 1, 1)) + res, 2e-5)
+    # GroupNorm statistics of the pre-activation output
+    stats = torch.zeros(B, 4, 2, dtype=torch.float64, device=ops.device)
+    y = ops.conv2d(pc, place(x8), gn_stats=stats, gn_groups=4)
+    ref = F.conv2d(x8, w3, b3, 1, 1).reshape(B, 4, -1)
+    got = stats.view(torch.int64).double().cpu() / 65536.0
+    assert float((got[..., 0] - ref.sum(-1).double()).abs().max()) < 1e-2
+    assert float((got[..., 1] - (ref.double() ** 2).sum(-1)).abs().max()) < 1e-1
+    close(y, F.conv2d(x8, w3, b3, 1, 1), 2e-5)
+    if W % 2 == 0:      # nearest-x2 residual
+        rs = rnd(B, 12, H // 2, W // 2, seed=11)
+        close(ops.conv2d(pc, place(x8), residual=place(rs), res_mode=K.IN_UPSAMPLE2), F.conv2d(x8, w3, b3, 1, 1) + F.interpolate(rs, scale_factor=2, mode="nearest"), 2e-5)
+
+
 @pytest.mark.parametrize("c0,c1,cout,H,W,res,act", [
     (16, 0, 1, 9, 12, None, "sigmoid"), (32, 0, 16, 21, 20, None, "relu"), (32, 0, 64, 10, 16, "up", "none"), (64, 0, 144, 7, 8, None, "none"),
     (48, 0, 13, 5, 44, "same", "relu"), (6, 0, 9, 33, 36, None, "tanh"), (20, 10, 16, 12, 28, "same", "none"), (64, 0, 16, 16, 64, "up", "relu"),
