@@ -1,12 +1,16 @@
 """CPU restatement of the reference's depth-map fusion arithmetic (filter.py) in NumPy -- TEST INFRASTRUCTURE ONLY: imported
 by tests/ to check the HIP kernel dmvs_geo_consistency_f32 and diffmvs_amd/fusion.py, never by the product.
 
-Parity status: UNPINNED for the cv2.remap step.  filter.py imports cv2 and plyfile, neither of which exists in the build
-container, so the reference's functions cannot be run here and no golden vectors could be generated for them.  Everything
-else below follows filter.py line by line in the dtypes NumPy's promotion gives it there (fp32 camera matrices and depth
-maps, int64 pixel grid => fp64 geometry); cv2.remap(INTER_LINEAR) is restated from OpenCV's published implementation
-(imgwarp.cpp, opencv 4.x: fixed-point map conversion with INTER_BITS = 5, i.e. coordinates rounded half-to-even to 1/32
-pixel, fp32 tap weights (1-fy)(1-fx) ..., BORDER_CONSTANT 0 per tap)."""
+Parity status: pinned EXCEPT the cv2.remap step.  filter.py imports cv2 and plyfile, neither of which exists in the build
+container.  tests/golden/make_golden_fusion.py therefore runs the reference's own reproject_with_depth /
+check_geometric_consistency / check_geometric_consistency_dynamic with cv2.remap replaced by remap_linear below (and an
+empty plyfile) and commits what they return (tests/golden/fusion.npz); tests/test_fusion.py checks this restatement against
+those arrays bit for bit -- the fp64 projection chain, the distance / relative-depth tests, the static and dynamic masks
+are pinned to the reference's code.  cv2.remap(INTER_LINEAR) itself remains UNPINNED: it is restated from OpenCV's
+published implementation (imgwarp.cpp, opencv 4.x: fixed-point map conversion with INTER_BITS = 5, i.e. coordinates rounded
+half-to-even to 1/32 pixel, fp32 tap weights (1-fy)(1-fx) ..., BORDER_CONSTANT 0 per tap) and there is no OpenCV here to
+compare it with.  Everything follows filter.py line by line in the dtypes NumPy's promotion gives it there (fp32 camera
+matrices and depth maps, int64 pixel grid => fp64 geometry)."""
 import numpy as np
 
 INTER_TAB = 32

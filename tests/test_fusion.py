@@ -118,3 +118,28 @@ def test_filter_depth_on_a_scene_tree(ops, tmp_path):
     a, c = rsn.uniform(-0.25, 0.25, 2)
     resid = pts["z"] - a * pts["x"] - c * pts["y"] - d0                 # the plane of synth_inputs(seed=11)
     assert float(np.abs(resid).mean()) < 0.5
+
+
+def _eq(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a, b, equal_nan=(a.dtype.kind == "f"))
+
+
+def test_fusion_oracle_matches_reference_filter_fixtures():
+    """tests/golden/fusion.npz = what the reference's OWN filter.py functions returned (make_golden_fusion.py: filter.py
+    imported with cv2.remap replaced by oracle/fusion_oracle.py:remap_linear, cv2 being absent from the image) -- pins the
+    fp64 projection chain, the distance / relative-depth tests and the static + dynamic masks of the restatement against the
+    reference's code, array for array, bit for bit.  (The remap step itself stays unpinned.)"""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fusion.npz"))
+    depths, K, E = g["depths"], g["K"], g["E"]
+    dmin, dmax = float(g["range"][0]), float(g["range"][1])
+    for s in range(1, depths.shape[0]):
+        r = FO.reproject_with_depth(depths[0], K[0], E[0], depths[s], K[s], E[s])
+        for name, arr in zip(("depth_reproj", "x_reproj", "y_reproj", "x_src", "y_src"), r):
+            assert _eq(arr, g[f"reproj{s}_{name}"]), (s, name)
+        m, d, xs, ys = FO.check_geometric_consistency(depths[0], K[0], E[0], depths[s], K[s], E[s], dmax, dmin, 0.75, 0.008)
+        assert _eq(m, g[f"static{s}_mask"]) and _eq(d, g[f"static{s}_depth"]) and _eq(xs, g[f"static{s}_x"]) and _eq(ys, g[f"static{s}_y"])
+        assert 0.02 < m.mean() < 0.98                      # the fixture separates passing from failing pixels
+        for tag, dh in (("a", (2, 4.0, 1300.0)), ("b", (4, 8.0, 1600.0))):
+            masks, mask, d, xs, ys = FO.check_geometric_consistency_dynamic(depths[0], K[0], E[0], depths[s], K[s], E[s], dh)
+            assert _eq(np.stack(masks), g[f"dyn{tag}{s}_masks"]) and _eq(d, g[f"dyn{tag}{s}_depth"])
