@@ -6,7 +6,9 @@ container.  tests/golden/make_golden_fusion.py therefore runs the reference's ow
 check_geometric_consistency / check_geometric_consistency_dynamic with cv2.remap replaced by remap_linear below (and an
 empty plyfile) and commits what they return (tests/golden/fusion.npz); tests/test_fusion.py checks this restatement against
 those arrays bit for bit -- the fp64 projection chain, the distance / relative-depth tests, the static and dynamic masks
-are pinned to the reference's code.  cv2.remap(INTER_LINEAR) itself remains UNPINNED: it is restated from OpenCV's
+are pinned to the reference's code (and tests/golden/fusion_tree.npz, the vertex tables of the reference's filter_depth /
+filter_depth_dynamic on a small scene tree, pins the product's whole chain the same way).  cv2.remap(INTER_LINEAR) itself
+remains UNPINNED: it is restated from OpenCV's
 published implementation (imgwarp.cpp, opencv 4.x: fixed-point map conversion with INTER_BITS = 5, i.e. coordinates rounded
 half-to-even to 1/32 pixel, fp32 tap weights (1-fy)(1-fx) ..., BORDER_CONSTANT 0 per tap) and there is no OpenCV here to
 compare it with.  Everything follows filter.py line by line in the dtypes NumPy's promotion gives it there (fp32 camera

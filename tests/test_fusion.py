@@ -143,3 +143,29 @@ def test_fusion_oracle_matches_reference_filter_fixtures():
         for tag, dh in (("a", (2, 4.0, 1300.0)), ("b", (4, 8.0, 1600.0))):
             masks, mask, d, xs, ys = FO.check_geometric_consistency_dynamic(depths[0], K[0], E[0], depths[s], K[s], E[s], dh)
             assert _eq(np.stack(masks), g[f"dyn{tag}{s}_masks"]) and _eq(d, g[f"dyn{tag}{s}_depth"])
+
+
+@pytest.mark.parametrize("tag,kw", [("cas", dict(method="casdiffmvs", geo_mask_thres=2, photo_thres=[0.3, 0.4, 0.5], dataset="dtu")),
+                                    ("diff", dict(method="diffmvs", geo_mask_thres=3, photo_thres=[0.35, 0.45, 0.5], dataset="dtu")),
+                                    ("dyn", dict(method="casdiffmvs", photo_thres=[0.3, 0.4, 0.5], dataset="tank", scan="Horse"))])
+def test_filter_depth_matches_reference_on_a_scene_tree(tag, kw, tmp_path):
+    """tests/golden/fusion_tree.npz = the vertex tables the reference's own filter_depth / filter_depth_dynamic produced on the
+    tree of tests/fusion_scene.py (make_golden_fusion_tree.py; cv2.remap replaced by the restatement, cv2 being absent).  This
+    package's filter_depth on the same tree -- file readers, photometric masks, the consistency kernel, depth averaging,
+    unprojection, colours, point order -- must give the same points.  (Host-emulated kernels: the comparison is about the
+    algorithm, and exact point counts depend on fp64 threshold decisions.)"""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    import fusion_scene
+    from conftest import emu_ops
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fusion_tree.npz"))
+    root = fusion_scene.build_tree(str(tmp_path / "scan"))
+    ply = str(tmp_path / "out.ply")
+    n = fusion.filter_depth(root, root, ply, ops=emu_ops(), **kw)
+    raw = open(ply, "rb").read().split(b"end_header\n")[1]
+    pts = np.frombuffer(raw, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("r", "u1"), ("g", "u1"), ("b", "u1")])
+    want_xyz, want_rgb = g[f"{tag}_xyz"], g[f"{tag}_rgb"]
+    assert n == want_xyz.shape[0] == pts.shape[0]
+    got_xyz = np.stack([pts["x"], pts["y"], pts["z"]], 1)
+    assert np.allclose(got_xyz, want_xyz, rtol=1e-6, atol=2e-4)
+    assert np.array_equal(np.stack([pts["r"], pts["g"], pts["b"]], 1), want_rgb)
