@@ -159,3 +159,37 @@ def test_ply_writer(tmp_path):
     assert b"element vertex 5" in head and len(body) == 5 * 15
     v = np.frombuffer(body, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("r", "u1"), ("g", "u1"), ("b", "u1")])
     assert np.array_equal(v["y"], xyz[:, 1]) and np.array_equal(v["b"], rgb[:, 2])
+
+
+def _same_sample(prefix, s, g):
+    n = sum(1 for k in g.files if k.startswith(prefix + ".img"))
+    assert len(s["imgs"]) == n
+    for i in range(n):
+        w = g[f"{prefix}.img{i}"]
+        assert s["imgs"][i].dtype == w.dtype and np.array_equal(s["imgs"][i], w)
+    for k in ("stage1", "stage2", "stage3", "stage4"):
+        w = g[f"{prefix}.proj.{k}"]
+        assert s["proj_matrices"][k].dtype == w.dtype and np.array_equal(s["proj_matrices"][k], w), k
+    assert s["depth_values"].dtype == g[f"{prefix}.depth_values"].dtype and np.array_equal(s["depth_values"], g[f"{prefix}.depth_values"])
+    assert s["filename"] == str(g[f"{prefix}.filename"])
+
+
+def test_dataset_samples_match_the_reference_dataset(tmp_path):
+    """tests/golden/dataset.npz = the sample dicts the reference's own datasets/mvs.py:MVSDataset returned on two scene trees
+    (make_golden_dataset.py; cv2 absent: its only use there, cv2.resize, is called with the source size -- a copy).  This
+    package's MVSDataset on the same trees must return the same dicts, array for array and bit for bit: view selection, image
+    scaling, camera parsing, per-stage projection matrices, the inverse-depth hypothesis grid, the filename pattern."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "dataset.npz"))
+    a = tmp_path / "a"
+    _write_scene(str(a), "", 64, 96, 4, seed=2)
+    os.rename(str(a / "cams_1"), str(a / "cams"))
+    ds = IO.MVSDataset(str(a), n_views=3, numdepth=48, dataset="general")
+    assert len(ds) == int(g["general.len"])
+    _same_sample("general.1", ds[1], g)
+    _same_sample("general.3", ds[3], g)
+    b = tmp_path / "b"
+    _write_scene(str(b), "scan9", 64, 96, 3, seed=4)
+    ds = IO.MVSDataset(str(b), n_views=3, numdepth=16, dataset="dtu", scan=["scan9"])
+    ds.img_wh = (96, 64)
+    assert len(ds) == int(g["dtu.len"])
+    _same_sample("dtu.0", ds[0], g)
