@@ -86,6 +86,28 @@ def test_conv2d_row_alignment(ops, cin, cout, k, stride, pad, W, misalign):
     close(out, ref, 2e-5)
 
 
+@pytest.mark.parametrize("c0,cout,H,W,res", [(32, 64, 10, 16, "up"), (64, 144, 7, 8, None), (48, 32, 5, 44, "same"), (6, 36, 33, 36, None), (64, 96, 16, 64, "up")])
+def test_conv2d_1x1_direct_wide_variants(c0, cout, H, W, res, monkeypatch):
+    """the 2..9 n-tile instantiations of the direct 1x1 kernel, dispatched only under DMVS_CONV1X1_WIDE=1 (kept for tuning:
+    they are not faster than the tiled kernel yet) -- host-emulated"""
+    from conftest import emu_ops
+    ops = emu_ops()
+    monkeypatch.setenv("DMVS_CONV1X1_WIDE", "1")
+    B = 2
+    x = rnd(B, c0, H, W, seed=1)
+    w, bias = rnd(cout, c0, 1, 1, seed=3) * 0.3, rnd(cout, seed=4)
+    ref = F.conv2d(x, w, bias)
+    r = None
+    if res == "same":
+        r = rnd(B, cout, H, W, seed=5)
+        ref = ref + r
+    elif res == "up":
+        r = rnd(B, cout, H // 2, W // 2, seed=5)
+        ref = ref + F.interpolate(r, scale_factor=2, mode="nearest")
+    out = ops.conv2d(K.pack_conv2d(w, bias), x, residual=r, res_mode=K.IN_UPSAMPLE2 if res == "up" else K.IN_PLAIN, act=K.ACT_RELU)
+    close(out, F.relu(ref), 2e-5)
+
+
 @pytest.mark.parametrize("W,misalign", [(13, False), (18, False), (16, True)])
 def test_conv2d_fusions_ragged_rows(ops, W, misalign):
     """the fused epilogues (GRU blend with r*h gating, residual before / after the activation, nearest-x2 residual, GroupNorm
