@@ -24,6 +24,8 @@
 //
 // Semantics kept from the reference: per-tap zero padding with align_corners=True pixel coordinates, NO behind-camera
 // mask, z == 0 -> z + 1e-8, non-finite coordinates sample 0.
+#include <stdlib.h>
+
 #include <utility>
 
 #include "dmvs_common.h"
@@ -51,6 +53,16 @@ __device__ __forceinline__ int quad_max(int v) {
 __device__ __forceinline__ unsigned quad_or(unsigned v) {
     v |= (unsigned)qperm<QP_XOR1>((int)v);
     return v | (unsigned)qperm<QP_XOR2>((int)v);
+}
+
+__device__ __forceinline__ unsigned mad_u24(unsigned a, unsigned b, unsigned c) {      // a * b + c, a and b below 2^24
+#ifdef DMVS_HOST_EMULATION
+    return a * b + c;
+#else
+    unsigned d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+#endif
 }
 
 struct RayQ {   // p(depth) = rot * (x, y, 1) * depth + trans   (reference module.py:199-205)
@@ -100,6 +112,24 @@ __device__ __forceinline__ HypQ project_q(const RayQ& r, float depth, bool exist
 }
 
 typedef float f2q __attribute__((vector_size(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// pointer into the workgroup's LDS (address space 3: the loads become ds_read_*; g++ of the host emulation ignores the attribute)
+typedef const __attribute__((address_space(3))) char* lds_cptr;
+template <typename P, typename T> struct PtrAs { typedef const T* type; };
+#ifndef DMVS_HOST_EMULATION
+template <typename T> struct PtrAs<lds_cptr, T> { typedef const __attribute__((address_space(3))) T* type; };
+#endif
+template <typename V, typename P> __device__ __forceinline__ V ldv(P p) {
+#ifdef DMVS_HOST_EMULATION
+    V v;
+    memcpy(&v, (const void*)p, sizeof(V));       // (the host's vector loads want natural alignment)
+    return v;
+#else
+    return *(typename PtrAs<P, V>::type)(p);
+#endif
+}
 
 // This lane's C/4 channels (= all channels of its correlation group) of one texel, for the three feature element types.
 //   fp32   : NHWC-g4, C/16 units of 64 bytes, the lane reads 16 bytes of each (4 channels)
@@ -114,22 +144,27 @@ template <int C, int FT> struct Feat {
 
     static __device__ __forceinline__ unsigned lane_bytes(int q) { return FT == DMVS_DTYPE_F32 ? (unsigned)q * 16u : (unsigned)q * (E * 2); }
 
-    __device__ __forceinline__ void load(const char* p) {
+    // P = const char* (global memory) or lds_cptr (the workgroup's staged band: ds_read_b128 / _b64)
+    template <typename P> __device__ __forceinline__ void load(P p) {
         if constexpr (FT == DMVS_DTYPE_F32) {
 #pragma unroll
             for (int j = 0; j < C / 16; ++j) {
-                const uint4 v = *reinterpret_cast<const uint4*>(p + j * 64);
-                w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
+                const u32x4 v = ldv<u32x4>(p + j * 64);
+                w[4 * j] = v[0]; w[4 * j + 1] = v[1]; w[4 * j + 2] = v[2]; w[4 * j + 3] = v[3];
             }
+        } else if constexpr (NW == 6) {
+            // 24 bytes per lane at an 8-byte aligned address: 8-byte pieces (a 16-byte LDS read needs a 16-byte aligned address)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const u32x2 v = ldv<u32x2>(p + j * 8);
+                w[2 * j] = v[0]; w[2 * j + 1] = v[1];
+            }
+        } else if constexpr (NW == 4) {
+            const u32x4 v = ldv<u32x4>(p);
+            w[0] = v[0]; w[1] = v[1]; w[2] = v[2]; w[3] = v[3];
         } else {
-            if constexpr (NW >= 4) {
-                const uint4 v = *reinterpret_cast<const uint4*>(p);
-                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-            }
-            if constexpr (NW == 2 || NW == 6) {
-                const uint2 v = *reinterpret_cast<const uint2*>(p + (NW == 6 ? 16 : 0));
-                w[NW - 2] = v.x; w[NW - 1] = v.y;
-            }
+            const u32x2 v = ldv<u32x2>(p);
+            w[0] = v[0]; w[1] = v[1];
         }
     }
     __device__ __forceinline__ float get(int i) const {      // channel i of the lane's group
@@ -147,6 +182,22 @@ __device__ __forceinline__ float dot_texel(const Feat<C, FT>& t, const float (&r
 #pragma unroll
     for (int i = 0; i < C / 4; i += 2) a = f2q{t.get(i), t.get(i + 1)} * f2q{ref[i], ref[i + 1]} + a;
     return a[0] + a[1];
+}
+
+// the TPT texels of a trip together, channel pairs outermost: the dependent packed-FMA chains of the texels interleave (a
+// v_pk_fma_f32 straight after the one it depends on costs a wait state)
+template <int C, int FT, int TPT>
+__device__ __forceinline__ void dot_texels(const Feat<C, FT> (&t)[TPT], const float (&ref)[C / 4], float (&dd)[TPT]) {
+    f2q a[TPT];
+#pragma unroll
+    for (int i = 0; i < TPT; ++i) a[i] = f2q{0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < C / 4; j += 2) {
+#pragma unroll
+        for (int i = 0; i < TPT; ++i) a[i] = f2q{t[i].get(j), t[i].get(j + 1)} * f2q{ref[j], ref[j + 1]} + a[i];
+    }
+#pragma unroll
+    for (int i = 0; i < TPT; ++i) dd[i] = a[i][0] + a[i][1];
 }
 
 // the lane's reference channels, scaled by 1 / (channels per group): cor = MEAN over the group (module.py:529-531)
@@ -210,9 +261,11 @@ __device__ __forceinline__ void scatter_pair(float (&acc)[NH], const float (&w0)
 #endif
 
 // acc[k] += wscale * (bilinear sample of the lane's group dot at hypothesis k), k < NH, for one (pixel, view).
-// own[h] = hypothesis q + 4h of the pixel (q = lane & 3).  base + view_off = the view's [Hs,Ws,C] NHWC-g4 image (+ 16q bytes).
-template <int C, int FT, int NH, int TPT>
-__device__ __forceinline__ void quad_accumulate(const char* base, unsigned view_off, const HypQ (&own)[(NH + 3) / 4], int Hs, int Ws,
+// own[h] = hypothesis q + 4h of the pixel (q = lane & 3).  Texel (x, y) of the view is read at base + origin + (y * pitch + x) *
+// TEXEL_BYTES (32-bit wrapping arithmetic): global memory -- base + origin = the view's [Hs,Ws,C] NHWC-g4 image (+ the lane's
+// 16q bytes), pitch = Ws -- or a band of the view staged in LDS (base = the band, origin = lane bytes - the band's corner).
+template <int C, int FT, int NH, int TPT, typename P>
+__device__ __forceinline__ void quad_accumulate(P base, unsigned view_off, int pitch, const HypQ (&own)[(NH + 3) / 4], int Hs, int Ws,
                                                 const float (&ref)[C / 4], float wscale, float (&acc)[NH]) {
     constexpr int HPL = (NH + 3) / 4, TB = Feat<C, FT>::TEXEL_BYTES;
     const int q = threadIdx.x & 3;
@@ -270,7 +323,7 @@ __device__ __forceinline__ void quad_accumulate(const char* base, unsigned view_
             mlo &= (unsigned)rowmask & colbits;
             mhi &= (unsigned)(rowmask >> 32) & colbits;
         }
-        const unsigned texel_off = view_off + (unsigned)(__mul24(ymin, Ws) + xmin) * (unsigned)TB;    // of grid cell (0, 0)
+        const unsigned texel_off = view_off + (unsigned)(__mul24(ymin, pitch) + xmin) * (unsigned)TB;    // of grid cell (0, 0)
         // rows 0..3 of the grid (mlo), then -- rarely non-empty -- rows 4..7 (mhi): 32-bit bit scans
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
@@ -291,7 +344,8 @@ __device__ __forceinline__ void quad_accumulate(const char* base, unsigned view_
 #pragma unroll
             for (int i = 0; i < TPT; ++i) {
                 const int c = bit[i] & 7, r = (bit[i] >> 3) + rbase;
-                t[i].load(base + (texel_off + (unsigned)(__mul24(r, Ws) + c) * (unsigned)TB));
+                // r * pitch + c < 2^24: one full-rate 24-bit multiply-add each (left alone, hipcc picks the 64-bit v_mad_u64_u32)
+                t[i].load(base + mad_u24(mad_u24((unsigned)r, (unsigned)pitch, (unsigned)c), (unsigned)TB, texel_off));
                 fc[i] = (float)c;
                 fr[i] = (float)r;
             }
@@ -299,9 +353,10 @@ __device__ __forceinline__ void quad_accumulate(const char* base, unsigned view_
             // more wave of occupancy, re-uses one texel's registers and serialises load -> wait -> FMAs per texel
             __builtin_amdgcn_sched_barrier(0);
             float dd[TPT], w[TPT][HPL];
+            dot_texels<C, FT, TPT>(t, ref, dd);
 #pragma unroll
             for (int i = 0; i < TPT; ++i) {
-                dd[i] = dot_texel<C, FT>(t[i], ref) * ((i == 0 || has[i]) ? wscale : 0.0f);
+                dd[i] *= (i == 0 || has[i]) ? wscale : 0.0f;
 #pragma unroll
                 for (int h = 0; h < HPL; ++h) w[i][h] = hat(ur[h], fc[i]) * hat(vr[h], fr[i]);
             }
@@ -370,7 +425,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) getcost_quad_kernel(const dmvs_get
 #pragma unroll
         for (int h = 0; h < HPL; ++h) own[h] = project_q(ray, own_depth[h], exists[h], H, W);
         const unsigned view_off = (unsigned)(((long)s * d.B + b) * (long)hw * Feat<C, FT>::TEXEL_BYTES) + Feat<C, FT>::lane_bytes(q);
-        quad_accumulate<C, FT, N, TPT>(base, view_off, own, H, W, ref, w, acc);
+        quad_accumulate<C, FT, N, TPT>(base, view_off, W, own, H, W, ref, w, acc);
     }
     if (live) {
         const float inv_w = 1.0f / wsum;
@@ -424,12 +479,164 @@ warp_init_quad_kernel(const void* __restrict__ ref_f, const void* __restrict__ s
         float acc[NB];
 #pragma unroll
         for (int k = 0; k < NB; ++k) acc[k] = 0.0f;
-        quad_accumulate<C, FT, NB, TPT>(base, view_off, own, Hs, Ws, ref, 1.0f, acc);
+        quad_accumulate<C, FT, NB, TPT>(base, view_off, Ws, own, Hs, Ws, ref, 1.0f, acc);
         if (live) {
 #pragma unroll
             for (int k = 0; k < NB; ++k)
                 if (d0 + k < D) op[(long)(d0 + k) * (long)hw] = acc[k];
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ stage-1 plane sweep, LDS band
+// The same quad arithmetic with the texels served from LDS.  The plane sweep's taps are the L1's worst case: every distinct
+// texel of a (pixel, 8-plane chunk) is a separate 64-byte request per quad (~54 texels x 192 B = 10 KB of L1 traffic per
+// pixel and view against 960 B of source actually needed: the launch moved ~25 GB through the 64 B/clk/CU vector L1s, which
+// alone is half of its run time), while neighbouring pixels and consecutive chunks walk the SAME few source rows.  Here a
+// workgroup owns a 16 x 4 pixel tile of one (batch item, view) and stages the source band its planes touch ONCE:
+//   * planes are taken in groups of whole 8-plane chunks; a group's band is the bounding box of every pixel's epipolar segment
+//     between the group's first and last plane (the projection of a depth interval is a straight image segment, monotonic in
+//     depth while z keeps its sign), +1 texel for the 2x2 footprint, +1 all round for rounding, clipped to the image;
+//   * the group size starts at all planes and halves until the band fits BAND_BYTES (typical: the whole sweep or half of it);
+//   * the band is copied by LDS-DMA in 16-byte pieces (rows are contiguous in the NHWC image: fully coalesced, each texel
+//     leaves L2 once per tile instead of once per pixel and chunk), byte-identical to the image, so the quads read it with
+//     the same offsets (ds_read_b128: 64 contiguous bytes per quad, conflict-free for adjacent texels at 192-byte pitch);
+//   * a group whose single chunk does not fit (or whose segment has a pole: z changes sign) reads global memory exactly like
+//     warp_init_quad_kernel -- same code path, other pointer type.
+constexpr int BTW = 16, BTH = 4;        // pixel tile of a workgroup (one quad per pixel, one 16-pixel row per wave)
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+template <int C, int TPT, int FT, int BAND_BYTES>
+__global__ void __launch_bounds__(DMVS_BLOCK)
+warp_init_band_kernel(const void* __restrict__ ref_f, const void* __restrict__ src, const float* __restrict__ rt,
+                      const float* __restrict__ disp_min, const float* __restrict__ disp_max, float* __restrict__ out, int B, int S,
+                      int D, int H, int W, int Hs, int Ws, int tiles_x) {
+    constexpr int NB = 8, HPL = 2, TB = Feat<C, FT>::TEXEL_BYTES, NWAVE = DMVS_BLOCK / 64;
+    constexpr int TAB = 256;
+    __shared__ __attribute__((aligned(16))) char band[BAND_BYTES];
+    __shared__ float depth_tab[TAB];
+    __shared__ int red[2][NWAVE][5];
+
+    const int tid = threadIdx.x, q = tid & 3, p = tid >> 2, lane = tid & 63, wave = tid >> 6;
+    const int hw = H * W;
+    const int b = blockIdx.y / S, s = blockIdx.y - b * S;        // (batch item, view): workgroup-uniform
+    const int tile = (int)dmvs_xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+    const int px = txi * BTW + (p & (BTW - 1)), py = tyi * BTH + (p >> 4);
+    const bool live = px < W && py < H;
+    const int x = min(px, W - 1), y = min(py, H - 1);
+    const int yx = y * W + x;
+    const long pq = (long)b * hw + yx;
+
+    float ref[C / 4];
+    load_ref<C, FT>(ref_f, pq, q, ref);
+    RayQ ray;
+    ray.init(rt + ((long)b * S + s) * 12, (float)x, (float)y);
+    const char* gbase = reinterpret_cast<const char*>(src);
+    const unsigned view_base = (unsigned)(((long)s * B + b) * (long)Hs * Ws * TB);
+    const unsigned view_off = view_base + Feat<C, FT>::lane_bytes(q);
+    const float dmin = disp_min[b], dmax = disp_max[b];
+    const float dm1 = (float)(D - 1);
+    if (tid < min(D, TAB)) depth_tab[tid] = dmvs_disp_to_depth((float)tid / dm1, dmin, dmax);
+    __syncthreads();
+    auto plane_depth = [&](int k) { return k < TAB ? depth_tab[k] : dmvs_disp_to_depth((float)k / dm1, dmin, dmax); };
+
+    // bounding box (clipped to the image, margins included) of the tile's footprints between planes ka and kb; false: some
+    // pixel's segment is not one (non-finite end or a pole between the ends).  Workgroup-collective, one barrier.
+    int par = 0;
+    auto group_box = [&](int ka, int kb, int& bx0, int& by0, int& ncols, int& nrows) -> bool {
+        float ua, va, ub, vb;
+        const float za = ray.rz * plane_depth(ka) + ray.tz, zb = ray.rz * plane_depth(kb) + ray.tz;
+        project_uv_q(ray, plane_depth(ka), ua, va);
+        project_uv_q(ray, plane_depth(kb), ub, vb);
+        const bool fin = fabsf(ua) < 1.0e9f && fabsf(va) < 1.0e9f && fabsf(ub) < 1.0e9f && fabsf(vb) < 1.0e9f;      // false for NaN
+        int bad = (live && (!fin || ((za < 0.0f) != (zb < 0.0f)))) ? 1 : 0;
+        int lx = BIG, ly = BIG, hx = -BIG, hy = -BIG;
+        if (live && !bad) {
+            lx = (int)floorf(fminf(ua, ub)); hx = (int)floorf(fmaxf(ua, ub));
+            ly = (int)floorf(fminf(va, vb)); hy = (int)floorf(fmaxf(va, vb));
+        }
+        lx = wave_min_i(lx); ly = wave_min_i(ly); hx = wave_max_i(hx); hy = wave_max_i(hy); bad = wave_max_i(bad);
+        int (*rd)[5] = red[par];
+        par ^= 1;
+        if (lane == 0) {
+            rd[wave][0] = lx; rd[wave][1] = ly; rd[wave][2] = hx; rd[wave][3] = hy; rd[wave][4] = bad;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < NWAVE; ++w) {
+            lx = min(lx, rd[w][0]); ly = min(ly, rd[w][1]); hx = max(hx, rd[w][2]); hy = max(hy, rd[w][3]); bad = max(bad, rd[w][4]);
+        }
+        bx0 = max(lx - 1, 0); by0 = max(ly - 1, 0);
+        const int bx1 = min(hx + 2, Ws - 1), by1 = min(hy + 2, Hs - 1);
+        ncols = (hx < lx) ? 0 : max(bx1 - bx0 + 1, 0);        // hx < lx: no live pixel
+        nrows = max(by1 - by0 + 1, 0);
+        return bad == 0;
+    };
+
+    float* op = out + ((((long)b * S + s) * 4 + q) * D) * (long)hw + yx;
+    const int nchunk = (D + NB - 1) / NB;
+    int cpg = nchunk;                                          // chunks per group: halved until a group's band fits
+    for (int c0 = 0; c0 < nchunk;) {
+        int cnt, bx0 = 0, by0 = 0, ncols = 0, nrows = 0;
+        bool staged;
+        for (;;) {
+            cnt = min(cpg, nchunk - c0);
+            const bool seg = group_box(c0 * NB, min((c0 + cnt) * NB, D) - 1, bx0, by0, ncols, nrows);
+            // an empty box (every tap of the group is padding) needs no band: the texel masks come out empty
+            staged = seg && ncols > 0 && nrows > 0 && ncols * nrows * TB <= BAND_BYTES;
+            if (staged || cpg == 1 || (seg && (ncols == 0 || nrows == 0))) break;
+            cpg = (cpg + 1) >> 1;
+        }
+        if (staged) {
+            // every wave is past group_box's barrier, i.e. done with the previous band
+            const int ppr = ncols * (TB / 16), npieces = nrows * ppr;       // 16-byte pieces per band row / in the band
+            const float inv_ppr = 1.0f / (float)ppr;
+            const unsigned corner = view_base + (unsigned)(__mul24(by0, Ws) + bx0) * (unsigned)TB;
+            for (int i0 = wave * 64; i0 < npieces; i0 += DMVS_BLOCK) {
+                const int i = i0 + lane;
+                if (i < npieces) {
+                    int r = (int)((float)i * inv_ppr);
+                    r -= (r * ppr > i) ? 1 : 0;
+                    r += ((r + 1) * ppr <= i) ? 1 : 0;
+                    const int pc = i - r * ppr;
+                    const char* srcp = gbase + (corner + (unsigned)__mul24(r, Ws) * (unsigned)TB + (unsigned)pc * 16u);
+                    __builtin_amdgcn_global_load_lds(srcp, (__attribute__((address_space(3))) void*)(band + (size_t)i0 * 16), 16, 0, 0);
+                }
+            }
+            __syncthreads();                                   // (waits out this wave's LDS-DMA, then the barrier)
+        }
+        const unsigned band_off = Feat<C, FT>::lane_bytes(q) - (unsigned)(__mul24(by0, ncols) + bx0) * (unsigned)TB;
+        for (int ch = c0; ch < c0 + cnt; ++ch) {
+            const int d0 = ch * NB;
+            HypQ own[HPL];
+#pragma unroll
+            for (int h = 0; h < HPL; ++h) {
+                const int dk = d0 + q + 4 * h;
+                own[h] = project_q(ray, plane_depth(min(dk, D - 1)), dk < D, Hs, Ws);
+            }
+            float acc[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) acc[k] = 0.0f;
+            if (staged) quad_accumulate<C, FT, NB, TPT>((lds_cptr)band, band_off, ncols, own, Hs, Ws, ref, 1.0f, acc);
+            else quad_accumulate<C, FT, NB, TPT>(gbase, view_off, Ws, own, Hs, Ws, ref, 1.0f, acc);
+            if (live) {
+#pragma unroll
+                for (int k = 0; k < NB; ++k)
+                    if (d0 + k < D) op[(long)(d0 + k) * (long)hw] = acc[k];
+            }
+        }
+        c0 += cnt;
     }
 }
 
@@ -480,6 +687,39 @@ static int launch_warp_init_quad(const void* ref, const void* src, const float* 
     return dmvs_launch_status();
 }
 
+// LDS-band form: band bytes per workgroup -- 48 KB = 3 workgroups (12 waves) per CU, 38 KB = 4 (DMVS_BAND_KB=38|48 for A/B runs)
+static int band_kb() {
+    static const int kb = [] {
+        const char* e = getenv("DMVS_BAND_KB");
+        return e ? atoi(e) : 48;
+    }();
+    return kb;
+}
+template <int FT>
+static int launch_warp_init_band(const void* ref, const void* src, const float* rt, const float* disp_min, const float* disp_max, float* out,
+                                 int B, int S, int C, int D, int H, int W, int Hs, int Ws, hipStream_t st) {
+    const int tiles_x = (W + BTW - 1) / BTW, tiles_y = (H + BTH - 1) / BTH;
+    dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(B * S)), block(DMVS_BLOCK);
+#define DMVS_WIB(CC, KB) hipLaunchKernelGGL((warp_init_band_kernel<CC, QUAD_TPT, FT, KB * 1024>), grid, block, 0, st, ref, src, rt, disp_min, disp_max, out, B, S, D, H, W, Hs, Ws, tiles_x)
+    const bool small = band_kb() < 48;
+    if (C == 48 && small) DMVS_WIB(48, 38);
+    else if (C == 48) DMVS_WIB(48, 48);
+    else if (C == 32) DMVS_WIB(32, 48);
+    else if (C == 16) DMVS_WIB(16, 48);
+    else return DMVS_EINVAL;
+#undef DMVS_WIB
+    return dmvs_launch_status();
+}
+
+// DMVS_PLANE_SWEEP=quad: the round-2 kernel (every texel from global memory / L1) for A/B runs; default: the LDS-band kernel
+static bool plane_sweep_band() {
+    static const bool band = [] {
+        const char* e = getenv("DMVS_PLANE_SWEEP");
+        return !(e && e[0] == 'q');
+    }();
+    return band;
+}
+
 extern "C" int dmvs_warp_corr_init_quad_f32(const void* ref, const void* src, const float* rt, const float* disp_min,
                                             const float* disp_max, float* out, int32_t B, int32_t S, int32_t C, int32_t G,
                                             int32_t D, int32_t H, int32_t W, int32_t Hs, int32_t Ws, int32_t feat_dtype, void* stream) {
@@ -488,6 +728,11 @@ extern "C" int dmvs_warp_corr_init_quad_f32(const void* ref, const void* src, co
     if ((long)S * B * Hs * Ws * C * (feat_dtype == DMVS_DTYPE_F32 ? 4 : 2) >= (1L << 32)) return DMVS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if ((long)H * W >= (1L << 24) || (long)Hs * Ws >= (1L << 24) || (long)B * S > 65535) return DMVS_EINVAL;
+    if (plane_sweep_band()) {
+        if (feat_dtype == DMVS_DTYPE_BF16) return launch_warp_init_band<DMVS_DTYPE_BF16>(ref, src, rt, disp_min, disp_max, out, B, S, C, D, H, W, Hs, Ws, st);
+        if (feat_dtype == DMVS_DTYPE_F16) return launch_warp_init_band<DMVS_DTYPE_F16>(ref, src, rt, disp_min, disp_max, out, B, S, C, D, H, W, Hs, Ws, st);
+        return launch_warp_init_band<DMVS_DTYPE_F32>(ref, src, rt, disp_min, disp_max, out, B, S, C, D, H, W, Hs, Ws, st);
+    }
     dim3 grid(dmvs_ceil_div((long)H * W, DMVS_BLOCK / 4), (unsigned)(B * S)), block(DMVS_BLOCK);
     if (feat_dtype == DMVS_DTYPE_BF16) return launch_warp_init_quad<DMVS_DTYPE_BF16>(ref, src, rt, disp_min, disp_max, out, B, S, C, D, H, W, Hs, Ws, grid, block, st);
     if (feat_dtype == DMVS_DTYPE_F16) return launch_warp_init_quad<DMVS_DTYPE_F16>(ref, src, rt, disp_min, disp_max, out, B, S, C, D, H, W, Hs, Ws, grid, block, st);

@@ -121,8 +121,14 @@ struct Worker {
     std::vector<Fiber> fibers;
     char* stacks = nullptr;
     std::vector<uint64_t> slots;   // shuffle exchange, one per thread of the block
+    // rendezvous counters of the cross-lane exchanges, per thread and group kind (0 = wave-wide shuffles, 1 = DPP quad_perm):
+    // exchanges posted / exchanges whose partner slot has been read
+    std::vector<unsigned> xseq[2], xack[2];
     std::vector<float> slots_a, slots_b;   // MFMA operand exchange
     int current = -1;
+    int alive = 0;                 // fibers of the running block that have not returned yet
+    int bar_count = 0;             // arrivals at the current __syncthreads()
+    unsigned bar_gen = 0;          // barrier generation
     const std::function<void()>* body = nullptr;
 };
 inline thread_local Worker* g_worker = nullptr;
@@ -148,6 +154,10 @@ __attribute__((noinline)) inline void trampoline() {
 inline int linear_tid() { return g_threadIdx.x + g_blockDim.x * (g_threadIdx.y + g_blockDim.y * g_threadIdx.z); }
 
 inline void run_block(Worker& w, int nthreads) {
+    for (int k = 0; k < 2; ++k) {
+        std::fill(w.xseq[k].begin(), w.xseq[k].end(), 0u);
+        std::fill(w.xack[k].begin(), w.xack[k].end(), 0u);
+    }
     for (int t = 0; t < nthreads; ++t) {
         Fiber& f = w.fibers[t];
         f.done = false;
@@ -160,14 +170,15 @@ inline void run_block(Worker& w, int nthreads) {
         for (int i = 0; i < 6; ++i) sp[i] = nullptr;
         f.sp = sp;
     }
-    int alive = nthreads;
-    while (alive > 0) {
+    w.alive = nthreads;
+    w.bar_count = 0;
+    while (w.alive > 0) {
         for (int t = 0; t < nthreads; ++t) {
             if (w.fibers[t].done) continue;
             w.current = t;
             set_tid(t);
             hipemu_switch(&w.main_sp, w.fibers[t].sp);
-            if (w.fibers[t].done) --alive;
+            if (w.fibers[t].done) --w.alive;
         }
     }
 }
@@ -183,6 +194,10 @@ inline void launch(dim3 grid, dim3 block, size_t, const std::function<void()>& b
         w.fibers.resize(nthreads);
         w.stacks = stack_pool().get();
         w.slots.resize(nthreads);
+        for (int k = 0; k < 2; ++k) {
+            w.xseq[k].assign(nthreads, 0);
+            w.xack[k].assign(nthreads, 0);
+        }
         w.slots_a.resize(nthreads);
         w.slots_b.resize(nthreads);
         w.body = &body;
@@ -207,15 +222,28 @@ inline void launch(dim3 grid, dim3 block, size_t, const std::function<void()>& b
     for (auto& t : pool) t.join();
 }
 
+// Cross-lane exchange inside a group of `gsize` adjacent threads (64: the wave-wide shuffles; 4: DPP quad_perm).  The members
+// of a group rendezvous explicitly -- every live member has posted its value before anyone reads, everyone has read before
+// anyone posts the next one -- because the groups of a block do not run in lockstep here: the quad kernels loop a
+// data-dependent number of times per quad, and unlike a hardware wave the fibers do not reconverge afterwards.
 template <typename T>
-inline T shfl_from(T v, int src_lane_abs) {
+inline T shfl_from(T v, int src_lane_abs, int gsize = 64) {
     Worker* w = g_worker;
+    const int kind = gsize == 64 ? 0 : 1;
+    const int t = linear_tid(), g0 = t & ~(gsize - 1), g1 = std::min<int>(g0 + gsize, (int)w->fibers.size());
     uint64_t raw = 0;
     memcpy(&raw, &v, sizeof(T));
-    w->slots[linear_tid()] = raw;
-    yield();
+    w->slots[t] = raw;
+    const unsigned me = ++w->xseq[kind][t];
+    auto behind = [&](const std::vector<unsigned>& c) {
+        for (int u = g0; u < g1; ++u)
+            if (!w->fibers[u].done && (int)(c[u] - me) < 0) return true;
+        return false;
+    };
+    while (behind(w->xseq[kind])) yield();
     uint64_t got = w->slots[src_lane_abs];
-    yield();
+    w->xack[kind][t] = me;
+    while (behind(w->xack[kind])) yield();
     T r;
     memcpy(&r, &got, sizeof(T));
     return r;
@@ -229,7 +257,23 @@ inline T shfl_from(T v, int src_lane_abs) {
 #define hipLaunchKernelGGL(k, g, b, sh, st, ...) \
     hipemu::launch((g), (b), (sh), std::function<void()>([=]() { k(__VA_ARGS__); }))
 
-static inline void __syncthreads() { hipemu::yield(); }
+// A real barrier (arrival count + generation), like s_barrier: fibers may reach it after different numbers of yields -- the
+// quad kernels run DPP exchanges (two yields each) inside per-quad loops of data-dependent length.  Fibers that have returned
+// no longer count, as on the hardware.
+static inline void __syncthreads() {
+    hipemu::Worker* w = hipemu::g_worker;
+    const unsigned gen = w->bar_gen;
+    ++w->bar_count;
+    for (;;) {
+        if (w->bar_gen != gen) break;
+        if (w->bar_count >= w->alive) {
+            w->bar_count = 0;
+            ++w->bar_gen;
+            break;
+        }
+        hipemu::yield();
+    }
+}
 template <typename T>
 static inline T __shfl_down(T v, unsigned delta, int width = 64) {
     int t = hipemu::linear_tid();
@@ -314,7 +358,7 @@ static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }
 // DPP quad_perm: lane l of every quad reads lane (ctrl >> 2*(l&3)) & 3 of the same quad
 static inline int hipemu_quad_perm(int v, int ctrl) {
     const int t = hipemu::linear_tid(), lane = t & 63;
-    return hipemu::shfl_from(v, (t & ~63) + ((lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3)));
+    return hipemu::shfl_from(v, (t & ~63) + ((lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3)), 4);
 }
 #define DMVS_QUAD_PERM(v, ctrl) hipemu_quad_perm((v), (ctrl))
 #define DMVS_HOST_EMULATION 1

@@ -961,18 +961,25 @@ def test_getcost_quad_extreme_geometry(ops, golden):
 
 
 @pytest.mark.parametrize("C,H,W,D,scene", [(48, 20, 28, 16, True), (48, 18, 15, 48, True), (48, 12, 20, 9, False), (32, 11, 14, 7, False),
-                                           (16, 11, 14, 10, False)])
+                                           (16, 11, 14, 10, False), (48, 10, 150, 48, "wide"), (48, 70, 21, 44, "tall")])
 def test_warp_corr_init_quad(ops, C, H, W, D, scene):
     """quad-per-pixel plane sweep: planes in chunks of 8 (ragged last chunk), synthetic cameras and strongly rotated ones
-    (chunks whose planes spread over more than 8 texels take the per-plane path).  Against the oracle and the per-pixel kernel."""
+    (chunks whose planes spread over more than 8 texels take the per-plane path).  "wide" / "tall": baselines long enough
+    (~55 texels of disparity range along x / along y) that the LDS band of the whole sweep exceeds its 48 KB and the plane
+    groups are halved, down to single chunks.  Against the oracle and the per-pixel kernel."""
     B, S = 2, 3
     feats = [rnd(B, C, H, W, seed=80 + v) for v in range(S + 1)]
-    if scene:
+    if scene is True:
         _, proj, dvs = synth.synth_inputs(H * 8, W * 8, S, B=B, seed=7)
         pm = proj["stage1"]
         dv = torch.stack([dvs[:, 0], dvs[:, -1]], 1)
     else:
         pm = _cams(B, S + 1, H, W, 9)
+        if scene == "wide":
+            pm[:, :, 0, 0, 3] *= 4.0                      # t_x: -100 .. -300 mm
+        elif scene == "tall":
+            pm[:, :, 0, 1, 3] = pm[:, :, 0, 0, 3] * 4.0   # the long baseline along y
+            pm[:, :, 0, 0, 3] *= 0.1
         dv = torch.tensor([[1 / 935.0, 1 / 425.0], [1 / 800.0, 1 / 500.0]])
     disp_min, disp_max = dv[:, 0].contiguous(), dv[:, 1].contiguous()
     hyp = (torch.arange(D).view(1, -1, 1, 1) / (D - 1.0)).repeat(B, 1, H, W)
@@ -985,7 +992,8 @@ def test_warp_corr_init_quad(ops, C, H, W, D, scene):
     src_nhwc = torch.stack([f.permute(0, 2, 3, 1) for f in feats[1:]])
     out = ops.warp_corr_init_quad(dev(ops, _g4(ref_nhwc)), dev(ops, _g4(src_nhwc)), rt, dev(ops, disp_min), dev(ops, disp_max), D)
     out_g = ops.warp_corr_init(dev(ops, ref_nhwc), dev(ops, src_nhwc), rt, dev(ops, disp_min), dev(ops, disp_max), D, gather=True)
-    close(out, want, 1e-4)
+    # long baselines: the fp32 projection chain of oracle and kernels differs by ~1e-5 texels per texel of disparity
+    close(out, want, 1e-4 if isinstance(scene, bool) else 5e-4)
     close(out, out_g.cpu(), 2e-5)
 
 

@@ -96,8 +96,11 @@ def main():
     ap.add_argument("--min-radius", type=float, default=0.25)
     ap.add_argument("--max-radius", type=float, default=4.0)
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--init-only", action="store_true", help="only the stage-1 plane sweep (DMVS_PLANE_SWEEP=quad: the round-2 kernel)")
     a = ap.parse_args()
     o = Ops.for_device("cuda:0")
+    if a.init_only:
+        return init_case(o, a, 48, 48)
     for geometry, conf in (("noise", None), ("noise", 0.5), ("scene", 0.5), ("scene", 0.9)):
         getcost_case(o, a, 2, 32, 6, geometry, conf)
     if not a.quick:
