@@ -180,6 +180,74 @@ def stub_main(a):
         td.destroy_process_group()
 
 
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) of the warp kernels' source: PMC traffic files record it, a stale file is refused"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("warp_quad.hip", "dmvs_common.h"):
+        with open(os.path.join(ROOT, "diffmvs_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def train_main(a):
+    """BASELINE.json configs[3]: CasDiffMVS training step (forward(train) -> compute_inverse_loss -> backward -> ONE all-reduce of
+    the flat gradient bucket over RCCL -> clip(2.0) -> AdamW; reference train.py:179-209, :351), 768x576, 9 views, batch 4 per
+    GPU, fp32, through Trainer.train_sample.  A second line, never the headline: samples/s over all ranks, ms inside the
+    all-reduce, the RCCL world size seen."""
+    from diffmvs_amd import shard
+    from diffmvs_amd.trainer import Trainer
+    from models import CasDiffMVS
+    rank, world, local = shard.env_rank_world()
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    td = shard.init_distributed(a.backend, dev) if world > 1 else None
+    H, W, S = 576, 768, 8
+    B = a.batch if "--batch" in sys.argv else 4
+    args = synth.make_args("casdiffmvs", numdepth_initial=48)
+    model = CasDiffMVS(args, test=False)
+    model.load_state_dict(synth.synth_state_dict(model.state_dict(), 123), strict=True)
+    model.to(dev).train()
+    tr = Trainer(model, args, total_steps=1000000)
+    tr.time_allreduce = True
+    imgs, proj, dv, gt, mask = synth.synth_inputs(H, W, S, B=B, seed=300 + rank, with_gt=True)
+    sample = {"imgs": [i.to(dev) for i in imgs], "proj_matrices": {k: v.to(dev) for k, v in proj.items()}, "depth_values": dv.to(dev),
+              "depth": {k: v.to(dev) for k, v in gt.items()}, "mask": {k: v.to(dev) for k, v in mask.items()}}
+
+    def barrier():
+        if td:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    last = {}
+
+    def step():
+        last["loss"] = tr.train_sample(sample)[0]
+
+    for _ in range(a.warmup):
+        step()
+    tr.allreduce_events.clear()
+    elapsed = timed_steps(step, a.steps, 0, barrier)
+    elapsed = shard.barrier_and_max(elapsed, dev)
+    ar_ms = [s_.elapsed_time(e_) for s_, e_ in tr.allreduce_events]
+    if rank == 0:
+        print(json.dumps({
+            "metric": "training samples/sec (CasDiffMVS 768x576, 9 views)", "value": round(B * world * a.steps / elapsed, 3), "unit": "samples/s",
+            "n_gpus": world, "rccl_world_size": (td.get_world_size() if td else 1), "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (rendered slanted-plane scenes with ground-truth depth)",
+            "config": {"workload": "CasDiffMVS training step 768x576, 8 src views, batch 4 per GPU, fp32 (BASELINE.json configs[3]; not the headline)",
+                       "batch_per_gpu": B, "parallelism": f"data parallel x{world}: one all-reduce (SUM) of the {tr.flat.numel * 4 / 1e6:.2f} MB flat fp32 gradient bucket per step",
+                       "weights": "seeded random init"},
+            "allreduce_ms_per_step": round(sum(ar_ms) / max(1, len(ar_ms)), 4) if ar_ms else None,
+            "allreduce_bytes": tr.flat.numel * 4, "loss": float(last["loss"]),
+            "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}), flush=True)
+    if td:
+        td.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,9 +259,10 @@ def main():
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--src-views", type=int, default=5)
-    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3"],
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4"],
                     help="cfg2 = BASELINE.json configs[1] (the metric's configuration, default); cfg3 = configs[2]: CasDiffMVS 1152x864, "
-                         "7 source views, bf16 feature storage (a second line, not the headline)")
+                         "7 source views, bf16 feature storage; cfg4 = configs[3]: the CasDiffMVS training step, data parallel (second "
+                         "lines, not the headline)")
     ap.add_argument("--precision", default=None, choices=["fp32", "bf16", "fp16"], help="feature storage precision (default: the config's)")
     ap.add_argument("--graphs", action="store_true", help="run the timed steps through the captured HIP graph of the forward")
     ap.add_argument("--no-batch-sweep", action="store_true")
@@ -211,6 +280,8 @@ def main():
         return spawn_ranks(a.gpus)              # plain `python bench.py --gpus N`: start the N ranks ourselves
     if a.stub_model:
         return stub_main(a)
+    if a.config == "cfg4":
+        return train_main(a)
 
     from diffmvs_amd import shard
     rank, world, local = shard.env_rank_world()
@@ -308,6 +379,18 @@ def main():
     n_hybrid, n_plain, n_quad = len(timers["dmvs_getcost_f32"]), len(timers["dmvs_getcost_gather_f32"]), len(timers["dmvs_getcost_quad_f32"])
     wi_ms = [s.elapsed_time(e) for s, e in timers["dmvs_warp_corr_init_f32"] + timers["dmvs_warp_corr_init_quad_f32"]]
     gc_avg_s = sum(gc_ms) / max(1, len(gc_ms)) * 1e-3
+    # the launches of a step in order = the GRU iterations of the diffusion stage(s): iteration 1 samples around pure noise
+    # (scale * randn, update.py:472), iterations 2.. around the network's own estimate
+    per_step = len(gc_ms) // max(1, a.steps) if not a.graphs else len(gc_ms)
+    gc_bytes = timers.get("_getcost_bytes") or []
+    by_iter = []
+    for it in range(per_step if per_step and len(gc_ms) % per_step == 0 else 0):
+        ms_it = gc_ms[it::per_step]
+        by_it = gc_bytes[it::per_step] if len(gc_bytes) == len(gc_ms) else []
+        avg_us = sum(ms_it) / len(ms_it) * 1e3
+        bts = sum(by_it) / len(by_it) if by_it else None
+        by_iter.append({"launch_in_step": it + 1, "avg_launch_us": round(avg_us, 2), "launches": len(ms_it),
+                        "frac": round(bts / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if bts else None})
     h2, w2 = H // 4, W // 4
     alg = getcost_algorithmic_bytes(B, 32, S, args.CostNum[1], 4, h2, w2)
     h1, w1 = H // 8, W // 8
@@ -323,13 +406,17 @@ def main():
 
     # HBM traffic per getcost launch from the PMC passes (rocprofv3 cannot run inside the timed process); only
     # quoted when the committed measurement was taken at this batch size
-    traffic = None
-    tj = os.path.join(ROOT, "profiles", "r2_getcost_traffic.json" if eng.quad else "r1_getcost_traffic.json")   # the kernel of the timed steps
-    if os.path.exists(tj):
+    traffic, traffic_note = None, None
+    tj = os.path.join(ROOT, "profiles", "r3_getcost_traffic.json")
+    if eng.quad and os.path.exists(tj):
         with open(tj) as f:
             tinfo = json.load(f)
-        if tinfo.get("batch") == B and (H, W, S) == (512, 640, 5):
+        if tinfo.get("kernel_source_sha") != kernel_source_hash():
+            traffic_note = f"{os.path.relpath(tj, ROOT)} was measured on another version of warp_quad.hip: not quoted"
+        elif tinfo.get("batch") == B and (H, W, S) == (512, 640, 5):
             traffic = tinfo["traffic_bytes_per_launch"]
+            traffic_note = (os.path.relpath(tj, ROOT) + " (rocprofv3 PMC passes of this command on this kernel source, counters scaled by the "
+                            "factors of profiles/r3_traffic_calibration.json; not measured by this process)")
 
     result = {
         "metric": "depth-maps/sec (640x512, 5 src views)", "value": round(value, 3), "unit": "depth-maps/s",
@@ -344,9 +431,9 @@ def main():
                                 "GetCost: getcost_win_kernel<32,6> (LDS-staged source windows) / getcost_kernel<32,4,6> (per-pixel gather), picked per launch"),
                      "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "traffic_source": (os.path.relpath(tj, ROOT) + " (rocprofv3 PMC passes of an earlier run of this command; not measured by this process)") if traffic else None,
+                     "traffic_source": traffic_note,
                      "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(gc_avg_s * 1e6, 2),
-                     "launches_timed": len(gc_ms),
+                     "launches_timed": len(gc_ms), "per_gru_iteration": by_iter,
                      "launches_quad": n_quad, "launches_hybrid": n_hybrid, "launches_plain_gather": n_plain,
                      "tiles_on_gather_path": gather_tiles[0], "tiles_total": gather_tiles[1]},
         "roofline_warp_init": {"kernel": ("warp_init_quad_kernel<48> (stage-1 plane sweep, quad per pixel)" if eng.quad else

@@ -44,14 +44,30 @@ __device__ __forceinline__ float dmvs_act(float v, int act) {
 // GroupNorm statistics (per-(batch item, group) sum and sum of squares) are accumulated from many workgroups.  Floating-point
 // atomics would make the result depend on the arrival order; the 8-byte slots therefore hold FIXED-POINT integers (2^-16
 // units): integer addition is associative, so the statistics -- and with them the whole forward -- are bit-reproducible
-// run to run.  Range +-1.4e14, resolution 1.5e-5 per contribution (a workgroup's partial sum, magnitude 1e2..1e6).
+// run to run.  Resolution 1.5e-5 per contribution (a workgroup's partial sum, magnitude 1e2..1e6).
+// Magnitude contract: a contribution that is not finite, or whose magnitude reaches 2^34 (1.7e10: a 16 x 16 x 16 tile of
+// values with an rms of ~2000), POISONS the slot -- it is overwritten with a value no sum of in-range contributions can
+// move back below 2^62 -- and dmvs_gn_read returns NaN for it: a NaN / Inf / out-of-range activation makes its group's
+// outputs NaN, like the floating-point statistics of the reference would, instead of finite garbage or a silent wrap.
 // Callers keep treating the buffer as opaque zero-initialised 8-byte slots (all-zero bits = 0 in either reading).
 #define DMVS_GN_FIX 65536.0
+#define DMVS_GN_POISON 0x6000000000000000ull
 __device__ __forceinline__ void dmvs_gn_accumulate(double* slot, double v) {
-    atomicAdd(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)(long long)llrint(v * DMVS_GN_FIX));
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(slot);
+    if (!(fabs(v) < 17179869184.0)) {            // 2^34; false for NaN as well
+#ifdef DMVS_HOST_EMULATION
+        __atomic_store_n(p, DMVS_GN_POISON, __ATOMIC_RELAXED);
+#else
+        atomicExch(p, DMVS_GN_POISON);
+#endif
+        return;
+    }
+    atomicAdd(p, (unsigned long long)(long long)llrint(v * DMVS_GN_FIX));
 }
 __device__ __forceinline__ double dmvs_gn_read(const double* slot) {
-    return (double)(*reinterpret_cast<const long long*>(slot)) * (1.0 / DMVS_GN_FIX);
+    const long long f = *reinterpret_cast<const long long*>(slot);
+    if (f >= (1ll << 62) || f <= -(1ll << 62)) return __builtin_nan("");
+    return (double)f * (1.0 / DMVS_GN_FIX);
 }
 
 // 16-bit feature storage (DMVS_DTYPE_BF16 / DMVS_DTYPE_F16): round-to-nearest-even conversions; arithmetic stays fp32.

@@ -424,8 +424,9 @@ __global__ void __launch_bounds__(DMVS_BLOCK) getcost_quad_kernel(const dmvs_get
         HypQ own[HPL];
 #pragma unroll
         for (int h = 0; h < HPL; ++h) own[h] = project_q(ray, own_depth[h], exists[h], H, W);
-        const unsigned view_off = (unsigned)(((long)s * d.B + b) * (long)hw * Feat<C, FT>::TEXEL_BYTES) + Feat<C, FT>::lane_bytes(q);
-        quad_accumulate<C, FT, N, TPT>(base, view_off, W, own, H, W, ref, w, acc);
+        // the view's image: a 64-bit workgroup-uniform (scalar) base, 32-bit offsets inside the view
+        const char* vbase = base + ((long)s * d.B + b) * (long)hw * Feat<C, FT>::TEXEL_BYTES;
+        quad_accumulate<C, FT, N, TPT>(vbase, Feat<C, FT>::lane_bytes(q), W, own, H, W, ref, w, acc);
     }
     if (live) {
         const float inv_w = 1.0f / wsum;
@@ -456,8 +457,8 @@ warp_init_quad_kernel(const void* __restrict__ ref_f, const void* __restrict__ s
     load_ref<C, FT>(ref_f, pq, q, ref);
     RayQ ray;
     ray.init(rt + ((long)b * S + s) * 12, (float)x, (float)y);
-    const char* base = reinterpret_cast<const char*>(src);
-    const unsigned view_off = (unsigned)(((long)s * B + b) * (long)Hs * Ws * Feat<C, FT>::TEXEL_BYTES) + Feat<C, FT>::lane_bytes(q);
+    const char* base = reinterpret_cast<const char*>(src) + ((long)s * B + b) * (long)Hs * Ws * Feat<C, FT>::TEXEL_BYTES;   // this view (scalar)
+    const unsigned view_off = Feat<C, FT>::lane_bytes(q);
     const float dmin = disp_min[b], dmax = disp_max[b];
     const float dm1 = (float)(D - 1);
     // the plane depths are the same for every pixel of the batch item: one table per workgroup instead of a division chain
@@ -542,9 +543,8 @@ warp_init_band_kernel(const void* __restrict__ ref_f, const void* __restrict__ s
     load_ref<C, FT>(ref_f, pq, q, ref);
     RayQ ray;
     ray.init(rt + ((long)b * S + s) * 12, (float)x, (float)y);
-    const char* gbase = reinterpret_cast<const char*>(src);
-    const unsigned view_base = (unsigned)(((long)s * B + b) * (long)Hs * Ws * TB);
-    const unsigned view_off = view_base + Feat<C, FT>::lane_bytes(q);
+    const char* gbase = reinterpret_cast<const char*>(src) + ((long)s * B + b) * (long)Hs * Ws * TB;      // this view (scalar base)
+    const unsigned view_off = Feat<C, FT>::lane_bytes(q);
     const float dmin = disp_min[b], dmax = disp_max[b];
     const float dm1 = (float)(D - 1);
     if (tid < min(D, TAB)) depth_tab[tid] = dmvs_disp_to_depth((float)tid / dm1, dmin, dmax);
@@ -602,7 +602,7 @@ warp_init_band_kernel(const void* __restrict__ ref_f, const void* __restrict__ s
             // every wave is past group_box's barrier, i.e. done with the previous band
             const int ppr = ncols * (TB / 16), npieces = nrows * ppr;       // 16-byte pieces per band row / in the band
             const float inv_ppr = 1.0f / (float)ppr;
-            const unsigned corner = view_base + (unsigned)(__mul24(by0, Ws) + bx0) * (unsigned)TB;
+            const unsigned corner = (unsigned)(__mul24(by0, Ws) + bx0) * (unsigned)TB;
             for (int i0 = wave * 64; i0 < npieces; i0 += DMVS_BLOCK) {
                 const int i = i0 + lane;
                 if (i < npieces) {
@@ -665,10 +665,10 @@ extern "C" int dmvs_getcost_quad_f32(const dmvs_getcost_desc* dp, void* stream) 
     const dmvs_getcost_desc& d = *dp;
     if (d.G != 4 || !d.ref || !d.src || !d.rt || !d.inv_depth || !d.view_w || !d.out_cost || !d.out_samples) return DMVS_EINVAL;
     if (d.feat_dtype < DMVS_DTYPE_F32 || d.feat_dtype > DMVS_DTYPE_F16) return DMVS_EINVAL;
-    const int esize = d.feat_dtype == DMVS_DTYPE_F32 ? 4 : 2;
-    if ((long)d.S * d.B * d.H * d.W * d.C * esize >= (1L << 32)) return DMVS_EINVAL;   // 32-bit byte offsets over the source stack
     hipStream_t st = (hipStream_t)stream;
-    if ((long)d.H * d.W >= (1L << 24) || d.B > 65535) return DMVS_EINVAL;          // 24-bit row multiplies, grid.y
+    // 24-bit row multiplies and 32-bit byte offsets inside ONE view's image (2^24 texels x <= 192 bytes < 2^32); the source
+    // stack as a whole may be any size (64-bit per-view bases); grid.y
+    if ((long)d.H * d.W >= (1L << 24) || d.B > 65535) return DMVS_EINVAL;
     dim3 grid(dmvs_ceil_div((long)d.H * d.W, DMVS_BLOCK / 4), (unsigned)d.B), block(DMVS_BLOCK);
     if (d.feat_dtype == DMVS_DTYPE_BF16) return launch_getcost_quad<DMVS_DTYPE_BF16>(d, grid, block, st);
     if (d.feat_dtype == DMVS_DTYPE_F16) return launch_getcost_quad<DMVS_DTYPE_F16>(d, grid, block, st);
@@ -687,25 +687,25 @@ static int launch_warp_init_quad(const void* ref, const void* src, const float* 
     return dmvs_launch_status();
 }
 
-// LDS-band form: band bytes per workgroup -- 48 KB = 3 workgroups (12 waves) per CU, 38 KB = 4 (DMVS_BAND_KB=38|48 for A/B runs)
-static int band_kb() {
-    static const int kb = [] {
-        const char* e = getenv("DMVS_BAND_KB");
-        return e ? atoi(e) : 48;
+// LDS-band form: 48 KB of band per workgroup = 3 workgroups (12 waves) per CU; occupancy is set by LDS, not registers, so the
+// texel loop can afford 4 texels per trip (DMVS_BAND_TPT=2|4 for A/B runs)
+static int band_tpt() {
+    static const int v = [] {
+        const char* e = getenv("DMVS_BAND_TPT");
+        return e ? atoi(e) : 2;
     }();
-    return kb;
+    return v;
 }
 template <int FT>
 static int launch_warp_init_band(const void* ref, const void* src, const float* rt, const float* disp_min, const float* disp_max, float* out,
                                  int B, int S, int C, int D, int H, int W, int Hs, int Ws, hipStream_t st) {
     const int tiles_x = (W + BTW - 1) / BTW, tiles_y = (H + BTH - 1) / BTH;
     dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(B * S)), block(DMVS_BLOCK);
-#define DMVS_WIB(CC, KB) hipLaunchKernelGGL((warp_init_band_kernel<CC, QUAD_TPT, FT, KB * 1024>), grid, block, 0, st, ref, src, rt, disp_min, disp_max, out, B, S, D, H, W, Hs, Ws, tiles_x)
-    const bool small = band_kb() < 48;
-    if (C == 48 && small) DMVS_WIB(48, 38);
-    else if (C == 48) DMVS_WIB(48, 48);
-    else if (C == 32) DMVS_WIB(32, 48);
-    else if (C == 16) DMVS_WIB(16, 48);
+#define DMVS_WIB(CC, TPT) hipLaunchKernelGGL((warp_init_band_kernel<CC, TPT, FT, 48 * 1024>), grid, block, 0, st, ref, src, rt, disp_min, disp_max, out, B, S, D, H, W, Hs, Ws, tiles_x)
+    if (C == 48 && band_tpt() == 4) DMVS_WIB(48, 4);
+    else if (C == 48) DMVS_WIB(48, 2);
+    else if (C == 32) DMVS_WIB(32, 2);
+    else if (C == 16) DMVS_WIB(16, 2);
     else return DMVS_EINVAL;
 #undef DMVS_WIB
     return dmvs_launch_status();
@@ -725,7 +725,6 @@ extern "C" int dmvs_warp_corr_init_quad_f32(const void* ref, const void* src, co
                                             int32_t D, int32_t H, int32_t W, int32_t Hs, int32_t Ws, int32_t feat_dtype, void* stream) {
     if (G != 4 || D < 2 || !ref || !src || !rt || !out) return DMVS_EINVAL;
     if (feat_dtype < DMVS_DTYPE_F32 || feat_dtype > DMVS_DTYPE_F16) return DMVS_EINVAL;
-    if ((long)S * B * Hs * Ws * C * (feat_dtype == DMVS_DTYPE_F32 ? 4 : 2) >= (1L << 32)) return DMVS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if ((long)H * W >= (1L << 24) || (long)Hs * Ws >= (1L << 24) || (long)B * S > 65535) return DMVS_EINVAL;
     if (plane_sweep_band()) {

@@ -186,16 +186,19 @@ def run_encoder(o: Ops, enc, cost, samples, out=None, out_cstride=None, out_coff
 
 class GnArena:
     """GroupNorm statistics scratch: [slot][B*4*2] doubles, zeroed with one memset per forward; the
-    producing conv's epilogue accumulates into a slot, groupnorm_apply consumes it."""
+    producing conv's epilogue accumulates into a slot, groupnorm_apply consumes it.
+    One buffer PER BATCH SIZE, kept for the life of the engine (16 KB x B): a captured HIP graph holds the raw pointer of
+    the buffer it was captured with in its memset / atomics / reads, so a buffer must never go back to the allocator
+    while a graph of that batch size may still be replayed (an eval run whose last batch is smaller alternates sizes)."""
     SLOTS = 256
 
     def __init__(self, ops: Ops):
-        self.ops, self.buf, self.next = ops, None, 0
+        self.ops, self.bufs, self.buf, self.next = ops, {}, None, 0
 
     def reset(self, B):
-        need = (self.SLOTS, B * 8)
-        if self.buf is None or tuple(self.buf.shape) != need:
-            self.buf = torch.zeros(*need, dtype=torch.float64, device=self.ops.device)
+        self.buf = self.bufs.get(B)
+        if self.buf is None:
+            self.buf = self.bufs[B] = torch.zeros(self.SLOTS, B * 8, dtype=torch.float64, device=self.ops.device)
         else:
             self.buf.zero_()
         self.next = 0

@@ -88,7 +88,16 @@ def main(argv=None):
     ap.add_argument("--min_radius", type=float, default=None)
     ap.add_argument("--max_radius", type=float, default=None)
     ap.add_argument("--filter", action="store_true", help="fuse the written depth maps with the GPU consistency filter afterwards")
+    # post-processing thresholds: the reference's flags and defaults (test.py:69-76); Tanks&Temples / ETH3D scenes take their
+    # per-scene tables instead (test.py:217-293), as in the reference
+    ap.add_argument("--geo_mask_thres", type=int, default=2, help="depth must be consistent in at least N source views")
+    ap.add_argument("--geo_pixel_thres", type=float, default=1.0, help="reprojection error threshold in pixels")
+    ap.add_argument("--geo_depth_thres", type=float, default=0.01, help="relative depth error threshold")
+    ap.add_argument("--photo_thres", type=float, nargs="+", default=[0.3, 0.0, 0.0], help="confidence threshold per stage")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--noise_seed", type=int, default=None,
+                    help="draw the diffusion noise from synth.NoiseSource(seed) (a host generator stream: the same depth maps on any "
+                         "device and against the CPU oracle) instead of the device RNG of update.py:472")
     a = ap.parse_args(argv)
 
     rank, world, local = shard.env_rank_world()
@@ -103,17 +112,22 @@ def main(argv=None):
     else:
         model.load_state_dict(synth.synth_state_dict(model.state_dict(), 123))
     model.to(device)
-    scenes = [ln.strip() for ln in open(a.testlist)] if a.testlist else [""]
+    if a.noise_seed is not None:
+        model.noise_source = synth.NoiseSource(a.noise_seed)
+    scenes = [""]
+    if a.testlist:
+        with open(a.testlist) as f:
+            scenes = [ln.strip() for ln in f if ln.strip()]
     mine = shard.shard_scenes(scenes, rank, world)
     times, report = run_scenes(model, a, mine, device)
     res = {"rank": rank, "scenes": mine, "views": len(times), "avg_time_s": float(np.mean(times)) if times else None, "errors": report}
     if a.filter:
         from . import fusion
-        for scene in mine:
-            out_folder = os.path.join(a.outdir, scene)
-            n = fusion.filter_depth(os.path.join(a.testpath, scene), out_folder, os.path.join(a.outdir, (scene or "scene") + ".ply"),
-                                    method=a.method, dataset=a.dataset, scan=scene, device=device)
+        for scene in mine:      # the per-dataset protocol of test.py:298-367
+            kw = fusion.scene_protocol(a.dataset, scene, a.outdir, a.geo_mask_thres, a.geo_pixel_thres, a.geo_depth_thres, a.photo_thres)
+            n = fusion.filter_depth(os.path.join(a.testpath, scene), os.path.join(a.outdir, scene), method=a.method, device=device, **kw)
             res.setdefault("fused_points", {})[scene] = n
+            res.setdefault("ply", {})[scene] = kw["plyfilename"]
     print(json.dumps(res), flush=True)
     return res
 

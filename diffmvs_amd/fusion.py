@@ -25,6 +25,47 @@ DH_DIST = {"Family": 12, "Francis": 8, "Horse": 4, "Lighthouse": 8, "M60": 8, "P
 DH_REL_DIFF = {"Family": 1600, "Francis": 1600, "Horse": 1300, "Lighthouse": 1600, "M60": 1600, "Panther": 1300, "Playground": 1600,
                "Train": 1600, "Auditorium": 1300, "Ballroom": 1300, "Courtroom": 1300, "Museum": 1300, "Palace": 1300, "Temple": 1500}
 
+# test.py:217-232: photometric thresholds per Tanks&Temples scene (filter_depth_dynamic's `photo_thres`)
+TANK_PHOTO_THRES = {"Family": [0.8, 0.8, 0.95], "Francis": [0.3, 0.6, 0.6], "Horse": [0.15, 0.4, 0.8], "Lighthouse": [0.3, 0.8, 0.9],
+                    "M60": [0.7, 0.8, 0.95], "Panther": [0.3, 0.3, 0.95], "Playground": [0.3, 0.8, 0.9], "Train": [0.3, 0.6, 0.95],
+                    "Auditorium": [0.0, 0.0, 0.0], "Ballroom": [0.3, 0.3, 0.5], "Courtroom": [0.0, 0.2, 0.2], "Museum": [0.3, 0.3, 0.7],
+                    "Palace": [0.3, 0.3, 0.4], "Temple": [0.3, 0.5, 0.5]}
+# test.py:240-293: ETH3D per-scene geometric thresholds (views that must agree / reprojection error in pixels)
+ETH3D_GEO_MASK_THRES = {s: 1 for s in (
+    "courtyard", "delivery_area", "electro", "facade", "kicker", "meadow", "office", "pipes", "playground", "relief", "relief_2",
+    "terrace", "terrains", "botanical_garden", "boulders", "door", "exhibition_hall", "lecture_room", "living_room", "lounge",
+    "observatory", "old_computer", "statue", "terrace_2")}
+ETH3D_GEO_MASK_THRES["bridge"] = 2
+ETH3D_GEO_PIXEL_THRES = {"courtyard": 0.5, "delivery_area": 0.5, "electro": 1, "facade": 1, "kicker": 1, "meadow": 2, "office": 2,
+                         "pipes": 2, "playground": 1, "relief": 1, "relief_2": 1, "terrace": 0.5, "terrains": 1, "botanical_garden": 1,
+                         "boulders": 0.5, "bridge": 0.5, "door": 0.5, "exhibition_hall": 0.5, "lecture_room": 0.5, "living_room": 0.5,
+                         "lounge": 2, "observatory": 1, "old_computer": 2, "statue": 1, "terrace_2": 0.5}
+
+
+def scene_protocol(dataset: str, scene: str, outdir: str, geo_mask_thres=2, geo_pixel_thres=1.0, geo_depth_thres=0.01,
+                   photo_thres=(0.3, 0.0, 0.0)) -> dict:
+    """What the reference's test.py:298-367 passes to filter_depth / filter_depth_dynamic for one scene of a dataset: the
+    keyword arguments of filter_depth() below plus `plyfilename`.  dtu: the command-line thresholds, pc/mvs<id>_l3.ply;
+    tank: scan = the list entry without its 'intermediate/' / 'advanced/' prefix, that scene's photometric thresholds and
+    dynamic geometric rule; eth3d: that scene's geometric thresholds; general: the command-line thresholds, pc.ply."""
+    kw = dict(geo_mask_thres=geo_mask_thres, geo_pixel_thres=geo_pixel_thres, geo_depth_thres=geo_depth_thres,
+              photo_thres=list(photo_thres), dataset=dataset, scan=None)
+    if dataset == "dtu":
+        kw["plyfilename"] = os.path.join(outdir, "pc", "mvs{:0>3}_l3.ply".format(int(scene[4:])))
+    elif dataset == "tank":
+        scan = scene.split("/")[-1]
+        if scan not in DH_VIEW_NUM:
+            raise KeyError(f"no Tanks&Temples fusion parameters for scene {scan!r} (known: {sorted(DH_VIEW_NUM)})")
+        kw.update(scan=scan, photo_thres=list(TANK_PHOTO_THRES[scan]), plyfilename=os.path.join(outdir, "pc", f"{scan}.ply"))
+    elif dataset == "eth3d":
+        if scene not in ETH3D_GEO_MASK_THRES:
+            raise KeyError(f"no ETH3D fusion parameters for scene {scene!r}")
+        kw.update(geo_mask_thres=ETH3D_GEO_MASK_THRES[scene], geo_pixel_thres=ETH3D_GEO_PIXEL_THRES[scene],
+                  plyfilename=os.path.join(outdir, "pc", f"{scene}.ply"))
+    else:
+        kw["plyfilename"] = os.path.join(outdir, "pc.ply")
+    return kw
+
 
 def compose_mats(ref_K: np.ndarray, ref_E: np.ndarray, src_K: np.ndarray, src_E: np.ndarray) -> np.ndarray:
     """the six matrices of one (reference, source) pair in the kernel's layout, composed in fp32 like filter.py:22-45"""
@@ -100,6 +141,8 @@ def filter_depth(pair_folder, out_folder, plyfilename, geo_mask_thres=3, geo_pix
     scene's output tree; writes mask/*.png and the fused point cloud.  -> number of fused points."""
     from PIL import Image
     ops = ops or Ops.for_device(device)
+    if os.path.dirname(plyfilename):
+        os.makedirs(os.path.dirname(plyfilename), exist_ok=True)
     pairs = IO.read_pair_file(os.path.join(pair_folder, "pair.txt"), dataset)
     nconf = 3 if method == "casdiffmvs" else 2
     dynamic = [DH_VIEW_NUM[scan], DH_DIST[scan], DH_REL_DIFF[scan]] if dataset == "tank" else None

@@ -8,14 +8,26 @@ One process per GPU.  All trainable parameters live in ONE flat fp32 bucket (Fla
 i.e. three launches that read each array once, instead of ~600 per-tensor optimizer launches.
 The LR schedule is the reference's OneCycle (linear anneal, pct_start 0.05, no momentum cycling); checkpoints use
 the reference's layout {'epoch', 'model', 'optimizer'} with a torch.optim.AdamW-compatible optimizer state.
-The reference's default `--lr_sche mslr` (MultiStepLR) has no counterpart here: every training script of the reference
-passes `--lr_sche onecycle`, which is what is reproduced; a constant lr is the other option (total_steps=None)."""
+The reference's default `--lr_sche mslr` (MultiStepLR over epochs, `--lrepochs "10,12,14:2"`, train.py:34-36, :367-371) is
+`milestones` / `lr_gamma` / `steps_per_epoch`; a constant lr is total_steps=None without milestones."""
 from __future__ import annotations
 
 import torch
 import torch.distributed as dist
 
 from .ops import Ops
+
+
+def parse_lrepochs(spec: str = "10,12,14:2"):
+    """the reference's `--lrepochs` string -> (milestone epochs, gamma): "10,12,14:2" = halve at epochs 10, 12, 14 (train.py:368-369)"""
+    ms, rate = spec.split(":")
+    return [int(e) for e in ms.split(",")], 1.0 / float(rate)
+
+
+def multi_step_lr(step: int, base_lr: float, milestones, gamma: float, steps_per_epoch: int) -> float:
+    """lr of optimisation step `step` (0-based) under torch's MultiStepLR stepped once per EPOCH (train.py:133, :370)"""
+    epoch = step // steps_per_epoch
+    return base_lr * gamma ** sum(1 for m in milestones if m <= epoch)
 
 
 def one_cycle_lr(step: int, max_lr: float, total_steps: int, pct_start: float = 0.05, div_factor: float = 25.0,
@@ -71,13 +83,17 @@ class FlatParams:
 
 class Trainer:
     def __init__(self, model, args, ops: Ops | None = None, lr=1e-3, wd=1e-3, betas=(0.9, 0.999), eps=1e-8, max_norm=2.0,
-                 total_steps: int | None = None, loss_rate=0.9, distributed: bool = True):
-        """`total_steps` = len(loader) * epochs + 100 for the reference's onecycle schedule (train.py:374); None = constant lr"""
+                 total_steps: int | None = None, loss_rate=0.9, distributed: bool = True, milestones=None, lr_gamma: float = 0.5,
+                 steps_per_epoch: int | None = None):
+        """`total_steps` = len(loader) * epochs + 100 for the reference's onecycle schedule (train.py:374); `milestones` (+
+        `lr_gamma`, `steps_per_epoch` = len(loader)) for its default MultiStepLR (parse_lrepochs); neither = constant lr"""
+        if milestones is not None and (total_steps is not None or not steps_per_epoch):
+            raise ValueError("MultiStepLR needs steps_per_epoch and excludes the onecycle schedule (total_steps)")
+        self.milestones, self.lr_gamma, self.steps_per_epoch = milestones, lr_gamma, steps_per_epoch
         from models import compute_inverse_loss
         self.model, self.args, self.loss_fn = model, args, compute_inverse_loss
         dev = next(model.parameters()).device
         self.ops = ops if ops is not None else Ops.for_device(dev)
-        model._train_ops = self.ops
         self.flat = FlatParams(model)
         self.exp_avg = torch.zeros_like(self.flat.data)
         self.exp_avg_sq = torch.zeros_like(self.flat.data)
@@ -85,6 +101,7 @@ class Trainer:
         self.lr, self.wd, self.betas, self.eps, self.max_norm = lr, wd, betas, eps, max_norm
         self.total_steps, self.loss_rate = total_steps, loss_rate
         self.step_count = 0
+        self.time_allreduce, self.allreduce_events = False, []        # bench: an event pair around the collective
         self.world = dist.get_world_size() if distributed and dist.is_available() and dist.is_initialized() else 1
         if self.world > 1:                                    # identical start on every rank (DDP's initial broadcast)
             dist.broadcast(self.flat.data, src=0)
@@ -92,6 +109,8 @@ class Trainer:
                 dist.broadcast(b, src=0)
 
     def current_lr(self):
+        if self.milestones is not None:
+            return multi_step_lr(self.step_count, self.lr, self.milestones, self.lr_gamma, self.steps_per_epoch)
         return self.lr if self.total_steps is None else one_cycle_lr(self.step_count, self.lr, self.total_steps)
 
     def zero_grad(self):
@@ -103,7 +122,13 @@ class Trainer:
         loss.backward()
         f.check_views()
         if self.world > 1:
+            if self.time_allreduce:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             dist.all_reduce(f.grad, op=dist.ReduceOp.SUM)     # the one collective of the training path
+            if self.time_allreduce:
+                ev[1].record()
+                self.allreduce_events.append(ev)
         o.sumsq(f.grad, self.sumsq)
         lr = self.current_lr()
         self.step_count += 1
@@ -134,6 +159,8 @@ class Trainer:
                  "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "amsgrad": False, "maximize": False,
                  "foreach": None, "capturable": False, "differentiable": False, "fused": None,
                  "params": list(range(len(self.flat.params)))}
+        if self.milestones is not None:
+            group["initial_lr"] = self.lr                      # what MultiStepLR(last_epoch = start_epoch - 1) reads on resume
         if self.total_steps is not None:
             # what torch's OneCycleLR(last_epoch != -1) reads on resume (reference train.py:372-376; div_factor 25,
             # final_div_factor 1e4, cycle_momentum=False)

@@ -72,7 +72,6 @@ class CasDiffMVS(nn.Module):
         # ~350 launches per forward are host-bound; the returned tensors are then overwritten by the next call
         self.hip_graphs = os.environ.get("DMVS_GRAPHS", "0") == "1"
         self.t_source = None          # train mode: callable (B, timesteps, device) -> int64 [B]; None = torch.randint
-        self._train_ops = None        # tests pin the host-emulated library here
         self._engine = None
         self._engine_key = None
 
@@ -112,9 +111,7 @@ class CasDiffMVS(nn.Module):
             if depth_gt_ms is None:
                 raise ValueError("CasDiffMVS in train mode needs depth_gt_ms (reference diffusion.py:169)")
             from diffmvs_amd.train import forward_train
-            ops = self._train_ops
-            if ops is None:
-                ops = Ops.for_device(next(self.parameters()).device)
+            ops = Ops.for_device(next(self.parameters()).device)
             return forward_train(self, imgs, proj_matrices, depth_values, depth_gt_ms, ops)
         eng = self.engine()
         if self.hip_graphs:

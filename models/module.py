@@ -19,13 +19,10 @@ from diffmvs_amd.ops import Ops
 
 class HipModule(nn.Module):
     """nn.Module whose forward() runs on libdmvs_hip.so.  Weights are packed into kernel layout on first
-    use and re-packed when any parameter / buffer changes; `_ops` may be pinned by tests, otherwise
-    it is bound to the parameters' HIP device (no CPU path)."""
-    _ops = None
+    use and re-packed when any parameter / buffer changes; the library binding is that of the parameters' HIP
+    device (Ops.for_device: no CPU path)."""
 
     def ops(self, like=None) -> Ops:
-        if self._ops is not None:
-            return self._ops
         t = next(self.parameters(), None)
         if t is None:
             t = like
@@ -298,7 +295,7 @@ class SepConvGRU(HipModule):        # reference models/module.py:152-179
 def differentiable_warping(src_fea, src_proj, ref_proj, depth_values):
     """get warped source image features (reference models/module.py:181-218): src_fea [B,C,Hs,Ws], projs [B,4,4],
     depth_values [B,D,H,W] -> [B,C,D,H,W]."""
-    o = HipModule._ops or Ops.for_device(src_fea.device)
+    o = Ops.for_device(src_fea.device)
     proj = torch.matmul(src_proj.double(), torch.linalg.inv(ref_proj.double()))      # 4x4 camera algebra
     rt = torch.cat([proj[:, :3, :3].reshape(-1, 9), proj[:, :3, 3]], 1).float().contiguous()
     return o.warp_volume(_dev(o, src_fea), rt.to(o.device), _dev(o, depth_values))
@@ -306,7 +303,7 @@ def differentiable_warping(src_fea, src_proj, ref_proj, depth_values):
 
 def upsample_depth(depth, mask, ratio=8):
     """upsample depth map using convex combination (reference models/module.py:237-248): [N,1,H,W] -> [N,rH,rW]."""
-    o = HipModule._ops or Ops.for_device(depth.device)
+    o = Ops.for_device(depth.device)
     N = depth.shape[0]
     one, zero = torch.ones(N, device=o.device), torch.zeros(N, device=o.device)     # identity depth transform
     up, _ = o.convex_upsample(_dev(o, depth), _dev(o, mask), zero, one, ratio)

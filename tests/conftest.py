@@ -105,6 +105,16 @@ def hip_ops():
     return Ops.for_device("cuda:0")
 
 
+def pin_ops(monkeypatch, ops):
+    """Make `ops` the binding every model / module forward resolves (Ops.for_device) for the duration of a test: the CPU
+    tests run the drop-in package on the host emulation this way; the product has no such switch."""
+    from diffmvs_amd.ops import Ops
+    monkeypatch.setattr(Ops, "for_device", classmethod(lambda cls, device: ops))
+
+
 @pytest.fixture(params=[pytest.param("emu"), pytest.param("hip", marks=pytest.mark.gpu)])
-def ops(request):
-    return emu_ops() if request.param == "emu" else hip_ops()
+def ops(request, monkeypatch):
+    o = emu_ops() if request.param == "emu" else hip_ops()
+    if request.param == "emu":
+        pin_ops(monkeypatch, o)
+    return o

@@ -121,9 +121,10 @@ struct Worker {
     std::vector<Fiber> fibers;
     char* stacks = nullptr;
     std::vector<uint64_t> slots;   // shuffle exchange, one per thread of the block
-    // rendezvous counters of the cross-lane exchanges, per thread and group kind (0 = wave-wide shuffles, 1 = DPP quad_perm):
-    // exchanges posted / exchanges whose partner slot has been read
-    std::vector<unsigned> xseq[2], xack[2];
+    // rendezvous of the cross-lane exchanges, one counting barrier per group and group kind (0 = waves: the shuffles,
+    // 1 = quads: DPP quad_perm)
+    struct GroupBar { int arrived = 0, live = 0; unsigned gen = 0; };
+    std::vector<GroupBar> gbar[2];
     std::vector<float> slots_a, slots_b;   // MFMA operand exchange
     int current = -1;
     int alive = 0;                 // fibers of the running block that have not returned yet
@@ -155,8 +156,11 @@ inline int linear_tid() { return g_threadIdx.x + g_blockDim.x * (g_threadIdx.y +
 
 inline void run_block(Worker& w, int nthreads) {
     for (int k = 0; k < 2; ++k) {
-        std::fill(w.xseq[k].begin(), w.xseq[k].end(), 0u);
-        std::fill(w.xack[k].begin(), w.xack[k].end(), 0u);
+        const int gs = k == 0 ? 64 : 4;
+        for (size_t g = 0; g < w.gbar[k].size(); ++g) {
+            w.gbar[k][g].arrived = 0;
+            w.gbar[k][g].live = std::min(gs, nthreads - (int)g * gs);
+        }
     }
     for (int t = 0; t < nthreads; ++t) {
         Fiber& f = w.fibers[t];
@@ -178,7 +182,11 @@ inline void run_block(Worker& w, int nthreads) {
             w.current = t;
             set_tid(t);
             hipemu_switch(&w.main_sp, w.fibers[t].sp);
-            if (w.fibers[t].done) --w.alive;
+            if (w.fibers[t].done) {
+                --w.alive;
+                --w.gbar[0][t >> 6].live;
+                --w.gbar[1][t >> 2].live;
+            }
         }
     }
 }
@@ -194,10 +202,8 @@ inline void launch(dim3 grid, dim3 block, size_t, const std::function<void()>& b
         w.fibers.resize(nthreads);
         w.stacks = stack_pool().get();
         w.slots.resize(nthreads);
-        for (int k = 0; k < 2; ++k) {
-            w.xseq[k].assign(nthreads, 0);
-            w.xack[k].assign(nthreads, 0);
-        }
+        w.gbar[0].resize((nthreads + 63) / 64);
+        w.gbar[1].resize((nthreads + 3) / 4);
         w.slots_a.resize(nthreads);
         w.slots_b.resize(nthreads);
         w.body = &body;
@@ -226,24 +232,30 @@ inline void launch(dim3 grid, dim3 block, size_t, const std::function<void()>& b
 // of a group rendezvous explicitly -- every live member has posted its value before anyone reads, everyone has read before
 // anyone posts the next one -- because the groups of a block do not run in lockstep here: the quad kernels loop a
 // data-dependent number of times per quad, and unlike a hardware wave the fibers do not reconverge afterwards.
+inline void group_barrier(Worker::GroupBar& gb) {
+    const unsigned gen = gb.gen;
+    ++gb.arrived;
+    for (;;) {
+        if (gb.gen != gen) return;
+        if (gb.arrived >= gb.live) {      // (re-checked while waiting: members may return meanwhile)
+            gb.arrived = 0;
+            ++gb.gen;
+            return;
+        }
+        yield();
+    }
+}
 template <typename T>
 inline T shfl_from(T v, int src_lane_abs, int gsize = 64) {
     Worker* w = g_worker;
-    const int kind = gsize == 64 ? 0 : 1;
-    const int t = linear_tid(), g0 = t & ~(gsize - 1), g1 = std::min<int>(g0 + gsize, (int)w->fibers.size());
+    const int t = linear_tid();
+    Worker::GroupBar& gb = gsize == 64 ? w->gbar[0][t >> 6] : w->gbar[1][t >> 2];
     uint64_t raw = 0;
     memcpy(&raw, &v, sizeof(T));
     w->slots[t] = raw;
-    const unsigned me = ++w->xseq[kind][t];
-    auto behind = [&](const std::vector<unsigned>& c) {
-        for (int u = g0; u < g1; ++u)
-            if (!w->fibers[u].done && (int)(c[u] - me) < 0) return true;
-        return false;
-    };
-    while (behind(w->xseq[kind])) yield();
+    group_barrier(gb);                    // every live member has posted
     uint64_t got = w->slots[src_lane_abs];
-    w->xack[kind][t] = me;
-    while (behind(w->xack[kind])) yield();
+    group_barrier(gb);                    // every live member has read: the slots may be overwritten
     T r;
     memcpy(&r, &got, sizeof(T));
     return r;

@@ -6,43 +6,94 @@ import os
 
 import numpy as np
 import pytest
+import torch
 
+from conftest import rel_l1
 from diffmvs_amd import formats as IO
 from diffmvs_amd import synth
+from oracle import diffmvs_oracle as O
 
 pytestmark = pytest.mark.gpu
 
 
-def test_eval_driver_and_fusion(tmp_path, capsys):
+def _write_scene(root, H, W, V, seed, cam_folder="cams", with_gt=True):
+    """a scene tree in the reference's input layout: images/%08d.jpg, <cam_folder>/%08d_cam.txt, pair.txt (+ depth_gt PFMs)"""
     from PIL import Image
-    from diffmvs_amd import eval as EV
-    H, W, V = 64, 96, 4
-    imgs, proj, dv = synth.synth_inputs(H, W, V - 1, B=1, seed=4)
-    depths = synth.synth_view_depths(H, W, V, seed=4)
-    root = tmp_path / "scene"
-    for d in ("images", "cams", "depth_gt"):
+    imgs, proj, dv = synth.synth_inputs(H, W, V - 1, B=1, seed=seed)
+    depths = synth.synth_view_depths(H, W, V, seed=seed)
+    for d in ("images", cam_folder) + (("depth_gt",) if with_gt else ()):
         os.makedirs(root / d)
     for v in range(V):
         Image.fromarray((imgs[v][0].permute(1, 2, 0).numpy() * 255).astype(np.uint8)).save(str(root / f"images/{v:08d}.png"))
         os.rename(root / f"images/{v:08d}.png", root / f"images/{v:08d}.jpg")
         cam = proj["stage4"][0, v].numpy()
-        with open(root / f"cams/{v:08d}_cam.txt", "w") as f:
+        with open(root / f"{cam_folder}/{v:08d}_cam.txt", "w") as f:
             f.write("extrinsic\n" + "\n".join(" ".join(repr(float(x)) for x in row) for row in cam[0]) + "\n\nintrinsic\n" +
                     "\n".join(" ".join(repr(float(x)) for x in row) for row in cam[1, :3, :3]) + "\n\n425.0 2.5 192 935.0\n")
-        IO.save_pfm(str(root / f"depth_gt/{v:08d}.pfm"), depths[v])
+        if with_gt:
+            IO.save_pfm(str(root / f"depth_gt/{v:08d}.pfm"), depths[v])
     with open(root / "pair.txt", "w") as f:
         f.write(f"{V}\n")
         for v in range(V):
             o = [u for u in range(V) if u != v]
             f.write(f"{v}\n{len(o)} " + " ".join(f"{u} {10.0 - u}" for u in o) + "\n")
+
+
+def test_eval_driver_and_fusion(tmp_path, capsys):
+    """general layout, DiffMVS: the PFMs the driver writes are the CPU oracle's depth maps / confidences for the samples the
+    dataset produces (same weights, same host-generated diffusion noise), the depth errors are reported, the reference's
+    default fusion thresholds (test.py:69-76) fuse them into <outdir>/pc.ply."""
+    from diffmvs_amd import eval as EV
+    from models import CasDiffMVS
+    H, W, V = 64, 96, 4
+    root = tmp_path / "scene"
+    _write_scene(root, H, W, V, seed=4)
     out = tmp_path / "out"
     res = EV.main(["--testpath", str(root), "--dataset", "general", "--outdir", str(out), "--method", "diffmvs", "--num_view", "4",
-                   "--numdepth_initial", "16", "--batch_size", "2", "--filter"])
+                   "--numdepth_initial", "16", "--batch_size", "2", "--filter", "--noise_seed", "31"])
     assert res["views"] == 2 and res["avg_time_s"] > 0
-    for v in range(V):
-        d, _ = IO.read_pfm(str(out / f"depth_est/{v:08d}.pfm"))
-        assert d.shape == (H, W) and np.isfinite(d).all() and d.min() >= 424.9 and d.max() <= 935.1
-        assert os.path.exists(out / f"conf1/{v:08d}.pfm") and os.path.exists(out / f"cams/{v:08d}_cam.txt")
+    # the oracle on the very samples the driver fed the model (one noise stream across the two batches, like the driver's)
+    args = synth.make_args("diffmvs", numdepth_initial=16)
+    sd = synth.synth_state_dict(CasDiffMVS(args, test=True).state_dict(), 123)
+    ds = IO.MVSDataset(str(root), 4, 384, dataset="general", scan=[""])
+    noise = synth.NoiseSource(31)
+    for i0 in (0, 2):
+        sample = IO.collate([ds[i] for i in (i0, i0 + 1)])
+        with torch.no_grad():
+            want = O.forward(sd, args, sample["imgs"], sample["proj_matrices"], sample["depth_values"], noise_fn=lambda shape: noise(shape, "cpu"))
+        for b in range(2):
+            v = i0 + b
+            d, _ = IO.read_pfm(str(out / f"depth_est/{v:08d}.pfm"))
+            assert d.shape == (H, W) and np.isfinite(d).all() and d.min() >= 424.9 and d.max() <= 935.1
+            assert rel_l1(torch.from_numpy(np.ascontiguousarray(d)), want["depth"][-1][b]) < 1e-3, v
+            c1, _ = IO.read_pfm(str(out / f"conf1/{v:08d}.pfm"))
+            assert rel_l1(torch.from_numpy(np.ascontiguousarray(c1)), want["photometric_confidence"][1][b]) < 5e-3, v
+            assert os.path.exists(out / f"cams/{v:08d}_cam.txt")
     assert "" in res["errors"] and res["errors"][""]["views"] == V and res["errors"][""]["abs_rel"] > 0
-    assert os.path.exists(out / "mask/00000000_final.png") and os.path.exists(out / "scene.ply")
+    assert os.path.exists(out / "mask/00000000_final.png") and res["ply"][""] == str(out / "pc.ply") and os.path.exists(out / "pc.ply")
+    assert res["fused_points"][""] > 0
     json.dumps(res)
+
+
+def test_eval_tank_layout_uses_the_scene_tables(tmp_path):
+    """Tanks&Temples protocol (test.py:331-340): the list entry 'intermediate/Horse' (+ a trailing blank line in the list) is
+    evaluated from <testpath>/intermediate/Horse, fused with filter_depth_dynamic's rule under the scene name 'Horse' (its
+    photometric thresholds and dynamic parameters) into <outdir>/pc/Horse.ply -- the same points as calling the fusion
+    directly with those parameters."""
+    from diffmvs_amd import eval as EV
+    from diffmvs_amd import fusion
+    root = tmp_path / "tt"
+    os.makedirs(root / "intermediate")
+    _write_scene(root / "intermediate" / "Horse", 64, 96, 3, seed=6, cam_folder="cams_1", with_gt=False)
+    lst = tmp_path / "list.txt"
+    lst.write_text("intermediate/Horse\n\n")
+    out = tmp_path / "out"
+    res = EV.main(["--testpath", str(root), "--dataset", "tank", "--testlist", str(lst), "--outdir", str(out), "--method", "casdiffmvs",
+                   "--num_view", "3", "--numdepth_initial", "16", "--max_h", "256", "--max_w", "384", "--filter", "--noise_seed", "2"])
+    assert res["scenes"] == ["intermediate/Horse"] and res["views"] == 3
+    ply = out / "pc" / "Horse.ply"
+    assert res["ply"]["intermediate/Horse"] == str(ply) and os.path.exists(ply)
+    n = fusion.filter_depth(str(root / "intermediate/Horse"), str(out / "intermediate/Horse"), str(tmp_path / "direct.ply"),
+                            photo_thres=fusion.TANK_PHOTO_THRES["Horse"], method="casdiffmvs", dataset="tank", scan="Horse")
+    assert n == res["fused_points"]["intermediate/Horse"]
+    assert open(ply, "rb").read() == open(tmp_path / "direct.ply", "rb").read()

@@ -120,6 +120,22 @@ def test_filter_depth_on_a_scene_tree(ops, tmp_path):
     assert float(np.abs(resid).mean()) < 0.5
 
 
+def test_scene_protocol_tables():
+    """the per-dataset fusion protocol of test.py:298-367: thresholds and point-cloud names"""
+    kw = fusion.scene_protocol("dtu", "scan114", "/o", 2, 0.125, 0.01, [0.3, 0.5, 0.5])
+    assert kw["plyfilename"] == "/o/pc/mvs114_l3.ply" and kw["geo_pixel_thres"] == 0.125 and kw["photo_thres"] == [0.3, 0.5, 0.5]
+    kw = fusion.scene_protocol("tank", "advanced/Temple", "/o")
+    assert kw["scan"] == "Temple" and kw["photo_thres"] == [0.3, 0.5, 0.5] and kw["plyfilename"] == "/o/pc/Temple.ply"
+    assert (fusion.DH_VIEW_NUM["Temple"], fusion.DH_DIST["Temple"], fusion.DH_REL_DIFF["Temple"]) == (1, 4, 1500)
+    kw = fusion.scene_protocol("eth3d", "bridge", "/o")
+    assert kw["geo_mask_thres"] == 2 and kw["geo_pixel_thres"] == 0.5 and kw["photo_thres"] == [0.3, 0.0, 0.0]
+    assert fusion.scene_protocol("eth3d", "meadow", "/o")["geo_pixel_thres"] == 2
+    assert fusion.scene_protocol("general", "", "/o")["plyfilename"] == "/o/pc.ply"
+    assert set(fusion.TANK_PHOTO_THRES) == set(fusion.DH_VIEW_NUM) and set(fusion.ETH3D_GEO_MASK_THRES) == set(fusion.ETH3D_GEO_PIXEL_THRES)
+    with pytest.raises(KeyError):
+        fusion.scene_protocol("tank", "intermediate/Nowhere", "/o")
+
+
 def _eq(a, b):
     a, b = np.asarray(a), np.asarray(b)
     return a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a, b, equal_nan=(a.dtype.kind == "f"))
@@ -148,20 +164,19 @@ def test_fusion_oracle_matches_reference_filter_fixtures():
 @pytest.mark.parametrize("tag,kw", [("cas", dict(method="casdiffmvs", geo_mask_thres=2, photo_thres=[0.3, 0.4, 0.5], dataset="dtu")),
                                     ("diff", dict(method="diffmvs", geo_mask_thres=3, photo_thres=[0.35, 0.45, 0.5], dataset="dtu")),
                                     ("dyn", dict(method="casdiffmvs", photo_thres=[0.3, 0.4, 0.5], dataset="tank", scan="Horse"))])
-def test_filter_depth_matches_reference_on_a_scene_tree(tag, kw, tmp_path):
+def test_filter_depth_matches_reference_on_a_scene_tree(ops, tag, kw, tmp_path):
     """tests/golden/fusion_tree.npz = the vertex tables the reference's own filter_depth / filter_depth_dynamic produced on the
     tree of tests/fusion_scene.py (make_golden_fusion_tree.py; cv2.remap replaced by the restatement, cv2 being absent).  This
     package's filter_depth on the same tree -- file readers, photometric masks, the consistency kernel, depth averaging,
-    unprojection, colours, point order -- must give the same points.  (Host-emulated kernels: the comparison is about the
-    algorithm, and exact point counts depend on fp64 threshold decisions.)"""
+    unprojection, colours, point order -- must give the same points, through the host emulation AND on the MI355X (the
+    kernel's fp64 chain is written without contractions, so its threshold decisions are NumPy's)."""
     import sys
     sys.path.insert(0, os.path.dirname(__file__))
     import fusion_scene
-    from conftest import emu_ops
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fusion_tree.npz"))
     root = fusion_scene.build_tree(str(tmp_path / "scan"))
     ply = str(tmp_path / "out.ply")
-    n = fusion.filter_depth(root, root, ply, ops=emu_ops(), **kw)
+    n = fusion.filter_depth(root, root, ply, ops=ops, **kw)
     raw = open(ply, "rb").read().split(b"end_header\n")[1]
     pts = np.frombuffer(raw, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("r", "u1"), ("g", "u1"), ("b", "u1")])
     want_xyz, want_rgb = g[f"{tag}_xyz"], g[f"{tag}_rgb"]

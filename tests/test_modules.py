@@ -5,17 +5,16 @@ Runs on the host emulation (CPU) and, with -m gpu, on the MI355X."""
 import pytest
 import torch
 
-from conftest import emu_ops, hip_ops
+from conftest import emu_ops, hip_ops, pin_ops
 from diffmvs_amd import synth
 
 
 @pytest.fixture(params=[pytest.param("emu"), pytest.param("hip", marks=pytest.mark.gpu)])
-def backend(request):
-    import models.module as M
+def backend(request, monkeypatch):
     ops = emu_ops() if request.param == "emu" else hip_ops()
-    M.HipModule._ops = ops
-    yield ops
-    M.HipModule._ops = None
+    if request.param == "emu":
+        pin_ops(monkeypatch, ops)
+    return ops
 
 
 def build(variant, ops, nd=32):

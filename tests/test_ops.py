@@ -555,6 +555,23 @@ def test_conv_fused_groupnorm_stats(ops, cin, cout, HW):
     close(out, want, 3e-5)
 
 
+@pytest.mark.parametrize("bad", [float("nan"), float("inf"), 3.0e6])
+def test_groupnorm_stats_propagate_non_finite_and_out_of_range(ops, bad):
+    """the fixed-point statistics slots (dmvs_common.h): a NaN / Inf activation -- or one beyond the documented magnitude
+    contract -- makes ITS group's outputs NaN (as fp statistics would), the other batch item stays exact"""
+    B, C, H, W = 2, 16, 16, 16
+    x = rnd(B, C, H, W, seed=1)
+    x[1, 5, 3, 4] = bad                                   # batch item 1: reaches channels of every group through the 3x3 conv
+    w = rnd(C, C, 3, 3, seed=2) * 0.3
+    gamma, beta = rnd(C, seed=4, lo=0.5, hi=1.5), rnd(C, seed=5)
+    stats = torch.zeros(B * 8, dtype=torch.float64, device=ops.device)
+    h = ops.conv2d(K.pack_conv2d(dev(ops, w), pad=1), dev(ops, x), gn_stats=stats)
+    out = ops.groupnorm_apply(h, *dev(ops, gamma, beta), 4, stats).cpu()
+    want0 = F.silu(F.group_norm(F.conv2d(x[:1], w, None, 1, 1), 4, gamma, beta, 1e-5))
+    close(out[:1], want0, 3e-5)
+    assert torch.isnan(out[1]).all()
+
+
 # ------------------------------------------------------------------ backward kernels (training step)
 def _oracle_init_cor(feats, pm, dv, D):
     B, _, H, W = feats[0].shape

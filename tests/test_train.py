@@ -29,7 +29,6 @@ def _run_step(variant, g, ops):
     model = CasDiffMVS(args, test=False)
     model.load_state_dict(synth.synth_state_dict(model.state_dict(), meta["weight_seed"]), strict=True)
     model.to(ops.device).train()
-    model._train_ops = ops
     model.noise_source = synth.NoiseSource(meta["noise_seed"])
     model.t_source = _t_source()
     imgs, proj, dv, gt, mask = synth.synth_inputs(meta["H"], meta["W"], meta["S"], B=meta["B"], seed=meta["scene_seed"], with_gt=True)

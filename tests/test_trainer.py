@@ -151,6 +151,8 @@ from diffmvs_amd.trainer import Trainer
 from diffmvs_amd.shard import init_distributed
 from models import CasDiffMVS
 from test_train import _t_source
+from diffmvs_amd.ops import Ops
+Ops.for_device = classmethod(lambda cls, device: emu_ops())      # this CPU worker runs the package on the host emulation
 
 def make(seed_w):
     args = synth.make_args("diffmvs", numdepth_initial=8)
@@ -283,7 +285,6 @@ def test_submodule_eval_after_train_step(golden, ops):
     B, H, W = 1, 8, 12
     dev = ops.device
     depth, samples, cost = (torch.rand(B, 1, H, W).to(dev), torch.rand(B, 6, H, W).to(dev), torch.rand(B, 24, H, W).to(dev))
-    M.HipModule._ops = ops
     try:
         model.eval()
         y0 = enc(depth, samples, cost).clone()
@@ -299,7 +300,7 @@ def test_submodule_eval_after_train_step(golden, ops):
         fresh.to(dev)
         y2 = fresh.update_block_depth2.encoder(depth, samples, cost)
     finally:
-        M.HipModule._ops = None
+        pass
     assert float((y1 - y0).abs().max()) > 0                      # the step moved the encoder
     assert torch.allclose(y1, y2, rtol=1e-6, atol=1e-7)
 
@@ -344,3 +345,91 @@ def test_cfg4_full_size_training_step():
               f"{torch.cuda.max_memory_allocated() / 2 ** 30:.2f} GiB")
     assert abs(runs[0][0] - runs[1][0]) <= 1e-5 * abs(runs[0][0])
     assert abs(runs[0][1] - runs[1][1]) <= 1e-3 * runs[0][1]
+
+
+def test_multi_step_lr_matches_torch():
+    """the reference's DEFAULT schedule (--lr_sche mslr, --lrepochs "10,12,14:2", train.py:34-36, :367-371): torch's
+    MultiStepLR stepped once per epoch"""
+    from diffmvs_amd.trainer import multi_step_lr, parse_lrepochs
+    ms, gamma = parse_lrepochs("10,12,14:2")
+    assert ms == [10, 12, 14] and gamma == 0.5
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=1e-3)
+    sch = torch.optim.lr_scheduler.MultiStepLR(opt, ms, gamma=gamma)
+    spe = 7
+    for epoch in range(17):
+        for i in range(spe):
+            assert multi_step_lr(epoch * spe + i, 1e-3, ms, gamma, spe) == pytest.approx(opt.param_groups[0]["lr"], rel=1e-12)
+        opt.step()
+        sch.step()
+
+
+_NCCL_WORKER = r"""
+import os, sys, json, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from diffmvs_amd import synth
+from diffmvs_amd.trainer import Trainer
+from diffmvs_amd.shard import init_distributed
+from models import CasDiffMVS
+rank, local = int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"])
+torch.cuda.set_device(local)
+dev = torch.device("cuda", local)
+init_distributed("nccl", dev)
+args = synth.make_args("diffmvs", numdepth_initial=8)
+model = CasDiffMVS(args, test=False)
+model.load_state_dict(synth.synth_state_dict(model.state_dict(), 7 + rank), strict=True)      # the Trainer broadcasts rank 0's
+model.to(dev).train()
+model.noise_source = synth.NoiseSource(90 + rank)
+tr = Trainer(model, args, lr=1e-3, wd=1e-3)
+imgs, proj, dv, gt, mask = synth.synth_inputs(64, 96, 2, B=1, seed=40 + rank, with_gt=True)
+mv = lambda d: {{k: v.to(dev) for k, v in d.items()}}
+sample = dict(imgs=[i.to(dev) for i in imgs], proj_matrices=mv(proj), depth_values=dv.to(dev), depth=mv(gt), mask=mv(mask))
+tr.zero_grad()
+out = model(sample["imgs"], sample["proj_matrices"], sample["depth_values"], sample["depth"])
+loss, _ = tr.loss_fn(args, out["depth"], out["conf"], sample["depth"], sample["mask"], sample["depth_values"], loss_rate=0.9, iters=args.stage_iters)
+loss.backward()
+local_grad = tr.flat.grad.clone()
+grads = [torch.zeros_like(local_grad) for _ in range(dist.get_world_size())]
+dist.all_gather(grads, local_grad)                     # what the all-reduce of the step must produce: the sum over ranks
+tr.zero_grad()
+loss2, parts, gnorm, _ = tr.train_sample(sample)       # (same draws are not needed: only the collective is under test)
+flat = tr.flat.data.clone()
+gathered = [torch.zeros_like(flat) for _ in range(dist.get_world_size())]
+dist.all_gather(gathered, flat)
+t = torch.ones(1 << 20, device=dev) * (rank + 1)
+dist.all_reduce(t)
+if rank == 0:
+    print(json.dumps(dict(world=dist.get_world_size(), same=bool(all(torch.equal(gathered[0], x) for x in gathered)),
+                          sum_ok=bool((t == 3.0).all()), finite=bool(torch.isfinite(flat).all()), loss=float(loss2),
+                          grads_differ=bool(not torch.equal(grads[0], grads[1])))), flush=True)
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_data_parallel_step_rccl_two_gpus(tmp_path):
+    """The training path's one collective on the real transport: 2 ranks, backend "nccl" (= RCCL over xGMI), one process per GPU.
+    Ranks start from different weights and train on different samples; after one Trainer.train_sample the parameters are
+    bit-identical on both ranks (broadcast + all-reduce of the flat gradient bucket + identical clip / AdamW), and a plain
+    all-reduce sums.  Skipped on a 1-GPU box (the arithmetic of the step is pinned by test_data_parallel_step_gloo)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs on the box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(_NCCL_WORKER.format(root=root))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    res = json.loads([ln for ln in outs[0].splitlines() if ln.startswith("{")][-1])
+    assert res["world"] == 2 and res["same"] and res["sum_ok"] and res["finite"] and res["grads_differ"]
