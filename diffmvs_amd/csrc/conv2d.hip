@@ -66,23 +66,43 @@ constexpr int conv_min_waves(int nt, int mt) { return (nt == 2 && mt == 4) ? 4 :
 
 // OT = element type of a channel-last output (DMVS_DTYPE_*): 16-bit feature storage is its own instantiation so that the
 // fp32 kernels keep their register allocation.
-template <int KH, int KW, int S, int NT, int MT, bool ZI, int OT = DMVS_DTYPE_F32, bool TR = false>
+//
+// WALK = resident, tile-walking workgroups: the grid holds only as many workgroups as fit the chip at once and workgroup w
+// takes tiles w, w + gridDim.x, ...; while the matrix cores sweep the LAST channel chunk of a tile, the FIRST chunk of the
+// workgroup's next tile already streams into the other LDS buffer, and that tile's index decode happens under those MFMAs.
+// A one-tile-per-workgroup launch pays, per tile, the index decode + the full HBM/L2 latency of its first chunk + the
+// epilogue with the matrix pipe idle; with 2-4 chunks per tile (the 16- and 32-channel layers) that is half of a tile's
+// life, and it does not average out over co-resident workgroups because a launch starts them all in the same phase
+// (SQ PMC on the 16 -> 16 layer: matrix pipe busy 41 % of the cycles, waves waiting 27 %).  Same arithmetic, same order.
+template <int KH, int KW, int S, int NT, int MT, bool ZI, int OT = DMVS_DTYPE_F32, bool TR = false, bool WALK = false>
 __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfma_kernel(const dmvs_conv2d_desc d, int tiles_x, int tiles_y) {
     using Cfg = ConvCfg<KH, KW, S, NT, MT>;
     constexpr int T = Cfg::T, TW = Cfg::TW, TH = Cfg::TH, PLANE = Cfg::PLANE, NW = Cfg::NW, WPAD = Cfg::WPAD;
     constexpr int CK = Cfg::CK, BUF = Cfg::BUF, IN_IT = Cfg::IN_IT, W_IT = Cfg::W_IT;
-    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+    // one LDS object on purpose (tile buffers + the 32-float GroupNorm scratch): with separate objects hipcc orders reads of
+    // one against LDS-DMA into another with vmcnt(0) waits (conv3d.hip, conv3d_mfma_stream_kernel)
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF + 32];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA bases in SGPRs
     const int m = lane & 15, kq = lane >> 4;
     int tile = blockIdx.x;   // round-robin over XCDs: an XCD-contiguous remap measured 6-8 % SLOWER here (HBM channel spread)
-    const int tx = tile % tiles_x; tile /= tiles_x;
-    const int ty = tile % tiles_y;
-    const int b = tile / tiles_y;
-    const int ox0 = tx * 16, oy0 = ty * Cfg::ROWS;
+    const int ntiles = tiles_x * tiles_y * d.B;
+    // s_* / gy0 / gx0: the tile whose input is being STAGED; b / ox0 / oy0 (set at the top of the tile loop): the tile being
+    // computed and stored.  They differ only while WALK prefetches the next tile under the last chunk of the current one.
+    int s_b, s_ox0, s_oy0, gy0, gx0;
+    auto decode_tile = [&](int t) {
+        const int tx = t % tiles_x;
+        t /= tiles_x;
+        const int ty = t % tiles_y;
+        s_b = t / tiles_y;
+        s_ox0 = tx * 16;
+        s_oy0 = ty * Cfg::ROWS;
+        gy0 = s_oy0 * S - d.pad_h;
+        gx0 = s_ox0 * S - d.pad_w;
+    };
+    decode_tile(tile);
     const int nbase = blockIdx.y * NW;
     const int cin = d.c0 + d.c1;
-    const int gy0 = oy0 * S - d.pad_h, gx0 = ox0 * S - d.pad_w;
 
     // ---- addressing of the logical input, all in 32-bit element offsets from per-batch bases
     const int mode = ZI ? DMVS_IN_UPSAMPLE2 : d.in_mode;      // zero-insert addresses like nearest-x2 (plus a parity predicate)
@@ -90,9 +110,14 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     const int pH = mode == DMVS_IN_UPSAMPLE2 ? (d.Hin >> 1) : (mode == DMVS_IN_UNSHUFFLE2 ? (d.Hin << 1) : d.Hin);
     const int plane0 = pH * pW, plane1 = d.Hin * d.Win;
     const int pc0 = mode == DMVS_IN_UNSHUFFLE2 ? (d.c0 >> 2) : d.c0;
-    const float* in0b = d.in0 + (size_t)b * pc0 * plane0;
-    const float* mul0b = d.mul0 ? d.mul0 + (size_t)b * (d.gate_cstride ? d.gate_cstride : pc0) * plane0 : nullptr;
-    const float* in1b = d.in1 ? d.in1 + (size_t)b * d.c1 * plane1 : d.in0;
+    const float *in0b, *mul0b, *in1b;      // per-batch-item input bases of the tile being staged
+    auto set_bases = [&]() {
+        in0b = d.in0 + (size_t)s_b * pc0 * plane0;
+        mul0b = d.mul0 ? d.mul0 + (size_t)s_b * (d.gate_cstride ? d.gate_cstride : pc0) * plane0 : nullptr;
+        in1b = d.in1 ? d.in1 + (size_t)s_b * d.c1 * plane1 : d.in0;
+    };
+    set_bases();
+    static_assert(!(WALK && ZI), "the tile-walking form is an inference kernel");
 
     // element e of the padded LDS input image of chunk c0 -> global source (or nullptr for padding)
     auto in_src = [&](int c0, int e, int& off_out) -> const float* {
@@ -118,18 +143,21 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     // plus a 32-bit lane offset.
     constexpr int P_IT = (PLANE + DMVS_BLOCK - 1) / DMVS_BLOCK;
     int p_sp[P_IT];                        // spatial source offset of plane position it*256 + tid, -1: padding / not staged
+    auto map_tile = [&]() {                // for the tile (gy0, gx0) about to be staged
 #pragma unroll
-    for (int it = 0; it < P_IT; ++it) {
-        const int rem = it * DMVS_BLOCK + tid;
-        const int r = rem / TW, c = rem - r * TW;
-        const int iy = gy0 + r, ix = gx0 + c;
-        const bool ok = rem < TH * TW && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win && !(ZI && ((iy | ix) & 1));
-        int sp;
-        if (mode == DMVS_IN_PLAIN) sp = iy * pW + ix;
-        else if (mode == DMVS_IN_UPSAMPLE2) sp = (iy >> 1) * pW + (ix >> 1);
-        else sp = iy * 2 * pW + ix * 2;
-        p_sp[it] = ok ? sp : -1;
-    }
+        for (int it = 0; it < P_IT; ++it) {
+            const int rem = it * DMVS_BLOCK + tid;
+            const int r = rem / TW, c = rem - r * TW;
+            const int iy = gy0 + r, ix = gx0 + c;
+            const bool ok = rem < TH * TW && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win && !(ZI && ((iy | ix) & 1));
+            int sp;
+            if (mode == DMVS_IN_PLAIN) sp = iy * pW + ix;
+            else if (mode == DMVS_IN_UPSAMPLE2) sp = (iy >> 1) * pW + (ix >> 1);
+            else sp = iy * 2 * pW + ix * 2;
+            p_sp[it] = ok ? sp : -1;
+        }
+    };
+    map_tile();
     int w_ci[W_IT], w_off[W_IT];           // weight slab piece -> (channel within the chunk, offset inside its [T][cout_pad] block)
 #pragma unroll
     for (int i = 0; i < W_IT; ++i) {
@@ -198,14 +226,29 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
         else stage_as(std::false_type{}, c0, buf);
     };
 
+    // padding positions of a BORDER tile in a buffer about to be re-staged: a walking workgroup's previous tile left data there
+    auto zero_padding = [&](float* buf) {
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it) {
+            const int rem = it * DMVS_BLOCK + tid;
+            if (rem < TH * TW && p_sp[it] < 0) {
+#pragma unroll
+                for (int ci = 0; ci < CK; ++ci) buf[ci * PLANE + rem] = 0.0f;
+            }
+        }
+    };
+    float* const gn_scratch = lds + 2 * BUF;      // (not the tile buffers: a walking workgroup's next tile is streaming into them)
+
+    stage(0, lds);
+    int cur = 0;
+    bool border = false;                   // the tile being staged has padding positions (workgroup-uniform)
+    for (;;) {      // tiles of this workgroup (one unless WALK)
+    const int b = s_b, ox0 = s_ox0, oy0 = s_oy0;
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-
-    stage(0, lds);
-    int cur = 0;
     for (int c0 = 0; c0 < cin; c0 += CK, cur ^= 1) {
         float* s_in = lds + cur * BUF;
         float* s_w = s_in + CK * PLANE;
@@ -223,7 +266,19 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
             }
             __syncthreads();
         }
-        if (c0 + CK < cin) stage(c0 + CK, lds + (cur ^ 1) * BUF);   // lands while the matrix cores chew on chunk c0
+        float* other = lds + (cur ^ 1) * BUF;
+        if (c0 + CK < cin) {
+            if (WALK && border) zero_padding(other);
+            stage(c0 + CK, other);   // lands while the matrix cores chew on chunk c0
+        } else if (WALK && tile + (int)gridDim.x < ntiles) {
+            // last chunk of this tile: the workgroup's next tile starts streaming now
+            decode_tile(tile + (int)gridDim.x);
+            set_bases();
+            map_tile();
+            border = gy0 < 0 || gx0 < 0 || gy0 + TH > d.Hin || gx0 + TW > d.Win;
+            if (border) zero_padding(other);
+            stage(0, other);
+        }
         const int live_c = cin - c0 < CK ? cin - c0 : CK;
         const int nc4 = (live_c + 3) >> 2;          // all-zero 4-channel groups of the last chunk are skipped
 #pragma unroll 1
@@ -486,21 +541,33 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
                 gq[gi] += __shfl_down(gq[gi], o, 64);
             }
         }
-        __syncthreads();                  // every wave is done with the LDS tiles: reuse them as scratch
+        DMVS_LDS_BARRIER();               // the previous tile's readers of gn_scratch are done (LDS-only: a prefetch DMA stays in flight)
         if (lane == 0) {
 #pragma unroll
             for (int gi = 0; gi < 4; ++gi) {
-                lds[wave * 8 + gi] = gs[gi];
-                lds[wave * 8 + 4 + gi] = gq[gi];
+                gn_scratch[wave * 8 + gi] = gs[gi];
+                gn_scratch[wave * 8 + 4 + gi] = gq[gi];
             }
         }
-        __syncthreads();
+        DMVS_LDS_BARRIER();
         if (tid < 8) {
-            const float tot = lds[tid] + lds[8 + tid] + lds[16 + tid] + lds[24 + tid];
+            const float tot = gn_scratch[tid] + gn_scratch[8 + tid] + gn_scratch[16 + tid] + gn_scratch[24 + tid];
             const int gi = tid & 3, which = tid >> 2;
             if (tot != 0.0f) dmvs_gn_accumulate(&d.gn_stats[((size_t)b * 4 + gi) * 2 + which], (double)tot);
         }
     }
+    if constexpr (!WALK) break;
+    tile += (int)gridDim.x;
+    if (tile >= ntiles) break;
+    }      // tiles
+}
+
+static bool conv_walk_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("DMVS_CONV_WALK");
+        return !(e && e[0] == '0');
+    }();
+    return on;
 }
 
 // 16-bit channel-last outputs (FeatureNet's out1 / out2 / out3 in the reduced-precision configurations): 1x1 and 3x3 stride 1
@@ -529,6 +596,25 @@ int launch_conv2d_mt(const dmvs_conv2d_desc& d, hipStream_t st, int nt, int ngro
     const int tiles_x = (d.Wout + 15) / 16, tiles_y = (d.Hout + 4 * MT - 1) / (4 * MT);
     dim3 grid((unsigned)(tiles_x * tiles_y * d.B), (unsigned)ngroups), block(DMVS_BLOCK);
     if (d.out_layout == DMVS_LAYOUT_NCHW) {      // transposed accumulators: 16-byte NCHW stores
+        if constexpr (!ZI) {
+            if (conv_walk_enabled()) {           // resident, tile-walking workgroups (DMVS_CONV_WALK=0: one tile per workgroup)
+                const long ntiles = (long)tiles_x * tiles_y * d.B;
+#define DMVS_WALK(NTV) do { \
+                    auto kfn = conv2d_mfma_kernel<KH, KW, S, NTV, MT, false, DMVS_DTYPE_F32, true, true>; \
+                    static const int resident = dmvs_resident_workgroups(reinterpret_cast<const void*>(kfn)); \
+                    const long per_group = resident / ngroups > 0 ? resident / ngroups : 1; \
+                    dim3 g((unsigned)(ntiles < per_group ? ntiles : per_group), (unsigned)ngroups); \
+                    hipLaunchKernelGGL(kfn, g, block, 0, st, d, tiles_x, tiles_y); } while (0)
+                switch (nt) {
+                    case 1: DMVS_WALK(1); break;
+                    case 2: DMVS_WALK(2); break;
+                    case 3: DMVS_WALK(3); break;
+                    default: DMVS_WALK(4); break;
+                }
+#undef DMVS_WALK
+                return dmvs_launch_status();
+            }
+        }
         switch (nt) {
             case 1: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 1, MT, ZI, DMVS_DTYPE_F32, true>), grid, block, 0, st, d, tiles_x, tiles_y); break;
             case 2: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 2, MT, ZI, DMVS_DTYPE_F32, true>), grid, block, 0, st, d, tiles_x, tiles_y); break;

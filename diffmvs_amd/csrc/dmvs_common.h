@@ -26,6 +26,23 @@ static inline int dmvs_launch_status() {
     return e == hipSuccess ? 0 : (int)e;
 }
 
+// Workgroups of `kernel` (256 threads, static LDS only) the whole chip holds at once: the grid of a resident, tile-walking
+// launch.  The occupancy query over-reports by one workgroup per CU for SGPR-heavy kernels at 7-8 per CU
+// (MI355X_MICROARCH.md, residency) -- and a surplus workgroup would start only when a resident one has walked ALL its tiles
+// (a tail as long as the launch) -- so the count is capped at 6 per CU, below that band.
+#ifdef DMVS_HOST_EMULATION
+static inline int dmvs_resident_workgroups(const void*) { return 2; }       // (so that the CPU tests walk several tiles per workgroup)
+#else
+static inline int dmvs_resident_workgroups(const void* kernel) {
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, DMVS_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (per_cu > 6) per_cu = 6;
+    return per_cu * prop.multiProcessorCount;
+}
+#endif
+
 static inline unsigned dmvs_ceil_div(long a, long b) { return (unsigned)((a + b - 1) / b); }
 __device__ __forceinline__ unsigned dmvs_ceil_div_dev(long a, long b) { return (unsigned)((a + b - 1) / b); }
 
@@ -45,16 +62,17 @@ __device__ __forceinline__ float dmvs_act(float v, int act) {
 // atomics would make the result depend on the arrival order; the 8-byte slots therefore hold FIXED-POINT integers (2^-16
 // units): integer addition is associative, so the statistics -- and with them the whole forward -- are bit-reproducible
 // run to run.  Resolution 1.5e-5 per contribution (a workgroup's partial sum, magnitude 1e2..1e6).
-// Magnitude contract: a contribution that is not finite, or whose magnitude reaches 2^34 (1.7e10: a 16 x 16 x 16 tile of
-// values with an rms of ~2000), POISONS the slot -- it is overwritten with a value no sum of in-range contributions can
-// move back below 2^62 -- and dmvs_gn_read returns NaN for it: a NaN / Inf / out-of-range activation makes its group's
-// outputs NaN, like the floating-point statistics of the reference would, instead of finite garbage or a silent wrap.
+// Magnitude contract: statistics up to 3.5e13 (|fixed| < 2^61; a random-weight network's pre-normalisation planes reach
+// 1e12).  A contribution that is not finite, or whose magnitude reaches 2^44 (1.8e13), POISONS the slot -- it is overwritten
+// with 3 * 2^61, which in-range contributions do not bring back below 2^61 -- and dmvs_gn_read returns NaN for any slot at
+// or beyond +-2^61: a NaN / Inf / out-of-range activation makes its group's outputs NaN, like the floating-point statistics
+// of the reference would, instead of finite garbage or a silent wrap.
 // Callers keep treating the buffer as opaque zero-initialised 8-byte slots (all-zero bits = 0 in either reading).
 #define DMVS_GN_FIX 65536.0
 #define DMVS_GN_POISON 0x6000000000000000ull
 __device__ __forceinline__ void dmvs_gn_accumulate(double* slot, double v) {
     unsigned long long* p = reinterpret_cast<unsigned long long*>(slot);
-    if (!(fabs(v) < 17179869184.0)) {            // 2^34; false for NaN as well
+    if (!(fabs(v) < 17592186044416.0)) {         // 2^44; false for NaN as well
 #ifdef DMVS_HOST_EMULATION
         __atomic_store_n(p, DMVS_GN_POISON, __ATOMIC_RELAXED);
 #else
@@ -66,7 +84,7 @@ __device__ __forceinline__ void dmvs_gn_accumulate(double* slot, double v) {
 }
 __device__ __forceinline__ double dmvs_gn_read(const double* slot) {
     const long long f = *reinterpret_cast<const long long*>(slot);
-    if (f >= (1ll << 62) || f <= -(1ll << 62)) return __builtin_nan("");
+    if (f >= (1ll << 61) || f <= -(1ll << 61)) return __builtin_nan("");
     return (double)f * (1.0 / DMVS_GN_FIX);
 }
 

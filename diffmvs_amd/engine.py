@@ -225,9 +225,12 @@ def run_resblock(o: Ops, arena: GnArena, rb, x0, x1=None, scale_shift=None):
     return o.groupnorm_apply(h2, rb["g2"][0], rb["g2"][1], 4, st2, residual=res, out=h2)
 
 
-def run_unet(o: Ops, arena: GnArena, ub, X, hidden, ss_of):
-    """Unet.forward (update.py:245-274).  X [B,input_dim,H,W], hidden [B,hd,h,w]; ss_of(rb) -> [B,2*dim_out] | None."""
-    x = o.conv2d(ub.init_conv, X)
+def run_unet(o: Ops, arena: GnArena, ub, E, ctx_part, hidden, ss_of):
+    """Unet.forward (update.py:245-274).  The Unet input is cat(relu(context), encoder output) (update.py:497-498); its
+    7x7 init_conv is linear in the input channels, so the context half -- the same tensor in every GRU iteration and DDIM
+    step of the stage -- is convolved ONCE per stage (ctx_part = init_conv[:, :cd](context) + bias) and each iteration adds
+    the encoder half's convolution to it: E [B,cd,H,W], hidden [B,hd,h,w]; ss_of(rb) -> [B,2*dim_out] | None."""
+    x = o.conv2d(ub.init_enc, E, residual=ctx_part)
     r = x
     skips = []
     L = len(ub.mults)
@@ -268,7 +271,9 @@ class _UpdateBlock:
         self.enc = pack_encoder(sd, p + ".encoder")
         self.mask = pack_mask(sd, p + ".mask")
         u = p + ".unet"
-        self.init_conv = c2("unet.init_conv", pad=3)
+        wi, bi = sd[f"{p}.unet.init_conv.weight"], sd.get(f"{p}.unet.init_conv.bias")
+        self.init_ctx = pack_conv2d(wi[:, :self.cd], bi, pad=3)        # input channels = cat(relu(context), encoder output)
+        self.init_enc = pack_conv2d(wi[:, self.cd:], None, pad=3)
         L = len(self.mults)
         self.downs = []
         for i in range(L):
@@ -461,7 +466,8 @@ class Engine:
     def update_block(self, ub: _UpdateBlock, feats_ref, feats_src, rt, inv_depth, hidden, X, view_w, vw_shift,
                      disp_min, disp_max, interval, noise_fn):
         """DiffusionUpdateBlockDepth.forward eval branch (update.py:466-521).
-        X: Unet input buffer [B,2cd,H,W] whose first cd channels already hold relu(context)."""
+        X: [B,2cd,H,W] whose first cd channels hold relu(context) (the rest is unused: the encoder output lives in its own
+        [B,cd,H,W] tensor, see run_unet)."""
         o = self.ops
         a = self.args
         B, _, H, W = inv_depth.shape
@@ -470,6 +476,8 @@ class Engine:
         # mask head reads relu(context) = X[:, :cd]; for B > 1 that slice is strided, so give it its own copy
         context = o.act_slice(X, K.ACT_NONE, 0, cd)
         mask = run_mask(o, ub.mask, context)
+        ctx_part = o.conv2d(ub.init_ctx, context)             # the context half of the Unet's 7x7 init_conv, once per stage
+        E = o.empty(B, cd, H, W)                              # encoder output (cd - 1 channels) + current inverse depth
         img, img_scale = noise, float(ub.scale)
         inv_list: List[torch.Tensor] = []
         conf_list: List[torch.Tensor] = []
@@ -477,7 +485,7 @@ class Engine:
         for time, time_next in ub.time_pairs:
             ss_of = self._ss_of(ub.ss_tables[time], B)
             inv_list, conf_list = [], []
-            delta, new = o.delta_update(inv_depth, img, None, img_scale, new2=X, new2_cstride=2 * cd, new2_coffset=2 * cd - 1)
+            delta, new = o.delta_update(inv_depth, img, None, img_scale, new2=E, new2_cstride=cd, new2_coffset=cd - 1)
             img, img_scale = delta, 1.0
             cur_hidden, confidence = hidden, None
             for it in range(ub.iters):
@@ -488,10 +496,10 @@ class Engine:
                     cost, samples = o.getcost(feats_ref, feats_src, rt, new, confidence, view_w, disp_min, disp_max, n,
                                               interval, a.min_radius, a.max_radius, vw_shift, G=self.G_cost,
                                               policy_key=(vw_shift, it))
-                run_encoder(o, ub.enc, cost, samples, out=X, out_cstride=2 * cd, out_coffset=cd)
-                cur_hidden, upd, conf = run_unet(o, self.arena, ub, X, cur_hidden, ss_of)
+                run_encoder(o, ub.enc, cost, samples, out=E, out_cstride=cd, out_coffset=0)
+                cur_hidden, upd, conf = run_unet(o, self.arena, ub, E, ctx_part, cur_hidden, ss_of)
                 confidence = conf.view(B, H, W)
-                delta, new = o.delta_update(inv_depth, delta, upd, 1.0, new2=X, new2_cstride=2 * cd, new2_coffset=2 * cd - 1)
+                delta, new = o.delta_update(inv_depth, delta, upd, 1.0, new2=E, new2_cstride=cd, new2_coffset=cd - 1)
                 conf_list.append(confidence)
                 inv_list.append(new)
             if time_next < 0:

@@ -80,7 +80,8 @@ class Unet(HipModule):                        # reference models/update.py:161-2
             ub = SimpleNamespace(mults=self._mults, dim=self._dim)
             L = len(self._mults)
             rb = E._UpdateBlock._resblock
-            ub.init_conv = K.pack_conv2d(u["u.init_conv.weight"], u["u.init_conv.bias"], pad=3)
+            # stand-alone module call: the whole input through one convolution (the engine splits off the context half)
+            ub.init_enc = K.pack_conv2d(u["u.init_conv.weight"], u["u.init_conv.bias"], pad=3)
             ub.downs, ub.ups = [], []
             for i in range(L):
                 ds = (K.pack_conv2d(u[f"u.downs.{i}.1.1.weight"], u[f"u.downs.{i}.1.1.bias"]) if i < L - 1
@@ -115,7 +116,7 @@ class Unet(HipModule):                        # reference models/update.py:161-2
             return None if row is None else row.expand(B, -1).contiguous()
         arena = self.__dict__.setdefault("_arena", E.GnArena(o))
         arena.reset(B)
-        return E.run_unet(o, arena, ub, _dev(o, x), _dev(o, hidden), ss_of)
+        return E.run_unet(o, arena, ub, _dev(o, x), None, _dev(o, hidden), ss_of)
 
 
 class ConditionEncoder(HipModule):            # reference models/update.py:276-297

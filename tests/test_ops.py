@@ -555,7 +555,7 @@ def test_conv_fused_groupnorm_stats(ops, cin, cout, HW):
     close(out, want, 3e-5)
 
 
-@pytest.mark.parametrize("bad", [float("nan"), float("inf"), 3.0e6])
+@pytest.mark.parametrize("bad", [float("nan"), float("inf"), 3.0e7])
 def test_groupnorm_stats_propagate_non_finite_and_out_of_range(ops, bad):
     """the fixed-point statistics slots (dmvs_common.h): a NaN / Inf activation -- or one beyond the documented magnitude
     contract -- makes ITS group's outputs NaN (as fp statistics would), the other batch item stays exact"""
