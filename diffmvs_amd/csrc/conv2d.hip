@@ -74,6 +74,10 @@ constexpr int conv_min_waves(int nt, int mt) { return (nt == 2 && mt == 4) ? 4 :
 // epilogue with the matrix pipe idle; with 2-4 chunks per tile (the 16- and 32-channel layers) that is half of a tile's
 // life, and it does not average out over co-resident workgroups because a launch starts them all in the same phase
 // (SQ PMC on the 16 -> 16 layer: matrix pipe busy 41 % of the cycles, waves waiting 27 %).  Same arithmetic, same order.
+// STATUS (round 3): correct (CPU emulation + MI355X test suite) but SLOWER -- the B=96 step 83.9 -> 90.9 ms, every layer
+// 5-20 % down (profiles/r3_conv_walk_ab.txt): carrying two tiles' state through the loop costs 112 instead of 63 VGPRs
+// (3 instead of 5 waves per SIMD) and 217 SGPR-spill reads on the <3,3,1,1,4> instantiation (tools/isa_stats.py).  Only
+// instantiated with -DDMVS_CONV_WALK; the register work it needs is listed in DESIGN.md.
 template <int KH, int KW, int S, int NT, int MT, bool ZI, int OT = DMVS_DTYPE_F32, bool TR = false, bool WALK = false>
 __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfma_kernel(const dmvs_conv2d_desc d, int tiles_x, int tiles_y) {
     using Cfg = ConvCfg<KH, KW, S, NT, MT>;
@@ -562,7 +566,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     }      // tiles
 }
 
-static bool conv_walk_enabled() {
+[[maybe_unused]] static bool conv_walk_enabled() {
     static const bool on = [] {
         const char* e = getenv("DMVS_CONV_WALK");
         return !(e && e[0] == '0');
@@ -596,6 +600,7 @@ int launch_conv2d_mt(const dmvs_conv2d_desc& d, hipStream_t st, int nt, int ngro
     const int tiles_x = (d.Wout + 15) / 16, tiles_y = (d.Hout + 4 * MT - 1) / (4 * MT);
     dim3 grid((unsigned)(tiles_x * tiles_y * d.B), (unsigned)ngroups), block(DMVS_BLOCK);
     if (d.out_layout == DMVS_LAYOUT_NCHW) {      // transposed accumulators: 16-byte NCHW stores
+#ifdef DMVS_CONV_WALK      // experiment, not built by default: measured 8 % SLOWER end to end (see the kernel's header comment)
         if constexpr (!ZI) {
             if (conv_walk_enabled()) {           // resident, tile-walking workgroups (DMVS_CONV_WALK=0: one tile per workgroup)
                 const long ntiles = (long)tiles_x * tiles_y * d.B;
@@ -615,6 +620,7 @@ int launch_conv2d_mt(const dmvs_conv2d_desc& d, hipStream_t st, int nt, int ngro
                 return dmvs_launch_status();
             }
         }
+#endif
         switch (nt) {
             case 1: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 1, MT, ZI, DMVS_DTYPE_F32, true>), grid, block, 0, st, d, tiles_x, tiles_y); break;
             case 2: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 2, MT, ZI, DMVS_DTYPE_F32, true>), grid, block, 0, st, d, tiles_x, tiles_y); break;

@@ -12,6 +12,8 @@
 // wave-uniform.  The transposed convolution is evaluated in gather form, one output parity
 // class (od&1, oh&1, ow&1) per blockIdx.z so that the live taps stay wave-uniform:
 //   o = 2j   : k = 1 reads i = j            o = 2j+1 : k = 0 reads i = j+1, k = 2 reads i = j
+#include <stdlib.h>
+
 #include "dmvs_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -401,11 +403,15 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_pair_kernel(con
     if (pb >= 0) store(pend, pb, ptd, pty, ptx);
 }
 
-template <int NT>
+// S = 2: the stride-2 layers of CostRegNet_small (conv2 8 -> 16, conv4 16 -> 32, reference module.py:428-433) as the same
+// implicit GEMM: a 16 x 4 x 4 tile of OUTPUT voxels reads a 33 x 9 x 9 input halo, the B operand walks it with stride 2.
+template <int NT, int S = 1>
 __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_kernel(const dmvs_conv3d_desc d, int tiles_x, int tiles_y, int tiles_d) {
     constexpr int TX = 16, TY = 4, TD = 4;
-    constexpr int IW = TX + 2, IH = TY + 2, ID = TD + 2;
-    constexpr int PLANE = pad16mod32_3d(ID * IH * IW);
+    constexpr int IW = (TX - 1) * S + 3, IH = (TY - 1) * S + 3, ID = (TD - 1) * S + 3;
+    // channel pitch: the 16 lanes of a k-group read 16 consecutive words (S = 1) or every second word (S = 2); the two k-groups
+    // of a 32-lane half must land on disjoint banks: pitch = 16 mod 32 (S = 1), odd (17 mod 32: S = 2)
+    constexpr int PLANE = S == 1 ? pad16mod32_3d(ID * IH * IW) : pad16mod32_3d(ID * IH * IW - 1) + 1;
     constexpr int NW = NT * 16;
     constexpr int WPAD = pad16mod32_3d(27 * NW);
     // input channels per LDS chunk (double buffered): 8 if that stays within 48 KB, else 4
@@ -431,8 +437,8 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_kernel(const dmvs_conv
     Slab slab;
     slab.init(tid, nbase, d.cout_pad);
     unsigned lo, him1;
-    Halo::bounds(d0 - 1, y0 - 1, x0 - 1, d.Din, d.Hin, d.Win, lo, him1);
-    const float* origin = d.in + (size_t)b * d.cin * vol + ((long)(d0 - 1) * d.Hin + (y0 - 1)) * d.Win + (x0 - 1);
+    Halo::bounds(d0 * S - 1, y0 * S - 1, x0 * S - 1, d.Din, d.Hin, d.Win, lo, him1);
+    const float* origin = d.in + (size_t)b * d.cin * vol + ((long)(d0 * S - 1) * d.Hin + (y0 * S - 1)) * d.Win + (x0 * S - 1);
 
     // LDS-DMA staging (global_load_lds): halo tile 4 bytes per lane, weight slab 16 bytes per lane
     auto stage = [&](int c0, float* buf) {
@@ -460,7 +466,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_kernel(const dmvs_conv
         for (int c4 = 0; c4 < nc4; ++c4) {
             const int ci = c4 * 4 + kq;
             const float* wp = s_w + ci * WPAD + m;
-            const float* ipb = s_in + ci * PLANE + wave * (IH * IW) + m;
+            const float* ipb = s_in + ci * PLANE + wave * S * (IH * IW) + m * S;
 #pragma unroll 1
             for (int kd = 0; kd < 3; ++kd) {
 #pragma unroll
@@ -472,7 +478,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_kernel(const dmvs_conv
                         for (int nt = 0; nt < NT; ++nt) av[nt] = wp[((kd * 3 + ky) * 3 + kx) * NW + nt * 16];
 #pragma unroll
                         for (int mt = 0; mt < 4; ++mt) {
-                            const float bv = ipb[(kd * IH + ky + mt) * IW + kx];
+                            const float bv = ipb[(kd * IH + ky + mt * S) * IW + kx];
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
                                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av[nt], acc[mt][nt], 0, 0, 0);      // D[voxel][cout] (TileEpi)
@@ -864,38 +870,45 @@ __global__ void __launch_bounds__(DMVS_BLOCK) deconv3d_mfma_kernel(const dmvs_co
     const int vol = d.Din * d.Hin * d.Win, ovol = d.Dout * d.Hout * d.Wout;
     const int jx0 = tx * TX, jy0 = ty * TY, jd0 = td * TD;
 
+    // output channels co_base .. co_base + 7 (blockIdx.y: wider layers -- CostRegNet conv6, 32 -> 16 -- take 8 channels per
+    // workgroup); input channels in chunks of CK (single-buffered: 2 chunks at most in the reference's networks)
+    const int co_base = blockIdx.y * 8;
     Halo halo;
     halo.init(tid, d.Hin, d.Win);
+    f32x4 acc[4][4];                    // [pz * 2 + py][input row mt]
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[c][i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+    for (int c0 = 0; c0 < d.cin; c0 += CK) {
+    if (c0 > 0) __syncthreads();        // every wave is done with the previous chunk's halo and slabs
     {
         unsigned lo, him1;
         Halo::bounds(jd0, jy0, jx0, d.Din, d.Hin, d.Win, lo, him1);
-        const float* origin = d.in + (size_t)b * d.cin * vol + ((long)jd0 * d.Hin + jy0) * d.Win + jx0;
+        const float* origin = d.in + ((size_t)b * d.cin + c0) * vol + ((long)jd0 * d.Hin + jy0) * d.Win + jx0;
 #pragma unroll 4
-        for (int ci = 0; ci < CK; ++ci) halo.stage(origin + (long)ci * vol, ci < d.cin, lo, him1, lds + ci * PLANE, wave);
+        for (int ci = 0; ci < CK; ++ci) halo.stage(origin + (long)ci * vol, c0 + ci < d.cin, lo, him1, lds + ci * PLANE, wave);
     }
-    // A slabs from the gather-form weights [cin][27][cout_pad = 8]: combination c of an axis = (offset, parity, tap):
+    // A slabs from the gather-form weights [cin][27][cout_pad]: combination c of an axis = (offset, parity, tap):
     // c = 0: (0, 0, k=1), c = 1: (0, 1, k=2), c = 2: (1, 1, k=0)
     for (int e = tid; e < CK * NS * 16; e += DMVS_BLOCK) {
         const int ci = e / (NS * 16), rem = e - ci * (NS * 16);
         const int sidx = rem >> 4, row = rem & 15;
         const int dx = sidx & 1, cy = (sidx >> 1) % 3, cz = (sidx >> 1) / 3;
         const int kd = cz == 0 ? 1 : (cz == 1 ? 2 : 0), ky = cy == 0 ? 1 : (cy == 1 ? 2 : 0);
-        const int co = row & 7;
+        const int co = co_base + (row & 7);
         int kx = -1;
         if (row < 8) kx = dx == 0 ? 1 : -1;
         else kx = dx == 0 ? 2 : 0;
         float v = 0.0f;
-        if (ci < d.cin && kx >= 0 && co < d.cout) v = d.weight[(ci * 27 + (kd * 3 + ky) * 3 + kx) * d.cout_pad + co];
+        if (c0 + ci < d.cin && kx >= 0 && co < d.cout) v = d.weight[((c0 + ci) * 27 + (kd * 3 + ky) * 3 + kx) * d.cout_pad + co];
         s_w[ci * WP + sidx * 16 + row] = v;
     }
-    f32x4 acc[4][4];                    // [pz * 2 + py][input row mt]
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[c][i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     __syncthreads();                    // halo (LDS-DMA) and slabs (ds_write) landed
 
-    const int ngroups = (d.cin + 3) >> 2;
+    const int live_c = d.cin - c0 < CK ? d.cin - c0 : CK;
+    const int ngroups = (live_c + 3) >> 2;
 #pragma unroll 1
     for (int g = 0; g < ngroups; ++g) {
         const int ci = g * 4 + kq;
@@ -919,13 +932,14 @@ __global__ void __launch_bounds__(DMVS_BLOCK) deconv3d_mfma_kernel(const dmvs_co
             }
         }
     }
+    }      // input-channel chunks
 
-    // epilogue: this lane holds x-parity kq >> 1, channels (kq & 1) * 4 + r of input position (jd0 + wave, jy0 + mt, jx0 + m).
+    // epilogue: this lane holds x-parity kq >> 1, channels co_base + (kq & 1) * 4 + r of input position (jd0 + wave, jy0 + mt, jx0 + m).
     // The two x-parities of a channel sit 32 lanes apart; stored as they are, every store instruction would write 4-byte
     // elements at an 8-byte stride.  Lanes 0-31 therefore take the (pz, py) classes 0, 1 and lanes 32-63 the classes 2, 3 of
     // BOTH parities (one cross-half exchange per value) and write / read 8-byte pairs: 128 contiguous bytes per 16 lanes.
     const bool lowhalf = kq < 2;
-    const int cg0 = (kq & 1) * 4;
+    const int cg0 = co_base + (kq & 1) * 4;
     const int jx = jx0 + m, jd = jd0 + wave;
     const bool live = jx < d.Win && jd < d.Din;
     float* outb = d.out + (size_t)b * d.cout * ovol;
@@ -959,6 +973,15 @@ __global__ void __launch_bounds__(DMVS_BLOCK) deconv3d_mfma_kernel(const dmvs_co
     }
 }
 
+// DMVS_CONV3D_S2=direct: the round-1 direct VALU kernels for the stride-2 layers (A/B runs)
+static bool conv3d_s2_mfma() {
+    static const bool on = [] {
+        const char* e = getenv("DMVS_CONV3D_S2");
+        return !(e && e[0] == 'd');
+    }();
+    return on;
+}
+
 extern "C" int dmvs_conv3d_f32(const dmvs_conv3d_desc* dp, void* stream) {
     if (!dp) return DMVS_EINVAL;
     const dmvs_conv3d_desc& d = *dp;
@@ -969,10 +992,10 @@ extern "C" int dmvs_conv3d_f32(const dmvs_conv3d_desc* dp, void* stream) {
     if (d.transposed) {
         if (d.stride != 2 || d.Dout != 2 * d.Din || d.Hout != 2 * d.Hin || d.Wout != 2 * d.Win) return DMVS_EINVAL;
         const long total = (long)d.B * d.Din * d.Hin * d.Win;
-        if (d.cout <= 8 && d.cout_pad == 8 && d.cin <= kDeconvCin && (long)d.cout * d.Dout * d.Hout * d.Wout < (1L << 31) &&
-            (long)d.cin * d.Din * d.Hin * d.Win < (1L << 31)) {      // matrix-core form (CostRegNet conv7)
+        if ((long)d.cout * d.Dout * d.Hout * d.Wout < (1L << 31) && (long)d.cin * d.Din * d.Hin * d.Win < (1L << 31)) {
+            // matrix-core form (CostRegNet conv7 16 -> 8, conv6 32 -> 16): 8 output channels per workgroup
             const int tiles_x = (d.Win + 15) / 16, tiles_y = (d.Hin + 3) / 4, tiles_d = (d.Din + 3) / 4;
-            dim3 g((unsigned)(tiles_x * tiles_y * tiles_d * d.B));
+            dim3 g((unsigned)(tiles_x * tiles_y * tiles_d * d.B), (unsigned)((d.cout + 7) / 8));
             hipLaunchKernelGGL(deconv3d_mfma_kernel, g, block, 0, st, d, tiles_x, tiles_y, tiles_d);
             return dmvs_launch_status();
         }
@@ -1023,6 +1046,16 @@ extern "C" int dmvs_conv3d_f32(const dmvs_conv3d_desc* dp, void* stream) {
         if (ntiles == 1) hipLaunchKernelGGL((conv3d_mfma_kernel<1>), g, block, 0, st, d, tiles_x, tiles_y, tiles_d);
         else hipLaunchKernelGGL((conv3d_mfma_kernel<2>), g, block, 0, st, d, tiles_x, tiles_y, tiles_d);
     } else {
+        // stride 2 on the matrix cores (32-bit element offsets inside a batch item, like the stride-1 kernels)
+        const bool fits32 = (long)d.cin * d.Din * d.Hin * d.Win < (1L << 31) && (long)d.cout * d.Dout * d.Hout * d.Wout < (1L << 31);
+        const int ntiles = (d.cout_pad + 15) / 16;
+        if (fits32 && ntiles <= 2 && conv3d_s2_mfma()) {
+            const int tiles_x = (d.Wout + 15) / 16, tiles_y = (d.Hout + 3) / 4, tiles_d = (d.Dout + 3) / 4;
+            dim3 g((unsigned)(tiles_x * tiles_y * tiles_d * d.B), 1);
+            if (ntiles == 1) hipLaunchKernelGGL((conv3d_mfma_kernel<1, 2>), g, block, 0, st, d, tiles_x, tiles_y, tiles_d);
+            else hipLaunchKernelGGL((conv3d_mfma_kernel<2, 2>), g, block, 0, st, d, tiles_x, tiles_y, tiles_d);
+            return dmvs_launch_status();
+        }
         if (co == 16) hipLaunchKernelGGL((conv3d_kernel<16, 2>), grid, block, 0, st, d);
         else hipLaunchKernelGGL((conv3d_kernel<8, 2>), grid, block, 0, st, d);
     }

@@ -687,25 +687,18 @@ static int launch_warp_init_quad(const void* ref, const void* src, const float* 
     return dmvs_launch_status();
 }
 
-// LDS-band form: 48 KB of band per workgroup = 3 workgroups (12 waves) per CU; occupancy is set by LDS, not registers, so the
-// texel loop can afford 4 texels per trip (DMVS_BAND_TPT=2|4 for A/B runs)
-static int band_tpt() {
-    static const int v = [] {
-        const char* e = getenv("DMVS_BAND_TPT");
-        return e ? atoi(e) : 2;
-    }();
-    return v;
-}
+// LDS-band form: 48 KB of band per workgroup = 3 workgroups (12 waves) per CU.  Measured on the MI355X and left as they are:
+// 38 KB bands (4 workgroups per CU, more plane groups) 797 vs 809 us, 4 texels per trip (141 VGPRs) 837 vs 813 us per B=96
+// launch -- the kernel is bound by the VALU work per texel, not by occupancy or LDS latency.
 template <int FT>
 static int launch_warp_init_band(const void* ref, const void* src, const float* rt, const float* disp_min, const float* disp_max, float* out,
                                  int B, int S, int C, int D, int H, int W, int Hs, int Ws, hipStream_t st) {
     const int tiles_x = (W + BTW - 1) / BTW, tiles_y = (H + BTH - 1) / BTH;
     dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(B * S)), block(DMVS_BLOCK);
-#define DMVS_WIB(CC, TPT) hipLaunchKernelGGL((warp_init_band_kernel<CC, TPT, FT, 48 * 1024>), grid, block, 0, st, ref, src, rt, disp_min, disp_max, out, B, S, D, H, W, Hs, Ws, tiles_x)
-    if (C == 48 && band_tpt() == 4) DMVS_WIB(48, 4);
-    else if (C == 48) DMVS_WIB(48, 2);
-    else if (C == 32) DMVS_WIB(32, 2);
-    else if (C == 16) DMVS_WIB(16, 2);
+#define DMVS_WIB(CC) hipLaunchKernelGGL((warp_init_band_kernel<CC, QUAD_TPT, FT, 48 * 1024>), grid, block, 0, st, ref, src, rt, disp_min, disp_max, out, B, S, D, H, W, Hs, Ws, tiles_x)
+    if (C == 48) DMVS_WIB(48);
+    else if (C == 32) DMVS_WIB(32);
+    else if (C == 16) DMVS_WIB(16);
     else return DMVS_EINVAL;
 #undef DMVS_WIB
     return dmvs_launch_status();

@@ -833,6 +833,24 @@ def test_conv3d_streamed_tiles(ops, cin, cout, with_res):
     close(out, ref, 2e-5)
 
 
+@pytest.mark.parametrize("cin,cout,D,H,W,with_res", [(8, 16, 11, 18, 70, False), (16, 32, 8, 9, 33, True), (6, 12, 5, 7, 20, False)])
+def test_conv3d_stride2_matrix_core_form(ops, cin, cout, D, H, W, with_res):
+    """CostRegNet_small's stride-2 layers (conv2 8 -> 16, conv4 16 -> 32) on the matrix cores: several output tiles per axis, odd and
+    even input sizes (the last output voxel's window ends on / beyond the volume), 2 and 4 channel chunks, one and two n-tiles"""
+    B = 2
+    x = rnd(B, cin, D, H, W, seed=1)
+    w = rnd(cout, cin, 3, 3, 3, seed=2) * 0.2
+    bn = {"weight": rnd(cout, seed=4, lo=0.5, hi=1.5), "bias": rnd(cout, seed=5),
+          "running_mean": rnd(cout, seed=6), "running_var": rnd(cout, seed=7, lo=0.5, hi=1.5)}
+    ref = F.relu(F.batch_norm(F.conv3d(x, w, None, 2, 1), bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"], False, 0.0, 1e-5))
+    res = rnd(*ref.shape, seed=9) if with_res else None
+    if with_res:
+        ref = ref + res
+    pc = K.pack_conv3d(dev(ops, w), bn={k_: v.to(ops.device) for k_, v in bn.items()}, stride=2)
+    out = ops.conv3d(pc, dev(ops, x), act=K.ACT_RELU, residual=dev(ops, res))
+    close(out, ref, 2e-5)
+
+
 @pytest.mark.parametrize("cin,cout,D,H,W", [(4, 8, 1, 1, 1), (8, 8, 2, 3, 17), (8, 1, 1, 2, 33), (16, 16, 5, 4, 16), (3, 1, 4, 8, 32)])
 def test_conv3d_volumes_smaller_than_a_tile(ops, cin, cout, D, H, W):
     """degenerate volumes: every staged halo element is border or padding in at least one axis (packed border test),
@@ -1075,7 +1093,8 @@ def test_warp_corr_init_quad_16bit_features(ops, dt):
     close(out, want, 1e-4)
 
 
-@pytest.mark.parametrize("cin,cout,D,H,W,with_res", [(16, 8, 6, 9, 21, True), (8, 8, 5, 4, 16, False), (12, 6, 3, 5, 33, True), (4, 3, 2, 2, 2, False)])
+@pytest.mark.parametrize("cin,cout,D,H,W,with_res", [(16, 8, 6, 9, 21, True), (8, 8, 5, 4, 16, False), (12, 6, 3, 5, 33, True), (4, 3, 2, 2, 2, False),
+                                                     (32, 16, 5, 6, 20, True), (20, 12, 3, 4, 17, False)])
 def test_deconv3d_matrix_core_form(ops, cin, cout, D, H, W, with_res):
     """transposed conv, stride 2, output_padding 1 with cout <= 8 on the matrix cores (CostRegNet conv7): several tiles per
     axis, ragged last tiles, channel counts that do not fill the 4-channel MFMA groups, both x-parities sharing the A rows"""
