@@ -264,6 +264,9 @@ def main():
                          "7 source views, bf16 feature storage; cfg4 = configs[3]: the CasDiffMVS training step, data parallel (second "
                          "lines, not the headline)")
     ap.add_argument("--precision", default=None, choices=["fp32", "bf16", "fp16"], help="feature storage precision (default: the config's)")
+    ap.add_argument("--conv-arith", default=None, choices=["fp32", "bf16"],
+                    help="matrix arithmetic of the 2-D convolutions (default: fp32 for cfg2 -- the headline is an fp32 number -- and "
+                         "bf16 for cfg3, whose BASELINE.json entry is a bf16 configuration)")
     ap.add_argument("--graphs", action="store_true", help="run the timed steps through the captured HIP graph of the forward")
     ap.add_argument("--no-batch-sweep", action="store_true")
     ap.add_argument("--conv-table", action="store_true", help="print the per-shape table of the step's conv2d launches to stderr")
@@ -301,8 +304,10 @@ def main():
         if "DMVS_BENCH_BATCH" not in os.environ and "--batch" not in sys.argv:
             a.batch = 4
         a.precision = a.precision or "bf16"
+        a.conv_arith = a.conv_arith or "bf16"
     prec = a.precision or "fp32"
-    args = synth.make_args(variant, numdepth_initial=48, precision=prec)
+    arith = a.conv_arith or "fp32"
+    args = synth.make_args(variant, numdepth_initial=48, precision=prec, conv_arith=arith)
     model = CasDiffMVS(args, test=True).eval()
     sd = synth.synth_state_dict(model.state_dict(), 123)
     model.load_state_dict(sd)
@@ -454,10 +459,16 @@ def main():
     if a.config != "cfg2":
         result["metric"] = f"depth-maps/sec ({W}x{H}, {S} src views)"
         result["config"]["workload"] = (f"CasDiffMVS DTU eval {W}x{H}, {S} src views, numdepth_initial=48, sampling_timesteps 0/1/1, "
-                                        f"{prec} feature storage + fp32 arithmetic (BASELINE.json configs[2]; not the headline configuration)")
+                                        f"{prec} feature storage, {arith} matrix arithmetic in the 2-D convolutions (fp32 accumulation), everything else "
+                                        f"fp32 (BASELINE.json configs[2]; not the headline configuration)")
+        result["dtype"] = "bf16" if arith == "bf16" else "f32"
         result["roofline"]["kernel"] = "GetCost: getcost_quad_kernel<32,4> + <16,4> (stage 2 and stage 3 launches, bytes averaged per launch)"
         result["roofline_conv2d"] = None
     result["config"]["feature_storage"] = prec
+    result["config"]["conv_arith"] = arith
+    if arith != "fp32" and a.config == "cfg2":      # an experiment line, never the headline: say so where the driver reads it
+        result["dtype"] = "bf16"
+        result["config"]["workload"] += " -- NON-HEADLINE EXPERIMENT: bf16 matrix arithmetic in the 2-D convolutions"
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.config == "cfg2":
         # the CPU leg runs in a child process with a hard time limit so that an oversubscribed or slow
         # host can never stall the GPU measurement

@@ -16,6 +16,7 @@ ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_SILU = range(5)
 IN_PLAIN, IN_UPSAMPLE2, IN_UNSHUFFLE2, IN_ZEROINSERT2 = range(4)
 LAYOUT_NCHW, LAYOUT_NHWC, LAYOUT_NHWC_BF16, LAYOUT_NHWC_F16 = 0, 1, 2, 3
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
+ARITH_F32, ARITH_BF16 = 0, 1
 EW_DEPTH_TO_DISP, EW_DISP_TO_DEPTH = 0, 1
 
 _P = C.c_void_p
@@ -31,7 +32,7 @@ class Conv2dDesc(C.Structure):
         ("cout", _I), ("cout_pad", _I), ("kh", _I), ("kw", _I), ("stride", _I), ("pad_h", _I), ("pad_w", _I),
         ("in_mode", _I), ("act", _I), ("res_mode", _I), ("res_after_act", _I),
         ("out_layout", _I), ("out_cstride", _I), ("out_coffset", _I), ("gn_groups", _I), ("post_scale", _F),
-        ("gate_cstride", _I),
+        ("gate_cstride", _I), ("arith", _I),
     ]
 
 

@@ -29,6 +29,37 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// 8 bf16 operand values of a lane for v_mfma_f32_16x16x32_bf16 (k-slots 8*(lane>>4) .. +7), as raw 16-bit patterns
+#ifdef DMVS_HOST_EMULATION
+typedef hipemu_s16x8 bf16x8;
+__device__ __forceinline__ bf16x8 dmvs_pack_bf16x8(const float (&v)[8]) {
+    bf16x8 r;
+    for (int j = 0; j < 8; ++j) r[j] = (short)dmvs_f32_to_bf16(v[j]);
+    return r;
+}
+__device__ __forceinline__ f32x4 dmvs_mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) { return hipemu_mfma_f32_16x16x32_bf16(a, b, c); }
+#else
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 dmvs_pack_bf16x8(const float (&v)[8]) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const bf16x2 p = __builtin_convertvector(f32x2{v[j], v[j + 1]}, bf16x2);       // v_cvt_pk_bf16_f32: round to nearest even
+        const s16x2 q = __builtin_bit_cast(s16x2, p);
+        r[j] = q[0];
+        r[j + 1] = q[1];
+    }
+    return r;
+}
+__device__ __forceinline__ f32x4 dmvs_mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+    typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, a), __builtin_bit_cast(mfma_bf16x8, b), c, 0, 0, 0);
+}
+#endif
+
 namespace {
 
 constexpr int pad16mod32(int n) {   // smallest m >= n with m % 32 == 16
@@ -42,7 +73,7 @@ __device__ __attribute__((aligned(16))) const float dmvs_zero16[4] = {0.0f, 0.0f
 
 #define DMVS_LDS(p) ((__attribute__((address_space(3))) void*)(p))
 
-template <int KH, int KW, int S, int NT, int MT>
+template <int KH, int KW, int S, int NT, int MT, int AR = DMVS_ARITH_F32>
 struct ConvCfg {
     static constexpr int T = KH * KW;
     static constexpr int ROWS = 4 * MT;
@@ -50,8 +81,9 @@ struct ConvCfg {
     static constexpr int PLANE = pad16mod32(TH * TW);
     static constexpr int NW = NT * 16;
     static constexpr int WPAD = pad16mod32(T * NW);
-    // input channels per LDS chunk: 8 when the double-buffered chunk stays within 40 KB, else 4
-    static constexpr int CK = (2 * 8 * (PLANE + WPAD) * 4 > 40960) ? 4 : 8;
+    // input channels per LDS chunk: 8 when the double-buffered chunk stays within 40 KB, else 4 (the bf16 form: always 8,
+    // its matrix instruction spans 8 channels)
+    static constexpr int CK = AR == DMVS_ARITH_BF16 ? 8 : ((2 * 8 * (PLANE + WPAD) * 4 > 40960) ? 4 : 8);
     static constexpr int BUF = CK * (PLANE + WPAD);            // floats per pipeline stage
     static constexpr int IN_IT = (CK * PLANE + DMVS_BLOCK - 1) / DMVS_BLOCK;           // 4-byte DMA pieces per thread
     static constexpr int W_IT = (CK * WPAD / 4 + DMVS_BLOCK - 1) / DMVS_BLOCK;         // 16-byte DMA pieces per thread
@@ -78,9 +110,15 @@ constexpr int conv_min_waves(int nt, int mt) { return (nt == 2 && mt == 4) ? 4 :
 // 5-20 % down (profiles/r3_conv_walk_ab.txt): carrying two tiles' state through the loop costs 112 instead of 63 VGPRs
 // (3 instead of 5 waves per SIMD) and 217 SGPR-spill reads on the <3,3,1,1,4> instantiation (tools/isa_stats.py).  Only
 // instantiated with -DDMVS_CONV_WALK; the register work it needs is listed in DESIGN.md.
-template <int KH, int KW, int S, int NT, int MT, bool ZI, int OT = DMVS_DTYPE_F32, bool TR = false, bool WALK = false>
+//
+// AR = DMVS_ARITH_BF16: the same kernel -- same fp32 tensors, same LDS-DMA staging of fp32 tiles, same epilogue -- with the
+// operands rounded to bf16 (nearest even, v_cvt_pk_bf16_f32) as they leave LDS and v_mfma_f32_16x16x32_bf16 (fp32
+// accumulation) in place of the fp32 MFMA.  One bf16 MFMA spans K = 32 = the 8 input channels of an LDS chunk x 4 TAPS: lane
+// group kq carries tap 4g + kq (taps beyond KH*KW meet zero weights), its 8 k-slots are the 8 channels.  3 MFMAs replace the
+// 18 fp32 ones of a 3x3 chunk, at half the cycles each; the loop is then bound by its (unchanged) 8 LDS reads per operand.
+template <int KH, int KW, int S, int NT, int MT, bool ZI, int OT = DMVS_DTYPE_F32, bool TR = false, bool WALK = false, int AR = DMVS_ARITH_F32>
 __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfma_kernel(const dmvs_conv2d_desc d, int tiles_x, int tiles_y) {
-    using Cfg = ConvCfg<KH, KW, S, NT, MT>;
+    using Cfg = ConvCfg<KH, KW, S, NT, MT, AR>;
     constexpr int T = Cfg::T, TW = Cfg::TW, TH = Cfg::TH, PLANE = Cfg::PLANE, NW = Cfg::NW, WPAD = Cfg::WPAD;
     constexpr int CK = Cfg::CK, BUF = Cfg::BUF, IN_IT = Cfg::IN_IT, W_IT = Cfg::W_IT;
     // one LDS object on purpose (tile buffers + the 32-float GroupNorm scratch): with separate objects hipcc orders reads of
@@ -283,6 +321,37 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
             if (border) zero_padding(other);
             stage(0, other);
         }
+        if constexpr (AR == DMVS_ARITH_BF16) {
+            static_assert(CK == 8, "the bf16 form maps the 8 channels of an LDS chunk onto the 8 k-slots of a lane");
+            constexpr int NG = (T + 3) / 4;          // tap groups: K = 32 = 4 taps x 8 channels
+#pragma unroll 1
+            for (int g = 0; g < NG; ++g) {
+                const int t = 4 * g + kq;
+                const bool tv = t < T;
+                const int tc = tv ? t : T - 1;
+                const int ky = tc / KW, kx = tc - ky * KW;
+                const float* wp = s_w + tc * NW + m;
+                const float* ip = s_in + ((wave * MT * S) + ky) * TW + m * S + kx;
+                bf16x8 av[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    float a[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a[j] = tv ? wp[j * WPAD + nt * 16] : 0.0f;      // tap beyond the kernel: zero weights
+                    av[nt] = dmvs_pack_bf16x8(a);
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    float bb[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bb[j] = ip[j * PLANE + (mt * S) * TW];
+                    const bf16x8 bv = dmvs_pack_bf16x8(bb);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = TR ? dmvs_mfma_bf16(bv, av[nt], acc[mt][nt]) : dmvs_mfma_bf16(av[nt], bv, acc[mt][nt]);
+                }
+            }
+        } else {
         const int live_c = cin - c0 < CK ? cin - c0 : CK;
         const int nc4 = (live_c + 3) >> 2;          // all-zero 4-channel groups of the last chunk are skipped
 #pragma unroll 1
@@ -307,6 +376,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
                     }
                 }
             }
+        }
         }
     }
 
@@ -600,6 +670,23 @@ int launch_conv2d_mt(const dmvs_conv2d_desc& d, hipStream_t st, int nt, int ngro
     const int tiles_x = (d.Wout + 15) / 16, tiles_y = (d.Hout + 4 * MT - 1) / (4 * MT);
     dim3 grid((unsigned)(tiles_x * tiles_y * d.B), (unsigned)ngroups), block(DMVS_BLOCK);
     if (d.out_layout == DMVS_LAYOUT_NCHW) {      // transposed accumulators: 16-byte NCHW stores
+        if constexpr (!ZI && MT == 2 && KH * KW > 1) {      // bf16 matrix arithmetic: one tile shape (16 x 8), NCHW fp32 outputs
+            if (d.arith == DMVS_ARITH_BF16) {
+#define DMVS_BF(NTV) do { \
+                    using BCfg = ConvCfg<KH, KW, S, NTV, MT, DMVS_ARITH_BF16>; \
+                    if constexpr ((2 * BCfg::BUF + 32) * 4 <= 150 * 1024) { \
+                        hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, NTV, MT, false, DMVS_DTYPE_F32, true, false, DMVS_ARITH_BF16>), grid, block, 0, st, d, tiles_x, tiles_y); \
+                        return dmvs_launch_status(); \
+                    } } while (0)
+                switch (nt) {      // (a shape whose 8-channel double buffer exceeds the LDS falls through to the fp32 kernel)
+                    case 1: DMVS_BF(1); break;
+                    case 2: DMVS_BF(2); break;
+                    case 3: DMVS_BF(3); break;
+                    default: DMVS_BF(4); break;
+                }
+#undef DMVS_BF
+            }
+        }
 #ifdef DMVS_CONV_WALK      // experiment, not built by default: measured 8 % SLOWER end to end (see the kernel's header comment)
         if constexpr (!ZI) {
             if (conv_walk_enabled()) {           // resident, tile-walking workgroups (DMVS_CONV_WALK=0: one tile per workgroup)
@@ -658,6 +745,8 @@ int launch_conv2d(const dmvs_conv2d_desc& d, hipStream_t st) {
     //   24->32 at 128x160 70.1 / 65.0 / 67.7;  16->16 at 128x160 (one n-tile) 38.0 / 30.7 / 29.3.
     constexpr bool heavy = (S == 2) || (KH * KW >= 25);
     if (d.out_layout == DMVS_LAYOUT_NHWC_BF16 || d.out_layout == DMVS_LAYOUT_NHWC_F16)      // one tile shape (16x8) for the 16-bit outputs
+        return launch_conv2d_mt<KH, KW, S, 2, false>(d, st, nt, ngroups);
+    if (d.arith == DMVS_ARITH_BF16 && d.out_layout == DMVS_LAYOUT_NCHW && KH * KW > 1)      // and for the bf16 matrix arithmetic
         return launch_conv2d_mt<KH, KW, S, 2, false>(d, st, nt, ngroups);
     const long wg16 = (long)((d.Wout + 15) / 16) * ((d.Hout + 15) / 16) * d.B * ngroups;
     static const int force_mt = getenv("DMVS_CONV_MT") ? atoi(getenv("DMVS_CONV_MT")) : 0;      // experiments: force the tile height
@@ -1075,6 +1164,7 @@ extern "C" int dmvs_conv2d_f32(const dmvs_conv2d_desc* dp, void* stream) {
     if (d.gru_z && (!d.gru_h || d.act != DMVS_ACT_TANH)) return DMVS_EINVAL;
     if (d.gate_cstride < 0 || (d.gate_cstride && d.in_mode != DMVS_IN_PLAIN)) return DMVS_EINVAL;
     if (d.gn_stats && (d.gn_groups != 4 || d.cout % 4)) return DMVS_EINVAL;
+    if (d.arith != DMVS_ARITH_F32 && d.arith != DMVS_ARITH_BF16) return DMVS_EINVAL;
     const int eh = (d.Hin + 2 * d.pad_h - d.kh) / d.stride + 1, ew = (d.Win + 2 * d.pad_w - d.kw) / d.stride + 1;
     if (eh != d.Hout || ew != d.Wout) return DMVS_EINVAL;
     // 32-bit element offsets inside one batch item

@@ -386,7 +386,7 @@ class GraphedForward:
 
 class Engine:
     def __init__(self, sd: Dict[str, torch.Tensor], args, ops: Ops):
-        self.ops = ops
+        self.ops = self.base_ops = ops       # (self.ops may become a copy bound to another conv arithmetic, see conv_arith)
         self._graphs = {}
         self.args = args
         self.arena = GnArena(ops)
@@ -407,6 +407,17 @@ class Engine:
         if prec not in K.FEATURE_DTYPES:
             raise K._lib.DmvsError(f"precision '{prec}': expected one of {sorted(K.FEATURE_DTYPES)}")
         self.precision, self.feat_dtype = prec, K.FEATURE_DTYPES[prec]
+        # matrix arithmetic of the 2-D convolutions: args.conv_arith / DMVS_CONV_ARITH in {"fp32", "bf16"}.  "bf16" rounds the
+        # inputs and weights of every multi-tap convolution with a planar output to bf16 as they enter the matrix cores (fp32
+        # accumulation; tensors in memory, the FeatureNet stem, the 1x1 layers, the channel-last feature outputs, the 3-D
+        # convolutions, the warps and every epilogue stay fp32) -- the arithmetic of BASELINE.json's bf16 configuration.  The
+        # reference's eps switch for non-fp32 activations (update.py:87,102) does not apply: activations are fp32 here.
+        arith = os.environ.get("DMVS_CONV_ARITH") or getattr(args, "conv_arith", "fp32") or "fp32"
+        if arith not in K.CONV_ARITH:
+            raise K._lib.DmvsError(f"conv_arith '{arith}': expected one of {sorted(K.CONV_ARITH)}")
+        self.conv_arith = arith
+        if K.CONV_ARITH[arith] != self.ops.conv_arith:
+            self.ops = self.ops.with_conv_arith(K.CONV_ARITH[arith])
         if self.feat_dtype != torch.float32 and not self.quad:
             raise K._lib.DmvsError("16-bit feature storage needs the quad-per-pixel warp kernels (unset DMVS_WARP=legacy)")
         self.feat = pack_feature(sd, "feature", g4=self.quad, feat_dtype=self.feat_dtype)

@@ -15,9 +15,11 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU, ACT_TANH, DTYPE_BF16, DTYPE_F16, DTYPE_F32, IN_PLAIN,  # noqa: F401
+from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU, ACT_TANH, ARITH_BF16, ARITH_F32, DTYPE_BF16, DTYPE_F16, DTYPE_F32, IN_PLAIN,  # noqa: F401
                    IN_UNSHUFFLE2, IN_UPSAMPLE2, IN_ZEROINSERT2, LAYOUT_NCHW, LAYOUT_NHWC, LAYOUT_NHWC_BF16, LAYOUT_NHWC_F16)
 
+# matrix arithmetic of the multi-tap 2-D convolutions: "fp32" (exact, the reference's) | "bf16" (bf16 products, fp32 accumulation)
+CONV_ARITH = {"fp32": ARITH_F32, "bf16": ARITH_BF16}
 # reduced-precision FEATURE storage (BASELINE.json's bf16 / fp16 configurations): torch dtype <-> C-ABI codes
 FEATURE_DTYPES = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
 _DTYPE_CODE = {torch.float32: DTYPE_F32, torch.bfloat16: DTYPE_BF16, torch.float16: DTYPE_F16}
@@ -150,6 +152,14 @@ class Ops:
         self._getcost_state = {}     # per launch shape: which GetCost device path the last probe favoured (see getcost)
         self.getcost_tiles = None
         self.last_getcost_worklist = None
+        self.conv_arith = ARITH_F32      # matrix arithmetic of the multi-tap 2-D convolutions (with_conv_arith)
+
+    def with_conv_arith(self, arith: int) -> "Ops":
+        """a binding of the same library whose conv2d() computes in `arith` (ARITH_F32 | ARITH_BF16) by default"""
+        import copy
+        o = copy.copy(self)
+        o.conv_arith = arith
+        return o
 
     def _call(self, name, *args):
         if self.timers is not None and name in self.timers:
@@ -199,10 +209,12 @@ class Ops:
     def conv2d(self, pc: PackedConv, x0, x1=None, *, mul0=None, in_mode=IN_PLAIN, act=ACT_NONE, residual=None,
                res_mode=IN_PLAIN, res_after_act=False, post_scale=1.0, gru_z=None, gru_h=None, out=None,
                out_layout=LAYOUT_NCHW, out_cstride=None, out_coffset=0, gn_stats=None, gn_groups=4, out_dtype=torch.float32,
-               gate_cstride=0):
+               gate_cstride=0, arith=None):
         """gn_stats: zeroed float64 [B*gn_groups*2] tensor that receives the GroupNorm statistics of
         the (pre-activation) output, for a following groupnorm_apply().  out_dtype (channel-last outputs only): bf16 / fp16
-        feature storage, rounded to nearest even in the epilogue."""
+        feature storage, rounded to nearest even in the epilogue.  arith: ARITH_F32 | ARITH_BF16 (default: this binding's
+        conv_arith) -- bf16 rounds inputs and weights as they enter the matrix cores (fp32 accumulation, fp32 tensors); layers
+        with one tap and channel-last outputs always compute in fp32."""
         if gate_cstride:      # mul0 / gru_z are channel slices of one [B,gate_cstride,H,W] tensor (merged z|r gate convolution)
             self._chk(x0, x1, residual, gru_h)
             for t in (mul0, gru_z):
@@ -242,7 +254,8 @@ class Ops:
             gn_stats=_ptr(gn_stats), gn_groups=(gn_groups if gn_stats is not None else 0), B=B, c0=c0, c1=c1, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, cout=pc.cout, cout_pad=pc.cout_pad,
             kh=kh, kw=kw, stride=pc.stride, pad_h=pc.pad[0], pad_w=pc.pad[1], in_mode=in_mode, act=act,
             res_mode=res_mode, res_after_act=int(res_after_act), out_layout=out_layout, out_cstride=out_cstride,
-            out_coffset=out_coffset, post_scale=post_scale, gate_cstride=gate_cstride)
+            out_coffset=out_coffset, post_scale=post_scale, gate_cstride=gate_cstride,
+            arith=(self.conv_arith if arith is None else arith))
         self._call("dmvs_conv2d_f32", C.byref(d), self.stream())
         if self.timers is not None and "dmvs_conv2d_f32" in self.timers:      # bench: MFMA roofline over every conv launch
             self.timers.setdefault("_conv2d_flops", []).append(2.0 * B * Hout * Wout * pc.cout * pc.cin * kh * kw)
@@ -296,7 +309,7 @@ class Ops:
             gru_h=None, out=None, gn_stats=None, gn_groups=0, B=B, c0=c0, c1=c1, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout,
             cout=pc.cout, cout_pad=pc.cout_pad, kh=kh, kw=kw, stride=pc.stride, pad_h=pc.pad[0], pad_w=pc.pad[1],
             in_mode=in_mode, act=ACT_NONE, res_mode=IN_PLAIN, res_after_act=0, out_layout=LAYOUT_NCHW,
-            out_cstride=pc.cout, out_coffset=0, post_scale=1.0)
+            out_cstride=pc.cout, out_coffset=0, post_scale=1.0, gate_cstride=0, arith=ARITH_F32)
         nbytes = C.c_int64(0)
         self._call("dmvs_conv2d_wgrad_workspace_f32", C.byref(d), C.byref(nbytes))
         ws = self.empty(nbytes.value // 4)

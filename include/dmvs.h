@@ -62,6 +62,9 @@ int dmvs_abi_version(void);
  * Output is written at channel offset out_coffset of a tensor with out_cstride channels
  * (so that concatenations never have to be materialised), NCHW or NHWC.
  */
+#define DMVS_ARITH_F32 0
+#define DMVS_ARITH_BF16 1
+
 typedef struct dmvs_conv2d_desc {
     const float* in0;       /* [B,c0,*,*] physical tensor                                   */
     const float* in1;       /* [B,c1,Hin,Win] or NULL; only with DMVS_IN_PLAIN               */
@@ -93,6 +96,11 @@ typedef struct dmvs_conv2d_desc {
     int32_t gate_cstride;   /* 0: mul0 / gru_z are dense [B,c0,..] / [B,cout,..] tensors.  > 0: both are channel slices (the pointers
                                include the channel offset) of tensors with this many channels per batch item -- SepConvGRU's z and
                                r gates computed by ONE convolution with 2x cout (models/module.py:164-177)              */
+    int32_t arith;          /* DMVS_ARITH_F32 (0): exact fp32 products (v_mfma_f32_16x16x4_f32), the reference's precision.
+                               DMVS_ARITH_BF16 (1): inputs and weights rounded to bf16 (nearest even) as they enter the matrix
+                               cores, fp32 accumulation (v_mfma_f32_16x16x32_bf16) -- the reduced-precision configurations of
+                               BASELINE.json (configs[2], [4]); tensors in memory stay fp32.  Honoured by layers with more than
+                               one tap; 1x1 layers always compute in fp32.                                                */
 } dmvs_conv2d_desc;
 
 /* Size limits (DMVS_EINVAL beyond them; the kernels address one batch item with 32-bit element offsets):

@@ -97,7 +97,7 @@ class CasDiffMVS(nn.Module):
         """The packed inference engine for the current weights (rebuilt when they change)."""
         device = next(self.parameters()).device
         key = self._weights_key(device)
-        if self._engine is None or self._engine_key != key or (ops is not None and ops is not self._engine.ops):
+        if self._engine is None or self._engine_key != key or (ops is not None and ops is not self._engine.base_ops):
             if ops is None:
                 ops = Ops.for_device(device)       # raises unless `device` is a HIP device and the .so exists
             self._engine = Engine(self.state_dict(), self.args, ops)

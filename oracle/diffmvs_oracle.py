@@ -25,6 +25,19 @@ BN_EPS = 1e-5
 
 
 # ------------------------------------------------------------------ small helpers
+# Reduced-precision matrix arithmetic of the product's bf16 configuration (NOT reference behaviour): the inputs and
+# weights of a multi-tap 2-D convolution are rounded to `_CONV_DTYPE` before the (fp32-accumulated) convolution; tensors
+# stay fp32.  exact=True marks the layers the product always computes in fp32: FeatureNet's fused stem (conv0.0 / conv0.1)
+# and its channel-last output convolutions (out1..3); 1x1 layers are exempt by their shape.
+_CONV_DTYPE = None
+
+
+def _c2d(x, w, b=None, stride=1, pad=0, exact=False):
+    if _CONV_DTYPE is not None and not exact and w.shape[2] * w.shape[3] > 1:
+        x, w = x.to(_CONV_DTYPE).float(), w.to(_CONV_DTYPE).float()
+    return F.conv2d(x, w, b, stride, pad)
+
+
 def _bn(x, sd, p):
     """eval-mode BatchNorm{2,3}d (models/module.py:46,90; torch defaults eps=1e-5)."""
     shape = [1, -1] + [1] * (x.dim() - 2)
@@ -32,16 +45,16 @@ def _bn(x, sd, p):
     return (x - sd[p + ".running_mean"].view(shape)) * inv.view(shape) + sd[p + ".bias"].view(shape)
 
 
-def _cbr2(x, sd, p, stride=1, pad=1, relu=True):
+def _cbr2(x, sd, p, stride=1, pad=1, relu=True, exact=False):
     """module.Conv2d / ConvBnReLU / ConvBn: conv(no bias) -> BN -> optional ReLU
     (models/module.py:24-58, :279-301)."""
-    x = F.conv2d(x, sd[p + ".conv.weight"], None, stride, pad)
+    x = _c2d(x, sd[p + ".conv.weight"], None, stride, pad, exact)
     x = _bn(x, sd, p + ".bn")
     return F.relu(x) if relu else x
 
 
-def _conv2(x, sd, p, stride=1, pad=0):
-    return F.conv2d(x, sd[p + ".weight"], sd.get(p + ".bias"), stride, pad)
+def _conv2(x, sd, p, stride=1, pad=0, exact=False):
+    return _c2d(x, sd[p + ".weight"], sd.get(p + ".bias"), stride, pad, exact)
 
 
 def _cbr3(x, sd, p, stride=1, relu=True):
@@ -61,7 +74,7 @@ def _dbr3(x, sd, p):
 def feature_net(sd, x, p="feature"):
     """models/module.py:357-420."""
     has3 = (p + ".out3.weight") in sd
-    c0 = _cbr2(_cbr2(x, sd, p + ".conv0.0"), sd, p + ".conv0.1")
+    c0 = _cbr2(_cbr2(x, sd, p + ".conv0.0", exact=True), sd, p + ".conv0.1", exact=True)
     c1 = _cbr2(c0, sd, p + ".conv1.0", 2, 2)
     c1 = _cbr2(_cbr2(c1, sd, p + ".conv1.1"), sd, p + ".conv1.2")
     c2 = _cbr2(c1, sd, p + ".conv2.0", 2, 2)
@@ -70,10 +83,10 @@ def feature_net(sd, x, p="feature"):
     c3 = _cbr2(_cbr2(c3, sd, p + ".conv3.1"), sd, p + ".conv3.2")
     out = {"stage1": _conv2(c3, sd, p + ".out1")}
     intra = F.interpolate(c3, scale_factor=2, mode="nearest") + _conv2(c2, sd, p + ".inner1")
-    out["stage2"] = _conv2(intra, sd, p + ".out2", pad=1)
+    out["stage2"] = _conv2(intra, sd, p + ".out2", pad=1, exact=True)
     if has3:
         intra = F.interpolate(intra, scale_factor=2, mode="nearest") + _conv2(c1, sd, p + ".inner2")
-        out["stage3"] = _conv2(intra, sd, p + ".out3", pad=1)
+        out["stage3"] = _conv2(intra, sd, p + ".out3", pad=1, exact=True)
     return out
 
 
@@ -298,9 +311,9 @@ def sep_conv_gru(sd, p, h, x):
     """models/module.py:152-179."""
     for suffix, pad in (("1", (0, 2)), ("2", (2, 0))):
         hx = torch.cat([h, x], 1)
-        z = torch.sigmoid(F.conv2d(hx, sd[f"{p}.convz{suffix}.weight"], sd[f"{p}.convz{suffix}.bias"], 1, pad))
-        r = torch.sigmoid(F.conv2d(hx, sd[f"{p}.convr{suffix}.weight"], sd[f"{p}.convr{suffix}.bias"], 1, pad))
-        q = torch.tanh(F.conv2d(torch.cat([r * h, x], 1), sd[f"{p}.convq{suffix}.weight"],
+        z = torch.sigmoid(_c2d(hx, sd[f"{p}.convz{suffix}.weight"], sd[f"{p}.convz{suffix}.bias"], 1, pad))
+        r = torch.sigmoid(_c2d(hx, sd[f"{p}.convr{suffix}.weight"], sd[f"{p}.convr{suffix}.bias"], 1, pad))
+        q = torch.tanh(_c2d(torch.cat([r * h, x], 1), sd[f"{p}.convq{suffix}.weight"],
                                 sd[f"{p}.convq{suffix}.bias"], 1, pad))
         h = (1 - z) * h + z * q
     return h
@@ -313,7 +326,7 @@ def _ws_block(sd, p, x, scale_shift=None, groups=4):
     mean = w.mean(dim=(1, 2, 3), keepdim=True)
     var = w.var(dim=(1, 2, 3), unbiased=False, keepdim=True)
     wn = (w - mean) * torch.rsqrt(var + 1e-5)
-    x = F.conv2d(x, wn, sd[p + ".proj.bias"], 1, 1)
+    x = _c2d(x, wn, sd[p + ".proj.bias"], 1, 1)
     x = F.group_norm(x, groups, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 1e-5)
     if scale_shift is not None:
         x = x * (scale_shift[0] + 1) + scale_shift[1]
@@ -453,7 +466,18 @@ def upsample_depth(depth, mask, ratio):
 
 
 # ------------------------------------------------------------------ a14 whole forward
-def forward(sd, args, imgs, proj_matrices, depth_values, noise_fn=None, test=True, feature_dtype=None):
+def forward(sd, args, imgs, proj_matrices, depth_values, noise_fn=None, test=True, feature_dtype=None, conv_dtype=None):
+    """conv_dtype (e.g. torch.bfloat16): the product's reduced-precision MATRIX ARITHMETIC (engine conv_arith): operands of
+    the multi-tap 2-D convolutions rounded to it, see _c2d.  None: the reference's fp32."""
+    global _CONV_DTYPE
+    prev, _CONV_DTYPE = _CONV_DTYPE, conv_dtype
+    try:
+        return _forward(sd, args, imgs, proj_matrices, depth_values, noise_fn, test, feature_dtype)
+    finally:
+        _CONV_DTYPE = prev
+
+
+def _forward(sd, args, imgs, proj_matrices, depth_values, noise_fn=None, test=True, feature_dtype=None):
     """CasDiffMVS.forward, eval mode (models/diffusion.py:139-295); test=False keeps every iterate and the Unet
     confidences (diffusion.py:264-270)."""
     if noise_fn is None:
@@ -499,7 +523,7 @@ def forward(sd, args, imgs, proj_matrices, depth_values, noise_fn=None, test=Tru
             hidden = _cbr2(hidden, sd, hp + ".0", 2)
             if s == 2:
                 hidden = _cbr2(hidden, sd, hp + ".1", 2)
-            hidden = torch.tanh(F.conv2d(hidden, sd[f"{hp}.{s}.weight"], None, 1, 1))
+            hidden = torch.tanh(_c2d(hidden, sd[f"{hp}.{s}.weight"], None, 1, 1))
             context = torch.relu(context)
             n = args.CostNum[s]
 

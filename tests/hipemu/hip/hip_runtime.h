@@ -349,6 +349,31 @@ static inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b
     hipemu::yield();
     return c;
 }
+// v_mfma_f32_16x16x32_bf16: A[i = lane&15][k = 8*(lane>>4) + j], B[k = 8*(lane>>4) + j][n = lane&15], j = 0..7 (raw bf16 bit
+// patterns); D[row = 4*(lane>>4) + r][col = lane&15]; products exact in fp32, fp32 accumulation (the summation order inside
+// the instruction is not architecturally specified: k-ascending here)
+typedef short hipemu_s16x8 __attribute__((vector_size(16)));
+static inline hipemu_f32x4 hipemu_mfma_f32_16x16x32_bf16(hipemu_s16x8 a, hipemu_s16x8 b, hipemu_f32x4 c) {
+    hipemu::Worker* w = hipemu::g_worker;
+    const int t = hipemu::linear_tid(), lane = t & 63, base = t & ~63;
+    static thread_local std::vector<float> sa, sb;
+    if (sa.size() < w->fibers.size() * 8) { sa.resize(w->fibers.size() * 8); sb.resize(w->fibers.size() * 8); }
+    for (int j = 0; j < 8; ++j) {
+        uint32_t ua = (uint32_t)(uint16_t)a[j] << 16, ub = (uint32_t)(uint16_t)b[j] << 16;
+        memcpy(&sa[t * 8 + j], &ua, 4);
+        memcpy(&sb[t * 8 + j], &ub, 4);
+    }
+    hipemu::yield();
+    const int col = lane & 15;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (lane >> 4) + r;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k) acc += sa[(base + (k >> 3) * 16 + row) * 8 + (k & 7)] * sb[(base + (k >> 3) * 16 + col) * 8 + (k & 7)];
+        c[r] = acc;
+    }
+    hipemu::yield();
+    return c;
+}
 // LDS-DMA (global_load_lds_dword / _dwordx4): per-lane global source, LDS destination =
 // wave-uniform base + lane * size.  Synchronous here; the kernels' barriers make that equivalent.
 static inline void __builtin_amdgcn_global_load_lds(const void* g, void* lds_base, unsigned size, int offset, int) {

@@ -142,3 +142,34 @@ def test_reduced_precision_feature_storage_emulated(golden, variant, prec):
     loose = [rel_l1(a, b) for a, b in zip(out["depth"], e.seq("out.depth"))]
     print(variant, prec, "vs fp32 reference:", ["%.2e" % x for x in loose])
     assert max(loose) < (2e-3 if prec == "bf16" else 2e-4), loose
+
+
+@pytest.mark.parametrize("variant", ["casdiffmvs", "diffmvs"])
+def test_bf16_matrix_arithmetic_emulated(golden, variant):
+    """conv_arith = "bf16" (+ bf16 feature storage: BASELINE.json configs[2] as stated): the multi-tap 2-D convolutions round
+    their inputs and weights to bf16 on the way into the matrix cores and accumulate in fp32.  Against the oracle doing the
+    same rounding (O.forward(conv_dtype=, feature_dtype=)) the depth maps agree to rounding-order noise amplified by the
+    network (a flipped bf16 rounding of an activation is a 4e-3 relative step); against the fp32 reference they stay inside a
+    stated band -- and outside the fp32 path's own agreement, i.e. the mode is really on."""
+    import torch as _t
+    from models import CasDiffMVS
+    from oracle import diffmvs_oracle as O
+    e = golden(f"e2e_{variant}_b2.npz")
+    meta = e.meta()
+    args = synth.make_args(variant, numdepth_initial=meta["nd_init"], precision="bf16", conv_arith="bf16")
+    model = CasDiffMVS(args, test=True).eval()
+    sd = synth.synth_state_dict(model.state_dict(), meta["weight_seed"])
+    model.load_state_dict(sd, strict=True)
+    imgs, proj, dv = synth.synth_inputs(meta["H"], meta["W"], meta["n_src"], B=meta["B"], seed=meta["scene_seed"])
+    eng = model.engine(emu_ops())
+    assert eng.conv_arith == "bf16" and eng.precision == "bf16"
+    out = eng.forward(imgs, proj, dv, noise_fn=synth.NoiseSource(meta["noise_seed"]))
+    src = synth.NoiseSource(meta["noise_seed"])
+    with _t.no_grad():
+        want = O.forward(sd, args, imgs, proj, dv, noise_fn=lambda shape: src(shape, "cpu"), feature_dtype=_t.bfloat16,
+                         conv_dtype=_t.bfloat16)
+    errs = [rel_l1(a, b) for a, b in zip(out["depth"], want["depth"])]
+    loose = [rel_l1(a, b) for a, b in zip(out["depth"], e.seq("out.depth"))]
+    print(variant, "bf16 arithmetic vs the bf16 oracle:", ["%.2e" % x for x in errs], "vs the fp32 reference:", ["%.2e" % x for x in loose])
+    assert max(errs) < 2e-3, errs
+    assert 1e-5 < max(loose) < 2e-2, loose

@@ -136,6 +136,26 @@ def test_full_size_against_oracle(cfg, variant, H, W, S, nd, prec):
         assert rel_l1(a.cpu(), b) < 5e-3
 
 
+def test_cfg3_full_size_bf16_matrix_arithmetic():
+    """BASELINE.json configs[2] with BOTH reduced-precision pieces: bf16 feature storage and bf16 matrix arithmetic in the 2-D
+    convolutions (conv_arith = "bf16", fp32 accumulation), at 1152x864 with 7 source views, against the oracle applying the
+    same roundings.  Tolerance 3e-3: a bf16 rounding that flips between the two summation orders is a 4e-3 relative step of
+    one activation (the host-emulation test pins the same comparison at 2e-3 on the small goldens)."""
+    model, sd, args = make_model("casdiffmvs", 48, precision="bf16", conv_arith="bf16")
+    imgs, proj, dv = synth.synth_inputs(864, 1152, 7, B=1, seed=9)
+    out = run(model, imgs, proj, dv, 2)
+    assert model.engine().conv_arith == "bf16"
+    src = synth.NoiseSource(2)
+    with torch.no_grad():
+        want = O.forward(sd, args, imgs, proj, dv, noise_fn=lambda shape: src(shape, "cpu"), feature_dtype=torch.bfloat16,
+                         conv_dtype=torch.bfloat16)
+    errs = [rel_l1(a.cpu(), b) for a, b in zip(out["depth"], want["depth"])]
+    print("cfg3 bf16 arithmetic, depth rel-L1 vs the bf16 oracle:", ["%.2e" % x for x in errs])
+    assert max(errs) < 3e-3, errs
+    for d in out["depth"]:
+        assert torch.isfinite(d).all() and float(d.min()) >= 424.9 and float(d.max()) <= 935.1
+
+
 def test_full_size_properties():
     """BASELINE.json configs[1] (640x512, 5 src, nd_init 48), batch 2: size-independent properties on top of
     test_full_size_against_oracle: batch items are independent (B=2 equals two B=1 runs bit-for-bit

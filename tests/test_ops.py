@@ -555,6 +555,64 @@ def test_conv_fused_groupnorm_stats(ops, cin, cout, HW):
     close(out, want, 3e-5)
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,HW,extras", [
+    (16, 16, (3, 3), 1, (21, 37), "plain"), (20, 31, (3, 3), 1, (16, 33), "res_relu"), (8, 16, (5, 5), 2, (37, 50), "bn"),
+    (32, 64, (5, 5), 2, (20, 24), "bn"), (64, 16, (7, 7), 1, (18, 20), "plain"), (64, 64, (1, 5), 1, (9, 40), "gru"),
+    (64, 32, (5, 1), 1, (12, 17), "plain"), (16, 32, (3, 3), 2, (22, 30), "plain"), (24, 48, (3, 3), 1, (8, 8), "concat_gn")])
+def test_conv2d_bf16_matrix_arithmetic(ops, cin, cout, k, stride, HW, extras):
+    """arith = ARITH_BF16: inputs and weights rounded to bf16 (nearest even) on their way into the matrix cores, fp32
+    accumulation, fp32 tensors and epilogue -- against torch's fp32 convolution of the ROUNDED operands (exact products, only
+    the summation order differs), for every kernel shape of the networks, channel counts that are not multiples of the
+    8-channel chunks, and the fused staging / epilogue paths (concat, GRU gating + blend, residual, BN, GroupNorm statistics).
+    The fp32 result of the same call differs by the bf16 rounding (~4e-3 relative), i.e. the mode is really on."""
+    B = 2
+    kh, kw = k
+    pad = (kh // 2, kw // 2)
+    x = rnd(B, cin, *HW, seed=1)
+    w = rnd(cout, cin, kh, kw, seed=2) * (2.0 / (cin * kh * kw) ** 0.5)
+    rb = lambda t: t.to(torch.bfloat16).float()      # noqa: E731
+    kw_call, ref_in, x0, x1 = {}, x, x, None
+    bn = None
+    if extras == "bn":
+        bn = {"weight": rnd(cout, seed=4, lo=0.5, hi=1.5), "bias": rnd(cout, seed=5), "running_mean": rnd(cout, seed=6),
+              "running_var": rnd(cout, seed=7, lo=0.5, hi=1.5)}
+    if extras == "concat_gn":
+        x0, x1 = x[:, :10].contiguous(), x[:, 10:].contiguous()
+    if extras == "gru":      # candidate conv of SepConvGRU: input cat(r * h, x), output blended with z and h
+        r = rnd(B, 32, *HW, seed=11, lo=0.0, hi=1.0)
+        h = x[:, :32].contiguous()
+        x0, x1 = h, x[:, 32:].contiguous()
+        ref_in = torch.cat([r * h, x[:, 32:]], 1)
+        z, hh = rnd(B, cout, *HW, seed=12, lo=0.0, hi=1.0), rnd(B, cout, *HW, seed=13)
+    ref = F.conv2d(rb(ref_in), rb(w), None, stride, pad)
+    full = F.conv2d(ref_in, w, None, stride, pad)
+    if bn is not None:
+        f = lambda t: F.relu(F.batch_norm(t, bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"], False, 0.0, 1e-5))      # noqa: E731
+        ref, full = f(ref), f(full)
+        kw_call["act"] = K.ACT_RELU
+    if extras == "res_relu":
+        res = rnd(*ref.shape, seed=9)
+        ref, full = F.relu(ref + res), F.relu(full + res)
+        kw_call.update(residual=dev(ops, res), act=K.ACT_RELU)
+    if extras == "gru":
+        ref, full = (1 - z) * hh + z * torch.tanh(ref), (1 - z) * hh + z * torch.tanh(full)
+        kw_call.update(mul0=dev(ops, r), gru_z=dev(ops, z), gru_h=dev(ops, hh), act=K.ACT_TANH)
+    stats = None
+    if extras == "concat_gn":
+        stats = torch.zeros(B * 8, dtype=torch.float64, device=ops.device)
+        kw_call.update(gn_stats=stats)
+    pc = K.pack_conv2d(dev(ops, w), bn=None if bn is None else {k_: v.to(ops.device) for k_, v in bn.items()}, stride=stride, pad=pad)
+    out = ops.conv2d(pc, dev(ops, x0), None if x1 is None else dev(ops, x1), arith=K.ARITH_BF16, **kw_call)
+    close(out, ref, 2e-5)
+    assert float((out.cpu() - full).abs().max()) > 1e-4 * float(full.abs().max())       # not the fp32 kernel
+    out32 = ops.conv2d(pc, dev(ops, x0), None if x1 is None else dev(ops, x1), **{k_: v for k_, v in kw_call.items() if k_ != "gn_stats"})
+    close(out32, full, 2e-5)
+    if stats is not None:
+        st = (stats.cpu().view(torch.int64).double() / 65536.0).view(B, 4, 2)
+        yg = ref.view(B, 4, -1).double()
+        assert torch.allclose(st[..., 0] / yg.shape[-1], yg.mean(-1), atol=1e-4)
+
+
 @pytest.mark.parametrize("bad", [float("nan"), float("inf"), 3.0e7])
 def test_groupnorm_stats_propagate_non_finite_and_out_of_range(ops, bad):
     """the fixed-point statistics slots (dmvs_common.h): a NaN / Inf activation -- or one beyond the documented magnitude
