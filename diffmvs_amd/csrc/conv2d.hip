@@ -73,11 +73,12 @@ __device__ __attribute__((aligned(16))) const float dmvs_zero16[4] = {0.0f, 0.0f
 
 #define DMVS_LDS(p) ((__attribute__((address_space(3))) void*)(p))
 
-template <int KH, int KW, int S, int NT, int MT, int AR = DMVS_ARITH_F32>
+template <int KH, int KW, int S, int NT, int MT, int AR = DMVS_ARITH_F32, int WX = 1>
 struct ConvCfg {
     static constexpr int T = KH * KW;
-    static constexpr int ROWS = 4 * MT;
-    static constexpr int TW = 15 * S + KW, TH = (ROWS - 1) * S + KH;
+    static constexpr int COLS = 16 * WX;                      // pixel tile of the workgroup: the 4 waves sit WX across, 4 / WX down
+    static constexpr int ROWS = (4 / WX) * MT;
+    static constexpr int TW = (COLS - 1) * S + KW, TH = (ROWS - 1) * S + KH;
     static constexpr int PLANE = pad16mod32(TH * TW);
     static constexpr int NW = NT * 16;
     static constexpr int WPAD = pad16mod32(T * NW);
@@ -116,9 +117,15 @@ constexpr int conv_min_waves(int nt, int mt) { return (nt == 2 && mt == 4) ? 4 :
 // accumulation) in place of the fp32 MFMA.  One bf16 MFMA spans K = 32 = the 8 input channels of an LDS chunk x 4 TAPS: lane
 // group kq carries tap 4g + kq (taps beyond KH*KW meet zero weights), its 8 k-slots are the 8 channels.  3 MFMAs replace the
 // 18 fp32 ones of a 3x3 chunk, at half the cycles each; the loop is then bound by its (unchanged) 8 LDS reads per operand.
-template <int KH, int KW, int S, int NT, int MT, bool ZI, int OT = DMVS_DTYPE_F32, bool TR = false, bool WALK = false, int AR = DMVS_ARITH_F32>
+//
+// WX = waves side by side in a workgroup's pixel tile (1: 16 x 16*MT pixels, 2: 32 x 8*MT): 128-byte instead of 64-byte runs
+// per channel row in the stores and the halo reads.  Worth 6-9 % on the two-n-tile layers of the large planes, a loss on the
+// others (conv_tile_waves_x); it is NOT what holds the 16-channel layers at ~0.5 (unchanged by it, as by a 6x cut of the
+// matrix time and by register staging: DESIGN.md section 4).
+template <int KH, int KW, int S, int NT, int MT, bool ZI, int OT = DMVS_DTYPE_F32, bool TR = false, bool WALK = false, int AR = DMVS_ARITH_F32,
+          int WX = 1>
 __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfma_kernel(const dmvs_conv2d_desc d, int tiles_x, int tiles_y) {
-    using Cfg = ConvCfg<KH, KW, S, NT, MT, AR>;
+    using Cfg = ConvCfg<KH, KW, S, NT, MT, AR, WX>;
     constexpr int T = Cfg::T, TW = Cfg::TW, TH = Cfg::TH, PLANE = Cfg::PLANE, NW = Cfg::NW, WPAD = Cfg::WPAD;
     constexpr int CK = Cfg::CK, BUF = Cfg::BUF, IN_IT = Cfg::IN_IT, W_IT = Cfg::W_IT;
     // one LDS object on purpose (tile buffers + the 32-float GroupNorm scratch): with separate objects hipcc orders reads of
@@ -127,6 +134,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA bases in SGPRs
     const int m = lane & 15, kq = lane >> 4;
+    const int wx = wave % WX, wy = wave / WX;      // this wave's 16-pixel column block and row block inside the tile
     int tile = blockIdx.x;   // round-robin over XCDs: an XCD-contiguous remap measured 6-8 % SLOWER here (HBM channel spread)
     const int ntiles = tiles_x * tiles_y * d.B;
     // s_* / gy0 / gx0: the tile whose input is being STAGED; b / ox0 / oy0 (set at the top of the tile loop): the tile being
@@ -137,7 +145,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
         t /= tiles_x;
         const int ty = t % tiles_y;
         s_b = t / tiles_y;
-        s_ox0 = tx * 16;
+        s_ox0 = tx * Cfg::COLS;
         s_oy0 = ty * Cfg::ROWS;
         gy0 = s_oy0 * S - d.pad_h;
         gx0 = s_ox0 * S - d.pad_w;
@@ -331,7 +339,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
                 const int tc = tv ? t : T - 1;
                 const int ky = tc / KW, kx = tc - ky * KW;
                 const float* wp = s_w + tc * NW + m;
-                const float* ip = s_in + ((wave * MT * S) + ky) * TW + m * S + kx;
+                const float* ip = s_in + ((wy * MT * S) + ky) * TW + (wx * 16 + m) * S + kx;
                 bf16x8 av[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
@@ -358,7 +366,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
         for (int c4 = 0; c4 < nc4; ++c4) {
             const int ci = c4 * 4 + kq;
             const float* wp = s_w + ci * WPAD + m;
-            const float* ip = s_in + ci * PLANE + (wave * MT * S) * TW + m * S;
+            const float* ip = s_in + ci * PLANE + (wy * MT * S) * TW + (wx * 16 + m) * S;
 #pragma unroll 1
             for (int ky = 0; ky < KH; ++ky) {
 #pragma unroll
@@ -381,7 +389,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     }
 
     // ---- epilogue: this lane holds couts nbase + nt*16 + 4*kq + r of pixels (oy0 + MT*wave + mt, ox0 + m)
-    const int ox = ox0 + m;
+    const int ox = ox0 + wx * 16 + m;
     const int oplane = d.Hout * d.Wout;
     const bool rup = d.res_mode == DMVS_IN_UPSAMPLE2;
     const int rW = rup ? (d.Wout >> 1) : d.Wout, rH = rup ? (d.Hout >> 1) : d.Hout;
@@ -402,7 +410,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
         // the 4 CONSECUTIVE pixels ox0 + 4*kq + r of row oy0 + MT*wave + mt -- one 16-byte NCHW store (and one 16-byte
         // residual / GRU-gate read) per (row, n-tile) instead of four 4-byte ones, one bounds predicate and one offset
         // per four values.  NCHW fp32 outputs only; the values are those of the other form bit for bit.
-        const int oxb = ox0 + 4 * kq;
+        const int oxb = ox0 + wx * 16 + 4 * kq;
         const bool vec = (d.Wout & 3) == 0 && (((uintptr_t)d.out | (uintptr_t)d.residual | (uintptr_t)d.gru_z | (uintptr_t)d.gru_h) & 15) == 0 &&
                          ((oplane * d.out_coffset) & 3) == 0;
         float sc[NT], sh[NT];
@@ -416,7 +424,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int oy = oy0 + wave * MT + mt;
+            const int oy = oy0 + wy * MT + mt;
             const int opix = oy * d.Wout + oxb;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -509,7 +517,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
             }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int oy = oy0 + wave * MT + mt;
+            const int oy = oy0 + wy * MT + mt;
             const bool okp = ox < d.Wout && oy < d.Hout;
             const int opix = oy * d.Wout + ox;
             const int rpix = rup ? (oy >> 1) * rW + (ox >> 1) : opix;
@@ -636,6 +644,29 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     }      // tiles
 }
 
+// Which layers compute in bf16 when the caller asks for DMVS_ARITH_BF16: stride-1 layers with more than one tap, at least 24
+// input channels and a planar output.  Measured at B = 96 (profiles/r3_conv_bf16_ab.txt): those run 1.4-1.9x faster (32 -> 32
+// 4.88 -> 3.08 ms, 64 -> 64 3.63 -> 1.88); the 16-channel layers do not move at all (5.09 -> 5.06: they are not bound by the
+// matrix cores) and the stride-2 / 3-channel layers LOSE with the 8-channel chunks the bf16 form needs (3.80 -> 5.09), so
+// those keep the exact-fp32 kernels in either mode.  (dmvs.h documents this as the contract of `arith`.)
+static bool conv_bf16_honoured(const dmvs_conv2d_desc& d) {
+    return d.arith == DMVS_ARITH_BF16 && d.out_layout == DMVS_LAYOUT_NCHW && d.stride == 1 && d.kh * d.kw > 1 && d.c0 + d.c1 >= 24;
+}
+
+// Waves side by side in a workgroup's tile (template WX) for a 3x3 / 5x5 layer with planar output.  Measured at B = 96
+// (profiles/r3_conv_wx_ab.txt; WX = 1 / 2 / 4, ms per step): two n-tiles on planes of >= 128 x 160 pixels gain with 32-wide tiles
+// -- 32 -> 32 3x3 4.79 / 4.46 / 5.32 and 4.21 / 3.96 / 4.73, 16 -> 32 5x5 stride 2 3.14 / 2.95 / 4.25, 24 -> 32 1.18 / 1.08 /
+// 1.26, 6 -> 32 0.57 / 0.47 / 0.56 -- one n-tile and the small planes lose (16 -> 16 2.44 / 2.56 / 2.89, 32 -> 32 at 64 x 80
+// 1.48 / 1.64 / 2.36), 64-wide tiles lose nearly everywhere.  DMVS_CONV_WX = 1 | 2 forces it for A/B runs.
+static int conv_tile_waves_x(long out_pixels, int nt) {
+    static const int forced = [] {
+        const char* e = getenv("DMVS_CONV_WX");
+        return e ? atoi(e) : 0;
+    }();
+    if (forced) return forced >= 2 ? 2 : 1;
+    return (nt == 2 && out_pixels >= 128L * 160) ? 2 : 1;
+}
+
 [[maybe_unused]] static bool conv_walk_enabled() {
     static const bool on = [] {
         const char* e = getenv("DMVS_CONV_WALK");
@@ -670,8 +701,8 @@ int launch_conv2d_mt(const dmvs_conv2d_desc& d, hipStream_t st, int nt, int ngro
     const int tiles_x = (d.Wout + 15) / 16, tiles_y = (d.Hout + 4 * MT - 1) / (4 * MT);
     dim3 grid((unsigned)(tiles_x * tiles_y * d.B), (unsigned)ngroups), block(DMVS_BLOCK);
     if (d.out_layout == DMVS_LAYOUT_NCHW) {      // transposed accumulators: 16-byte NCHW stores
-        if constexpr (!ZI && MT == 2 && KH * KW > 1) {      // bf16 matrix arithmetic: one tile shape (16 x 8), NCHW fp32 outputs
-            if (d.arith == DMVS_ARITH_BF16) {
+        if constexpr (!ZI && MT == 2 && KH * KW > 1 && S == 1) {      // bf16 matrix arithmetic: one tile shape (16 x 8), NCHW fp32 outputs
+            if (conv_bf16_honoured(d)) {
 #define DMVS_BF(NTV) do { \
                     using BCfg = ConvCfg<KH, KW, S, NTV, MT, DMVS_ARITH_BF16>; \
                     if constexpr ((2 * BCfg::BUF + 32) * 4 <= 150 * 1024) { \
@@ -708,6 +739,19 @@ int launch_conv2d_mt(const dmvs_conv2d_desc& d, hipStream_t st, int nt, int ngro
             }
         }
 #endif
+        if constexpr (!ZI && (KH * KW == 9 || KH * KW == 25)) {      // wide tiles: 128-byte runs per channel row
+            const int wxv = conv_tile_waves_x((long)d.Hout * d.Wout, nt);
+            if (wxv > 1 && nt <= 2) {
+#define DMVS_WX(NTV, WXV) do { \
+                    const int tx_ = (d.Wout + 16 * WXV - 1) / (16 * WXV), rows_ = (4 / WXV) * MT, ty_ = (d.Hout + rows_ - 1) / rows_; \
+                    dim3 g((unsigned)(tx_ * ty_ * d.B), (unsigned)ngroups); \
+                    hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, NTV, MT, false, DMVS_DTYPE_F32, true, false, DMVS_ARITH_F32, WXV>), g, block, 0, st, d, tx_, ty_); \
+                    return dmvs_launch_status(); } while (0)
+                if (nt == 1) DMVS_WX(1, 2);
+                DMVS_WX(2, 2);
+#undef DMVS_WX
+            }
+        }
         switch (nt) {
             case 1: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 1, MT, ZI, DMVS_DTYPE_F32, true>), grid, block, 0, st, d, tiles_x, tiles_y); break;
             case 2: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 2, MT, ZI, DMVS_DTYPE_F32, true>), grid, block, 0, st, d, tiles_x, tiles_y); break;
@@ -746,7 +790,7 @@ int launch_conv2d(const dmvs_conv2d_desc& d, hipStream_t st) {
     constexpr bool heavy = (S == 2) || (KH * KW >= 25);
     if (d.out_layout == DMVS_LAYOUT_NHWC_BF16 || d.out_layout == DMVS_LAYOUT_NHWC_F16)      // one tile shape (16x8) for the 16-bit outputs
         return launch_conv2d_mt<KH, KW, S, 2, false>(d, st, nt, ngroups);
-    if (d.arith == DMVS_ARITH_BF16 && d.out_layout == DMVS_LAYOUT_NCHW && KH * KW > 1)      // and for the bf16 matrix arithmetic
+    if (S == 1 && KH * KW > 1 && conv_bf16_honoured(d))      // and for the bf16 matrix arithmetic
         return launch_conv2d_mt<KH, KW, S, 2, false>(d, st, nt, ngroups);
     const long wg16 = (long)((d.Wout + 15) / 16) * ((d.Hout + 15) / 16) * d.B * ngroups;
     static const int force_mt = getenv("DMVS_CONV_MT") ? atoi(getenv("DMVS_CONV_MT")) : 0;      // experiments: force the tile height

@@ -99,8 +99,9 @@ typedef struct dmvs_conv2d_desc {
     int32_t arith;          /* DMVS_ARITH_F32 (0): exact fp32 products (v_mfma_f32_16x16x4_f32), the reference's precision.
                                DMVS_ARITH_BF16 (1): inputs and weights rounded to bf16 (nearest even) as they enter the matrix
                                cores, fp32 accumulation (v_mfma_f32_16x16x32_bf16) -- the reduced-precision configurations of
-                               BASELINE.json (configs[2], [4]); tensors in memory stay fp32.  Honoured by layers with more than
-                               one tap; 1x1 layers always compute in fp32.                                                */
+                               BASELINE.json (configs[2], [4]); tensors in memory stay fp32.  Honoured by stride-1 layers with
+                               more than one tap, >= 24 input channels and an NCHW output (where it is faster); every other
+                               layer computes in fp32 in either mode.                                                     */
 } dmvs_conv2d_desc;
 
 /* Size limits (DMVS_EINVAL beyond them; the kernels address one batch item with 32-bit element offsets):

@@ -27,13 +27,17 @@ BN_EPS = 1e-5
 # ------------------------------------------------------------------ small helpers
 # Reduced-precision matrix arithmetic of the product's bf16 configuration (NOT reference behaviour): the inputs and
 # weights of a multi-tap 2-D convolution are rounded to `_CONV_DTYPE` before the (fp32-accumulated) convolution; tensors
-# stay fp32.  exact=True marks the layers the product always computes in fp32: FeatureNet's fused stem (conv0.0 / conv0.1)
-# and its channel-last output convolutions (out1..3); 1x1 layers are exempt by their shape.
+# stay fp32.  The product honours the mode where it is faster (include/dmvs.h, dmvs_conv2d_desc.arith): stride-1 layers with more
+# than one tap and >= 24 input channels; exact=True marks FeatureNet's channel-last output convolutions (out2 / out3), which
+# always compute in fp32 (its fused stem and the 1x1 / stride-2 / narrow layers are exempt by their shape).
 _CONV_DTYPE = None
 
 
-def _c2d(x, w, b=None, stride=1, pad=0, exact=False):
-    if _CONV_DTYPE is not None and not exact and w.shape[2] * w.shape[3] > 1:
+def _c2d(x, w, b=None, stride=1, pad=0, exact=False, cin_div=1):
+    """cin_div: the product evaluates this layer as `cin_div` convolutions over equal slices of the input channels (the Unet's
+    init_conv: context half once per stage + encoder half per iteration), and its >= 24-channel rule sees one slice"""
+    stride1 = (stride == 1) if isinstance(stride, int) else tuple(stride) == (1, 1)
+    if _CONV_DTYPE is not None and not exact and stride1 and w.shape[2] * w.shape[3] > 1 and w.shape[1] // cin_div >= 24:
         x, w = x.to(_CONV_DTYPE).float(), w.to(_CONV_DTYPE).float()
     return F.conv2d(x, w, b, stride, pad)
 
@@ -53,8 +57,8 @@ def _cbr2(x, sd, p, stride=1, pad=1, relu=True, exact=False):
     return F.relu(x) if relu else x
 
 
-def _conv2(x, sd, p, stride=1, pad=0, exact=False):
-    return _c2d(x, sd[p + ".weight"], sd.get(p + ".bias"), stride, pad, exact)
+def _conv2(x, sd, p, stride=1, pad=0, exact=False, cin_div=1):
+    return _c2d(x, sd[p + ".weight"], sd.get(p + ".bias"), stride, pad, exact, cin_div)
 
 
 def _cbr3(x, sd, p, stride=1, relu=True):
@@ -364,7 +368,7 @@ def _pixel_unshuffle(x):
 
 def unet(sd, p, x, hidden, t, dim, n_levels):
     """Unet.forward (models/update.py:245-274)."""
-    x = _conv2(x, sd, p + ".init_conv", pad=3)
+    x = _conv2(x, sd, p + ".init_conv", pad=3, cin_div=2)
     r = x
     te = time_mlp(sd, p + ".time_mlp", t, dim)
     skips = []

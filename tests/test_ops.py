@@ -556,15 +556,17 @@ def test_conv_fused_groupnorm_stats(ops, cin, cout, HW):
 
 
 @pytest.mark.parametrize("cin,cout,k,stride,HW,extras", [
-    (16, 16, (3, 3), 1, (21, 37), "plain"), (20, 31, (3, 3), 1, (16, 33), "res_relu"), (8, 16, (5, 5), 2, (37, 50), "bn"),
+    (16, 16, (3, 3), 1, (21, 37), "plain"), (28, 31, (3, 3), 1, (16, 33), "res_relu"), (8, 16, (5, 5), 2, (37, 50), "bn"),
     (32, 64, (5, 5), 2, (20, 24), "bn"), (64, 16, (7, 7), 1, (18, 20), "plain"), (64, 64, (1, 5), 1, (9, 40), "gru"),
-    (64, 32, (5, 1), 1, (12, 17), "plain"), (16, 32, (3, 3), 2, (22, 30), "plain"), (24, 48, (3, 3), 1, (8, 8), "concat_gn")])
+    (64, 32, (5, 1), 1, (12, 17), "plain"), (32, 32, (3, 3), 2, (22, 30), "plain"), (24, 48, (3, 3), 1, (8, 8), "concat_gn"),
+    (37, 20, (3, 3), 1, (40, 70), "plain")])
 def test_conv2d_bf16_matrix_arithmetic(ops, cin, cout, k, stride, HW, extras):
     """arith = ARITH_BF16: inputs and weights rounded to bf16 (nearest even) on their way into the matrix cores, fp32
     accumulation, fp32 tensors and epilogue -- against torch's fp32 convolution of the ROUNDED operands (exact products, only
     the summation order differs), for every kernel shape of the networks, channel counts that are not multiples of the
     8-channel chunks, and the fused staging / epilogue paths (concat, GRU gating + blend, residual, BN, GroupNorm statistics).
-    The fp32 result of the same call differs by the bf16 rounding (~4e-3 relative), i.e. the mode is really on."""
+    The fp32 result of the same call differs by the bf16 rounding (~4e-3 relative), i.e. the mode is really on.  Layers the
+    contract exempts (stride 2, fewer than 24 input channels: include/dmvs.h) return the fp32 result in either mode."""
     B = 2
     kh, kw = k
     pad = (kh // 2, kw // 2)
@@ -584,7 +586,8 @@ def test_conv2d_bf16_matrix_arithmetic(ops, cin, cout, k, stride, HW, extras):
         x0, x1 = h, x[:, 32:].contiguous()
         ref_in = torch.cat([r * h, x[:, 32:]], 1)
         z, hh = rnd(B, cout, *HW, seed=12, lo=0.0, hi=1.0), rnd(B, cout, *HW, seed=13)
-    ref = F.conv2d(rb(ref_in), rb(w), None, stride, pad)
+    honoured = stride == 1 and cin >= 24
+    ref = F.conv2d(rb(ref_in), rb(w), None, stride, pad) if honoured else F.conv2d(ref_in, w, None, stride, pad)
     full = F.conv2d(ref_in, w, None, stride, pad)
     if bn is not None:
         f = lambda t: F.relu(F.batch_norm(t, bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"], False, 0.0, 1e-5))      # noqa: E731
@@ -604,7 +607,8 @@ def test_conv2d_bf16_matrix_arithmetic(ops, cin, cout, k, stride, HW, extras):
     pc = K.pack_conv2d(dev(ops, w), bn=None if bn is None else {k_: v.to(ops.device) for k_, v in bn.items()}, stride=stride, pad=pad)
     out = ops.conv2d(pc, dev(ops, x0), None if x1 is None else dev(ops, x1), arith=K.ARITH_BF16, **kw_call)
     close(out, ref, 2e-5)
-    assert float((out.cpu() - full).abs().max()) > 1e-4 * float(full.abs().max())       # not the fp32 kernel
+    if honoured:
+        assert float((out.cpu() - full).abs().max()) > 1e-4 * float(full.abs().max())       # not the fp32 kernel
     out32 = ops.conv2d(pc, dev(ops, x0), None if x1 is None else dev(ops, x1), **{k_: v for k_, v in kw_call.items() if k_ != "gn_stats"})
     close(out32, full, 2e-5)
     if stats is not None:
