@@ -13,7 +13,7 @@ def _design():
 
 
 def test_design_quotes_the_committed_bench_line():
-    line = json.load(open(os.path.join(ROOT, "profiles", "r2_bench_line.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r3_bench_line.json")))
     text = _design()
     text = text[text.index("End-of-round numbers"):]
     text = text[:text.index("**Batch 1**")]
@@ -34,9 +34,9 @@ def test_design_quotes_the_committed_bench_line():
 
 def test_kernel_stats_agree_with_the_bench_line():
     """the rocprof average of the plane-sweep kernel and the event-timed figure on the bench line of the same run agree"""
-    line = json.load(open(os.path.join(ROOT, "profiles", "r2_bench_b96_profiled_line.json")))
-    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r2_bench_b96_kernel_stats.csv"))))
-    wi = [r for r in rows if "warp_init_quad_kernel" in r["Name"]]
+    line = json.load(open(os.path.join(ROOT, "profiles", "r3_bench_b96_profiled_line.json")))
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r3_bench_b96_kernel_stats.csv"))))
+    wi = [r for r in rows if "warp_init_band_kernel" in r["Name"]]
     assert len(wi) == 1
     prof_us = float(wi[0]["AverageNs"]) / 1e3
     assert abs(prof_us - line["roofline_warp_init"]["avg_launch_us"]) / prof_us < 0.03
@@ -46,3 +46,25 @@ def test_kernel_stats_agree_with_the_bench_line():
     side = line["roofline_scene_geometry"]["avg_launch_us"]
     steps_avg = (n * avg - 25 * side) / (n - 25)
     assert abs(steps_avg - line["roofline"]["avg_launch_us"]) / steps_avg < 0.05
+
+
+def test_design_test_counts_match_the_suite():
+    """DESIGN.md section 5 quotes how many tests each marker selects; count them"""
+    import subprocess
+    import sys
+    m = re.search(r"`pytest -m gpu`: (\d+) tests.*?`-m \"not gpu\"`: (\d+) tests", _design(), re.S)
+    assert m, "DESIGN.md section 5 no longer states the test counts"
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "-q", "--collect-only", "-m", "gpu"],
+                         capture_output=True, text=True, cwd=ROOT).stdout
+    n_gpu, n_all = map(int, re.search(r"(\d+)/(\d+) tests collected", out).groups())
+    assert (n_gpu, n_all - n_gpu) == (int(m.group(1)), int(m.group(2))), (n_gpu, n_all - n_gpu, m.groups())
+
+
+def test_traffic_file_matches_the_kernel_source():
+    """profiles/r3_getcost_traffic.json was measured on the committed warp kernels (bench.py refuses it otherwise)"""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    t = json.load(open(os.path.join(ROOT, "profiles", "r3_getcost_traffic.json")))
+    assert t["kernel_source_sha"] == bench.kernel_source_hash()
+    assert 0.8 < t["traffic_bytes_per_launch"] / 1785200640 < 1.2
