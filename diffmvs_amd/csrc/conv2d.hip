@@ -108,10 +108,11 @@ constexpr int conv_min_waves(int nt, int mt) { return (nt == 2 && mt == 4) ? 4 :
 // epilogue with the matrix pipe idle; with 2-4 chunks per tile (the 16- and 32-channel layers) that is half of a tile's
 // life, and it does not average out over co-resident workgroups because a launch starts them all in the same phase
 // (SQ PMC on the 16 -> 16 layer: matrix pipe busy 41 % of the cycles, waves waiting 27 %).  Same arithmetic, same order.
-// STATUS (round 3): correct (CPU emulation + MI355X test suite) but SLOWER -- the B=96 step 83.9 -> 90.9 ms, every layer
-// 5-20 % down (profiles/r3_conv_walk_ab.txt): carrying two tiles' state through the loop costs 112 instead of 63 VGPRs
-// (3 instead of 5 waves per SIMD) and 217 SGPR-spill reads on the <3,3,1,1,4> instantiation (tools/isa_stats.py).  Only
-// instantiated with -DDMVS_CONV_WALK; the register work it needs is listed in DESIGN.md.
+// First attempt (every NCHW layer walked, all fused paths in the loop): correct but SLOWER -- the B=96 step 83.9 -> 90.9 ms
+// (profiles/r3_conv_walk_ab.txt): 112 instead of 63 VGPRs (3 instead of 5 waves per SIMD) and 217 SGPR-spill reads on the
+// <3,3,1,1,4> instantiation.  Second form (this one): compiled for the "lean" layers only (kLean below: the other fused paths are
+// compiled out) with the lane coordinates redefined opaquely per tile so that hipcc does not hoist the chunk loop's and the
+// epilogue's lane-dependent addresses out of the tile loop: 59 VGPRs, 46 spill accesses.
 //
 // AR = DMVS_ARITH_BF16: the same kernel -- same fp32 tensors, same LDS-DMA staging of fp32 tiles, same epilogue -- with the
 // operands rounded to bf16 (nearest even, v_cvt_pk_bf16_f32) as they leave LDS and v_mfma_f32_16x16x32_bf16 (fp32
@@ -133,8 +134,9 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     // one against LDS-DMA into another with vmcnt(0) waits (conv3d.hip, conv3d_mfma_stream_kernel)
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF + 32];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA bases in SGPRs
-    const int m = lane & 15, kq = lane >> 4;
+    int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA bases in SGPRs
+    int m = lane & 15, kq = lane >> 4;       // (tid, m, kq not const: the tile-walking form redefines them per tile, see the tile loop)
     const int wx = wave % WX, wy = wave / WX;      // this wave's 16-pixel column block and row block inside the tile
     int tile = blockIdx.x;   // round-robin over XCDs: an XCD-contiguous remap measured 6-8 % SLOWER here (HBM channel spread)
     const int ntiles = tiles_x * tiles_y * d.B;
@@ -153,10 +155,14 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     };
     decode_tile(tile);
     const int nbase = blockIdx.y * NW;
-    const int cin = d.c0 + d.c1;
+    // The tile-walking form is built for the PLAIN layers only (FeatureNet / ContextNet trunks, the plain Unet layers): one input
+    // tensor, no gating / GRU blend / GroupNorm statistics, ReLU or no activation, optional same-size residual, 16-byte stores.
+    // Compiling the other paths out is what lets two tiles' state fit the register file (the dispatcher checks the conditions).
+    constexpr bool kLean = WALK;
+    const int cin = kLean ? d.c0 : d.c0 + d.c1;
 
     // ---- addressing of the logical input, all in 32-bit element offsets from per-batch bases
-    const int mode = ZI ? DMVS_IN_UPSAMPLE2 : d.in_mode;      // zero-insert addresses like nearest-x2 (plus a parity predicate)
+    const int mode = ZI ? DMVS_IN_UPSAMPLE2 : (kLean ? DMVS_IN_PLAIN : d.in_mode);      // zero-insert addresses like nearest-x2 (plus a parity predicate)
     const int pW = mode == DMVS_IN_UPSAMPLE2 ? (d.Win >> 1) : (mode == DMVS_IN_UNSHUFFLE2 ? (d.Win << 1) : d.Win);
     const int pH = mode == DMVS_IN_UPSAMPLE2 ? (d.Hin >> 1) : (mode == DMVS_IN_UNSHUFFLE2 ? (d.Hin << 1) : d.Hin);
     const int plane0 = pH * pW, plane1 = d.Hin * d.Win;
@@ -164,8 +170,8 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     const float *in0b, *mul0b, *in1b;      // per-batch-item input bases of the tile being staged
     auto set_bases = [&]() {
         in0b = d.in0 + (size_t)s_b * pc0 * plane0;
-        mul0b = d.mul0 ? d.mul0 + (size_t)s_b * (d.gate_cstride ? d.gate_cstride : pc0) * plane0 : nullptr;
-        in1b = d.in1 ? d.in1 + (size_t)s_b * d.c1 * plane1 : d.in0;
+        mul0b = (!kLean && d.mul0) ? d.mul0 + (size_t)s_b * (d.gate_cstride ? d.gate_cstride : pc0) * plane0 : nullptr;
+        in1b = (!kLean && d.in1) ? d.in1 + (size_t)s_b * d.c1 * plane1 : d.in0;
     };
     set_bases();
     static_assert(!(WALK && ZI), "the tile-walking form is an inference kernel");
@@ -237,7 +243,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
             }
         }
     }
-    const bool simple = d.c1 == 0 && mode != DMVS_IN_UNSHUFFLE2;      // one input tensor: the channel base just advances by a plane
+    const bool simple = kLean || (d.c1 == 0 && mode != DMVS_IN_UNSHUFFLE2);      // one input tensor: the channel base just advances by a plane
     auto stage_as = [&](auto simple_tag, int c0, float* buf) __attribute__((always_inline)) {
         constexpr bool kSimple = decltype(simple_tag)::value;          // two instantiations: no mode decisions inside the simple one
         const float* cb = in0b + (size_t)c0 * plane0;                  // wave-uniform base of the channel being staged
@@ -294,6 +300,13 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     int cur = 0;
     bool border = false;                   // the tile being staged has padding positions (workgroup-uniform)
     for (;;) {      // tiles of this workgroup (one unless WALK)
+    if constexpr (WALK) {
+        // Opaque redefinition of the lane coordinates: without it hipcc hoists every lane-dependent address of the chunk loop and
+        // the epilogue out of the tile loop and keeps them all live (112 instead of 63 VGPRs, 3 instead of 5 waves per SIMD)
+#ifndef DMVS_HOST_EMULATION
+        asm volatile("" : "+v"(m), "+v"(kq), "+v"(tid));
+#endif
+    }
     const int b = s_b, ox0 = s_ox0, oy0 = s_oy0;
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -306,7 +319,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
         // __syncthreads() drains this wave's LDS-DMA (vmcnt) and orders it against everyone's ds_reads:
         // after it, chunk c0 is complete in `cur` and the other buffer is free for the next chunk
         __syncthreads();
-        if (mul0b) {   // r*h gating of the GRU candidate conv: scale the staged in0 channels in place
+        if (!kLean && mul0b) {   // r*h gating of the GRU candidate conv: scale the staged in0 channels in place
             for (int i = 0; i < IN_IT; ++i) {
                 const int e = i * DMVS_BLOCK + tid;
                 if (e < CK * PLANE) {
@@ -392,7 +405,9 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     // ---- epilogue: this lane holds couts nbase + nt*16 + 4*kq + r of pixels (oy0 + MT*wave + mt, ox0 + m)
     const int ox = ox0 + wx * 16 + m;
     const int oplane = d.Hout * d.Wout;
-    const bool rup = d.res_mode == DMVS_IN_UPSAMPLE2;
+    const bool rup = !kLean && d.res_mode == DMVS_IN_UPSAMPLE2;
+    const bool do_gn = !kLean && d.gn_stats, do_gru = !kLean && d.gru_z;
+    const int act = kLean ? (d.act == DMVS_ACT_RELU ? DMVS_ACT_RELU : DMVS_ACT_NONE) : d.act;
     const int rW = rup ? (d.Wout >> 1) : d.Wout, rH = rup ? (d.Hout >> 1) : d.Hout;
     // per-batch-item bases (wave-uniform, 64-bit) + 32-bit element offsets `channel * plane + pixel` (one full-rate
     // v_mad_u32_u24 per value; the 64-bit multiply-adds this replaces are quarter rate and were ~30 % of the VALU time
@@ -401,19 +416,19 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     float* const outb = d.out_layout == DMVS_LAYOUT_NCHW ? d.out + ((size_t)b * d.out_cstride + d.out_coffset) * oplane
                                                          : d.out + (size_t)b * oplane * d.out_cstride + d.out_coffset;
     const float* const resb = d.residual ? d.residual + (size_t)b * d.cout * rplane : nullptr;
-    const float* const gzb = d.gru_z ? d.gru_z + (size_t)b * (d.gate_cstride ? d.gate_cstride : d.cout) * oplane : nullptr;
-    const float* const ghb = d.gru_z ? d.gru_h + (size_t)b * d.cout * oplane : nullptr;
+    const float* const gzb = do_gru ? d.gru_z + (size_t)b * (d.gate_cstride ? d.gate_cstride : d.cout) * oplane : nullptr;
+    const float* const ghb = do_gru ? d.gru_h + (size_t)b * d.cout * oplane : nullptr;
     // GroupNorm statistics of the pre-activation output (4 groups), reduced lane -> wave -> workgroup
     float gs[4] = {0.0f, 0.0f, 0.0f, 0.0f}, gq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    const int gn_cg = d.gn_stats ? d.cout / d.gn_groups : 1;
+    const int gn_cg = do_gn ? d.cout / d.gn_groups : 1;
     if constexpr (TR) {
         // Transposed accumulators (the MFMA was issued with the operands swapped): this lane holds cout nbase + nt*16 + m of
         // the 4 CONSECUTIVE pixels ox0 + 4*kq + r of row oy0 + MT*wave + mt -- one 16-byte NCHW store (and one 16-byte
         // residual / GRU-gate read) per (row, n-tile) instead of four 4-byte ones, one bounds predicate and one offset
         // per four values.  NCHW fp32 outputs only; the values are those of the other form bit for bit.
         const int oxb = ox0 + wx * 16 + 4 * kq;
-        const bool vec = (d.Wout & 3) == 0 && (((uintptr_t)d.out | (uintptr_t)d.residual | (uintptr_t)d.gru_z | (uintptr_t)d.gru_h) & 15) == 0 &&
-                         ((oplane * d.out_coffset) & 3) == 0;
+        const bool vec = kLean || ((d.Wout & 3) == 0 && (((uintptr_t)d.out | (uintptr_t)d.residual | (uintptr_t)d.gru_z | (uintptr_t)d.gru_h) & 15) == 0 &&
+                                   ((oplane * d.out_coffset) & 3) == 0);
         float sc[NT], sh[NT];
         int cgs[NT];
 #pragma unroll
@@ -438,7 +453,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
                 f32x4 y;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) y[r] = acc[mt][nt][r] * sc[nt] + sh[nt];
-                if (d.gn_stats) {
+                if (do_gn) {
                     const int g = cg / gn_cg;
                     float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
@@ -470,18 +485,18 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
                             res[r] = ok[r] ? rv : 0.0f;
                         }
                     }
-                    if (!d.res_after_act) y += res;
+                    if (kLean || !d.res_after_act) y += res;
                 }
-                if (d.act == DMVS_ACT_RELU) {
+                if (act == DMVS_ACT_RELU) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) y[r] = fmaxf(y[r], 0.0f);
-                } else if (d.act != DMVS_ACT_NONE) {
+                } else if (!kLean && act != DMVS_ACT_NONE) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) y[r] = dmvs_act(y[r], d.act);
+                    for (int r = 0; r < 4; ++r) y[r] = dmvs_act(y[r], act);
                 }
-                y *= d.post_scale;
-                if (d.residual && d.res_after_act) y += res;
-                if (d.gru_z) {
+                if (!kLean) y *= d.post_scale;
+                if (!kLean && d.residual && d.res_after_act) y += res;
+                if (do_gru) {
                     f32x4 z, h;
                     if (fast) {
                         z = *reinterpret_cast<const f32x4*>(gzb + o0);
@@ -527,7 +542,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) y[nt][r] = acc[mt][nt][r] * sc[nt][r] + sh[nt][r];
-            if (d.gn_stats) {
+            if (do_gn) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -555,16 +570,16 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
                         if (!d.res_after_act) y[nt][r] += res[nt][r];
                     }
             }
-            if (d.act == DMVS_ACT_RELU) {
+            if (act == DMVS_ACT_RELU) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) y[nt][r] = fmaxf(y[nt][r], 0.0f);
-            } else if (d.act != DMVS_ACT_NONE) {
+            } else if (!kLean && act != DMVS_ACT_NONE) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) y[nt][r] = dmvs_act(y[nt][r], d.act);
+                    for (int r = 0; r < 4; ++r) y[nt][r] = dmvs_act(y[nt][r], act);
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -576,7 +591,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
 #pragma unroll
                     for (int r = 0; r < 4; ++r) y[nt][r] += res[nt][r];
             }
-            if (d.gru_z) {
+            if (do_gru) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -615,7 +630,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
             }
         }
     }
-    if (d.gn_stats) {
+    if (do_gn) {
 #pragma unroll
         for (int gi = 0; gi < 4; ++gi) {
 #pragma unroll
@@ -668,12 +683,24 @@ static int conv_tile_waves_x(long out_pixels, int nt) {
     return (nt == 2 && out_pixels >= 128L * 160) ? 2 : 1;
 }
 
-[[maybe_unused]] static bool conv_walk_enabled() {
+// The tile-walking kernels are compiled for "lean" layers only (kLean in the kernel): one plain input tensor, exact fp32, ReLU or
+// no activation, no gating / GRU blend / GroupNorm statistics / post-scale, an optional same-size residual added before the
+// activation, rows of 16-byte multiples on 16-byte aligned tensors.  DMVS_CONV_WALK=0: one tile per workgroup everywhere (A/B).
+static bool conv_walk_ok(const dmvs_conv2d_desc& d) {
     static const bool on = [] {
         const char* e = getenv("DMVS_CONV_WALK");
         return !(e && e[0] == '0');
     }();
-    return on;
+    if (!on || d.arith != DMVS_ARITH_F32 || d.c1 != 0 || d.in_mode != DMVS_IN_PLAIN || d.mul0 || d.gru_z || d.gn_stats) return false;
+    if ((d.act != DMVS_ACT_NONE && d.act != DMVS_ACT_RELU) || d.post_scale != 1.0f) return false;
+    if (d.residual && (d.res_after_act || d.res_mode != DMVS_IN_PLAIN)) return false;
+    if ((d.Wout & 3) || ((((uintptr_t)d.out | (uintptr_t)d.residual) & 15) != 0) || (((long)d.Hout * d.Wout * d.out_coffset) & 3)) return false;
+    // Measured at B = 96 (profiles/r3_conv_walk2_ab.txt, ms per step, one tile per workgroup -> walking): the lean layers gain
+    // (3 -> 8 at 512x640 0.76 -> 0.64, 8 -> 16 stride 2 0.92 -> 0.85, 16 -> 32 stride 2 0.55 -> 0.48, 16 -> 32 at 64x80 0.28 -> 0.22,
+    // 16 -> 32 5x5 stride 2 3.05 -> 2.94) EXCEPT the stride-1 one-n-tile layers with >= 16 input channels (16 -> 16 at 256x320:
+    // 5.01 -> 5.49 and 1.41 -> 1.50) -- whatever holds those at ~0.5 is not the per-tile prologue either.
+    if (d.stride == 1 && d.cout_pad <= 16 && d.c0 >= 16) return false;
+    return true;
 }
 
 // 16-bit channel-last outputs (FeatureNet's out1 / out2 / out3 in the reduced-precision configurations): 1x1 and 3x3 stride 1
@@ -719,39 +746,31 @@ int launch_conv2d_mt(const dmvs_conv2d_desc& d, hipStream_t st, int nt, int ngro
 #undef DMVS_BF
             }
         }
-#ifdef DMVS_CONV_WALK      // experiment, not built by default: measured 8 % SLOWER end to end (see the kernel's header comment)
-        if constexpr (!ZI) {
-            if (conv_walk_enabled()) {           // resident, tile-walking workgroups (DMVS_CONV_WALK=0: one tile per workgroup)
-                const long ntiles = (long)tiles_x * tiles_y * d.B;
-#define DMVS_WALK(NTV) do { \
-                    auto kfn = conv2d_mfma_kernel<KH, KW, S, NTV, MT, false, DMVS_DTYPE_F32, true, true>; \
-                    static const int resident = dmvs_resident_workgroups(reinterpret_cast<const void*>(kfn)); \
-                    const long per_group = resident / ngroups > 0 ? resident / ngroups : 1; \
-                    dim3 g((unsigned)(ntiles < per_group ? ntiles : per_group), (unsigned)ngroups); \
-                    hipLaunchKernelGGL(kfn, g, block, 0, st, d, tiles_x, tiles_y); } while (0)
-                switch (nt) {
-                    case 1: DMVS_WALK(1); break;
-                    case 2: DMVS_WALK(2); break;
-                    case 3: DMVS_WALK(3); break;
-                    default: DMVS_WALK(4); break;
-                }
-#undef DMVS_WALK
-                return dmvs_launch_status();
-            }
-        }
-#endif
-        if constexpr (!ZI && (KH * KW == 9 || KH * KW == 25)) {      // wide tiles: 128-byte runs per channel row
-            const int wxv = conv_tile_waves_x((long)d.Hout * d.Wout, nt);
-            if (wxv > 1 && nt <= 2) {
-#define DMVS_WX(NTV, WXV) do { \
+        if constexpr (!ZI && (KH * KW == 9 || KH * KW == 25)) {
+            // the plain 3x3 / 5x5 layers with one or two n-tiles: 32-pixel-wide tiles where measured better (conv_tile_waves_x) and,
+            // when the layer is "lean" (conv_walk_ok), resident tile-walking workgroups
+            const int wxv = nt <= 2 ? conv_tile_waves_x((long)d.Hout * d.Wout, nt) : 1;
+            const bool walk = nt <= 2 && conv_walk_ok(d);
+#define DMVS_TILED(NTV, WXV, WALKV) do { \
                     const int tx_ = (d.Wout + 16 * WXV - 1) / (16 * WXV), rows_ = (4 / WXV) * MT, ty_ = (d.Hout + rows_ - 1) / rows_; \
-                    dim3 g((unsigned)(tx_ * ty_ * d.B), (unsigned)ngroups); \
-                    hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, NTV, MT, false, DMVS_DTYPE_F32, true, false, DMVS_ARITH_F32, WXV>), g, block, 0, st, d, tx_, ty_); \
+                    auto kfn = conv2d_mfma_kernel<KH, KW, S, NTV, MT, false, DMVS_DTYPE_F32, true, WALKV, DMVS_ARITH_F32, WXV>; \
+                    long gx = (long)tx_ * ty_ * d.B; \
+                    if (WALKV) { \
+                        static const int resident = dmvs_resident_workgroups(reinterpret_cast<const void*>(kfn)); \
+                        const long per_group = resident / ngroups > 0 ? resident / ngroups : 1; \
+                        if (gx > per_group) gx = per_group; \
+                    } \
+                    hipLaunchKernelGGL(kfn, dim3((unsigned)gx, (unsigned)ngroups), block, 0, st, d, tx_, ty_); \
                     return dmvs_launch_status(); } while (0)
-                if (nt == 1) DMVS_WX(1, 2);
-                DMVS_WX(2, 2);
-#undef DMVS_WX
+            if (walk) {
+                if (nt == 1) DMVS_TILED(1, 1, true);
+                if (wxv == 2) DMVS_TILED(2, 2, true);
+                DMVS_TILED(2, 1, true);
+            } else if (wxv == 2) {
+                if (nt == 1) DMVS_TILED(1, 2, false);
+                DMVS_TILED(2, 2, false);
             }
+#undef DMVS_TILED
         }
         switch (nt) {
             case 1: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 1, MT, ZI, DMVS_DTYPE_F32, true>), grid, block, 0, st, d, tiles_x, tiles_y); break;

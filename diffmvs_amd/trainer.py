@@ -82,6 +82,8 @@ class FlatParams:
 
 
 class Trainer:
+    milestones, lr_gamma, steps_per_epoch = None, 0.5, None      # MultiStepLR off unless the constructor sets it
+
     def __init__(self, model, args, ops: Ops | None = None, lr=1e-3, wd=1e-3, betas=(0.9, 0.999), eps=1e-8, max_norm=2.0,
                  total_steps: int | None = None, loss_rate=0.9, distributed: bool = True, milestones=None, lr_gamma: float = 0.5,
                  steps_per_epoch: int | None = None):

@@ -617,6 +617,27 @@ def test_conv2d_bf16_matrix_arithmetic(ops, cin, cout, k, stride, HW, extras):
         assert torch.allclose(st[..., 0] / yg.shape[-1], yg.mean(-1), atol=1e-4)
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,HW,with_res", [(16, 16, 3, 1, (40, 52), False), (32, 32, 3, 1, (37, 36), True), (8, 16, 5, 2, (50, 72), False),
+                                                          (16, 32, 3, 2, (44, 40), False), (12, 20, 3, 1, (17, 20), True), (16, 16, 3, 1, (128, 176), False)])
+def test_conv2d_tile_walking_workgroups(ops, cin, cout, k, stride, HW, with_res):
+    """"lean" layers (one plain input, BN + ReLU, optional residual, rows of 16-byte multiples) run on resident, tile-walking
+    workgroups: several tiles per workgroup (the emulation keeps 2 workgroups resident, the last case has more tiles than an
+    MI355X holds), interior tiles after border tiles and back (stale padding), partial last chunks, both tile widths."""
+    B = 3
+    x = rnd(B, cin, *HW, seed=1)
+    w = rnd(cout, cin, k, k, seed=2) * 0.2
+    bn = {"weight": rnd(cout, seed=4, lo=0.5, hi=1.5), "bias": rnd(cout, seed=5), "running_mean": rnd(cout, seed=6),
+          "running_var": rnd(cout, seed=7, lo=0.5, hi=1.5)}
+    ref = F.batch_norm(F.conv2d(x, w, None, stride, k // 2), bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"], False, 0.0, 1e-5)
+    res = rnd(*ref.shape, seed=9) if with_res else None
+    if with_res:
+        ref = ref + res
+    ref = F.relu(ref)
+    pc = K.pack_conv2d(dev(ops, w), bn={k_: v.to(ops.device) for k_, v in bn.items()}, stride=stride, pad=k // 2)
+    out = ops.conv2d(pc, dev(ops, x), act=K.ACT_RELU, residual=dev(ops, res))
+    close(out, ref, 2e-5)
+
+
 @pytest.mark.parametrize("bad", [float("nan"), float("inf"), 3.0e7])
 def test_groupnorm_stats_propagate_non_finite_and_out_of_range(ops, bad):
     """the fixed-point statistics slots (dmvs_common.h): a NaN / Inf activation -- or one beyond the documented magnitude
