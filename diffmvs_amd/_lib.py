@@ -61,6 +61,7 @@ SIGNATURES = {
     "dmvs_abi_version": [],
     "dmvs_conv2d_f32": [C.POINTER(Conv2dDesc), _P],
     "dmvs_featurenet_stem_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "dmvs_conv3x3_pair16_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "dmvs_conv2d_wgrad_workspace_f32": [C.POINTER(Conv2dDesc), C.POINTER(C.c_int64)],
     "dmvs_conv2d_wgrad_f32": [C.POINTER(Conv2dDesc), _P, _P, _P, _P, C.c_int64, _P],
     "dmvs_conv3d_f32": [C.POINTER(Conv3dDesc), _P],

@@ -25,7 +25,7 @@ constexpr int PC = 16;                             // channels in = mid = out
 constexpr int PTS = 16;                            // output tile
 constexpr int PMW = PTS + 2, PMP = PMW * PMW;      // intermediate tile 18 x 18 = 324
 constexpr int PIW = PTS + 4, PIP = PIW * PIW;      // input tile 20 x 20 = 400
-constexpr int PIPL = 400 + 16;                     // input channel pitch: 16 mod 32 (the 4 k-groups on disjoint banks)
+constexpr int PIPL = PIP;                          // input channel pitch: 400 = 16 mod 32 already (the 4 k-groups on disjoint banks)
 constexpr int PMPL = 336;                          // intermediate channel pitch: 324 padded to 16 mod 32
 constexpr int PWS = 9 * 16;                        // weight slab per input channel [tap][cout] (144 = 16 mod 32)
 constexpr int PIN_FLOATS = PC * PIPL;
@@ -60,7 +60,7 @@ conv3x3_pair16_kernel(const float* __restrict__ x, const float* __restrict__ wa,
     constexpr unsigned kGuard = 0x8080u;
     int e_off[S_IT];                         // r * W + c from the halo origin (the channel advances by a plane per 400 pieces)
     short e_rc[S_IT];                        // r | c << 8
-    // piece e = i * 256 + tid covers channel e / 400, position e % 400; a lane's pieces of consecutive i differ by 256 positions
+    // piece e = i * 256 + tid covers channel e / 400, position e % 400 (16 x 400 = 25 x 256 pieces: no tail)
 #pragma unroll
     for (int i = 0; i < S_IT; ++i) {
         const int e = i * DMVS_BLOCK + tid;
@@ -81,21 +81,10 @@ conv3x3_pair16_kernel(const float* __restrict__ x, const float* __restrict__ wa,
 #pragma unroll
         for (int i = 0; i < S_IT; ++i) {
             const int e0 = i * DMVS_BLOCK + wave * 64;           // first piece of this wave-instruction (wave-uniform)
-            if (e0 + lane < PC * PIP) {
-                const unsigned rc = (unsigned)(unsigned short)e_rc[i];
-                const bool ok = (((rc | kGuard) - lo) & (him1 - rc) & kGuard) == kGuard;
-                const float* srcp = ok ? origin + e_off[i] : pair_zero16;
-                // LDS image [ci][PIPL]: 400 positions per channel + 16 words of padding; a wave-instruction's 64 pieces stay inside
-                // one channel or straddle two -- the destination of piece e is ci * PIPL + rem = e + 16 * ci
-                const int ci0 = e0 / PIP, ci1 = (e0 + 63) / PIP;
-                if (ci0 == ci1) {
-                    __builtin_amdgcn_global_load_lds(srcp, DMVS_LDS_P(s_in + e0 + 16 * ci0), 4, 0, 0);
-                } else {                                          // straddling instruction: two exec-masked halves
-                    const int split = ci1 * PIP - e0;             // lanes >= split belong to channel ci1
-                    if (lane < split) __builtin_amdgcn_global_load_lds(srcp, DMVS_LDS_P(s_in + e0 + 16 * ci0), 4, 0, 0);
-                    else __builtin_amdgcn_global_load_lds(srcp, DMVS_LDS_P(s_in + e0 + 16 * ci1), 4, 0, 0);
-                }
-            }
+            const unsigned rc = (unsigned)(unsigned short)e_rc[i];
+            const bool ok = (((rc | kGuard) - lo) & (him1 - rc) & kGuard) == kGuard;
+            const float* srcp = ok ? origin + e_off[i] : pair_zero16;
+            __builtin_amdgcn_global_load_lds(srcp, DMVS_LDS_P(s_in + e0), 4, 0, 0);      // LDS image [ci][20 x 20] = piece order
         }
     };
 

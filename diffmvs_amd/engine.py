@@ -61,7 +61,11 @@ def run_feature(o: Ops, f, x, layout=K.LAYOUT_NHWC, feat_dtype=torch.float32):
     output convolutions' epilogue)."""
     R = K.ACT_RELU
     c0 = o.featurenet_stem(f["conv0.0"], f["conv0.1"], x)      # conv0.0 + conv0.1 fused: the 8-channel intermediate stays in LDS
-    c1 = o.conv2d(f["conv1.2"], o.conv2d(f["conv1.1"], o.conv2d(f["conv1.0"], c0, act=R), act=R), act=R)
+    c1 = o.conv2d(f["conv1.0"], c0, act=R)
+    if os.environ.get("DMVS_FEAT_PAIR", "1") != "0":      # conv1.1 + conv1.2 fused: the 16-channel intermediate stays in LDS
+        c1 = o.conv3x3_pair16(f["conv1.1"], f["conv1.2"], c1)
+    else:
+        c1 = o.conv2d(f["conv1.2"], o.conv2d(f["conv1.1"], c1, act=R), act=R)
     c2 = o.conv2d(f["conv2.2"], o.conv2d(f["conv2.1"], o.conv2d(f["conv2.0"], c1, act=R), act=R), act=R)
     c3 = o.conv2d(f["conv3.2"], o.conv2d(f["conv3.1"], o.conv2d(f["conv3.0"], c2, act=R), act=R), act=R)
     out = {"stage1": o.conv2d(f["out1"], c3, out_layout=layout, out_dtype=feat_dtype)}

@@ -288,6 +288,20 @@ class Ops:
         self._call("dmvs_featurenet_stem_f32", _ptr(x), _ptr(pc0.weight), _ptr(pc0.scale), _ptr(pc0.shift), _ptr(pc1.weight),
                    _ptr(pc1.scale), _ptr(pc1.shift), _ptr(y), N, H, W, self.stream())
 
+    def conv3x3_pair16(self, pca: PackedConv, pcb: PackedConv, x):
+        """relu(bn(conv_b(relu(bn(conv_a(x)))))) for two 16 -> 16 channel 3x3 layers in one kernel (FeatureNet conv1.1 + conv1.2):
+        x [N,16,H,W] -> [N,16,H,W]; the intermediate stays in LDS"""
+        self._chk(x)
+        N, cin, H, W = x.shape
+        for pc in (pca, pcb):
+            if not (cin == 16 and pc.cin == 16 and pc.cout == 16 and pc.cout_pad == 16 and pc.k == (3, 3) and pc.stride == 1 and
+                    pc.pad == (1, 1)):
+                raise _lib.DmvsError("conv3x3_pair16: expects two 16->16 3x3 stride-1 layers")
+        y = self.empty(N, 16, H, W)
+        self._call("dmvs_conv3x3_pair16_f32", _ptr(x), _ptr(pca.weight), _ptr(pca.scale), _ptr(pca.shift), _ptr(pcb.weight),
+                   _ptr(pcb.scale), _ptr(pcb.shift), _ptr(y), N, H, W, self.stream())
+        return y
+
     def conv2d_wgrad(self, pc: PackedConv, x0, grad_out, x1=None, *, mul0=None, in_mode=IN_PLAIN, want_bias=False):
         """Weight gradient of conv2d(pc, x0, x1, mul0=..., in_mode=...) in torch layout [cout, cin, kh, kw]
         (and the bias gradient [cout] when want_bias) -> gw | (gw, gb)."""

@@ -116,6 +116,14 @@ int dmvs_conv2d_f32(const dmvs_conv2d_desc* d, void* stream);
 int dmvs_featurenet_stem_f32(const float* x, const float* w0, const float* scale0, const float* shift0, const float* w1,
                              const float* scale1, const float* shift1, float* y, int32_t N, int32_t H, int32_t W, void* stream);
 
+/* Two 16 -> 16 channel 3x3 convolutions, each followed by folded eval BatchNorm + ReLU, in one kernel:
+ *   y = relu(bn_b(conv3x3_b(relu(bn_a(conv3x3_a(x))))))       FeatureNet conv1.1 + conv1.2 (models/module.py:368-371, :400)
+ * x, y [N,16,H,W] NCHW, padding 1; wa, wb [16][9][16] in the kernel weight layout of dmvs_conv2d_f32 (cout_pad = 16); scale / shift
+ * [16] (NULL = 1 / 0).  The 16-channel intermediate never leaves LDS: half the HBM traffic of the two dmvs_conv2d_f32 launches
+ * it replaces, whose results it reproduces (same products, same summation order). */
+int dmvs_conv3x3_pair16_f32(const float* x, const float* wa, const float* scale_a, const float* shift_a, const float* wb,
+                            const float* scale_b, const float* shift_b, float* y, int32_t N, int32_t H, int32_t W, void* stream);
+
 /* Weight (and bias) gradient of the convolution described by `d` (its input side: in0 / in1 / mul0 / in_mode / kh /
  * kw / stride / pad / cout / cout_pad / B / Hin / Win / Hout / Wout; epilogue fields are ignored):
  *   gw[co][ci][ky][kx] = sum_{b,y,x} grad_out[b,co,y,x] * X[b,ci,y*stride+ky-pad,x*stride+kx-pad]     (torch layout)

@@ -638,6 +638,24 @@ def test_conv2d_tile_walking_workgroups(ops, cin, cout, k, stride, HW, with_res)
     close(out, ref, 2e-5)
 
 
+@pytest.mark.parametrize("N,H,W", [(2, 16, 16), (3, 37, 50), (1, 5, 7), (2, 64, 96)])
+def test_conv3x3_pair16(ops, N, H, W):
+    """FeatureNet conv1.1 + conv1.2 in one kernel (intermediate in LDS): against torch and BIT FOR BIT against the two
+    dmvs_conv2d_f32 launches it replaces; several tiles per workgroup, ragged tiles, images smaller than a tile"""
+    x = rnd(N, 16, H, W, seed=1)
+    ws = [rnd(16, 16, 3, 3, seed=2 + i) * 0.2 for i in range(2)]
+    bns = [{"weight": rnd(16, seed=4 + i, lo=0.5, hi=1.5), "bias": rnd(16, seed=6 + i), "running_mean": rnd(16, seed=8 + i),
+            "running_var": rnd(16, seed=10 + i, lo=0.5, hi=1.5)} for i in range(2)]
+    ref = x
+    for w, bn in zip(ws, bns):
+        ref = F.relu(F.batch_norm(F.conv2d(ref, w, None, 1, 1), bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"], False, 0.0, 1e-5))
+    pcs = [K.pack_conv2d(dev(ops, w), bn={k_: v.to(ops.device) for k_, v in bn.items()}, pad=1) for w, bn in zip(ws, bns)]
+    out = ops.conv3x3_pair16(pcs[0], pcs[1], dev(ops, x))
+    close(out, ref, 2e-5)
+    two = ops.conv2d(pcs[1], ops.conv2d(pcs[0], dev(ops, x), act=K.ACT_RELU), act=K.ACT_RELU)
+    assert torch.equal(out.cpu(), two.cpu())
+
+
 @pytest.mark.parametrize("bad", [float("nan"), float("inf"), 3.0e7])
 def test_groupnorm_stats_propagate_non_finite_and_out_of_range(ops, bad):
     """the fixed-point statistics slots (dmvs_common.h): a NaN / Inf activation -- or one beyond the documented magnitude
