@@ -73,19 +73,24 @@ __device__ __attribute__((aligned(16))) const float dmvs_zero16[4] = {0.0f, 0.0f
 
 #define DMVS_LDS(p) ((__attribute__((address_space(3))) void*)(p))
 
-template <int KH, int KW, int S, int NT, int MT, int AR = DMVS_ARITH_F32, int WX = 1>
+template <int KH, int KW, int S, int NT, int MT, int AR = DMVS_ARITH_F32, int WX = 1, bool V16 = false>
 struct ConvCfg {
     static constexpr int T = KH * KW;
     static constexpr int COLS = 16 * WX;                      // pixel tile of the workgroup: the 4 waves sit WX across, 4 / WX down
     static constexpr int ROWS = (4 / WX) * MT;
     static constexpr int TW = (COLS - 1) * S + KW, TH = (ROWS - 1) * S + KH;
-    static constexpr int PLANE = pad16mod32(TH * TW);
+    // V16 (16-byte staging pieces, see the kernel): an LDS row starts SLACK floats left of the halo's first column, on a 16-byte
+    // boundary of the image row (tile origins are multiples of 16 pixels, the padding is (KW - 1) / 2), and its pitch TWL is a
+    // whole number of pieces
+    static constexpr int SLACK = V16 ? (4 - ((KW - 1) / 2) % 4) % 4 : 0;
+    static constexpr int TWL = V16 ? (SLACK + TW + 3) / 4 * 4 : TW;
+    static constexpr int PLANE = pad16mod32(TH * TWL);
     static constexpr int NW = NT * 16;
     static constexpr int WPAD = pad16mod32(T * NW);
     // input channels per LDS chunk: 8 when the double-buffered chunk stays within 40 KB, else 4 (the bf16 form: always 8,
-    // its matrix instruction spans 8 channels)
+    // its matrix instruction spans 8 channels); decided on the 4-byte form's plane so that both staging forms chunk alike
     // (4-channel chunks for the one-n-tile 3x3 layers -- half the LDS, 8 instead of 5 workgroups per CU -- measured 4-6 % slower)
-    static constexpr int CK = AR == DMVS_ARITH_BF16 ? 8 : ((2 * 8 * (PLANE + WPAD) * 4 > 40960) ? 4 : 8);
+    static constexpr int CK = AR == DMVS_ARITH_BF16 ? 8 : ((2 * 8 * (pad16mod32(TH * TW) + WPAD) * 4 > 40960) ? 4 : 8);
     static constexpr int BUF = CK * (PLANE + WPAD);            // floats per pipeline stage
     static constexpr int IN_IT = (CK * PLANE + DMVS_BLOCK - 1) / DMVS_BLOCK;           // 4-byte DMA pieces per thread
     static constexpr int W_IT = (CK * WPAD / 4 + DMVS_BLOCK - 1) / DMVS_BLOCK;         // 16-byte DMA pieces per thread
@@ -120,15 +125,27 @@ constexpr int conv_min_waves(int nt, int mt) { return (nt == 2 && mt == 4) ? 4 :
 // group kq carries tap 4g + kq (taps beyond KH*KW meet zero weights), its 8 k-slots are the 8 channels.  3 MFMAs replace the
 // 18 fp32 ones of a 3x3 chunk, at half the cycles each; the loop is then bound by its (unchanged) 8 LDS reads per operand.
 //
+// V16 = the input halo is staged in 16-BYTE pieces (global_load_lds_dwordx4) instead of 4-byte ones.  An LDS-DMA instruction costs
+// the texture path the same ~55-60 cycles whatever its width (measured on the cout = 1 3-D kernel), and the 4-byte
+// form needs one wave-level instruction per 64 halo floats: 96 + 10 per 16 -> 16 tile, ~6.0 k cycles of a CU's DMA issue against 4.6 k
+// matrix cycles per SIMD -- which is why those layers moved with NONE of: bf16 matrix arithmetic, register staging, tile width,
+// chunk size, tile walking (section 4.0).  Here an LDS row is the 16-byte aligned cover of the halo row (SLACK extra floats on the
+// left, pitch TWL: 24 instead of 18 floats for a 3x3 tile), so the image is a plain sequence of pieces: 2 wave instructions per
+// channel instead of 6.  A piece lies entirely inside or entirely outside the image (rows are multiples of 4 floats; the
+// dispatcher checks that, the 16-byte alignment of the bases, a PLAIN input and the usual "same" padding), so zero padding stays
+// all-or-nothing per piece.  The slack columns receive neighbouring pixels that no MFMA reads.  Same arithmetic, same order.
+//
 // WX = waves side by side in a workgroup's pixel tile (1: 16 x 16*MT pixels, 2: 32 x 8*MT): 128-byte instead of 64-byte runs
 // per channel row in the stores and the halo reads.  Worth 6-9 % on the two-n-tile layers of the large planes, a loss on the
 // others (conv_tile_waves_x); it is NOT what holds the 16-channel layers at ~0.5 (unchanged by it, as by a 6x cut of the
 // matrix time and by register staging: DESIGN.md section 4).
 template <int KH, int KW, int S, int NT, int MT, bool ZI, int OT = DMVS_DTYPE_F32, bool TR = false, bool WALK = false, int AR = DMVS_ARITH_F32,
-          int WX = 1>
+          int WX = 1, bool V16 = false>
 __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfma_kernel(const dmvs_conv2d_desc d, int tiles_x, int tiles_y) {
-    using Cfg = ConvCfg<KH, KW, S, NT, MT, AR, WX>;
+    using Cfg = ConvCfg<KH, KW, S, NT, MT, AR, WX, V16>;
+    static_assert(!(V16 && ZI), "16-byte staging pieces: PLAIN inputs only");
     constexpr int T = Cfg::T, TW = Cfg::TW, TH = Cfg::TH, PLANE = Cfg::PLANE, NW = Cfg::NW, WPAD = Cfg::WPAD;
+    constexpr int TWL = Cfg::TWL, SLACK = Cfg::SLACK;      // LDS row pitch and the halo's first column inside an LDS row
     constexpr int CK = Cfg::CK, BUF = Cfg::BUF, IN_IT = Cfg::IN_IT, W_IT = Cfg::W_IT;
     // one LDS object on purpose (tile buffers + the 32-float GroupNorm scratch): with separate objects hipcc orders reads of
     // one against LDS-DMA into another with vmcnt(0) waits (conv3d.hip, conv3d_mfma_stream_kernel)
@@ -179,9 +196,9 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     // element e of the padded LDS input image of chunk c0 -> global source (or nullptr for padding)
     auto in_src = [&](int c0, int e, int& off_out) -> const float* {
         const int ci = e / PLANE, rem = e - ci * PLANE;
-        const int r = rem / TW, c = rem - r * TW;
+        const int r = rem / TWL, c = rem - r * TWL - SLACK;
         const int cig = c0 + ci, iy = gy0 + r, ix = gx0 + c;
-        const bool ok = rem < TH * TW && cig < cin && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win && !(ZI && ((iy | ix) & 1));
+        const bool ok = rem < TH * TWL && cig < cin && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win && !(ZI && ((iy | ix) & 1));
         int off;
         if (mode == DMVS_IN_PLAIN) off = cig * plane0 + iy * pW + ix;
         else if (mode == DMVS_IN_UPSAMPLE2) off = cig * plane0 + (iy >> 1) * pW + (ix >> 1);
@@ -198,11 +215,20 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     // decoding it once per tile for all CK*PLANE/256 elements was still ~600 VALU per workgroup: a third of the issue
     // slots of the 16-channel layers.)  The channel is then a scalar loop variable: the DMA address is an SGPR base
     // plus a 32-bit lane offset.
-    constexpr int P_IT = (PLANE + DMVS_BLOCK - 1) / DMVS_BLOCK;
-    int p_sp[P_IT];                        // spatial source offset of plane position it*256 + tid, -1: padding / not staged
+    constexpr int PIECES = TH * TWL / 4;                  // (V16) 16-byte pieces of a channel plane; piece p = LDS floats 4p .. 4p+3
+    constexpr int P_IT = V16 ? (PIECES + DMVS_BLOCK - 1) / DMVS_BLOCK : (PLANE + DMVS_BLOCK - 1) / DMVS_BLOCK;
+    int p_sp[P_IT];                        // spatial source offset of plane position (V16: piece) it*256 + tid, -1: padding / not staged
     auto map_tile = [&]() {                // for the tile (gy0, gx0) about to be staged
 #pragma unroll
         for (int it = 0; it < P_IT; ++it) {
+            if constexpr (V16) {
+                const int pe = it * DMVS_BLOCK + tid;
+                const int r = pe / (TWL / 4), pc = pe - r * (TWL / 4);
+                const int iy = gy0 + r, ix = gx0 - SLACK + 4 * pc;      // a multiple of 4: the piece is inside or outside as a whole
+                const bool ok = pe < PIECES && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win;
+                p_sp[it] = ok ? iy * pW + ix : -1;
+                continue;
+            }
             const int rem = it * DMVS_BLOCK + tid;
             const int r = rem / TW, c = rem - r * TW;
             const int iy = gy0 + r, ix = gx0 + c;
@@ -235,7 +261,16 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
 #pragma unroll
     for (int it = 0; it < P_IT; ++it) {
         const int rem = it * DMVS_BLOCK + tid;
-        if (rem < PLANE) {
+        if constexpr (V16) {
+            if (rem < PIECES) {
+                const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int ci = 0; ci < CK; ++ci) {
+                    if (p_sp[it] < 0 || ci >= cin) *reinterpret_cast<f32x4*>(&lds[ci * PLANE + 4 * rem]) = z4;
+                    if (p_sp[it] < 0 || CK + ci >= cin) *reinterpret_cast<f32x4*>(&lds[BUF + ci * PLANE + 4 * rem]) = z4;
+                }
+            }
+        } else if (rem < PLANE) {
 #pragma unroll
             for (int ci = 0; ci < CK; ++ci) {
                 if (p_sp[it] < 0 || ci >= cin) lds[ci * PLANE + rem] = 0.0f;
@@ -260,8 +295,13 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
                 for (int it = 0; it < P_IT; ++it) {
                     if (p_sp[it] >= 0) {
                         const float* srcp = cb + (unsigned)p_sp[it];
-                        float* dstp = buf + ci * PLANE + it * DMVS_BLOCK + wave * 64;
-                        __builtin_amdgcn_global_load_lds(srcp, DMVS_LDS(dstp), 4, 0, 0);
+                        if constexpr (V16) {
+                            float* dstp = buf + ci * PLANE + (it * DMVS_BLOCK + wave * 64) * 4;
+                            __builtin_amdgcn_global_load_lds(srcp, DMVS_LDS(dstp), 16, 0, 0);
+                        } else {
+                            float* dstp = buf + ci * PLANE + it * DMVS_BLOCK + wave * 64;
+                            __builtin_amdgcn_global_load_lds(srcp, DMVS_LDS(dstp), 4, 0, 0);
+                        }
                     }
                 }
             }
@@ -288,7 +328,12 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
 #pragma unroll
         for (int it = 0; it < P_IT; ++it) {
             const int rem = it * DMVS_BLOCK + tid;
-            if (rem < TH * TW && p_sp[it] < 0) {
+            if constexpr (V16) {
+                if (rem < PIECES && p_sp[it] < 0) {
+#pragma unroll
+                    for (int ci = 0; ci < CK; ++ci) *reinterpret_cast<f32x4*>(&buf[ci * PLANE + 4 * rem]) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                }
+            } else if (rem < TH * TW && p_sp[it] < 0) {
 #pragma unroll
                 for (int ci = 0; ci < CK; ++ci) buf[ci * PLANE + rem] = 0.0f;
             }
@@ -353,7 +398,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
                 const int tc = tv ? t : T - 1;
                 const int ky = tc / KW, kx = tc - ky * KW;
                 const float* wp = s_w + tc * NW + m;
-                const float* ip = s_in + ((wy * MT * S) + ky) * TW + (wx * 16 + m) * S + kx;
+                const float* ip = s_in + ((wy * MT * S) + ky) * TWL + SLACK + (wx * 16 + m) * S + kx;
                 bf16x8 av[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
@@ -366,7 +411,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
                 for (int mt = 0; mt < MT; ++mt) {
                     float bb[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) bb[j] = ip[j * PLANE + (mt * S) * TW];
+                    for (int j = 0; j < 8; ++j) bb[j] = ip[j * PLANE + (mt * S) * TWL];
                     const bf16x8 bv = dmvs_pack_bf16x8(bb);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
@@ -380,7 +425,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
         for (int c4 = 0; c4 < nc4; ++c4) {
             const int ci = c4 * 4 + kq;
             const float* wp = s_w + ci * WPAD + m;
-            const float* ip = s_in + ci * PLANE + (wy * MT * S) * TW + (wx * 16 + m) * S;
+            const float* ip = s_in + ci * PLANE + (wy * MT * S) * TWL + SLACK + (wx * 16 + m) * S;
 #pragma unroll 1
             for (int ky = 0; ky < KH; ++ky) {
 #pragma unroll
@@ -390,7 +435,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
                     for (int nt = 0; nt < NT; ++nt) av[nt] = wp[(ky * KW + kx) * NW + nt * 16];
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
-                        const float bv = ip[(mt * S + ky) * TW + kx];
+                        const float bv = ip[(mt * S + ky) * TWL + kx];
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
                             acc[mt][nt] = TR ? __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av[nt], acc[mt][nt], 0, 0, 0)       // D[pixel][cout]
@@ -703,6 +748,19 @@ static bool conv_walk_ok(const dmvs_conv2d_desc& d) {
     return true;
 }
 
+// 16-byte staging pieces (template V16) need: a PLAIN input (and second concat input), image rows of 16-byte multiples on 16-byte
+// aligned tensors, and the "same" padding the LDS row alignment is built for.  DMVS_CONV_V16=0: 4-byte pieces everywhere (A/B).
+template <int KW>
+static bool conv_v16_ok(const dmvs_conv2d_desc& d) {
+    static const bool on = [] {
+        const char* e = getenv("DMVS_CONV_V16");
+        return !(e && e[0] == '0');
+    }();
+    if (!on || d.in_mode != DMVS_IN_PLAIN || (d.Win & 3) || d.pad_w != (KW - 1) / 2) return false;
+    if (((uintptr_t)d.in0 & 15) || (d.c1 > 0 && ((uintptr_t)d.in1 & 15))) return false;
+    return true;
+}
+
 // 16-bit channel-last outputs (FeatureNet's out1 / out2 / out3 in the reduced-precision configurations): 1x1 and 3x3 stride 1
 template <int KH, int KW, int MT, int OT>
 int launch_conv2d_x16(const dmvs_conv2d_desc& d, hipStream_t st, int nt, int ngroups) {
@@ -728,6 +786,7 @@ int launch_conv2d_mt(const dmvs_conv2d_desc& d, hipStream_t st, int nt, int ngro
     }
     const int tiles_x = (d.Wout + 15) / 16, tiles_y = (d.Hout + 4 * MT - 1) / (4 * MT);
     dim3 grid((unsigned)(tiles_x * tiles_y * d.B), (unsigned)ngroups), block(DMVS_BLOCK);
+    const bool v16 = !ZI && conv_v16_ok<KW>(d);
     if (d.out_layout == DMVS_LAYOUT_NCHW) {      // transposed accumulators: 16-byte NCHW stores
         if constexpr (!ZI && MT == 2 && KH * KW > 1 && S == 1) {      // bf16 matrix arithmetic: one tile shape (16 x 8), NCHW fp32 outputs
             if (conv_bf16_honoured(d)) {
@@ -751,9 +810,10 @@ int launch_conv2d_mt(const dmvs_conv2d_desc& d, hipStream_t st, int nt, int ngro
             // when the layer is "lean" (conv_walk_ok), resident tile-walking workgroups
             const int wxv = nt <= 2 ? conv_tile_waves_x((long)d.Hout * d.Wout, nt) : 1;
             const bool walk = nt <= 2 && conv_walk_ok(d);
-#define DMVS_TILED(NTV, WXV, WALKV) do { \
+#define DMVS_TILED(NTV, WXV, WALKV) do { if (v16) DMVS_TILED_(NTV, WXV, WALKV, true); else DMVS_TILED_(NTV, WXV, WALKV, false); } while (0)
+#define DMVS_TILED_(NTV, WXV, WALKV, V16V) do { \
                     const int tx_ = (d.Wout + 16 * WXV - 1) / (16 * WXV), rows_ = (4 / WXV) * MT, ty_ = (d.Hout + rows_ - 1) / rows_; \
-                    auto kfn = conv2d_mfma_kernel<KH, KW, S, NTV, MT, false, DMVS_DTYPE_F32, true, WALKV, DMVS_ARITH_F32, WXV>; \
+                    auto kfn = conv2d_mfma_kernel<KH, KW, S, NTV, MT, false, DMVS_DTYPE_F32, true, WALKV, DMVS_ARITH_F32, WXV, V16V>; \
                     long gx = (long)tx_ * ty_ * d.B; \
                     if (WALKV) { \
                         static const int resident = dmvs_resident_workgroups(reinterpret_cast<const void*>(kfn)); \
@@ -771,6 +831,18 @@ int launch_conv2d_mt(const dmvs_conv2d_desc& d, hipStream_t st, int nt, int ngro
                 DMVS_TILED(2, 2, false);
             }
 #undef DMVS_TILED
+#undef DMVS_TILED_
+        }
+        if constexpr (!ZI) {
+            if (v16) {
+                switch (nt) {
+                    case 1: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 1, MT, false, DMVS_DTYPE_F32, true, false, DMVS_ARITH_F32, 1, true>), grid, block, 0, st, d, tiles_x, tiles_y); break;
+                    case 2: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 2, MT, false, DMVS_DTYPE_F32, true, false, DMVS_ARITH_F32, 1, true>), grid, block, 0, st, d, tiles_x, tiles_y); break;
+                    case 3: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 3, MT, false, DMVS_DTYPE_F32, true, false, DMVS_ARITH_F32, 1, true>), grid, block, 0, st, d, tiles_x, tiles_y); break;
+                    default: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 4, MT, false, DMVS_DTYPE_F32, true, false, DMVS_ARITH_F32, 1, true>), grid, block, 0, st, d, tiles_x, tiles_y); break;
+                }
+                return dmvs_launch_status();
+            }
         }
         switch (nt) {
             case 1: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 1, MT, ZI, DMVS_DTYPE_F32, true>), grid, block, 0, st, d, tiles_x, tiles_y); break;
@@ -779,6 +851,17 @@ int launch_conv2d_mt(const dmvs_conv2d_desc& d, hipStream_t st, int nt, int ngro
             default: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 4, MT, ZI, DMVS_DTYPE_F32, true>), grid, block, 0, st, d, tiles_x, tiles_y); break;
         }
         return dmvs_launch_status();
+    }
+    if constexpr (!ZI) {      // fp32 channel-last outputs (FeatureNet's out1 / out2 / out3)
+        if (v16) {
+            switch (nt) {
+                case 1: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 1, MT, false, DMVS_DTYPE_F32, false, false, DMVS_ARITH_F32, 1, true>), grid, block, 0, st, d, tiles_x, tiles_y); break;
+                case 2: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 2, MT, false, DMVS_DTYPE_F32, false, false, DMVS_ARITH_F32, 1, true>), grid, block, 0, st, d, tiles_x, tiles_y); break;
+                case 3: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 3, MT, false, DMVS_DTYPE_F32, false, false, DMVS_ARITH_F32, 1, true>), grid, block, 0, st, d, tiles_x, tiles_y); break;
+                default: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 4, MT, false, DMVS_DTYPE_F32, false, false, DMVS_ARITH_F32, 1, true>), grid, block, 0, st, d, tiles_x, tiles_y); break;
+            }
+            return dmvs_launch_status();
+        }
     }
     switch (nt) {
         case 1: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 1, MT, ZI>), grid, block, 0, st, d, tiles_x, tiles_y); break;

@@ -86,6 +86,52 @@ def test_conv2d_row_alignment(ops, cin, cout, k, stride, pad, W, misalign):
     close(out, ref, 2e-5)
 
 
+def _at_4_byte_offset(ops, t):
+    td = dev(ops, t)
+    store = torch.zeros(t.numel() + 1, device=ops.device)
+    store[1:] = td.reshape(-1)
+    out = store[1:].view(t.shape)
+    assert out.data_ptr() % 16 == 4
+    return out
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,nhwc", [(16, 16, (3, 3), 1, (1, 1), False), (20, 32, (3, 3), 1, (1, 1), False), (32, 64, (3, 3), 1, (1, 1), False),
+                                                        (8, 16, (5, 5), 2, (2, 2), False), (16, 32, (5, 5), 2, (2, 2), False), (12, 16, (7, 7), 1, (3, 3), False),
+                                                        (16, 24, (1, 5), 1, (0, 2), False), (16, 24, (5, 1), 1, (2, 0), False), (8, 32, (3, 3), 2, (1, 1), False),
+                                                        (32, 144, (1, 1), 1, (0, 0), False), (32, 64, (1, 1), 1, (0, 0), True), (16, 32, (3, 3), 1, (1, 1), True)])
+@pytest.mark.parametrize("H,W", [(37, 52), (70, 40)])
+def test_conv2d_16_byte_staging_pieces(ops, cin, cout, k, stride, pad, nhwc, H, W):
+    """the input halo staged in 16-byte pieces (rows of 16-byte multiples on a 16-byte aligned tensor) against torch and BIT FOR BIT
+    against the 4-byte form (the same tensor at a 4-byte offset): every kernel shape, several tiles in both axes with ragged last
+    tiles, pieces outside the image on all four borders, partial last channel chunk, planar and channel-last outputs"""
+    B = 2
+    x = rnd(B, cin, H, W, seed=1)
+    w = rnd(cout, cin, *k, seed=2) * 0.3
+    bias = rnd(cout, seed=3)
+    ref = F.relu(F.conv2d(x, w, bias, stride, pad))
+    pc = K.pack_conv2d(*dev(ops, w, bias), stride=stride, pad=pad)
+    lay = K.LAYOUT_NHWC if nhwc else K.LAYOUT_NCHW
+    a = ops.conv2d(pc, dev(ops, x), act=K.ACT_RELU, out_layout=lay)
+    b = ops.conv2d(pc, _at_4_byte_offset(ops, x), act=K.ACT_RELU, out_layout=lay)
+    close(a, ref.permute(0, 2, 3, 1).contiguous() if nhwc else ref, 2e-5)
+    assert torch.equal(a.cpu(), b.cpu())
+
+
+def test_conv2d_16_byte_staging_pieces_fused_inputs(ops):
+    """... with the second concat input and the r*h gating of the GRU candidate conv (scales the staged tile in place)"""
+    B, H, W = 2, 21, 24
+    h, x = rnd(B, 12, H, W, seed=1), rnd(B, 10, H, W, seed=2)
+    r, z = torch.sigmoid(rnd(B, 12, H, W, seed=3)), torch.sigmoid(rnd(B, 12, H, W, seed=4))
+    for k, pad in (((1, 5), (0, 2)), ((5, 1), (2, 0)), ((3, 3), (1, 1))):
+        w, bias = rnd(12, 22, *k, seed=5) * 0.3, rnd(12, seed=6)
+        q = torch.tanh(F.conv2d(torch.cat([r * h, x], 1), w, bias, 1, pad))
+        pc = K.pack_conv2d(*dev(ops, w, bias), pad=pad)
+        a = ops.conv2d(pc, *dev(ops, h, x), mul0=dev(ops, r), act=K.ACT_TANH, gru_z=dev(ops, z), gru_h=dev(ops, h))
+        b = ops.conv2d(pc, _at_4_byte_offset(ops, h), dev(ops, x), mul0=dev(ops, r), act=K.ACT_TANH, gru_z=dev(ops, z), gru_h=dev(ops, h))
+        close(a, (1 - z) * h + z * q, 2e-5)
+        assert torch.equal(a.cpu(), b.cpu())
+
+
 @pytest.mark.parametrize("c0,cout,H,W,res", [(32, 64, 10, 16, "up"), (64, 144, 7, 8, None), (48, 32, 5, 44, "same"), (6, 36, 33, 36, None), (64, 96, 16, 64, "up")])
 def test_conv2d_1x1_direct_wide_variants(c0, cout, H, W, res, monkeypatch):
     """the 2..9 n-tile instantiations of the direct 1x1 kernel, dispatched only under DMVS_CONV1X1_WIDE=1 (kept for tuning:
