@@ -426,7 +426,16 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
             const int ci = c4 * 4 + kq;
             const float* wp = s_w + ci * WPAD + m;
             const float* ip = s_in + ci * PLANE + (wy * MT * S) * TWL + SLACK + (wx * 16 + m) * S;
-#pragma unroll 1
+            // All KH rows of taps of a 3x3 / 1x1 / 5x1 layer in one loop trip (36-72 MFMAs between two branches instead of 12-24): a loop
+            // of 4 MFMAs per trip runs the matrix pipe at 0.81 of the rate of 16 per trip (tools/calib/issue_probe.hip).  Measured per
+            // layer (profiles/r3_conv_ky_unroll_ab.txt): -1...-9 % on the >= 32-channel layers, 16 -> 16 unchanged; the 5x5 / 7x7 layers
+            // already have 10-40 per trip.  -DDMVS_CONV_KY_ROLLED restores one row per trip (A/B builds).  Same order of operations.
+#ifdef DMVS_CONV_KY_ROLLED
+            constexpr int kKyUnroll = 1;
+#else
+            constexpr int kKyUnroll = (KH * KW <= 9) ? KH : 1;
+#endif
+#pragma unroll kKyUnroll
             for (int ky = 0; ky < KH; ++ky) {
 #pragma unroll
                 for (int kx = 0; kx < KW; ++kx) {

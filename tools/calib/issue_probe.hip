@@ -75,9 +75,73 @@ __global__ void __launch_bounds__(512) split_kernel(float* out, int iters) {
     out[blockIdx.x * 512 + threadIdx.x] = s;
 }
 
+// matrix instruction shapes side by side: NACC independent accumulators, NM instructions per loop trip, nothing else in the loop.
+//   KIND 0: v_mfma_f32_16x16x4_f32 (8 passes = 32 cycles nominal)      KIND 1: v_mfma_f32_32x32x2_f32 (16 passes = 64 cycles)
+//   KIND 2: v_mfma_f32_16x16x32_bf16 (the bf16 form of conv2d.hip)      KIND 3: v_mfma_f32_32x32x16_bf16
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <int KIND, int NACC, int NM>
+__global__ void __launch_bounds__(256) shape_kernel(float* out, int iters) {
+    const float a = 1e-3f * (float)(threadIdx.x & 15), b = 1.0f + 1e-6f * (float)(threadIdx.x >> 4);
+    bf16x8 ha, hb;
+    for (int j = 0; j < 8; ++j) {
+        ha[j] = (__bf16)(a + (float)j);
+        hb[j] = (__bf16)(b - (float)j);
+    }
+    float s = 0.0f;
+    if constexpr (KIND == 0 || KIND == 2) {
+        f32x4 acc[NACC];
+        for (int j = 0; j < NACC; ++j) acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int j = 0; j < NM; ++j) {
+                if constexpr (KIND == 0) acc[j % NACC] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j % NACC], 0, 0, 0);
+                else acc[j % NACC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha, hb, acc[j % NACC], 0, 0, 0);
+            }
+        }
+        for (int j = 0; j < NACC; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+    } else {
+        f32x16 acc[NACC];
+        for (int j = 0; j < NACC; ++j)
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int j = 0; j < NM; ++j) {
+                if constexpr (KIND == 1) acc[j % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j % NACC], 0, 0, 0);
+                else acc[j % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha, hb, acc[j % NACC], 0, 0, 0);
+            }
+        }
+        for (int j = 0; j < NACC; ++j)
+            for (int r = 0; r < 16; ++r) s += acc[j][r];
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 static float* g_out;
 static long long* g_clk;
 static int g_cus;
+
+template <int KIND, int NACC, int NM>
+static void run_shape(int waves_per_simd, int iters) {
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((shape_kernel<KIND, NACC, NM>), dim3(g_cus * waves_per_simd), dim3(256), 0, 0, g_out, iters);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((shape_kernel<KIND, NACC, NM>), dim3(g_cus * waves_per_simd), dim3(256), 0, 0, g_out, iters);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipDeviceSynchronize());
+    float ms = 0.0f;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    static const char* names[4] = {"v_mfma_f32_16x16x4_f32", "v_mfma_f32_32x32x2_f32", "v_mfma_f32_16x16x32_bf16", "v_mfma_f32_32x32x16_bf16"};
+    static const double flops[4] = {2.0 * 16 * 16 * 4, 2.0 * 32 * 32 * 2, 2.0 * 16 * 16 * 32, 2.0 * 32 * 32 * 16};
+    const double n_instr = (double)iters * NM * waves_per_simd;                     // per SIMD
+    const double tf = flops[KIND] * n_instr * 4.0 * g_cus / ((double)ms * 1e-3) / 1e12;
+    printf("{\"probe\": \"shape\", \"instr\": \"%s\", \"accumulators\": %d, \"per_trip\": %d, \"waves_per_simd\": %d, \"ms\": %.4f, "
+           "\"ns_per_instr_per_simd\": %.3f, \"TFLOPs\": %.1f}\n", names[KIND], NACC, NM, waves_per_simd, ms, (double)ms * 1e6 / n_instr, tf);
+    fflush(stdout);
+}
 
 template <int NMFMA, int M>
 static void run_mix(int waves_per_simd, int iters) {
@@ -129,6 +193,15 @@ int main() {
     CHECK(hipMalloc(&g_out, (size_t)g_cus * 8 * 512 * sizeof(float)));
     CHECK(hipMalloc(&g_clk, 2 * sizeof(long long)));
     const int it = 20000;
+    if (getenv("PROBE_SHAPES")) {      // second run: matrix instruction shapes only
+        for (int w : {1, 2, 4, 5}) run_shape<0, 4, 16>(w, it);
+        for (int w : {1, 4}) run_shape<0, 8, 16>(w, it);
+        for (int w : {1, 2, 4}) run_shape<1, 2, 8>(w, it);
+        for (int w : {1, 2, 4}) run_shape<1, 4, 8>(w, it);
+        for (int w : {1, 2, 4}) run_shape<2, 4, 16>(w, it);
+        for (int w : {1, 2, 4}) run_shape<3, 2, 8>(w, it);
+        return 0;
+    }
     // 1. the two pipes alone
     for (int w : {1, 2, 4}) run_mix<4, 0>(w, it);
     for (int w : {1, 2, 4}) run_mix<0, 32>(w, it);

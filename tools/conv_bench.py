@@ -39,12 +39,12 @@ def main():
     if os.environ.get("CONV_LIB"):
         from diffmvs_amd import _lib
         o = K.Ops(_lib.Lib(os.path.abspath(os.environ["CONV_LIB"])), "cuda:0")
-    g3 = torch.Generator().manual_seed(1)
+    g3 = torch.Generator(device="cuda").manual_seed(1)      # (inputs drawn on the device: the N = 576 tensors take seconds on the host)
     for name, N, cin, cout, D, H, W, s in SHAPES3D:
-        if os.environ.get("CONV_ONLY") and os.environ["CONV_ONLY"] not in name:
+        if os.environ.get("CONV_2D_ONLY") or (os.environ.get("CONV_ONLY") and os.environ["CONV_ONLY"] not in name):
             continue
-        x = torch.randn(N, cin, D, H, W, generator=g3).cuda()
-        w = torch.randn(cout, cin, 3, 3, 3, generator=g3).cuda() * 0.1
+        x = torch.randn(N, cin, D, H, W, generator=g3, device="cuda")
+        w = torch.randn(cout, cin, 3, 3, 3, generator=g3, device="cuda") * 0.1
         pc = K.pack_conv3d(w, None, stride=s)
         for _ in range(3):
             y = o.conv3d(pc, x, act=K.ACT_RELU)
@@ -62,14 +62,14 @@ def main():
                           "TBs": round(gb / us * 1e3, 2)}))
     if os.environ.get("CONV_3D_ONLY"):
         return
-    g = torch.Generator().manual_seed(0)
+    g = torch.Generator(device="cuda").manual_seed(0)
     only = os.environ.get("CONV_ONLY")
     for name, N, cin, cout, k, s, H, W in SHAPES:
         if only and only not in name:
             continue
-        x = torch.randn(N, cin, H, W, generator=g).cuda()
+        x = torch.randn(N, cin, H, W, generator=g, device="cuda")
         kh, kw = k if isinstance(k, tuple) else (k, k)
-        w = torch.randn(cout, cin, kh, kw, generator=g).cuda() * 0.1
+        w = torch.randn(cout, cin, kh, kw, generator=g, device="cuda") * 0.1
         pc = K.pack_conv2d(w, None, stride=s, pad=(kh // 2, kw // 2))
         for _ in range(3):
             y = o.conv2d(pc, x, act=K.ACT_RELU)
