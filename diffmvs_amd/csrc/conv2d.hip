@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "dmvs_common.h"
+#include "dmvs_lds_poison.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -150,6 +151,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     // one LDS object on purpose (tile buffers + the 32-float GroupNorm scratch): with separate objects hipcc orders reads of
     // one against LDS-DMA into another with vmcnt(0) waits (conv3d.hip, conv3d_mfma_stream_kernel)
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF + 32];
+    DMVS_LDS_POISON(lds);
 
     int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA bases in SGPRs
@@ -936,6 +938,7 @@ template <int NT, int MT>
 __global__ void __launch_bounds__(DMVS_BLOCK) conv1x1_direct_kernel(const dmvs_conv2d_desc d, int tiles_per_item) {
     constexpr int NW = NT * 16, WS = (NW % 32 == 0) ? NW + 16 : NW;      // weight row stride: the four k-groups on disjoint banks
     __shared__ float s_w[kC11MaxCin * WS];
+    DMVS_LDS_POISON(s_w);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, kq = lane >> 4;
     const int cin = d.c0 + d.c1, cin4 = (cin + 3) >> 2;
@@ -1101,6 +1104,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_wgrad_kernel(const dmvs_con
     constexpr int NTN = (CK * T + 1 + 15) / 16;       // MFMA n-tiles over the (ci, tap) pairs of the chunk + the bias column
     constexpr int IN_IT = (CK * PLANE + DMVS_BLOCK - 1) / DMVS_BLOCK, G_IT = (16 * GROW + DMVS_BLOCK - 1) / DMVS_BLOCK;
     __shared__ float lds[CK * PLANE + 16 * GROW];
+    DMVS_LDS_POISON(lds);
     float* s_in = lds;
     float* s_g = lds + CK * PLANE;
 
@@ -1248,6 +1252,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_wgrad_reduce_kernel(const f
                                                                          int cout) {
     constexpr int CK = 8, NTN = (CK * T + 1 + 15) / 16, PER = NTN * 256, SL = 16;
     __shared__ float red[SL][17];
+    DMVS_LDS_POISON(red);
     const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int e = blockIdx.x * 16 + el;                // element of the [NTN*16][16] partial
     const int by = blockIdx.y, bz = blockIdx.z;

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "dmvs_common.h"
+#include "dmvs_lds_poison.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -183,6 +184,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_kernel(const dm
     using Halo = HaloMap<ID, IH, IW, PLANE>;
     using Slab = SlabMap<CK, NW, WPAD>;
     __shared__ __attribute__((aligned(16))) float lds[2 * CK * PLANE + CK * WPAD];
+    DMVS_LDS_POISON(lds);
     float* const s_w = lds + 2 * CK * PLANE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA bases stay in SGPRs
@@ -293,6 +295,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_pair_kernel(con
     constexpr int WP = pad16mod32_3d(36 * 16);             // paired weights of one input channel: [j 4][ky 3][kx 3][16 rows]
     using Halo = HaloMap<ID, IH, IW, PLANE>;
     __shared__ __attribute__((aligned(16))) float lds[2 * CK * PLANE + CK * WP];
+    DMVS_LDS_POISON(lds);
     float* const s_w = lds + 2 * CK * PLANE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -420,6 +423,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_kernel(const dmvs_conv
     using Halo = HaloMap<ID, IH, IW, PLANE>;
     using Slab = SlabMap<kCK, NW, WPAD>;
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+    DMVS_LDS_POISON(lds);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, kq = lane >> 4;
@@ -511,6 +515,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_c1_kernel(const dmvs_conv3d
     constexpr int PLANE = ID * IH * IW;
     using Halo = HaloMap<ID, IH, IW, PLANE>;
     __shared__ __attribute__((aligned(16))) float lds[2 * PLANE];
+    DMVS_LDS_POISON(lds);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile = blockIdx.x;
     const int tx = tile % tiles_x; tile /= tiles_x;
@@ -616,6 +621,7 @@ constexpr int kC1RowsPieces = 8;           // 16-byte pieces per lane and channe
 
 __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_c1_rows_kernel(const dmvs_conv3d_desc d, int XT, int YT, int DT, int tiles_y, int tiles_d) {
     __shared__ __attribute__((aligned(16))) float lds[kC1RowsLds];
+    DMVS_LDS_POISON(lds);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile = blockIdx.x;
     const int ty = tile % tiles_y; tile /= tiles_y;
@@ -858,6 +864,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) deconv3d_mfma_kernel(const dmvs_co
     constexpr int WP = pad16mod32_3d(NS * 16);
     using Halo = HaloMap<ID, IH, IW, PLANE>;
     __shared__ __attribute__((aligned(16))) float lds[CK * PLANE + CK * WP];
+    DMVS_LDS_POISON(lds);
     float* const s_w = lds + CK * PLANE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1080,6 +1087,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_wgrad_kernel(const dmvs_con
     constexpr int NTN = (CK * 27 + 1 + 15) / 16;     // (ci, tap) columns of the chunk + the bias column of ones
     constexpr int IN_IT = (CK * PLANE + DMVS_BLOCK - 1) / DMVS_BLOCK, G_IT = (16 * GROW + DMVS_BLOCK - 1) / DMVS_BLOCK;
     __shared__ float lds[CK * PLANE + 16 * GROW];
+    DMVS_LDS_POISON(lds);
     float* s_in = lds;
     float* s_g = lds + CK * PLANE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1177,6 +1185,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_wgrad_reduce_kernel(const f
                                                                          int cout) {
     constexpr int T = 27, NTN = (CK * T + 1 + 15) / 16, PER = NTN * 256, SL = 16;
     __shared__ float red[SL][17];
+    DMVS_LDS_POISON(red);
     const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int e = blockIdx.x * 16 + el;
     const int by = blockIdx.y, bz = blockIdx.z;

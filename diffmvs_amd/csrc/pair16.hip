@@ -15,6 +15,7 @@
 // Exact-fp32 MFMA; every output sums its products in (ci-group, ci, tap) order like dmvs_conv2d_f32: the results are those of the
 // two separate launches bit for bit.  1.31x the matrix work of conv A (the halo ring) for half the HBM traffic of the pair.
 #include "dmvs_common.h"
+#include "dmvs_lds_poison.h"
 
 namespace {
 
@@ -38,6 +39,7 @@ conv3x3_pair16_kernel(const float* __restrict__ x, const float* __restrict__ wa,
                       const float* __restrict__ shift_b, float* __restrict__ y, int N, int H, int W, int tiles_x, int tiles_y) {
     // one LDS object (see stem.hip: separate objects make hipcc wait out the LDS-DMA before unrelated ds_reads)
     __shared__ __attribute__((aligned(16))) float lds[PIN_FLOATS + PC * PMPL + 2 * PC * PWS];
+    DMVS_LDS_POISON(lds);
     float* const s_in = lds;
     float* const s_mid = lds + PIN_FLOATS;
     float* const s_wa = s_mid + PC * PMPL;

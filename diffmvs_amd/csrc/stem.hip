@@ -14,6 +14,7 @@
 // Exact-fp32 MFMA; conv0.0's 27 products are summed in (ci, tap) order here and in (tap, ci) order by the generic
 // kernel, so the two agree to the last bits, not bitwise.
 #include "dmvs_common.h"
+#include "dmvs_lds_poison.h"
 
 namespace {
 
@@ -38,6 +39,7 @@ featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0
     // the LDS-DMA into the OTHER buffer (same object) is in flight -- the prefetch this kernel is built around would
     // be waited out immediately.
     __shared__ __attribute__((aligned(16))) float lds[2 * IN_FLOATS + 8 * MPLANE + 28 * 16 + 8 * W1S];
+    DMVS_LDS_POISON(lds);
     float* const s_mid = lds + 2 * IN_FLOATS;
     float* const s_w0 = s_mid + 8 * MPLANE;
     float* const s_w1 = s_w0 + 28 * 16;

@@ -262,6 +262,13 @@ inline T shfl_from(T v, int src_lane_abs, int gsize = 64) {
 }
 }  // namespace hipemu
 
+// Real LDS holds whatever the previous workgroup left there; a `static thread_local` array starts as zeros, which hides reads of
+// positions a kernel never wrote (e.g. padding it forgot to clear).  Kernels call DMVS_LDS_POISON(array) (csrc/dmvs_lds_poison.h)
+// right after declaring their LDS: the block's first fiber -- fibers start in order and run until their first barrier / shuffle --
+// fills it with 0xff bytes (NaN as float / double, -1 as int) before any other fiber of the block has started.
+inline void hipemu_poison_lds(void* p, size_t bytes) {
+    if (hipemu::g_threadIdx.x == 0 && hipemu::g_threadIdx.y == 0 && hipemu::g_threadIdx.z == 0) memset(p, 0xff, bytes);
+}
 #define threadIdx hipemu::g_threadIdx
 #define blockIdx hipemu::g_blockIdx
 #define blockDim hipemu::g_blockDim
