@@ -14,6 +14,8 @@
 //   o = 2j   : k = 1 reads i = j            o = 2j+1 : k = 0 reads i = j+1, k = 2 reads i = j
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "dmvs_common.h"
 #include "dmvs_lds_poison.h"
 
@@ -76,6 +78,71 @@ struct HaloMap {
         }
     }
 };
+
+// The same halo tile in 16-BYTE pieces (conv2d.hip, template V16: an LDS-DMA instruction costs the texture path the same whatever
+// its width, and 4-byte pieces need one wave-level instruction per 64 halo floats).  A row of the LDS image is the 16-byte aligned
+// cover of the halo row: it starts SLACK = 3 floats left of the halo's first column (tile origins are multiples of 16 voxels, the
+// padding is 1, so column -4 is 16-byte aligned when rows are multiples of 4 floats and the tensor is 16-byte aligned) and its
+// pitch IWL is a whole number of pieces: 24 floats for the 18 of a 16-wide tile, 6 pieces instead of 18 elements per row.  A piece
+// lies wholly inside or outside the volume.  Opt-in (DMVS_CONV3D_V16=1) until it has been timed: the planes grow by a third
+// (the pair kernel then holds 2 instead of 3 workgroups per CU).
+template <int ID, int IH, int IW>
+struct HaloMap16 {
+    static constexpr int SLACK = 3;
+    static constexpr int IWL = (SLACK + IW + 3) / 4 * 4;
+    static constexpr int PIECES = ID * IH * IWL / 4;
+    static constexpr int PLANE = pad16mod32_3d(ID * IH * IWL);
+    static constexpr int P_IT = (PIECES + DMVS_BLOCK - 1) / DMVS_BLOCK;
+    int off[P_IT];       // (zz * Hin + yy) * Win + xx - SLACK of the piece's first float, relative to the tile's halo origin
+    int zyx[P_IT];       // zz | yy << 8 | xx << 16 (xx = 4 * piece column: its first float inside the LDS row), or -1: no such piece
+    __device__ __forceinline__ void init(int tid, int Hin, int Win) {
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it) {
+            const int pe = it * DMVS_BLOCK + tid;
+            const int zz = pe / (IH * (IWL / 4)), rem2 = pe - zz * (IH * (IWL / 4));
+            const int yy = rem2 / (IWL / 4), xx = (rem2 - yy * (IWL / 4)) * 4;
+            off[it] = (zz * Hin + yy) * Win + xx - SLACK;
+            zyx[it] = pe < PIECES ? (zz | (yy << 8) | (xx << 16)) : -1;
+        }
+    }
+    // as HaloMap::bounds, x in LDS-row coordinates (the row starts at volume column gx0 - SLACK, a multiple of 4)
+    static __device__ __forceinline__ void bounds(int gd0, int gy0, int gx0, int Din, int Hin, int Win, unsigned& lo, unsigned& him1) {
+        const int gxa = gx0 - SLACK;
+        const int zl = max(0, -gd0), yl = max(0, -gy0), xl = max(0, -gxa);
+        const int zh = min(ID, Din - gd0) - 1, yh = min(IH, Hin - gy0) - 1, xh = min(IWL, Win - gxa) - 1;
+        lo = (unsigned)(zl | (yl << 8) | (xl << 16));
+        him1 = (unsigned)(zh | (yh << 8) | (xh << 16)) | kHaloGuard;
+    }
+    __device__ __forceinline__ void stage(const float* origin, bool chan_live, unsigned lo, unsigned him1, float* dst_plane, int wave) const {
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it) {
+            if (zyx[it] >= 0) {
+                const unsigned z = (unsigned)zyx[it];
+                const bool in = chan_live && ((((z | kHaloGuard) - lo) & (him1 - z) & kHaloGuard) == kHaloGuard);
+                const float* srcp = in ? origin + off[it] : dmvs_zero16_3d;
+                float* dstp = dst_plane + (it * DMVS_BLOCK + wave * 64) * 4;
+                __builtin_amdgcn_global_load_lds(srcp, DMVS_LDS(dstp), 16, 0, 0);
+            }
+        }
+    }
+};
+
+// the two forms behind one name: Halo<V16, ID, IH, IW>::{type, PLANE, PITCH (LDS row pitch), X0 (halo column 0 inside an LDS row)}
+template <bool V16, int ID, int IH, int IW>
+struct HaloSel {
+    static constexpr int PLANE = pad16mod32_3d(ID * IH * IW), PITCH = IW, X0 = 0;
+    typedef HaloMap<ID, IH, IW, PLANE> type;
+};
+template <int ID, int IH, int IW>
+struct HaloSel<true, ID, IH, IW> {
+    typedef HaloMap16<ID, IH, IW> type;
+    static constexpr int PLANE = type::PLANE, PITCH = type::IWL, X0 = type::SLACK;
+};
+
+static bool conv3d_v16_ok(const dmvs_conv3d_desc& d) {
+    const char* e = getenv("DMVS_CONV3D_V16");      // (read per launch while it is an experiment: the tests switch it inside one process)
+    return e && e[0] == '1' && (d.Win & 3) == 0 && ((uintptr_t)d.in & 15) == 0;
+}
 
 // weight slab [CK][27][NW] (+ row padding to WPAD), 16 bytes per lane; decoded once per workgroup like the halo
 template <int CK, int NW, int WPAD>
@@ -174,14 +241,15 @@ constexpr int kStreamWgsPerCu = 5;
 // One __shared__ array on purpose: with the two halo buffers and the weights as separate LDS objects hipcc attaches
 // alias scopes and then waits vmcnt(0) before the first ds_read of a halo buffer while the DMA into the OTHER half is
 // in flight (same object) -- which serialised the pipeline this kernel exists for.
-template <int NT>
+template <int NT, bool V16 = false>
 __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_kernel(const dmvs_conv3d_desc d, int tiles_x, int tiles_y, int tiles_d) {
     constexpr int TX = 16, TY = 4, TD = 4, CK = 4;
     constexpr int IW = TX + 2, IH = TY + 2, ID = TD + 2;
-    constexpr int PLANE = pad16mod32_3d(ID * IH * IW);
+    using HS = HaloSel<V16, ID, IH, IW>;
+    constexpr int PLANE = HS::PLANE, IWP = HS::PITCH;      // LDS plane size and row pitch
     constexpr int NW = NT * 16;
     constexpr int WPAD = pad16mod32_3d(27 * NW);
-    using Halo = HaloMap<ID, IH, IW, PLANE>;
+    using Halo = typename HS::type;
     using Slab = SlabMap<CK, NW, WPAD>;
     __shared__ __attribute__((aligned(16))) float lds[2 * CK * PLANE + CK * WPAD];
     DMVS_LDS_POISON(lds);
@@ -248,7 +316,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_kernel(const dm
         {
             const int ci = kq;
             const float* wp = s_w + ci * WPAD + m;
-            const float* ipb = s_in + ci * PLANE + wave * (IH * IW) + m;
+            const float* ipb = s_in + ci * PLANE + wave * (IH * IWP) + HS::X0 + m;
 #pragma unroll 1
             for (int kd = 0; kd < 3; ++kd) {
 #pragma unroll
@@ -260,7 +328,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_kernel(const dm
                         for (int nt = 0; nt < NT; ++nt) av[nt] = wp[((kd * 3 + ky) * 3 + kx) * NW + nt * 16];
 #pragma unroll
                         for (int mt = 0; mt < 4; ++mt) {
-                            const float bv = ipb[(kd * IH + ky + mt) * IW + kx];
+                            const float bv = ipb[(kd * IH + ky + mt) * IWP + kx];
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
                                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av[nt], acc[mt][nt], 0, 0, 0);      // D[voxel][cout] (TileEpi)
@@ -288,12 +356,14 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_kernel(const dm
 // (each output still sums its 27 x cin products in (kd, ky, kx) order).  Same resident, tile-pipelined structure as
 // conv3d_mfma_stream_kernel.
 constexpr int kPairWgsPerCu = 3;       // 45 KB of LDS each
+template <bool V16>
 __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_pair_kernel(const dmvs_conv3d_desc d, int tiles_x, int tiles_y, int tiles_d) {
     constexpr int TX = 16, TY = 4, TD = 8, CK = 4;
     constexpr int IW = TX + 2, IH = TY + 2, ID = TD + 2;
-    constexpr int PLANE = pad16mod32_3d(ID * IH * IW);
+    using HS = HaloSel<V16, ID, IH, IW>;
+    constexpr int PLANE = HS::PLANE, IWP = HS::PITCH;
     constexpr int WP = pad16mod32_3d(36 * 16);             // paired weights of one input channel: [j 4][ky 3][kx 3][16 rows]
-    using Halo = HaloMap<ID, IH, IW, PLANE>;
+    using Halo = typename HS::type;
     __shared__ __attribute__((aligned(16))) float lds[2 * CK * PLANE + CK * WP];
     DMVS_LDS_POISON(lds);
     float* const s_w = lds + 2 * CK * PLANE;
@@ -381,7 +451,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_pair_kernel(con
         for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         {
             const float* wp = s_w + kq * WP + m;                                   // k = input channel kq
-            const float* ipb = s_in + kq * PLANE + (2 * wave) * (IH * IW) + m;      // halo slice 2w = input slice (2w - 1)
+            const float* ipb = s_in + kq * PLANE + (2 * wave) * (IH * IWP) + HS::X0 + m;      // halo slice 2w = input slice (2w - 1)
 #pragma unroll 1
             for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -391,7 +461,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_pair_kernel(con
                         const float av = wp[((j * 3 + ky) * 3 + kx) * 16];
 #pragma unroll
                         for (int mt = 0; mt < 4; ++mt) {
-                            const float bv = ipb[(j * IH + ky + mt) * IW + kx];
+                            const float bv = ipb[(j * IH + ky + mt) * IWP + kx];
                             acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[mt], 0, 0, 0);      // D[voxel][(slice, cout)]
                         }
                     }
@@ -408,19 +478,22 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_pair_kernel(con
 
 // S = 2: the stride-2 layers of CostRegNet_small (conv2 8 -> 16, conv4 16 -> 32, reference module.py:428-433) as the same
 // implicit GEMM: a 16 x 4 x 4 tile of OUTPUT voxels reads a 33 x 9 x 9 input halo, the B operand walks it with stride 2.
-template <int NT, int S = 1>
+template <int NT, int S = 1, bool V16 = false>
 __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_kernel(const dmvs_conv3d_desc d, int tiles_x, int tiles_y, int tiles_d) {
+    static_assert(!(V16 && S != 1), "16-byte halo pieces: the stride-1 form");
     constexpr int TX = 16, TY = 4, TD = 4;
     constexpr int IW = (TX - 1) * S + 3, IH = (TY - 1) * S + 3, ID = (TD - 1) * S + 3;
+    using HS = HaloSel<V16, ID, IH, IW>;
+    constexpr int IWP = HS::PITCH;
     // channel pitch: the 16 lanes of a k-group read 16 consecutive words (S = 1) or every second word (S = 2); the two k-groups
     // of a 32-lane half must land on disjoint banks: pitch = 16 mod 32 (S = 1), odd (17 mod 32: S = 2)
-    constexpr int PLANE = S == 1 ? pad16mod32_3d(ID * IH * IW) : pad16mod32_3d(ID * IH * IW - 1) + 1;
+    constexpr int PLANE = S == 1 ? HS::PLANE : pad16mod32_3d(ID * IH * IW - 1) + 1;
     constexpr int NW = NT * 16;
     constexpr int WPAD = pad16mod32_3d(27 * NW);
     // input channels per LDS chunk (double buffered): 8 if that stays within 48 KB, else 4
     constexpr int kCK = (2 * 8 * (PLANE + WPAD) * 4 > 49152) ? 4 : 8;
     constexpr int BUF = kCK * (PLANE + WPAD);
-    using Halo = HaloMap<ID, IH, IW, PLANE>;
+    using Halo = typename std::conditional<V16, typename HS::type, HaloMap<ID, IH, IW, PLANE>>::type;
     using Slab = SlabMap<kCK, NW, WPAD>;
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
     DMVS_LDS_POISON(lds);
@@ -470,7 +543,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_kernel(const dmvs_conv
         for (int c4 = 0; c4 < nc4; ++c4) {
             const int ci = c4 * 4 + kq;
             const float* wp = s_w + ci * WPAD + m;
-            const float* ipb = s_in + ci * PLANE + wave * S * (IH * IW) + m * S;
+            const float* ipb = s_in + ci * PLANE + wave * S * (IH * IWP) + HS::X0 + m * S;
 #pragma unroll 1
             for (int kd = 0; kd < 3; ++kd) {
 #pragma unroll
@@ -482,7 +555,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_kernel(const dmvs_conv
                         for (int nt = 0; nt < NT; ++nt) av[nt] = wp[((kd * 3 + ky) * 3 + kx) * NW + nt * 16];
 #pragma unroll
                         for (int mt = 0; mt < 4; ++mt) {
-                            const float bv = ipb[(kd * IH + ky + mt * S) * IW + kx];
+                            const float bv = ipb[(kd * IH + ky + mt * S) * IWP + kx];
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
                                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av[nt], acc[mt][nt], 0, 0, 0);      // D[voxel][cout] (TileEpi)
@@ -1037,20 +1110,26 @@ extern "C" int dmvs_conv3d_f32(const dmvs_conv3d_desc* dp, void* stream) {
         const int ntiles = (d.cout_pad + 15) / 16;
         dim3 g((unsigned)(tiles_x * tiles_y * tiles_d * d.B), (unsigned)((ntiles + 1) / 2));
         const long vtiles = (long)tiles_x * tiles_y * tiles_d * d.B;
+        const bool v16 = conv3d_v16_ok(d);
         if (d.cin <= 4 && d.cout <= 8 && d.cout_pad == 8) {      // 4 -> 8 layers: two output depth slices share the 16 MFMA rows
             const int tiles_d8 = (d.Dout + 7) / 8;
             if ((long)tiles_x * tiles_y * tiles_d8 * d.B >= 512) {
                 dim3 gs((unsigned)(256 * kPairWgsPerCu), 1);
-                hipLaunchKernelGGL(conv3d_mfma_stream_pair_kernel, gs, block, 0, st, d, tiles_x, tiles_y, tiles_d8);
+                if (v16) hipLaunchKernelGGL(conv3d_mfma_stream_pair_kernel<true>, dim3(256 * 2, 1), block, 0, st, d, tiles_x, tiles_y, tiles_d8);      // 56 KB of LDS each
+                else hipLaunchKernelGGL(conv3d_mfma_stream_pair_kernel<false>, gs, block, 0, st, d, tiles_x, tiles_y, tiles_d8);
                 return dmvs_launch_status();
             }
         }
         if (d.cin <= 4 && ntiles == 1 && vtiles >= 256 * kStreamWgsPerCu) {      // one K chunk, many tiles: resident workgroups, pipelined tiles
             dim3 gs((unsigned)(256 * kStreamWgsPerCu), 1);
-            hipLaunchKernelGGL((conv3d_mfma_stream_kernel<1>), gs, block, 0, st, d, tiles_x, tiles_y, tiles_d);
+            if (v16) hipLaunchKernelGGL((conv3d_mfma_stream_kernel<1, true>), dim3(256 * 4, 1), block, 0, st, d, tiles_x, tiles_y, tiles_d);      // 35 KB of LDS each
+            else hipLaunchKernelGGL((conv3d_mfma_stream_kernel<1>), gs, block, 0, st, d, tiles_x, tiles_y, tiles_d);
             return dmvs_launch_status();
         }
-        if (ntiles == 1) hipLaunchKernelGGL((conv3d_mfma_kernel<1>), g, block, 0, st, d, tiles_x, tiles_y, tiles_d);
+        if (v16) {
+            if (ntiles == 1) hipLaunchKernelGGL((conv3d_mfma_kernel<1, 1, true>), g, block, 0, st, d, tiles_x, tiles_y, tiles_d);
+            else hipLaunchKernelGGL((conv3d_mfma_kernel<2, 1, true>), g, block, 0, st, d, tiles_x, tiles_y, tiles_d);
+        } else if (ntiles == 1) hipLaunchKernelGGL((conv3d_mfma_kernel<1>), g, block, 0, st, d, tiles_x, tiles_y, tiles_d);
         else hipLaunchKernelGGL((conv3d_mfma_kernel<2>), g, block, 0, st, d, tiles_x, tiles_y, tiles_d);
     } else {
         // stride 2 on the matrix cores (32-bit element offsets inside a batch item, like the stride-1 kernels)

@@ -980,6 +980,25 @@ def test_conv3d_streamed_tiles(ops, cin, cout, with_res):
     close(out, ref, 2e-5)
 
 
+@pytest.mark.parametrize("cin,cout,B,D,H,W", [(4, 8, 2, 23, 62, 100),      # pair kernel (4 -> 8, two depth slices per MFMA), >= 512 tiles
+                                              (3, 16, 2, 23, 62, 100),     # streamed kernel (cin <= 4, one n-tile)
+                                              (8, 8, 1, 9, 14, 36), (16, 16, 2, 6, 10, 20), (8, 32, 1, 5, 6, 44)])      # generic kernel, one / two n-tiles
+def test_conv3d_16_byte_halo_pieces(ops, monkeypatch, cin, cout, B, D, H, W):
+    """DMVS_CONV3D_V16=1 (experiment, not yet timed): the halo tile of the stride-1 MFMA kernels staged in 16-byte pieces -- against
+    torch and BIT FOR BIT against the default 4-byte form; ragged volumes, pieces outside the volume on every face"""
+    x = rnd(B, cin, D, H, W, seed=1)
+    w = rnd(cout, cin, 3, 3, 3, seed=2) * 0.2
+    bias = rnd(cout, seed=3)
+    res = rnd(B, cout, D, H, W, seed=4)
+    ref = F.relu(F.conv3d(x, w, bias, 1, 1)) + res
+    pc = K.pack_conv3d(*dev(ops, w, bias))
+    a = ops.conv3d(pc, dev(ops, x), act=K.ACT_RELU, residual=dev(ops, res))
+    monkeypatch.setenv("DMVS_CONV3D_V16", "1")
+    b = ops.conv3d(pc, dev(ops, x), act=K.ACT_RELU, residual=dev(ops, res))
+    close(b, ref, 2e-5)
+    assert torch.equal(a.cpu(), b.cpu())
+
+
 @pytest.mark.parametrize("cin,cout,D,H,W,with_res", [(8, 16, 11, 18, 70, False), (16, 32, 8, 9, 33, True), (6, 12, 5, 7, 20, False)])
 def test_conv3d_stride2_matrix_core_form(ops, cin, cout, D, H, W, with_res):
     """CostRegNet_small's stride-2 layers (conv2 8 -> 16, conv4 16 -> 32) on the matrix cores: several output tiles per axis, odd and
