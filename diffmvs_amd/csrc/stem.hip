@@ -13,6 +13,8 @@
 //     weights B, so a lane ends up with 4 consecutive pixels of one (row, channel): BN + ReLU + one 16-byte NCHW store.
 // Exact-fp32 MFMA; conv0.0's 27 products are summed in (ci, tap) order here and in (tap, ci) order by the generic
 // kernel, so the two agree to the last bits, not bitwise.
+#include <stdlib.h>
+
 #include "dmvs_common.h"
 #include "dmvs_lds_poison.h"
 
@@ -26,10 +28,16 @@ constexpr int MW = TS + 2, MP = MW * MW;          // intermediate tile 18 x 18 =
 constexpr int IW = TS + 4, IP = IW * IW;          // input tile 20 x 20 = 400
 constexpr int MPLANE = 336;                        // 324 padded to 16 mod 32 (bank spread over the 4 k-groups)
 constexpr int IN_FLOATS = 3 * IP;                  // 1200
+// V16 (opt-in, DMVS_STEM_V16=1, not timed yet): the input halo in 16-byte LDS-DMA pieces (conv2d.hip, template V16).  An LDS row is
+// the 16-byte aligned 24-float cover of the 20-float halo row (it starts SLACK = 2 floats further left: tile origins are multiples
+// of 16 pixels, the halo starts 2 pixels left of them): 360 pieces instead of 1200 elements per tile, 6 instead of 19 wave-level DMA
+// instructions.  Needs rows of 16-byte multiples on a 16-byte aligned tensor; a piece lies wholly inside or outside the image.
+constexpr int IWL16 = 24, SLACK16 = 2;
 constexpr int W1S = 208;                           // conv0.1 paired weight slab [j 4][kx 3][16 rows] per input channel, padded (192 -> 16 mod 32)
 
 __device__ __attribute__((aligned(16))) const float stem_zero16[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
+template <bool V16>
 __global__ void __launch_bounds__(DMVS_BLOCK)
 featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0, const float* __restrict__ scale0,
                        const float* __restrict__ shift0, const float* __restrict__ w1, const float* __restrict__ scale1,
@@ -38,9 +46,11 @@ featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0
     // tags the accesses with alias scopes and then waits vmcnt(0) before the first ds_read of an input buffer while
     // the LDS-DMA into the OTHER buffer (same object) is in flight -- the prefetch this kernel is built around would
     // be waited out immediately.
-    __shared__ __attribute__((aligned(16))) float lds[2 * IN_FLOATS + 8 * MPLANE + 28 * 16 + 8 * W1S];
+    constexpr int IWP = V16 ? IWL16 : IW, X0 = V16 ? SLACK16 : 0;      // LDS row pitch of the input halo, halo column 0 inside a row
+    constexpr int IPL = IW * IWP, INF = 3 * IPL;                       // one channel plane / one input buffer in LDS
+    __shared__ __attribute__((aligned(16))) float lds[2 * INF + 8 * MPLANE + 28 * 16 + 8 * W1S];
     DMVS_LDS_POISON(lds);
-    float* const s_mid = lds + 2 * IN_FLOATS;
+    float* const s_mid = lds + 2 * INF;
     float* const s_w0 = s_mid + 8 * MPLANE;
     float* const s_w1 = s_w0 + 28 * 16;
 
@@ -64,16 +74,24 @@ featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0
     // Input halo staging (3 x 20 x 20, zero padded): 4-byte LDS-DMA, 64 consecutive words per wave.  Which (channel,
     // row, column) a lane's pieces are is tile-independent: decoded once; per tile the border test is one packed compare
     // (guard bit above each 7-bit field: ((f | 128) - lo) keeps it iff f >= lo, ((hi-1 | 128) - f) iff f <= hi-1).
-    constexpr int S_IT = (IN_FLOATS + DMVS_BLOCK - 1) / DMVS_BLOCK;
+    constexpr int NPIECE = V16 ? INF / 4 : IN_FLOATS;      // staging pieces per tile (16-byte / 4-byte)
+    constexpr int S_IT = (NPIECE + DMVS_BLOCK - 1) / DMVS_BLOCK;
     constexpr unsigned kGuard = 0x8080u;
     int e_off[S_IT], e_rc[S_IT];             // ci * plane + r * W + c from the halo origin; r | c << 8, or -1 beyond the tile
 #pragma unroll
     for (int i = 0; i < S_IT; ++i) {
         const int e = i * DMVS_BLOCK + tid;
-        const int ci = e / IP, rem = e - ci * IP;
-        const int r = rem / IW, c = rem - r * IW;
-        e_off[i] = ci * (int)plane + r * W + c;
-        e_rc[i] = e < IN_FLOATS ? (r | (c << 8)) : -1;
+        if constexpr (V16) {                 // piece e = LDS floats 4e .. 4e+3: column c = first float inside the LDS row
+            const int ci = e / (IPL / 4), rem = e - ci * (IPL / 4);
+            const int r = rem / (IWP / 4), c = (rem - r * (IWP / 4)) * 4;
+            e_off[i] = ci * (int)plane + r * W + c - SLACK16;
+            e_rc[i] = e < NPIECE ? (r | (c << 8)) : -1;
+        } else {
+            const int ci = e / IP, rem = e - ci * IP;
+            const int r = rem / IW, c = rem - r * IW;
+            e_off[i] = ci * (int)plane + r * W + c;
+            e_rc[i] = e < IN_FLOATS ? (r | (c << 8)) : -1;
+        }
     }
     auto stage = [&](int tile, float* buf) {
         int tq = tile;
@@ -82,16 +100,22 @@ featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0
         const int n = tq / tiles_y;
         const int gy0 = ty * TS - 2, gx0 = tx * TS - 2;
         const float* origin = x + (long)n * 3 * plane + (long)gy0 * W + gx0;       // may lie outside the tensor: only in-range pieces are read
-        const unsigned lo = (unsigned)(max(0, -gy0) | (max(0, -gx0) << 8));
-        const unsigned him1 = (unsigned)((min(IW, H - gy0) - 1) | ((min(IW, W - gx0) - 1) << 8)) | kGuard;
+        const int gxa = gx0 - X0;               // image column of LDS-row column 0
+        const unsigned lo = (unsigned)(max(0, -gy0) | (max(0, -gxa) << 8));
+        const unsigned him1 = (unsigned)((min(IW, H - gy0) - 1) | ((min(IWP, W - gxa) - 1) << 8)) | kGuard;
 #pragma unroll
         for (int i = 0; i < S_IT; ++i) {
             if (e_rc[i] >= 0) {
                 const unsigned rc = (unsigned)e_rc[i];
                 const bool ok = (((rc | kGuard) - lo) & (him1 - rc) & kGuard) == kGuard;
                 const float* srcp = ok ? origin + e_off[i] : stem_zero16;
-                float* dstp = buf + i * DMVS_BLOCK + wave * 64;
-                __builtin_amdgcn_global_load_lds(srcp, DMVS_LDS_S(dstp), 4, 0, 0);
+                if constexpr (V16) {
+                    float* dstp = buf + (i * DMVS_BLOCK + wave * 64) * 4;
+                    __builtin_amdgcn_global_load_lds(srcp, DMVS_LDS_S(dstp), 16, 0, 0);
+                } else {
+                    float* dstp = buf + i * DMVS_BLOCK + wave * 64;
+                    __builtin_amdgcn_global_load_lds(srcp, DMVS_LDS_S(dstp), 4, 0, 0);
+                }
             }
         }
     };
@@ -106,7 +130,7 @@ featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0
         a0[j] = s_w0[k * 16 + m];
         const int kk = k < 27 ? k : 0;           // the 28th k has zero weights: any valid address
         const int ci = kk / 9, t = kk - ci * 9;
-        koff[j] = ci * IP + (t / 3) * IW + (t % 3);
+        koff[j] = ci * IPL + (t / 3) * IWP + (t % 3);
     }
     float sc0[4], sh0[4];       // conv0.0: this lane's output channels 4*kq + r (lanes with kq >= 2 hold padding)
 #pragma unroll
@@ -155,15 +179,15 @@ featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0
         const int n = tq / tiles_y;
         const int ox0 = tx * TS, oy0 = ty * TS;
         __syncthreads();        // this tile's halo has landed; everyone is done with s_mid and the other input buffer
-        if (tile + (int)gridDim.x < ntiles) stage(tile + gridDim.x, lds + (cur ^ 1) * IN_FLOATS);
+        if (tile + (int)gridDim.x < ntiles) stage(tile + gridDim.x, lds + (cur ^ 1) * INF);
         if (pn >= 0) store_tile(pend, pn, pox0, poy0);
-        const float* in = lds + cur * IN_FLOATS;
+        const float* in = lds + cur * INF;
 
         // ---- conv0.0 -> s_mid: 21 groups of 16 intermediate pixels (row-major over 18 x 18), waves take groups round-robin
         for (int gidx = wave; gidx < (MP + 15) / 16; gidx += DMVS_BLOCK / 64) {
             const int p = min(gidx * 16 + m, MP - 1);
             const int py = p / MW, px = p - py * MW;
-            const float* ip = in + py * IW + px;
+            const float* ip = in + py * IWP + X0 + px;
             f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int j = 0; j < 7; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], ip[koff[j]], acc, 0, 0, 0);
@@ -215,7 +239,12 @@ extern "C" int dmvs_featurenet_stem_f32(const float* x, const float* w0, const f
     const long ntiles = (long)tiles_x * tiles_y * N;
     if (ntiles >= (1L << 31)) return DMVS_EINVAL;
     const unsigned grid = (unsigned)(ntiles < 256 * 6 ? ntiles : 256 * 6);      // persistent: ~6 workgroups per CU (22 KB LDS each)
-    hipLaunchKernelGGL(featurenet_stem_kernel, dim3(grid), dim3(DMVS_BLOCK), 0, (hipStream_t)stream, x, w0, scale0, shift0, w1,
-                       scale1, shift1, y, N, H, W, tiles_x, tiles_y);
+    const char* e16 = getenv("DMVS_STEM_V16");      // (read per launch while it is an experiment: the tests switch it inside one process)
+    if (e16 && e16[0] == '1' && (W & 3) == 0 && ((uintptr_t)x & 15) == 0)
+        hipLaunchKernelGGL(featurenet_stem_kernel<true>, dim3(grid), dim3(DMVS_BLOCK), 0, (hipStream_t)stream, x, w0, scale0, shift0, w1,
+                           scale1, shift1, y, N, H, W, tiles_x, tiles_y);
+    else
+        hipLaunchKernelGGL(featurenet_stem_kernel<false>, dim3(grid), dim3(DMVS_BLOCK), 0, (hipStream_t)stream, x, w0, scale0, shift0, w1,
+                           scale1, shift1, y, N, H, W, tiles_x, tiles_y);
     return dmvs_launch_status();
 }

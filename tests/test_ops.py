@@ -962,6 +962,23 @@ def test_featurenet_stem_fused(ops, N, H, W):
     close(out, two.cpu(), 1e-6)          # conv0.0 sums its 27 products in a different grouping: last-bit differences only
 
 
+@pytest.mark.parametrize("N,H,W", [(2, 37, 52), (1, 64, 96), (2, 9, 12)])
+def test_featurenet_stem_16_byte_pieces(N, H, W, monkeypatch):
+    """DMVS_STEM_V16=1 (experiment, not yet timed and not yet run on a GPU: host-emulated only, like the wide 1x1 variants): the
+    stem's input halo staged in 16-byte pieces, BIT FOR BIT the default kernel; several tiles per workgroup, all four borders"""
+    from conftest import emu_ops
+    ops = emu_ops()
+    x = rnd(N, 3, H, W, seed=1)
+    w0, w1 = rnd(8, 3, 3, 3, seed=2) * 0.4, rnd(8, 8, 3, 3, seed=3) * 0.3
+    pc0, pc1 = K.pack_conv2d(w0, rnd(8, seed=4), pad=1), K.pack_conv2d(w1, rnd(8, seed=5), pad=1)
+    a = ops.featurenet_stem(pc0, pc1, x)
+    monkeypatch.setenv("DMVS_STEM_V16", "1")
+    b = ops.featurenet_stem(pc0, pc1, x)
+    ref = F.relu(F.conv2d(F.relu(F.conv2d(x, w0, rnd(8, seed=4), 1, 1)), w1, rnd(8, seed=5), 1, 1))
+    close(b, ref, 2e-5)
+    assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("cin,cout,with_res", [(4, 8, False), (3, 8, True)])
 def test_conv3d_streamed_tiles(ops, cin, cout, with_res):
     """cin <= 4 on a volume with more tiles than resident workgroups: the persistent, tile-pipelined instantiation
