@@ -1,6 +1,6 @@
 """Per-kernel ISA statistics of one csrc/*.hip file (no GPU needed: hipcc cross-compiles gfx950):
 
-    python tools/isa_stats.py diffmvs_amd/csrc/conv2d.hip [kernel-name-substring] [--diff old.json] [--save new.json]
+    python tools/isa_stats.py diffmvs_amd/csrc/conv2d_k33.hip [kernel-name-substring] [--diff old.json] [--save new.json]
 
 For every kernel: instructions, MFMAs, LDS-DMA instructions, VGPRs, occupancy (waves/SIMD), SGPR-spill lanes read /
 written (v_readlane / v_writelane), scratch bytes, LDS bytes, and `vmcnt(0)` waits.  The convolution kernels are
