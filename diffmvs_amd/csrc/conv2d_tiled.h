@@ -242,6 +242,11 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     // Padding is written ONCE per workgroup, not per chunk: spatial padding stays padding in every chunk, and channels
     // beyond cin only ever meet zero weights, so they just must not hold non-finite LDS garbage on their first use.
     // The per-chunk DMA then touches valid elements only (exec-masked), with no zero-source pointer to select.
+    // An interior tile of a layer whose channel count is a multiple of the chunk has no such position that an MFMA reads: the pass
+    // (2 x CK predicated LDS writes per plane position: ~40 VALU + ~170 SALU per wave, a quarter of the scalar work of a 16 -> 16
+    // tile) is skipped then -- workgroup-uniform branch.  (A walking workgroup's later border tiles clear their own padding.)
+    const bool pad_pass = ZI || (cin & (CK - 1)) != 0 || gy0 < 0 || gx0 < 0 || gy0 + TH > d.Hin || gx0 + TW > d.Win;
+    if (pad_pass) {
 #pragma unroll
     for (int it = 0; it < P_IT; ++it) {
         const int rem = it * DMVS_BLOCK + tid;
@@ -261,6 +266,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
                 if (p_sp[it] < 0 || CK + ci >= cin) lds[BUF + ci * PLANE + rem] = 0.0f;
             }
         }
+    }
     }
     const bool simple = kLean || (d.c1 == 0 && mode != DMVS_IN_UNSHUFFLE2);      // one input tensor: the channel base just advances by a plane
     auto stage_as = [&](auto simple_tag, int c0, float* buf) __attribute__((always_inline)) {
