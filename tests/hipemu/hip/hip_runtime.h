@@ -383,9 +383,16 @@ static inline hipemu_f32x4 hipemu_mfma_f32_16x16x32_bf16(hipemu_s16x8 a, hipemu_
 }
 // LDS-DMA (global_load_lds_dword / _dwordx4): per-lane global source, LDS destination =
 // wave-uniform base + lane * size.  Synchronous here; the kernels' barriers make that equivalent.
+// The kernels only ever issue the 16-byte form with 16-byte aligned global sources and LDS destinations (their dispatch rules check
+// the tensors for it); the emulation enforces that invariant instead of relying on what a particular GPU tolerates.
 static inline void __builtin_amdgcn_global_load_lds(const void* g, void* lds_base, unsigned size, int offset, int) {
     const int lane = hipemu::linear_tid() & 63;
-    memcpy(static_cast<char*>(lds_base) + offset + size_t(lane) * size, g, size);
+    char* dst = static_cast<char*>(lds_base) + offset + size_t(lane) * size;
+    if (size == 16 && ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dst)) & 15) != 0) {
+        fprintf(stderr, "hipemu: 16-byte LDS-DMA with a misaligned source %p or destination %p\n", g, (void*)dst);
+        abort();
+    }
+    memcpy(dst, g, size);
 }
 // HIP's global integer min / max
 static inline int min(int a, int b) { return a < b ? a : b; }
