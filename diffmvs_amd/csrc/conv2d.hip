@@ -424,6 +424,7 @@ extern "C" int dmvs_conv2d_f32(const dmvs_conv2d_desc* dp, void* stream) {
     const dmvs_conv2d_desc& d = *dp;
     hipStream_t st = (hipStream_t)stream;
     if (d.cout_pad % 8 || d.cout > d.cout_pad || d.B <= 0 || !d.in0 || !d.weight || !d.out) return DMVS_EINVAL;
+    if ((uintptr_t)d.weight & 15) return DMVS_EINVAL;      // the weight slab is staged in 16-byte LDS-DMA pieces
     if (d.c1 > 0 && (!d.in1 || d.in_mode != DMVS_IN_PLAIN)) return DMVS_EINVAL;
     if (d.mul0 && d.in_mode != DMVS_IN_PLAIN) return DMVS_EINVAL;
     if (d.in_mode == DMVS_IN_UNSHUFFLE2 && (d.c0 % 4)) return DMVS_EINVAL;

@@ -1067,6 +1067,7 @@ extern "C" int dmvs_conv3d_f32(const dmvs_conv3d_desc* dp, void* stream) {
     const dmvs_conv3d_desc& d = *dp;
     hipStream_t st = (hipStream_t)stream;
     if (d.cout_pad % 8 || d.cout > d.cout_pad || !d.in || !d.weight || !d.out) return DMVS_EINVAL;
+    if ((uintptr_t)d.weight & 15) return DMVS_EINVAL;      // the weight slab is staged in 16-byte LDS-DMA pieces
     const int co = (d.cout_pad % 16 == 0) ? 16 : 8;
     dim3 block(DMVS_BLOCK);
     if (d.transposed) {

@@ -69,7 +69,7 @@ typedef struct dmvs_conv2d_desc {
     const float* in0;       /* [B,c0,*,*] physical tensor                                   */
     const float* in1;       /* [B,c1,Hin,Win] or NULL; only with DMVS_IN_PLAIN               */
     const float* mul0;      /* [B,c0,Hin,Win] or NULL: in0 is multiplied element-wise       */
-    const float* weight;
+    const float* weight;    /* 16-byte aligned (staged in 16-byte pieces); DMVS_EINVAL otherwise */
     const float* scale;
     const float* shift;
     const float* residual;  /* [B,cout,*,*] or NULL                                         */
@@ -147,7 +147,7 @@ int dmvs_conv2d_wgrad_f32(const dmvs_conv2d_desc* d, const float* grad_out, floa
  */
 typedef struct dmvs_conv3d_desc {
     const float* in;        /* [B,cin,Din,Hin,Win]                                          */
-    const float* weight;
+    const float* weight;    /* 16-byte aligned (staged in 16-byte pieces); DMVS_EINVAL otherwise */
     const float* scale;
     const float* shift;
     const float* residual;  /* [B,cout,Dout,Hout,Wout] or NULL, added after the activation  */

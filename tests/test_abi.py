@@ -72,6 +72,7 @@ def test_invalid_descriptors_are_rejected_before_any_launch():
 
     assert conv2d(in0=None) == -22
     assert conv2d(out=None) == -22
+    assert conv2d(weight=ctypes.c_void_p(4100)) == -22             # the weight slab is staged in 16-byte pieces
     assert conv2d(cout_pad=12) == -22                              # not a multiple of 8
     assert conv2d(Hout=63) == -22                                  # inconsistent with Hin / pad / stride
     assert conv2d(c1=8) == -22                                     # concat without a second tensor
@@ -87,6 +88,7 @@ def test_invalid_descriptors_are_rejected_before_any_launch():
         return lib.dll.dmvs_conv3d_f32(ctypes.byref(d), None)
 
     assert conv3d(weight=None) == -22
+    assert conv3d(weight=ctypes.c_void_p(4100)) == -22
     assert conv3d(stride=3) == -22
     assert conv3d(Dout=7) == -22
     assert conv3d(transposed=1, stride=1) == -22
