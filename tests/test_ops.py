@@ -117,6 +117,37 @@ def test_conv2d_16_byte_staging_pieces(ops, cin, cout, k, stride, pad, nhwc, H, 
     assert torch.equal(a.cpu(), b.cpu())
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_conv2d_random_shapes_16_byte_vs_4_byte_pieces(seed):
+    """seeded random layer shapes (every kernel-size family, 3..64 input and 1..144 output channels, planes from 1 x 4 to 40 x 68,
+    planar / channel-last output, optional residual): torch reference, and the 16-byte staging form BIT FOR BIT against the 4-byte
+    form.  Host-emulated only for now: random shapes reach instantiations no GPU run has exercised yet (add the hip arm after one)."""
+    import random
+    from conftest import emu_ops
+    o = emu_ops()
+    rng = random.Random(seed)
+    fams = [((3, 3), 1, (1, 1)), ((3, 3), 2, (1, 1)), ((5, 5), 2, (2, 2)), ((7, 7), 1, (3, 3)), ((1, 5), 1, (0, 2)), ((5, 1), 1, (2, 0)),
+            ((1, 1), 1, (0, 0))]
+    for it in range(12):
+        k, s, pad = rng.choice(fams)
+        cin = rng.choice([3, 4, 5, 8, 12, 16, 17, 24, 32, 33, 48, 64])
+        cout = rng.choice([1, 8, 12, 16, 20, 31, 32, 36, 48, 64, 144])
+        B, H, W = rng.choice([1, 2, 3]), rng.choice([1, 2, 5, 8, 9, 16, 17, 31, 33, 40]), 4 * rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 13, 16, 17])
+        if k == (7, 7) and (cin > 40 or cout > 32):
+            cin, cout = 12, 16
+        x = rnd(B, cin, H, W, seed=100 * seed + it)
+        w, b = rnd(cout, cin, *k, seed=7) * 0.3, rnd(cout, seed=8)
+        lay = rng.choice([K.LAYOUT_NCHW, K.LAYOUT_NCHW, K.LAYOUT_NHWC])
+        ref = F.conv2d(x, w, b, s, pad)
+        res = rnd(*ref.shape, seed=9) if (lay == K.LAYOUT_NCHW and rng.random() < 0.4) else None
+        ref = F.relu(ref + res if res is not None else ref)
+        pc = K.pack_conv2d(w, b, stride=s, pad=pad)
+        a = o.conv2d(pc, x, act=K.ACT_RELU, out_layout=lay, residual=res)
+        c = o.conv2d(pc, _at_4_byte_offset(o, x), act=K.ACT_RELU, out_layout=lay, residual=res)
+        close(a, ref.permute(0, 2, 3, 1).contiguous() if lay == K.LAYOUT_NHWC else ref, 2e-5)
+        assert torch.equal(a, c), (k, s, cin, cout, B, H, W, lay)
+
+
 def test_conv2d_16_byte_staging_pieces_fused_inputs(ops):
     """... with the second concat input and the r*h gating of the GRU candidate conv (scales the staged tile in place)"""
     B, H, W = 2, 21, 24
