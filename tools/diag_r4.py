@@ -1,0 +1,164 @@
+"""Round-4 diagnostics, one gpurun call (JSON lines on stdout):
+
+    python tools/diag_r4.py getcost     # which resource bounds getcost_quad_kernel<32,6> at the bench batch: the product build against
+                                        # the DMVS_GC_EXP builds (tools/build_variant.py gcexp1..3: compute-only / memory-only / half requests)
+    python tools/diag_r4.py optins      # the opt-in experiments round 3 left untimed: 16-byte halo pieces in the 3-D MFMA kernels and the
+                                        # fused stem (per-launch environment knobs), the padding-pass skip (variant build), per layer
+"""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from diffmvs_amd import _lib, synth  # noqa: E402
+from diffmvs_amd import ops as K  # noqa: E402
+from diffmvs_amd.ops import Ops, g4_channels  # noqa: E402
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st.record()
+    for _ in range(iters):
+        fn()
+    en.record()
+    torch.cuda.synchronize()
+    return st.elapsed_time(en) * 1e3 / iters
+
+
+def getcost_inputs(o, B, geometry, conf):
+    dev = o.device
+    nb = min(B, 16)                     # 16 rendered scenes, further batch items are copies (like bench.py)
+    gi = synth.getcost_scene_inputs(512, 640, 5, nb, stage=2, C=32, noise=0.01, conf=0.5)
+    inv, cf = gi["inv"], gi["conf"]
+    rep = (B + nb - 1) // nb
+
+    def tile(t, dim=0):
+        return torch.cat([t] * rep, dim)[:B] if dim == 0 else torch.cat([t] * rep, dim)[:, :B]
+
+    g = torch.Generator().manual_seed(5)
+    inv = tile(inv)
+    cf = tile(cf)
+    if geometry == "noise":
+        inv = (inv + 0.5 * torch.randn(inv.shape, generator=g)).clamp(0, 1)
+    if conf == "random":
+        cf = torch.rand(cf.shape, generator=g)
+    elif conf is None:
+        cf = None
+    perm = g4_channels(32)
+    ref = tile(gi["ref"])[..., perm].contiguous().to(dev)
+    src = tile(gi["src"], 1)[..., perm].contiguous().to(dev)
+    vw = tile(gi["view_w"]).contiguous().to(dev)
+    rt = o.compose_proj(tile(gi["proj"]).to(dev).float().contiguous())
+    kmin, kmax = tile(gi["disp_min"]).to(dev), tile(gi["disp_max"]).to(dev)
+    return (ref, src, rt, inv.to(dev).contiguous(), None if cf is None else cf.to(dev).contiguous(), vw, kmin, kmax, 6, gi["interval"],
+            0.25, 4.0, gi["vw_shift"])
+
+
+def getcost(B=96):
+    base = Ops.for_device("cuda:0")
+    libs = [("product", None)] + [(n, os.path.join(ROOT, "tools", "calib", "libdmvs_hip_%s.so" % n)) for n in ("gcexp1", "gcexp2", "gcexp3")]
+    alg = 4.0 * B * 128 * 160 * (32 + 5 * 32 + 6 + 5 + 24)
+    for geometry, conf in (("noise", None), ("noise", "random"), ("scene", 0.5)):
+        args = getcost_inputs(base, B, geometry, conf)
+        for name, path in libs:
+            if path is not None and not os.path.exists(path):
+                continue
+            o = base if path is None else Ops(_lib.Lib(path), "cuda:0")
+            us = timeit(lambda: o.getcost_quad(*args))
+            print(json.dumps({"diag": "getcost", "B": B, "geometry": geometry, "conf": conf, "build": name, "us": round(us, 1),
+                              "frac_of_8TBs": round(alg / (us * 1e-6) / 8e12, 4)}), flush=True)
+
+
+def warp_init(B=96):
+    """the stage-1 plane sweep at the bench batch: product build against gcexp2 (hat weights + scatter removed) and gcexp3 (one
+    64-byte unit of the three per texel read): how much of the launch is the per-texel vector work"""
+    base = Ops.for_device("cuda:0")
+    dev = base.device
+    proj, dv = synth.synth_cameras(512, 640, 5, B=16, numdepth=384)
+    rep = B // 16
+    g = torch.Generator().manual_seed(1)
+    perm = g4_channels(48)
+    ref = torch.randn(B, 64, 80, 48, generator=g)[..., perm].contiguous().to(dev)
+    src = torch.randn(5, B, 64, 80, 48, generator=g)[..., perm].contiguous().to(dev)
+    rt = base.compose_proj(torch.cat([proj["stage1"]] * rep, 0).to(dev).float().contiguous())
+    dvb = torch.cat([dv] * rep, 0)
+    kmin, kmax = dvb[:, 0].contiguous().to(dev), dvb[:, -1].contiguous().to(dev)
+    alg = 4.0 * B * 64 * 80 * (48 + 5 * 48 + 5 * 4 * 48)
+    for name in ("product", "gcexp2", "gcexp3"):
+        path = os.path.join(ROOT, "tools", "calib", "libdmvs_hip_%s.so" % name)
+        if name != "product" and not os.path.exists(path):
+            continue
+        o = base if name == "product" else Ops(_lib.Lib(path), "cuda:0")
+        us = timeit(lambda: o.warp_corr_init_quad(ref, src, rt, kmin, kmax, 48), iters=10)
+        print(json.dumps({"diag": "warp_init", "B": B, "build": name, "us": round(us, 1), "frac_of_8TBs": round(alg / (us * 1e-6) / 8e12, 4)}), flush=True)
+
+
+def getcost_pmc(B=96):
+    """the product kernel alone on the two noise geometries (for the rocprofv3 --pmc passes)"""
+    o = Ops.for_device("cuda:0")
+    for geometry, conf in (("noise", None), ("noise", "random")):
+        args = getcost_inputs(o, B, geometry, conf)
+        for _ in range(int(os.environ.get("DIAG_ITERS", "3"))):
+            o.getcost_quad(*args)
+        torch.cuda.synchronize()
+
+
+def optins():
+    o = Ops.for_device("cuda:0")
+    g = torch.Generator(device="cuda").manual_seed(0)
+    # fused stem, N = 96 x 6 images at 512 x 640
+    x = torch.randn(96, 3, 512, 640, generator=g, device="cuda")
+    w0, w1 = torch.randn(8, 3, 3, 3, generator=g, device="cuda") * 0.4, torch.randn(8, 8, 3, 3, generator=g, device="cuda") * 0.3
+    b0, b1 = torch.randn(8, generator=g, device="cuda"), torch.randn(8, generator=g, device="cuda")
+    pc0, pc1 = K.pack_conv2d(w0, b0, pad=1), K.pack_conv2d(w1, b1, pad=1)
+    ref = o.featurenet_stem(pc0, pc1, x)
+    for knob in ("0", "1"):
+        os.environ["DMVS_STEM_V16"] = knob
+        same = bool(torch.equal(ref, o.featurenet_stem(pc0, pc1, x)))
+        us = timeit(lambda: o.featurenet_stem(pc0, pc1, x), iters=10)
+        print(json.dumps({"diag": "stem", "DMVS_STEM_V16": knob, "us_per_96_images": round(us, 1), "bit_identical": same}), flush=True)
+    os.environ.pop("DMVS_STEM_V16", None)
+    del x, ref
+    # 3-D MFMA kernels: PixelViewWeight conv0 (480 volumes), CostRegNet conv0 / conv1 (96 volumes), stride 1
+    for name, N, cin, cout in (("pvw conv0 4->8 x480", 480, 4, 8), ("costreg conv0 4->8 x96", 96, 4, 8), ("costreg conv1 8->8 x96", 96, 8, 8),
+                               ("costreg conv3 16->16 x96", 96, 16, 16), ("costreg conv5 32->32 x96", 96, 32, 32)):
+        D, H, W = (48, 64, 80) if cin <= 8 else ((24, 32, 40) if cin == 16 else (12, 16, 20))
+        v = torch.randn(N, cin, D, H, W, generator=g, device="cuda")
+        w3 = torch.randn(cout, cin, 3, 3, 3, generator=g, device="cuda") * 0.2
+        pc3 = K.pack_conv3d(w3, None)
+        os.environ.pop("DMVS_CONV3D_V16", None)
+        r3 = o.conv3d(pc3, v, act=K.ACT_RELU)
+        for knob in ("0", "1"):
+            os.environ["DMVS_CONV3D_V16"] = knob
+            same = bool(torch.equal(r3, o.conv3d(pc3, v, act=K.ACT_RELU)))
+            us = timeit(lambda: o.conv3d(pc3, v, act=K.ACT_RELU), iters=10)
+            print(json.dumps({"diag": "conv3d", "layer": name, "DMVS_CONV3D_V16": knob, "us": round(us, 1), "bit_identical": same}), flush=True)
+        os.environ.pop("DMVS_CONV3D_V16", None)
+        del v, r3
+    # padding-pass skip (variant build) on the 16-channel layers it targets and two controls
+    path = os.path.join(ROOT, "tools", "calib", "libdmvs_hip_padskip.so")
+    if os.path.exists(path):
+        o2 = Ops(_lib.Lib(path), "cuda:0")
+        for name, N, cin, cout, k, H, W in (("16->16 3x3 256x320 x96", 96, 16, 16, 3, 256, 320), ("16->16 3x3 128x160 x96", 96, 16, 16, 3, 128, 160),
+                                            ("32->32 3x3 128x160 x96", 96, 32, 32, 3, 128, 160), ("32->16 3x3 128x160 x96", 96, 32, 16, 3, 128, 160),
+                                            ("64->64 3x3 64x80 x576", 576, 64, 64, 3, 64, 80)):
+            xx = torch.randn(N, cin, H, W, generator=g, device="cuda")
+            ww = torch.randn(cout, cin, k, k, generator=g, device="cuda") * 0.1
+            pc = K.pack_conv2d(ww, None, pad=k // 2)
+            a = o.conv2d(pc, xx, act=K.ACT_RELU)
+            b = o2.conv2d(pc, xx, act=K.ACT_RELU)
+            ua = timeit(lambda: o.conv2d(pc, xx, act=K.ACT_RELU), iters=10)
+            ub = timeit(lambda: o2.conv2d(pc, xx, act=K.ACT_RELU), iters=10)
+            print(json.dumps({"diag": "padskip", "layer": name, "product_us": round(ua, 1), "padskip_us": round(ub, 1),
+                              "bit_identical": bool(torch.equal(a, b))}), flush=True)
+            del xx, a, b
+
+
+if __name__ == "__main__":
+    {"getcost": getcost, "warp_init": warp_init, "getcost_pmc": getcost_pmc, "optins": optins}[sys.argv[1]]()
