@@ -259,10 +259,11 @@ def main():
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--src-views", type=int, default=5)
-    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4"],
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
                     help="cfg2 = BASELINE.json configs[1] (the metric's configuration, default); cfg3 = configs[2]: CasDiffMVS 1152x864, "
-                         "7 source views, bf16 feature storage; cfg4 = configs[3]: the CasDiffMVS training step, data parallel (second "
-                         "lines, not the headline)")
+                         "7 source views, bf16 feature storage; cfg4 = configs[3]: the CasDiffMVS training step, data parallel; cfg5 = "
+                         "configs[4]: CasDiffMVS 1920x1056, 11 source views, numdepth_initial 96, fp16 feature storage, scenes sharded "
+                         "over the ranks (second lines, not the headline)")
     ap.add_argument("--precision", default=None, choices=["fp32", "bf16", "fp16"], help="feature storage precision (default: the config's)")
     ap.add_argument("--conv-arith", default=None, choices=["fp32", "bf16"],
                     help="matrix arithmetic of the 2-D convolutions (default: fp32 for cfg2 -- the headline is an fp32 number -- and "
@@ -305,9 +306,22 @@ def main():
             a.batch = 4
         a.precision = a.precision or "bf16"
         a.conv_arith = a.conv_arith or "bf16"
+    nd_initial = 48
+    scene_note = None
+    if a.config == "cfg5":
+        # Tanks&Temples-sized inference (reference test.py:92-127: a per-scene loop): scenes, not reference views, are the unit
+        # that shards -- shard_scenes() keeps a scene's depth maps on one rank for the fusion step that follows
+        variant, nd_initial = "casdiffmvs", 96
+        a.height, a.width, a.src_views = 1056, 1920, 11
+        if "DMVS_BENCH_BATCH" not in os.environ and "--batch" not in sys.argv:
+            a.batch = 2
+        a.precision = a.precision or "fp16"
+        scenes = ["scene%02d" % i for i in range(2 * world)]
+        mine = shard.shard_scenes(scenes, rank, world)
+        scene_note = {"scenes_total": len(scenes), "scenes_of_rank0": mine, "sharding": "shard_scenes: scene i -> rank i % world, no collective"}
     prec = a.precision or "fp32"
     arith = a.conv_arith or "fp32"
-    args = synth.make_args(variant, numdepth_initial=48, precision=prec, conv_arith=arith)
+    args = synth.make_args(variant, numdepth_initial=nd_initial, precision=prec, conv_arith=arith)
     model = CasDiffMVS(args, test=True).eval()
     sd = synth.synth_state_dict(model.state_dict(), 123)
     model.load_state_dict(sd)
@@ -432,7 +446,7 @@ def main():
                    "weights": "seeded random init (no checkpoint offline)",
                    "launch": "captured HIP graph of the forward" if a.graphs else "eager launch sequence (~350 kernels per step)"},
         "batch_sweep_ms_per_map": sweep,
-        "roofline": {"kernel": ("GetCost: getcost_quad_kernel<32,6> (quad per pixel, one launch for any geometry)" if eng.quad else
+        "roofline": {"kernel": ("GetCost: getcost_quad_kernel<32,6> (quad per pixel, software-pipelined texel loop, one launch for any geometry)" if eng.quad else
                                 "GetCost: getcost_win_kernel<32,6> (LDS-staged source windows) / getcost_kernel<32,4,6> (per-pixel gather), picked per launch"),
                      "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -441,8 +455,10 @@ def main():
                      "launches_timed": len(gc_ms), "per_gru_iteration": by_iter,
                      "launches_quad": n_quad, "launches_hybrid": n_hybrid, "launches_plain_gather": n_plain,
                      "tiles_on_gather_path": gather_tiles[0], "tiles_total": gather_tiles[1]},
-        "roofline_warp_init": {"kernel": ("warp_init_quad_kernel<48> (stage-1 plane sweep, quad per pixel)" if eng.quad else
-                                          "warp_init_win_kernel<48> (stage-1 plane sweep, LDS-staged source windows)"), "bound": "hbm",
+        "roofline_warp_init": {"kernel": (("warp_init_quad_kernel<48> (stage-1 plane sweep, quad per pixel, texels from global memory: tune DMVS_TUNE_SWEEP_GLOBAL)"
+                                           if eng.ops.tune["sweep"] else
+                                           "warp_init_band_kernel<48> (stage-1 plane sweep, quad per pixel, source band of a 16x4 pixel tile staged in LDS)")
+                                          if eng.quad else "warp_init_win_kernel<48> (stage-1 plane sweep, LDS-staged source windows)"), "bound": "hbm",
                                "achieved": round(alg_init / wi_avg_s / 1e9, 2) if wi_avg_s > 0 else 0.0,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(alg_init / wi_avg_s / 1e9 / HBM_PEAK_GBS, 4) if wi_avg_s > 0 else 0.0,
@@ -457,13 +473,19 @@ def main():
     }
 
     if a.config != "cfg2":
+        which = "configs[2]" if a.config == "cfg3" else "configs[4]: Tanks&Temples full resolution, scene-sharded inference"
         result["metric"] = f"depth-maps/sec ({W}x{H}, {S} src views)"
-        result["config"]["workload"] = (f"CasDiffMVS DTU eval {W}x{H}, {S} src views, numdepth_initial=48, sampling_timesteps 0/1/1, "
+        result["config"]["workload"] = (f"CasDiffMVS eval {W}x{H}, {S} src views, numdepth_initial={nd_initial}, sampling_timesteps 0/1/1, "
                                         f"{prec} feature storage, {arith} matrix arithmetic in the 2-D convolutions (fp32 accumulation), everything else "
-                                        f"fp32 (BASELINE.json configs[2]; not the headline configuration)")
+                                        f"fp32 (BASELINE.json {which}; not the headline configuration)")
         result["dtype"] = "bf16" if arith == "bf16" else "f32"
         result["roofline"]["kernel"] = "GetCost: getcost_quad_kernel<32,4> + <16,4> (stage 2 and stage 3 launches, bytes averaged per launch)"
         result["roofline_conv2d"] = None
+        result["roofline_warp_init"]["kernel"] = result["roofline_warp_init"]["kernel"].replace("<48>", "<48> D=%d" % nd_initial)
+        if scene_note:
+            result["config"]["scene_sharding"] = scene_note
+            result["config"]["multi_gpu"] = ("measured on %d GPU(s) in this run" % world) + ("" if world > 1 else
+                                             "; --gpus N shards the scenes over N ranks (unmeasured on hardware: 1-GPU leases)")
     result["config"]["feature_storage"] = prec
     result["config"]["conv_arith"] = arith
     if arith != "fp32" and a.config == "cfg2":      # an experiment line, never the headline: say so where the driver reads it

@@ -32,7 +32,7 @@ class Conv2dDesc(C.Structure):
         ("cout", _I), ("cout_pad", _I), ("kh", _I), ("kw", _I), ("stride", _I), ("pad_h", _I), ("pad_w", _I),
         ("in_mode", _I), ("act", _I), ("res_mode", _I), ("res_after_act", _I),
         ("out_layout", _I), ("out_cstride", _I), ("out_coffset", _I), ("gn_groups", _I), ("post_scale", _F),
-        ("gate_cstride", _I), ("arith", _I),
+        ("gate_cstride", _I), ("arith", _I), ("tune", _I),
     ]
 
 
@@ -41,7 +41,7 @@ class Conv3dDesc(C.Structure):
         ("in_", _P), ("weight", _P), ("scale", _P), ("shift", _P), ("residual", _P), ("out", _P),
         ("B", _I), ("cin", _I), ("cout", _I), ("cout_pad", _I),
         ("Din", _I), ("Hin", _I), ("Win", _I), ("Dout", _I), ("Hout", _I), ("Wout", _I),
-        ("stride", _I), ("transposed", _I), ("act", _I),
+        ("stride", _I), ("transposed", _I), ("act", _I), ("tune", _I),
     ]
 
 
@@ -60,8 +60,7 @@ class GetCostDesc(C.Structure):
 SIGNATURES = {
     "dmvs_abi_version": [],
     "dmvs_conv2d_f32": [C.POINTER(Conv2dDesc), _P],
-    "dmvs_featurenet_stem_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
-    "dmvs_conv3x3_pair16_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "dmvs_featurenet_stem_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dmvs_conv2d_wgrad_workspace_f32": [C.POINTER(Conv2dDesc), C.POINTER(C.c_int64)],
     "dmvs_conv2d_wgrad_f32": [C.POINTER(Conv2dDesc), _P, _P, _P, _P, C.c_int64, _P],
     "dmvs_conv3d_f32": [C.POINTER(Conv3dDesc), _P],
@@ -74,7 +73,7 @@ SIGNATURES = {
     "dmvs_getcost_f32": [C.POINTER(GetCostDesc), _P],
     "dmvs_getcost_gather_f32": [C.POINTER(GetCostDesc), _P],
     "dmvs_getcost_quad_f32": [C.POINTER(GetCostDesc), _P],
-    "dmvs_warp_corr_init_quad_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "dmvs_warp_corr_init_quad_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "dmvs_warp_corr_init_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "dmvs_getcost_bwd_f32": [C.POINTER(GetCostDesc), _P, _P, _P, _P],
     "dmvs_view_aggregate_bwd_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -98,7 +97,19 @@ SIGNATURES = {
     "dmvs_sumsq_f32": [_P, C.c_int64, _P, _P],
     "dmvs_adamw_step_f32": [_P, _P, _P, _P, C.c_int64, _F, _F, _F, _F, _F, _I, _F, _P, _F, _P],
 }
-ABI_VERSION = 1
+ABI_VERSION = 2
+# dmvs.h: DMVS_TUNE_* (dmvs_conv2d_desc.tune, dmvs_featurenet_stem_f32), DMVS_TUNE3D_* (dmvs_conv3d_desc.tune), DMVS_TUNE_SWEEP_GLOBAL
+TUNE_NO_WALK, TUNE_PIECES4, TUNE_1X1_WIDE, TUNE_NO_LEAN = 0x4, 0x8, 0x80, 0x100
+TUNE3D_PIECES4, TUNE3D_S2_DIRECT = 0x1, 0x2
+TUNE_SWEEP_GLOBAL = 0x1
+
+
+def tune_tile_wx(n: int) -> int:
+    return n & 3
+
+
+def tune_tile_mt(n: int) -> int:
+    return (n & 7) << 4
 
 
 class DmvsError(RuntimeError):
@@ -113,13 +124,14 @@ class Lib:
             raise DmvsError(f"{path} not found: build it with `python -m diffmvs_amd.build`")
         self.path = path
         self.dll = C.CDLL(path)
+        self.dll.dmvs_abi_version.restype = C.c_int
+        v = self.dll.dmvs_abi_version()          # FIRST: a library of another ABI version may lack / re-type the symbols below
+        if v != ABI_VERSION:
+            raise DmvsError(f"{path}: ABI version {v}, binding expects {ABI_VERSION} (rebuild: python -m diffmvs_amd.build)")
         for name, argtypes in SIGNATURES.items():
             fn = getattr(self.dll, name)     # AttributeError if the library lacks a declared symbol
             fn.argtypes = argtypes
             fn.restype = C.c_int
-        v = self.dll.dmvs_abi_version()
-        if v != ABI_VERSION:
-            raise DmvsError(f"{path}: ABI version {v}, binding expects {ABI_VERSION}")
 
     def call(self, name: str, *args):
         rc = getattr(self.dll, name)(*args)

@@ -164,11 +164,8 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv1x1_direct_kernel(const dmvs_c
 static bool conv1x1_direct_ok(const dmvs_conv2d_desc& d) {
     if (d.kh != 1 || d.kw != 1 || d.stride != 1 || d.pad_h || d.pad_w || d.in_mode != DMVS_IN_PLAIN) return false;
     if (d.mul0 || d.gru_z || d.gn_stats || d.out_layout != DMVS_LAYOUT_NCHW) return false;
-    // DMVS_CONV1X1_WIDE=1 (experiments): also the 2..9 n-tile instantiations, which are not faster than the tiled kernel yet
-    static const int max_cout_pad = [] {                  // read once: this runs on every 1x1 launch
-        const char* wide = getenv("DMVS_CONV1X1_WIDE");
-        return (wide && wide[0] == '1') ? 144 : 16;
-    }();
+    // DMVS_TUNE_1X1_WIDE (experiments): also the 2..9 n-tile instantiations, which are not faster than the tiled kernel yet
+    const int max_cout_pad = (d.tune & DMVS_TUNE_1X1_WIDE) ? 144 : 16;
     if (d.c0 + d.c1 > kC11MaxCin || d.cout_pad > max_cout_pad || (d.Wout & 3)) return false;
     if (d.res_mode == DMVS_IN_UPSAMPLE2 && ((d.Hout | d.Wout) & 1)) return false;
     if ((((uintptr_t)d.in0 | (uintptr_t)d.in1 | (uintptr_t)d.out | (uintptr_t)d.residual) & 15) != 0) return false;
@@ -184,7 +181,7 @@ static int launch_conv1x1_direct(const dmvs_conv2d_desc& d, hipStream_t st) {
 }
 
 static int conv1x1_direct(const dmvs_conv2d_desc& d, hipStream_t st) {
-    switch ((d.cout_pad + 15) / 16) {      // n-tiles beyond 1 only under DMVS_CONV1X1_WIDE (conv1x1_direct_ok)
+    switch ((d.cout_pad + 15) / 16) {      // n-tiles beyond 1 only under DMVS_TUNE_1X1_WIDE (conv1x1_direct_ok)
         case 1: return launch_conv1x1_direct<1, 4>(d, st);
         case 2: return launch_conv1x1_direct<2, 4>(d, st);
         case 3: return launch_conv1x1_direct<3, 2>(d, st);

@@ -3,7 +3,6 @@
 // they were 6 of the 7 minutes of a library build.  Everything here has internal linkage; a translation unit exports plain
 // functions dmvs_detail::launch_conv2d_<kh><kw><stride>() (declared at the end of this file) for the entry point in conv2d.hip.
 #pragma once
-#include <cstdlib>
 #include <type_traits>
 
 #include "dmvs_common.h"
@@ -122,8 +121,14 @@ constexpr int conv_min_waves(int nt, int mt) { return (nt == 2 && mt == 4) ? 4 :
 // per channel row in the stores and the halo reads.  Worth 6-9 % on the two-n-tile layers of the large planes, a loss on the
 // others (conv_tile_waves_x); it is NOT what holds the 16-channel layers at ~0.5 (unchanged by it, as by a 6x cut of the
 // matrix time and by register staging: DESIGN.md section 4).
+//
+// LEAN (round 4) = the "lean" specialisation WITHOUT the tile walk: the generic instantiation resolves every fused path (second
+// input, gating, GRU blend, GroupNorm statistics, residual modes, five activations, post-scale) with wave-uniform run-time branches,
+// per (row, n-tile) of the epilogue and per chunk of the staging -- the 16 -> 16 generic kernel is 2517 vector + 2481 scalar static
+// instructions for 36 MFMAs, and its SQ counters show 747 scalar + 571 vector instructions per 144 MFMAs per wave at run time.  The
+// plain layers (FeatureNet / ContextNet trunks, encoder, heads: ~65 % of the conv2d time) need none of it.
 template <int KH, int KW, int S, int NT, int MT, bool ZI, int OT = DMVS_DTYPE_F32, bool TR = false, bool WALK = false, int AR = DMVS_ARITH_F32,
-          int WX = 1, bool V16 = false>
+          int WX = 1, bool V16 = false, bool LEAN = false>
 __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfma_kernel(const dmvs_conv2d_desc d, int tiles_x, int tiles_y) {
     using Cfg = ConvCfg<KH, KW, S, NT, MT, AR, WX, V16>;
     static_assert(!(V16 && ZI), "16-byte staging pieces: PLAIN inputs only");
@@ -159,8 +164,10 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     // The tile-walking form is built for the PLAIN layers only (FeatureNet / ContextNet trunks, the plain Unet layers): one input
     // tensor, no gating / GRU blend / GroupNorm statistics, ReLU or no activation, optional same-size residual, 16-byte stores.
     // Compiling the other paths out is what lets two tiles' state fit the register file (the dispatcher checks the conditions).
-    constexpr bool kLean = WALK;
-    const int cin = kLean ? d.c0 : d.c0 + d.c1;
+    constexpr bool kLean = WALK || LEAN;
+    // (LEAN keeps two things the walking form compiles out: a second PLAIN concat input and the GroupNorm statistics -- the Unet's
+    // weight-standardised convolutions are "plain" otherwise)
+    const int cin = WALK ? d.c0 : d.c0 + d.c1;
 
     // ---- addressing of the logical input, all in 32-bit element offsets from per-batch bases
     const int mode = ZI ? DMVS_IN_UPSAMPLE2 : (kLean ? DMVS_IN_PLAIN : d.in_mode);      // zero-insert addresses like nearest-x2 (plus a parity predicate)
@@ -172,10 +179,10 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     auto set_bases = [&]() {
         in0b = d.in0 + (size_t)s_b * pc0 * plane0;
         mul0b = (!kLean && d.mul0) ? d.mul0 + (size_t)s_b * (d.gate_cstride ? d.gate_cstride : pc0) * plane0 : nullptr;
-        in1b = (!kLean && d.in1) ? d.in1 + (size_t)s_b * d.c1 * plane1 : d.in0;
+        in1b = (!WALK && d.in1) ? d.in1 + (size_t)s_b * d.c1 * plane1 : d.in0;
     };
     set_bases();
-    static_assert(!(WALK && ZI), "the tile-walking form is an inference kernel");
+    static_assert(!((WALK || LEAN) && ZI), "the lean forms are inference kernels");
 
     // element e of the padded LDS input image of chunk c0 -> global source (or nullptr for padding)
     auto in_src = [&](int c0, int e, int& off_out) -> const float* {
@@ -245,13 +252,9 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     // An interior tile of a layer whose channel count is a multiple of the chunk has no such position that an MFMA reads: the pass
     // (2 x CK predicated LDS writes per plane position: ~40 VALU + ~170 SALU per wave, a quarter of the scalar work of a 16 -> 16
     // tile) is skipped then -- workgroup-uniform branch.  (A walking workgroup's later border tiles clear their own padding.)
-    // Built (and exercised with poisoned LDS) on the host emulation; the GPU library keeps the unconditional pass until the skip has
-    // run through the GPU parity suite and been timed: -DDMVS_CONV_SKIP_PAD_PASS (tests/hipemu/build.py defines it).
-#ifdef DMVS_CONV_SKIP_PAD_PASS
+    // Measured on the MI355X (profiles/r4_optins_ab.jsonl, bit-identical results): 16 -> 16 at 96 x 256 x 320 532 -> 471 us, the other
+    // layer shapes within 2 %.
     const bool pad_pass = ZI || (cin & (CK - 1)) != 0 || gy0 < 0 || gx0 < 0 || gy0 + TH > d.Hin || gx0 + TW > d.Win;
-#else
-    const bool pad_pass = true;
-#endif
     if (pad_pass) {
 #pragma unroll
     for (int it = 0; it < P_IT; ++it) {
@@ -274,7 +277,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
         }
     }
     }
-    const bool simple = kLean || (d.c1 == 0 && mode != DMVS_IN_UNSHUFFLE2);      // one input tensor: the channel base just advances by a plane
+    const bool simple = WALK || (d.c1 == 0 && mode != DMVS_IN_UNSHUFFLE2);      // one input tensor: the channel base just advances by a plane
     auto stage_as = [&](auto simple_tag, int c0, float* buf) __attribute__((always_inline)) {
         constexpr bool kSimple = decltype(simple_tag)::value;          // two instantiations: no mode decisions inside the simple one
         const float* cb = in0b + (size_t)c0 * plane0;                  // wave-uniform base of the channel being staged
@@ -456,7 +459,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     const int ox = ox0 + wx * 16 + m;
     const int oplane = d.Hout * d.Wout;
     const bool rup = !kLean && d.res_mode == DMVS_IN_UPSAMPLE2;
-    const bool do_gn = !kLean && d.gn_stats, do_gru = !kLean && d.gru_z;
+    const bool do_gn = !WALK && d.gn_stats, do_gru = !kLean && d.gru_z;
     const int act = kLean ? (d.act == DMVS_ACT_RELU ? DMVS_ACT_RELU : DMVS_ACT_NONE) : d.act;
     const int rW = rup ? (d.Wout >> 1) : d.Wout, rH = rup ? (d.Hout >> 1) : d.Hout;
     // per-batch-item bases (wave-uniform, 64-bit) + 32-bit element offsets `channel * plane + pixel` (one full-rate
@@ -723,28 +726,25 @@ static bool conv_bf16_honoured(const dmvs_conv2d_desc& d) {
 // (profiles/r3_conv_wx_ab.txt; WX = 1 / 2 / 4, ms per step): two n-tiles on planes of >= 128 x 160 pixels gain with 32-wide tiles
 // -- 32 -> 32 3x3 4.79 / 4.46 / 5.32 and 4.21 / 3.96 / 4.73, 16 -> 32 5x5 stride 2 3.14 / 2.95 / 4.25, 24 -> 32 1.18 / 1.08 /
 // 1.26, 6 -> 32 0.57 / 0.47 / 0.56 -- one n-tile and the small planes lose (16 -> 16 2.44 / 2.56 / 2.89, 32 -> 32 at 64 x 80
-// 1.48 / 1.64 / 2.36), 64-wide tiles lose nearly everywhere.  DMVS_CONV_WX = 1 | 2 forces it for A/B runs.
-static int conv_tile_waves_x(long out_pixels, int nt) {
-    static const int forced = [] {
-        const char* e = getenv("DMVS_CONV_WX");
-        return e ? atoi(e) : 0;
-    }();
+// 1.48 / 1.64 / 2.36), 64-wide tiles lose nearly everywhere.  DMVS_TUNE_TILE_WX(1 | 2) forces it for A/B runs.
+static int conv_tile_waves_x(const dmvs_conv2d_desc& d, long out_pixels, int nt) {
+    const int forced = d.tune & 3;
     if (forced) return forced >= 2 ? 2 : 1;
     return (nt == 2 && out_pixels >= 128L * 160) ? 2 : 1;
 }
 
 // The tile-walking kernels are compiled for "lean" layers only (kLean in the kernel): one plain input tensor, exact fp32, ReLU or
 // no activation, no gating / GRU blend / GroupNorm statistics / post-scale, an optional same-size residual added before the
-// activation, rows of 16-byte multiples on 16-byte aligned tensors.  DMVS_CONV_WALK=0: one tile per workgroup everywhere (A/B).
-static bool conv_walk_ok(const dmvs_conv2d_desc& d) {
-    static const bool on = [] {
-        const char* e = getenv("DMVS_CONV_WALK");
-        return !(e && e[0] == '0');
-    }();
-    if (!on || d.arith != DMVS_ARITH_F32 || d.c1 != 0 || d.in_mode != DMVS_IN_PLAIN || d.mul0 || d.gru_z || d.gn_stats) return false;
+// activation, rows of 16-byte multiples on 16-byte aligned tensors.  DMVS_TUNE_NO_WALK: one tile per workgroup everywhere (A/B).
+static bool conv_lean_ok(const dmvs_conv2d_desc& d) {
+    if ((d.tune & DMVS_TUNE_NO_LEAN) || d.arith != DMVS_ARITH_F32 || d.in_mode != DMVS_IN_PLAIN || d.mul0 || d.gru_z) return false;
     if ((d.act != DMVS_ACT_NONE && d.act != DMVS_ACT_RELU) || d.post_scale != 1.0f) return false;
     if (d.residual && (d.res_after_act || d.res_mode != DMVS_IN_PLAIN)) return false;
     if ((d.Wout & 3) || ((((uintptr_t)d.out | (uintptr_t)d.residual) & 15) != 0) || (((long)d.Hout * d.Wout * d.out_coffset) & 3)) return false;
+    return true;
+}
+static bool conv_walk_ok(const dmvs_conv2d_desc& d) {
+    if ((d.tune & DMVS_TUNE_NO_WALK) || !conv_lean_ok(d) || d.c1 != 0 || d.gn_stats) return false;
     // Measured at B = 96 (profiles/r3_conv_walk2_ab.txt, ms per step, one tile per workgroup -> walking): the lean layers gain
     // (3 -> 8 at 512x640 0.76 -> 0.64, 8 -> 16 stride 2 0.92 -> 0.85, 16 -> 32 stride 2 0.55 -> 0.48, 16 -> 32 at 64x80 0.28 -> 0.22,
     // 16 -> 32 5x5 stride 2 3.05 -> 2.94) EXCEPT the stride-1 one-n-tile layers with >= 16 input channels (16 -> 16 at 256x320:
@@ -754,14 +754,10 @@ static bool conv_walk_ok(const dmvs_conv2d_desc& d) {
 }
 
 // 16-byte staging pieces (template V16) need: a PLAIN input (and second concat input), image rows of 16-byte multiples on 16-byte
-// aligned tensors, and the "same" padding the LDS row alignment is built for.  DMVS_CONV_V16=0: 4-byte pieces everywhere (A/B).
+// aligned tensors, and the "same" padding the LDS row alignment is built for.  DMVS_TUNE_PIECES4: 4-byte pieces everywhere (A/B).
 template <int KW>
 static bool conv_v16_ok(const dmvs_conv2d_desc& d) {
-    static const bool on = [] {
-        const char* e = getenv("DMVS_CONV_V16");
-        return !(e && e[0] == '0');
-    }();
-    if (!on || d.in_mode != DMVS_IN_PLAIN || (d.Win & 3) || d.pad_w != (KW - 1) / 2) return false;
+    if ((d.tune & DMVS_TUNE_PIECES4) || d.in_mode != DMVS_IN_PLAIN || (d.Win & 3) || d.pad_w != (KW - 1) / 2) return false;
     if (((uintptr_t)d.in0 & 15) || (d.c1 > 0 && ((uintptr_t)d.in1 & 15))) return false;
     return true;
 }
@@ -813,7 +809,7 @@ int launch_conv2d_mt(const dmvs_conv2d_desc& d, hipStream_t st, int nt, int ngro
         if constexpr (!ZI && (KH * KW == 9 || KH * KW == 25)) {
             // the plain 3x3 / 5x5 layers with one or two n-tiles: 32-pixel-wide tiles where measured better (conv_tile_waves_x) and,
             // when the layer is "lean" (conv_walk_ok), resident tile-walking workgroups
-            const int wxv = nt <= 2 ? conv_tile_waves_x((long)d.Hout * d.Wout, nt) : 1;
+            const int wxv = nt <= 2 ? conv_tile_waves_x(d, (long)d.Hout * d.Wout, nt) : 1;
             const bool walk = nt <= 2 && conv_walk_ok(d);
 #define DMVS_TILED(NTV, WXV, WALKV) do { if (v16) DMVS_TILED_(NTV, WXV, WALKV, true); else DMVS_TILED_(NTV, WXV, WALKV, false); } while (0)
 #define DMVS_TILED_(NTV, WXV, WALKV, V16V) do { \
@@ -839,6 +835,18 @@ int launch_conv2d_mt(const dmvs_conv2d_desc& d, hipStream_t st, int nt, int ngro
 #undef DMVS_TILED_
         }
         if constexpr (!ZI) {
+            if (conv_lean_ok(d)) {      // plain layer, one tile per workgroup: the lean specialisation (template LEAN)
+#define DMVS_LEAN(NTV) do { if (v16) hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, NTV, MT, false, DMVS_DTYPE_F32, true, false, DMVS_ARITH_F32, 1, true, true>), grid, block, 0, st, d, tiles_x, tiles_y); \
+                            else hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, NTV, MT, false, DMVS_DTYPE_F32, true, false, DMVS_ARITH_F32, 1, false, true>), grid, block, 0, st, d, tiles_x, tiles_y); } while (0)
+                switch (nt) {
+                    case 1: DMVS_LEAN(1); break;
+                    case 2: DMVS_LEAN(2); break;
+                    case 3: DMVS_LEAN(3); break;
+                    default: DMVS_LEAN(4); break;
+                }
+#undef DMVS_LEAN
+                return dmvs_launch_status();
+            }
             if (v16) {
                 switch (nt) {
                     case 1: hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, 1, MT, false, DMVS_DTYPE_F32, true, false, DMVS_ARITH_F32, 1, true>), grid, block, 0, st, d, tiles_x, tiles_y); break;
@@ -901,7 +909,7 @@ int launch_conv2d(const dmvs_conv2d_desc& d, hipStream_t st) {
     if (S == 1 && KH * KW > 1 && conv_bf16_honoured(d))      // and for the bf16 matrix arithmetic
         return launch_conv2d_mt<KH, KW, S, 2, false>(d, st, nt, ngroups);
     const long wg16 = (long)((d.Wout + 15) / 16) * ((d.Hout + 15) / 16) * d.B * ngroups;
-    static const int force_mt = getenv("DMVS_CONV_MT") ? atoi(getenv("DMVS_CONV_MT")) : 0;      // experiments: force the tile height
+    const int force_mt = (d.tune >> 4) & 7;      // DMVS_TUNE_TILE_MT: experiments force the tile height
     if constexpr (!heavy) {
         if (force_mt == 4) return launch_conv2d_mt<KH, KW, S, 4, false>(d, st, nt, ngroups);
     }

@@ -12,7 +12,6 @@
 // wave-uniform.  The transposed convolution is evaluated in gather form, one output parity
 // class (od&1, oh&1, ow&1) per blockIdx.z so that the live taps stay wave-uniform:
 //   o = 2j   : k = 1 reads i = j            o = 2j+1 : k = 0 reads i = j+1, k = 2 reads i = j
-#include <stdlib.h>
 
 #include <type_traits>
 
@@ -84,8 +83,8 @@ struct HaloMap {
 // cover of the halo row: it starts SLACK = 3 floats left of the halo's first column (tile origins are multiples of 16 voxels, the
 // padding is 1, so column -4 is 16-byte aligned when rows are multiples of 4 floats and the tensor is 16-byte aligned) and its
 // pitch IWL is a whole number of pieces: 24 floats for the 18 of a 16-wide tile, 6 pieces instead of 18 elements per row.  A piece
-// lies wholly inside or outside the volume.  Opt-in (DMVS_CONV3D_V16=1) until it has been timed: the planes grow by a third
-// (the pair kernel then holds 2 instead of 3 workgroups per CU).
+// lies wholly inside or outside the volume.  The planes grow by a third (the pair kernel then holds 2 instead of 3 workgroups per
+// CU) and it still pays: 2-6 % per layer on the MI355X (conv3d_v16_ok), so it is the default wherever the alignment allows.
 template <int ID, int IH, int IW>
 struct HaloMap16 {
     static constexpr int SLACK = 3;
@@ -139,9 +138,11 @@ struct HaloSel<true, ID, IH, IW> {
     static constexpr int PLANE = type::PLANE, PITCH = type::IWL, X0 = type::SLACK;
 };
 
+// 16-byte halo pieces (HaloMap16) wherever rows are 16-byte multiples on a 16-byte aligned tensor: measured on the MI355X against the
+// 4-byte form, bit-identical (profiles/r4_optins_ab.jsonl): PixelViewWeight conv0 at 480 volumes 3318 -> 3231 us, CostRegNet conv0
+// 659 -> 646, conv1 1540 -> 1453, conv3 443 -> 415, conv5 268 -> 257.  DMVS_TUNE3D_PIECES4 forces the 4-byte form (A/B runs, tests).
 static bool conv3d_v16_ok(const dmvs_conv3d_desc& d) {
-    const char* e = getenv("DMVS_CONV3D_V16");      // (read per launch while it is an experiment: the tests switch it inside one process)
-    return e && e[0] == '1' && (d.Win & 3) == 0 && ((uintptr_t)d.in & 15) == 0;
+    return !(d.tune & DMVS_TUNE3D_PIECES4) && (d.Win & 3) == 0 && ((uintptr_t)d.in & 15) == 0;
 }
 
 // weight slab [CK][27][NW] (+ row padding to WPAD), 16 bytes per lane; decoded once per workgroup like the halo
@@ -1053,14 +1054,8 @@ __global__ void __launch_bounds__(DMVS_BLOCK) deconv3d_mfma_kernel(const dmvs_co
     }
 }
 
-// DMVS_CONV3D_S2=direct: the round-1 direct VALU kernels for the stride-2 layers (A/B runs)
-static bool conv3d_s2_mfma() {
-    static const bool on = [] {
-        const char* e = getenv("DMVS_CONV3D_S2");
-        return !(e && e[0] == 'd');
-    }();
-    return on;
-}
+// DMVS_TUNE3D_S2_DIRECT: the round-1 direct VALU kernels for the stride-2 layers (A/B runs)
+static bool conv3d_s2_mfma(const dmvs_conv3d_desc& d) { return !(d.tune & DMVS_TUNE3D_S2_DIRECT); }
 
 extern "C" int dmvs_conv3d_f32(const dmvs_conv3d_desc* dp, void* stream) {
     if (!dp) return DMVS_EINVAL;
@@ -1136,7 +1131,7 @@ extern "C" int dmvs_conv3d_f32(const dmvs_conv3d_desc* dp, void* stream) {
         // stride 2 on the matrix cores (32-bit element offsets inside a batch item, like the stride-1 kernels)
         const bool fits32 = (long)d.cin * d.Din * d.Hin * d.Win < (1L << 31) && (long)d.cout * d.Dout * d.Hout * d.Wout < (1L << 31);
         const int ntiles = (d.cout_pad + 15) / 16;
-        if (fits32 && ntiles <= 2 && conv3d_s2_mfma()) {
+        if (fits32 && ntiles <= 2 && conv3d_s2_mfma(d)) {
             const int tiles_x = (d.Wout + 15) / 16, tiles_y = (d.Hout + 3) / 4, tiles_d = (d.Dout + 3) / 4;
             dim3 g((unsigned)(tiles_x * tiles_y * tiles_d * d.B), 1);
             if (ntiles == 1) hipLaunchKernelGGL((conv3d_mfma_kernel<1, 2>), g, block, 0, st, d, tiles_x, tiles_y, tiles_d);

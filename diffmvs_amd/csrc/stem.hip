@@ -13,7 +13,6 @@
 //     weights B, so a lane ends up with 4 consecutive pixels of one (row, channel): BN + ReLU + one 16-byte NCHW store.
 // Exact-fp32 MFMA; conv0.0's 27 products are summed in (ci, tap) order here and in (tap, ci) order by the generic
 // kernel, so the two agree to the last bits, not bitwise.
-#include <stdlib.h>
 
 #include "dmvs_common.h"
 #include "dmvs_lds_poison.h"
@@ -28,7 +27,7 @@ constexpr int MW = TS + 2, MP = MW * MW;          // intermediate tile 18 x 18 =
 constexpr int IW = TS + 4, IP = IW * IW;          // input tile 20 x 20 = 400
 constexpr int MPLANE = 336;                        // 324 padded to 16 mod 32 (bank spread over the 4 k-groups)
 constexpr int IN_FLOATS = 3 * IP;                  // 1200
-// V16 (opt-in, DMVS_STEM_V16=1, not timed yet): the input halo in 16-byte LDS-DMA pieces (conv2d.hip, template V16).  An LDS row is
+// V16 (the default where the alignment allows; 1094 -> 938 us per 96 images on the MI355X): the input halo in 16-byte LDS-DMA pieces (conv2d.hip, template V16).  An LDS row is
 // the 16-byte aligned 24-float cover of the 20-float halo row (it starts SLACK = 2 floats further left: tile origins are multiples
 // of 16 pixels, the halo starts 2 pixels left of them): 360 pieces instead of 1200 elements per tile, 6 instead of 19 wave-level DMA
 // instructions.  Needs rows of 16-byte multiples on a 16-byte aligned tensor; a piece lies wholly inside or outside the image.
@@ -232,15 +231,17 @@ featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0
 
 extern "C" int dmvs_featurenet_stem_f32(const float* x, const float* w0, const float* scale0, const float* shift0,
                                         const float* w1, const float* scale1, const float* shift1, float* y, int32_t N,
-                                        int32_t H, int32_t W, void* stream) {
+                                        int32_t H, int32_t W, int32_t tune, void* stream) {
     if (!x || !w0 || !w1 || !y || N <= 0 || H <= 0 || W <= 0) return DMVS_EINVAL;
     if ((long)3 * H * W >= (1L << 31)) return DMVS_EINVAL;
     const int tiles_x = (W + TS - 1) / TS, tiles_y = (H + TS - 1) / TS;
     const long ntiles = (long)tiles_x * tiles_y * N;
     if (ntiles >= (1L << 31)) return DMVS_EINVAL;
     const unsigned grid = (unsigned)(ntiles < 256 * 6 ? ntiles : 256 * 6);      // persistent: ~6 workgroups per CU (22 KB LDS each)
-    const char* e16 = getenv("DMVS_STEM_V16");      // (read per launch while it is an experiment: the tests switch it inside one process)
-    if (e16 && e16[0] == '1' && (W & 3) == 0 && ((uintptr_t)x & 15) == 0)
+    // input halo in 16-byte LDS-DMA pieces wherever rows are 16-byte multiples on a 16-byte aligned tensor (6 instead of 19 wave-level
+    // DMA instructions per tile, 84 instead of 96 VGPRs): 1094 -> 938 us per 96 images on the MI355X, bit-identical
+    // (profiles/r4_optins_ab.jsonl); DMVS_TUNE_PIECES4 forces the 4-byte form
+    if (!(tune & DMVS_TUNE_PIECES4) && (W & 3) == 0 && ((uintptr_t)x & 15) == 0)
         hipLaunchKernelGGL(featurenet_stem_kernel<true>, dim3(grid), dim3(DMVS_BLOCK), 0, (hipStream_t)stream, x, w0, scale0, shift0, w1,
                            scale1, shift1, y, N, H, W, tiles_x, tiles_y);
     else

@@ -24,9 +24,6 @@
 //
 // Semantics kept from the reference: per-tap zero padding with align_corners=True pixel coordinates, NO behind-camera
 // mask, z == 0 -> z + 1e-8, non-finite coordinates sample 0.
-#include <stdlib.h>
-
-#include <type_traits>
 #include <utility>
 
 #include "dmvs_common.h"
@@ -37,15 +34,6 @@
 //      floor;   3: only the first 64-byte unit of a texel is loaded: half the requests, the same lines.
 #ifndef DMVS_GC_EXP
 #define DMVS_GC_EXP 0
-#endif
-
-// DMVS_QUAD_PIPE=0 (A/B builds): the round-2/3 texel loop (load the trip, wait, compute) instead of the software-pipelined one
-#ifndef DMVS_QUAD_PIPE
-#define DMVS_QUAD_PIPE 1
-#endif
-
-#ifndef DMVS_GC_MIN_WAVES      // waves per SIMD the GetCost kernel's register allocation must leave room for
-#define DMVS_GC_MIN_WAVES 1
 #endif
 
 #ifndef DMVS_QUAD_PERM      // (the host emulation predefines it)
@@ -278,75 +266,11 @@ __device__ __forceinline__ void scatter_pair(float (&acc)[NH], const float (&w0)
 #undef DMVS_QF
 #endif
 
-// ---- software-pipelined texel loads (quad_accumulate's fp32 global-memory form).  hipcc's wait-count insertion merges control-flow
-// paths conservatively: with the next trip's loads inside a per-lane `if`, the merge point waits for EVERYTHING (vmcnt(0)) and the
-// pipelining is gone.  So the loads of a trip are one asm block -- exec-masked by hand to the lanes that have a trip, no branch --
-// and the wait in front of a trip's arithmetic is written by hand: vmcnt(N) with N = the loads of the trip issued after it.
-// (Vector-memory loads return in order; the compiler does not know of these loads, so its own waits can only be stricter.)
-__device__ __forceinline__ unsigned long long quad_ballot(bool p) {
-#ifdef DMVS_HOST_EMULATION
-    return p ? ~0ull : 0ull;       // (per-fiber: "this lane")
-#else
-    return __builtin_amdgcn_ballot_w64(p);
-#endif
-}
-template <int U>
-__device__ __forceinline__ void load_pair_masked(const char* base, const unsigned (&off)[2], unsigned long long mask, u32x4 (&r)[2][U]) {
-#ifdef DMVS_HOST_EMULATION
-    if (mask) {
-        for (int i = 0; i < 2; ++i)
-            for (int j = 0; j < U; ++j) memcpy(&r[i][j], base + off[i] + j * 64, 16);
-    }
-#else
-    unsigned long long sv;
-    if constexpr (U == 1) {
-        asm volatile("s_mov_b64 %2, exec\n\ts_and_b64 exec, exec, %6\n\t"
-                     "global_load_dwordx4 %0, %3, %5\n\tglobal_load_dwordx4 %1, %4, %5\n\t"
-                     "s_mov_b64 exec, %2"
-                     : "=&v"(r[0][0]), "=&v"(r[1][0]), "=&s"(sv) : "v"(off[0]), "v"(off[1]), "s"(base), "s"(mask) : "scc", "memory");
-    } else if constexpr (U == 2) {
-        asm volatile("s_mov_b64 %4, exec\n\ts_and_b64 exec, exec, %8\n\t"
-                     "global_load_dwordx4 %0, %5, %7\n\tglobal_load_dwordx4 %1, %5, %7 offset:64\n\t"
-                     "global_load_dwordx4 %2, %6, %7\n\tglobal_load_dwordx4 %3, %6, %7 offset:64\n\t"
-                     "s_mov_b64 exec, %4"
-                     : "=&v"(r[0][0]), "=&v"(r[0][1]), "=&v"(r[1][0]), "=&v"(r[1][1]), "=&s"(sv)
-                     : "v"(off[0]), "v"(off[1]), "s"(base), "s"(mask) : "scc", "memory");
-    } else {
-        static_assert(U == 3, "load_pair_masked: 16, 32 or 48 channels");
-        asm volatile("s_mov_b64 %6, exec\n\ts_and_b64 exec, exec, %10\n\t"
-                     "global_load_dwordx4 %0, %7, %9\n\tglobal_load_dwordx4 %1, %7, %9 offset:64\n\tglobal_load_dwordx4 %2, %7, %9 offset:128\n\t"
-                     "global_load_dwordx4 %3, %8, %9\n\tglobal_load_dwordx4 %4, %8, %9 offset:64\n\tglobal_load_dwordx4 %5, %8, %9 offset:128\n\t"
-                     "s_mov_b64 exec, %6"
-                     : "=&v"(r[0][0]), "=&v"(r[0][1]), "=&v"(r[0][2]), "=&v"(r[1][0]), "=&v"(r[1][1]), "=&v"(r[1][2]), "=&s"(sv)
-                     : "v"(off[0]), "v"(off[1]), "s"(base), "s"(mask) : "scc", "memory");
-    }
-#endif
-}
-// wait until at most N vector-memory loads are outstanding; `r` passes through the block so that its readers stay behind the wait
-template <int N, int U>
-__device__ __forceinline__ void wait_loads(u32x4 (&r)[2][U]) {
-#ifndef DMVS_HOST_EMULATION
-    static_assert(N == 0 || N == 2 || N == 4 || N == 6, "wait_loads");
-    if constexpr (U == 1) {
-        if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0][0]), "+v"(r[1][0]));
-        else asm volatile("s_waitcnt vmcnt(2)" : "+v"(r[0][0]), "+v"(r[1][0]));
-    } else if constexpr (U == 2) {
-        if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[1][0]), "+v"(r[1][1]));
-        else asm volatile("s_waitcnt vmcnt(4)" : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[1][0]), "+v"(r[1][1]));
-    } else {
-        if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[0][2]), "+v"(r[1][0]), "+v"(r[1][1]), "+v"(r[1][2]));
-        else asm volatile("s_waitcnt vmcnt(6)" : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[0][2]), "+v"(r[1][0]), "+v"(r[1][1]), "+v"(r[1][2]));
-    }
-#else
-    (void)r;
-#endif
-}
-
 // acc[k] += wscale * (bilinear sample of the lane's group dot at hypothesis k), k < NH, for one (pixel, view).
 // own[h] = hypothesis q + 4h of the pixel (q = lane & 3).  Texel (x, y) of the view is read at base + origin + (y * pitch + x) *
 // TEXEL_BYTES (32-bit wrapping arithmetic): global memory -- base + origin = the view's [Hs,Ws,C] NHWC-g4 image (+ the lane's
 // 16q bytes), pitch = Ws -- or a band of the view staged in LDS (base = the band, origin = lane bytes - the band's corner).
-template <int C, int FT, int NH, int TPT, typename P, bool PIPE = false>
+template <int C, int FT, int NH, int TPT, typename P>
 __device__ __forceinline__ void quad_accumulate(P base, unsigned view_off, int pitch, const HypQ (&own)[(NH + 3) / 4], int Hs, int Ws,
                                                 const float (&ref)[C / 4], float wscale, float (&acc)[NH]) {
     constexpr int HPL = (NH + 3) / 4, TB = Feat<C, FT>::TEXEL_BYTES;
@@ -410,22 +334,28 @@ __device__ __forceinline__ void quad_accumulate(P base, unsigned view_off, int p
 #else
         const unsigned texel_off = view_off + (unsigned)(__mul24(ymin, pitch) + xmin) * (unsigned)TB;    // of grid cell (0, 0)
 #endif
-        // rows 0..3 of the grid (mlo), then -- rarely non-empty -- rows 4..7 (mhi): 32-bit bit scans.
-        // The texel loop is SOFTWARE-PIPELINED (DMVS_QUAD_PIPE, round 4): the loads of trip i+1 are issued before the arithmetic of
-        // trip i, into a second register set (the loop body is written out twice, A and B, so that the sets never move).  Measured
-        // before (profiles/r4_getcost_diag_b96.jsonl): the kernel is bound neither by its scattered lines (every address made
-        // coalesced: -7 %) nor by the hat weights + scatter (removed: -9 %) nor by the bytes (halved: -10 %) but by the dependent
-        // chain of a wave -- scan -> load -> wait -> ~95 instructions -> scan -> ... -- with 5-7 waves per SIMD to hide it: waves sat
-        // in s_waitcnt 64 % of their cycles (profiles/r4_pmc_getcost_quad_b96.txt).  Same texels, same order of accumulation: same bits.
-        auto scan = [&](unsigned& m, int (&bit)[TPT], bool (&has)[TPT]) {
+        // rows 0..3 of the grid (mlo), then -- rarely non-empty -- rows 4..7 (mhi): 32-bit bit scans
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+        unsigned m = half ? mhi : mlo;
+        const int rbase = half * 4;
+        // Round 4, measured and removed: a software-pipelined form of this loop (the next trip's loads issued before this trip's
+        // arithmetic, into a second register set; exec-masked asm loads and hand-placed vmcnt, because hipcc's wait-count insertion
+        // merges the two paths of a per-lane `if` to vmcnt(0)).  121 instead of 75 VGPRs (4 instead of 6 waves per SIMD) and ~15 % more
+        // instructions: 633 vs 560 us per B=96 launch on noise geometry, slower on every geometry and batch
+        // (profiles/r4_getcost_pipelined_ab_b96.jsonl).  The kernel is not waiting on any single load chain; DESIGN.md 3.1.
+        while (m != 0u) {
+            // TPT texels per trip (their loads in flight together); a pixel that runs out repeats its last texel with weight 0
+            int bit[TPT];
+            bool has[TPT];
 #pragma unroll
             for (int i = 0; i < TPT; ++i) {
                 has[i] = m != 0u;
                 bit[i] = (i == 0 || has[i]) ? __ffs((int)m) - 1 : bit[i > 0 ? i - 1 : 0];
                 m &= m - 1u;
             }
-        };
-        auto issue = [&](const int (&bit)[TPT], int rbase, Feat<C, FT> (&t)[TPT], float (&fc)[TPT], float (&fr)[TPT]) {
+            Feat<C, FT> t[TPT];
+            float fc[TPT], fr[TPT];
 #pragma unroll
             for (int i = 0; i < TPT; ++i) {
                 const int c = bit[i] & 7, r = (bit[i] >> 3) + rbase;
@@ -438,8 +368,9 @@ __device__ __forceinline__ void quad_accumulate(P base, unsigned view_off, int p
                 fc[i] = (float)c;
                 fr[i] = (float)r;
             }
-        };
-        auto consume = [&](const Feat<C, FT> (&t)[TPT], const bool (&has)[TPT], const float (&fc)[TPT], const float (&fr)[TPT]) {
+            // every load of the trip is issued before anything waits on one: without this fence the scheduler, chasing one
+            // more wave of occupancy, re-uses one texel's registers and serialises load -> wait -> FMAs per texel
+            __builtin_amdgcn_sched_barrier(0);
             float dd[TPT], w[TPT][HPL];
             dot_texels<C, FT, TPT>(t, ref, dd);
 #if DMVS_GC_EXP == 2
@@ -449,7 +380,6 @@ __device__ __forceinline__ void quad_accumulate(P base, unsigned view_off, int p
 #else
 #pragma unroll
             for (int i = 0; i < TPT; ++i) {
-                // (a select, not a multiplication by 0: a lane that sits a trip out may hold anything in its texel registers)
                 dd[i] = has[i] ? dd[i] * wscale : 0.0f;
 #pragma unroll
                 for (int h = 0; h < HPL; ++h) w[i][h] = hat(ur[h], fc[i]) * hat(vr[h], fr[i]);
@@ -457,104 +387,6 @@ __device__ __forceinline__ void quad_accumulate(P base, unsigned view_off, int p
 #pragma unroll
             for (int i = 0; i < TPT; i += 2) scatter_pair<NH, HPL>(acc, w[i], dd[i], w[i + 1], dd[i + 1]);
 #endif
-        };
-        auto addresses = [&](const int (&bit)[TPT], int rbase, unsigned (&off)[TPT], float (&fc)[TPT], float (&fr)[TPT]) {
-#pragma unroll
-            for (int i = 0; i < TPT; ++i) {
-                const int c = bit[i] & 7, r = (bit[i] >> 3) + rbase;
-#if DMVS_GC_EXP == 1
-                off[i] = mad_u24(mad_u24((unsigned)r, (unsigned)pitch, (unsigned)(c & 1)), (unsigned)TB, texel_off);
-#else
-                off[i] = mad_u24(mad_u24((unsigned)r, (unsigned)pitch, (unsigned)c), (unsigned)TB, texel_off);
-#endif
-                fc[i] = (float)c;
-                fr[i] = (float)r;
-            }
-        };
-        auto consume_regs = [&](const u32x4 (&r)[TPT][C / 16], const bool (&has)[TPT], const float (&fc)[TPT], const float (&fr)[TPT]) {
-            Feat<C, FT> t[TPT];
-            if constexpr (FT == DMVS_DTYPE_F32) {
-#pragma unroll
-                for (int i = 0; i < TPT; ++i)
-#pragma unroll
-                    for (int j = 0; j < C / 16; ++j) {
-                        t[i].w[4 * j] = r[i][j][0]; t[i].w[4 * j + 1] = r[i][j][1]; t[i].w[4 * j + 2] = r[i][j][2]; t[i].w[4 * j + 3] = r[i][j][3];
-                    }
-            }
-            consume(t, has, fc, fr);
-        };
-        // the pipelined form: fp32 texels from global memory in the GetCost kernels (template PIPE); texels in an LDS band (ds_read
-        // latency is short next to the ~95 instructions of a trip; the band kernel's global fall-back shares its registers with the
-        // band path) and 16-bit features keep the plain loop
-        constexpr bool kPipe = PIPE && DMVS_QUAD_PIPE && FT == DMVS_DTYPE_F32 && std::is_same<P, const char*>::value && TPT == 2;
-#pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
-        unsigned m = half ? mhi : mlo;
-        const int rbase = half * 4;
-        if constexpr (kPipe) {
-            // Wave-uniform control flow on purpose: the trip count is the wave's maximum, a lane without a texel in a trip runs it
-            // with its loads masked off and zero weights (dd is SELECTED to 0, so whatever its registers hold never reaches acc).
-            // Per-lane branches here make hipcc's structurizer carry both register sets through phi copies (~50 v_mov per trip).
-            if (quad_ballot(m != 0u) != 0ull) {
-                constexpr int U = C / 16;              // 16-byte loads per texel and lane
-#ifndef DMVS_HOST_EMULATION
-                // the view weight is a load the COMPILER tracks: make it wait for it here, once, not at its first use inside the loop
-                // (a compiler-placed vmcnt(0) in the loop body would drain the pipelined loads on every trip)
-                asm volatile("" : "+v"(wscale));
-#endif
-                int bitA[TPT], bitB[TPT];
-                bool hasA[TPT], hasB[TPT];
-                float fcA[TPT], frA[TPT], fcB[TPT], frB[TPT];
-                u32x4 rA[TPT][U], rB[TPT][U];
-                unsigned offA[TPT], offB[TPT];
-                const unsigned long long mask0 = quad_ballot(m != 0u);
-                scan(m, bitA, hasA);
-                addresses(bitA, rbase, offA, fcA, frA);
-                load_pair_masked<U>(base, offA, mask0, rA);
-                // straight-line loop body (no diamond around the loads: hipcc would carry both register sets through copies at the
-                // merge); the trip still in flight when the masks run out is finished after the loop
-                bool pendA = true;                     // wave-uniform: which register set the last trip is in
-                for (;;) {
-                    const unsigned long long maskB = quad_ballot(m != 0u);
-                    if (maskB == 0ull) break;
-                    scan(m, bitB, hasB);
-                    addresses(bitB, rbase, offB, fcB, frB);
-                    load_pair_masked<U>(base, offB, maskB, rB);
-                    wait_loads<TPT * U, U>(rA);        // trip A complete; trip B (the newest TPT * U loads) may still be in flight
-                    consume_regs(rA, hasA, fcA, frA);
-                    const unsigned long long maskA = quad_ballot(m != 0u);
-                    if (maskA == 0ull) {
-                        pendA = false;
-                        break;
-                    }
-                    scan(m, bitA, hasA);
-                    addresses(bitA, rbase, offA, fcA, frA);
-                    load_pair_masked<U>(base, offA, maskA, rA);
-                    wait_loads<TPT * U, U>(rB);
-                    consume_regs(rB, hasB, fcB, frB);
-                }
-                if (pendA) {
-                    wait_loads<0, U>(rA);
-                    consume_regs(rA, hasA, fcA, frA);
-                } else {
-                    wait_loads<0, U>(rB);
-                    consume_regs(rB, hasB, fcB, frB);
-                }
-            }
-        } else {
-        while (m != 0u) {
-            // TPT texels per trip (their loads in flight together); a pixel that runs out repeats its last texel with weight 0
-            int bit[TPT];
-            bool has[TPT];
-            scan(m, bit, has);
-            Feat<C, FT> t[TPT];
-            float fc[TPT], fr[TPT];
-            issue(bit, rbase, t, fc, fr);
-            // every load of the trip is issued before anything waits on one: without this fence the scheduler, chasing one
-            // more wave of occupancy, re-uses one texel's registers and serialises load -> wait -> FMAs per texel
-            __builtin_amdgcn_sched_barrier(0);
-            consume(t, has, fc, fr);
-        }
         }
         }
     }
@@ -562,7 +394,7 @@ __device__ __forceinline__ void quad_accumulate(P base, unsigned view_off, int p
 
 // ------------------------------------------------------------------------------------------ GetCost
 template <int C, int N, int TPT, int FT>
-__global__ void __launch_bounds__(DMVS_BLOCK, DMVS_GC_MIN_WAVES) getcost_quad_kernel(const dmvs_getcost_desc d) {
+__global__ void __launch_bounds__(DMVS_BLOCK) getcost_quad_kernel(const dmvs_getcost_desc d) {
     constexpr int HPL = (N + 3) / 4, PPB = DMVS_BLOCK / 4;
     const int q = threadIdx.x & 3;
     const int H = d.H, W = d.W;
@@ -620,9 +452,9 @@ __global__ void __launch_bounds__(DMVS_BLOCK, DMVS_GC_MIN_WAVES) getcost_quad_ke
         // the view's image: a 64-bit workgroup-uniform (scalar) base, 32-bit offsets inside the view
         const char* vbase = base + ((long)s * d.B + b) * (long)hw * Feat<C, FT>::TEXEL_BYTES;
 #if DMVS_GC_EXP == 1
-        quad_accumulate<C, FT, N, TPT, const char*, true>(vbase, Feat<C, FT>::lane_bytes(q) + (unsigned)min(yx, hw - 2) * (unsigned)Feat<C, FT>::TEXEL_BYTES, 0, own, H, W, ref, w, acc);
+        quad_accumulate<C, FT, N, TPT>(vbase, Feat<C, FT>::lane_bytes(q) + (unsigned)min(yx, hw - 2) * (unsigned)Feat<C, FT>::TEXEL_BYTES, 0, own, H, W, ref, w, acc);
 #else
-        quad_accumulate<C, FT, N, TPT, const char*, true>(vbase, Feat<C, FT>::lane_bytes(q), W, own, H, W, ref, w, acc);
+        quad_accumulate<C, FT, N, TPT>(vbase, Feat<C, FT>::lane_bytes(q), W, own, H, W, ref, w, acc);
 #endif
     }
     if (live) {
@@ -901,23 +733,15 @@ static int launch_warp_init_band(const void* ref, const void* src, const float* 
     return dmvs_launch_status();
 }
 
-// DMVS_PLANE_SWEEP=quad: the round-2 kernel (every texel from global memory / L1) for A/B runs; default: the LDS-band kernel
-static bool plane_sweep_band() {
-    static const bool band = [] {
-        const char* e = getenv("DMVS_PLANE_SWEEP");
-        return !(e && e[0] == 'q');
-    }();
-    return band;
-}
-
 extern "C" int dmvs_warp_corr_init_quad_f32(const void* ref, const void* src, const float* rt, const float* disp_min,
                                             const float* disp_max, float* out, int32_t B, int32_t S, int32_t C, int32_t G,
-                                            int32_t D, int32_t H, int32_t W, int32_t Hs, int32_t Ws, int32_t feat_dtype, void* stream) {
+                                            int32_t D, int32_t H, int32_t W, int32_t Hs, int32_t Ws, int32_t feat_dtype, int32_t tune,
+                                            void* stream) {
     if (G != 4 || D < 2 || !ref || !src || !rt || !out) return DMVS_EINVAL;
     if (feat_dtype < DMVS_DTYPE_F32 || feat_dtype > DMVS_DTYPE_F16) return DMVS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if ((long)H * W >= (1L << 24) || (long)Hs * Ws >= (1L << 24) || (long)B * S > 65535) return DMVS_EINVAL;
-    if (plane_sweep_band()) {
+    if (!(tune & DMVS_TUNE_SWEEP_GLOBAL)) {      // default: the LDS-band kernel; the flag: the round-2 kernel (every texel from global memory / L1), A/B runs
         if (feat_dtype == DMVS_DTYPE_BF16) return launch_warp_init_band<DMVS_DTYPE_BF16>(ref, src, rt, disp_min, disp_max, out, B, S, C, D, H, W, Hs, Ws, st);
         if (feat_dtype == DMVS_DTYPE_F16) return launch_warp_init_band<DMVS_DTYPE_F16>(ref, src, rt, disp_min, disp_max, out, B, S, C, D, H, W, Hs, Ws, st);
         return launch_warp_init_band<DMVS_DTYPE_F32>(ref, src, rt, disp_min, disp_max, out, B, S, C, D, H, W, Hs, Ws, st);

@@ -62,12 +62,7 @@ def run_feature(o: Ops, f, x, layout=K.LAYOUT_NHWC, feat_dtype=torch.float32):
     R = K.ACT_RELU
     c0 = o.featurenet_stem(f["conv0.0"], f["conv0.1"], x)      # conv0.0 + conv0.1 fused: the 8-channel intermediate stays in LDS
     c1 = o.conv2d(f["conv1.0"], c0, act=R)
-    if os.environ.get("DMVS_FEAT_PAIR", "0") == "1":
-        # conv1.1 + conv1.2 fused, the 16-channel intermediate in LDS: half the HBM traffic of the pair and bit-identical, but
-        # measured SLOWER (5.52 ms against 2 x 2.5 at N = 576: these layers are not bound by memory) -- opt-in
-        c1 = o.conv3x3_pair16(f["conv1.1"], f["conv1.2"], c1)
-    else:
-        c1 = o.conv2d(f["conv1.2"], o.conv2d(f["conv1.1"], c1, act=R), act=R)
+    c1 = o.conv2d(f["conv1.2"], o.conv2d(f["conv1.1"], c1, act=R), act=R)
     c2 = o.conv2d(f["conv2.2"], o.conv2d(f["conv2.1"], o.conv2d(f["conv2.0"], c1, act=R), act=R), act=R)
     c3 = o.conv2d(f["conv3.2"], o.conv2d(f["conv3.1"], o.conv2d(f["conv3.0"], c2, act=R), act=R), act=R)
     out = {"stage1": o.conv2d(f["out1"], c3, out_layout=layout, out_dtype=feat_dtype)}
@@ -409,7 +404,7 @@ class Engine:
         # feature storage precision: args.precision / DMVS_PRECISION in {"fp32", "bf16", "fp16"} (BASELINE.json configs[2] /
         # [4]).  The image features FeatureNet hands to the warp kernels are stored in 16 bits (half the bytes of the path's
         # dominant gather traffic); projection, hypotheses, correlation, every convolution and all accumulators stay fp32
-        prec = os.environ.get("DMVS_PRECISION") or getattr(args, "precision", "fp32") or "fp32"
+        prec = getattr(args, "precision", None) or os.environ.get("DMVS_PRECISION") or "fp32"      # an explicit args value wins
         if prec not in K.FEATURE_DTYPES:
             raise K._lib.DmvsError(f"precision '{prec}': expected one of {sorted(K.FEATURE_DTYPES)}")
         self.precision, self.feat_dtype = prec, K.FEATURE_DTYPES[prec]
@@ -418,7 +413,7 @@ class Engine:
         # accumulation; tensors in memory, the FeatureNet stem, the 1x1 layers, the channel-last feature outputs, the 3-D
         # convolutions, the warps and every epilogue stay fp32) -- the arithmetic of BASELINE.json's bf16 configuration.  The
         # reference's eps switch for non-fp32 activations (update.py:87,102) does not apply: activations are fp32 here.
-        arith = os.environ.get("DMVS_CONV_ARITH") or getattr(args, "conv_arith", "fp32") or "fp32"
+        arith = getattr(args, "conv_arith", None) or os.environ.get("DMVS_CONV_ARITH") or "fp32"   # an explicit args value wins
         if arith not in K.CONV_ARITH:
             raise K._lib.DmvsError(f"conv_arith '{arith}': expected one of {sorted(K.CONV_ARITH)}")
         self.conv_arith = arith

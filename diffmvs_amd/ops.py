@@ -141,10 +141,29 @@ def bump_weights_generation() -> None:
     _weights_generation[0] += 1
 
 
+def _env_tune():
+    """A/B knobs of the kernels' `tune` arguments (include/dmvs.h), read ONCE per binding in the Python layer -- the C library
+    itself reads no environment variable.  All default to 0 = the library's measured-best path:
+      DMVS_CONV_WX=1|2, DMVS_CONV_MT=1|2|4, DMVS_CONV_WALK=0, DMVS_CONV_LEAN=0, DMVS_CONV_V16=0, DMVS_CONV1X1_WIDE=1   (dmvs_conv2d_desc.tune)
+      DMVS_CONV3D_V16=0, DMVS_CONV3D_S2=direct   (dmvs_conv3d_desc.tune)      DMVS_STEM_V16=0      DMVS_PLANE_SWEEP=quad"""
+    e = os.environ.get
+    t2 = _lib.tune_tile_wx(int(e("DMVS_CONV_WX", "0"))) | _lib.tune_tile_mt(int(e("DMVS_CONV_MT", "0")))
+    t2 |= _lib.TUNE_NO_WALK if e("DMVS_CONV_WALK") == "0" else 0
+    t2 |= _lib.TUNE_PIECES4 if e("DMVS_CONV_V16") == "0" else 0
+    t2 |= _lib.TUNE_1X1_WIDE if e("DMVS_CONV1X1_WIDE") == "1" else 0
+    t2 |= _lib.TUNE_NO_LEAN if e("DMVS_CONV_LEAN") == "0" else 0
+    t3 = (_lib.TUNE3D_PIECES4 if e("DMVS_CONV3D_V16") == "0" else 0) | (_lib.TUNE3D_S2_DIRECT if e("DMVS_CONV3D_S2") == "direct" else 0)
+    return {"conv2d": t2, "conv3d": t3, "stem": _lib.TUNE_PIECES4 if e("DMVS_STEM_V16") == "0" else 0,
+            "sweep": _lib.TUNE_SWEEP_GLOBAL if e("DMVS_PLANE_SWEEP") == "quad" else 0}
+
+
 class Ops:
+    _bindings = {}      # (library path, device) -> the one Ops of the process for it (for_device)
+
     def __init__(self, lib: _lib.Lib, device):
         self.lib = lib
         self.device = torch.device(device)
+        self.tune = _env_tune()
         # optional per-entry-point HIP-event timing on the launch stream (bench.py roofline leg):
         # {"dmvs_getcost_f32": [(start_event, end_event), ...]}
         self.timers = None
@@ -178,7 +197,16 @@ class Ops:
             raise _lib.DmvsError(
                 f"diffmvs_amd runs on MI355X only (got device '{device}'); there is no CPU path. "
                 "Move the model and inputs to a HIP device.")
-        return cls(_lib.hip_lib(), device)
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        lib = _lib.hip_lib()
+        # ONE binding per (library, device): the engine, the training forward and the Trainer then share its per-binding state
+        # (timers, conv_arith, the GetCost path probe) instead of each building a throw-away Ops per call
+        key = (lib.path, device.index)
+        o = cls._bindings.get(key)
+        if o is None:
+            o = cls._bindings[key] = cls(lib, device)
+        return o
 
     # ------------------------------------------------------------------ plumbing
     def stream(self):
@@ -209,7 +237,7 @@ class Ops:
     def conv2d(self, pc: PackedConv, x0, x1=None, *, mul0=None, in_mode=IN_PLAIN, act=ACT_NONE, residual=None,
                res_mode=IN_PLAIN, res_after_act=False, post_scale=1.0, gru_z=None, gru_h=None, out=None,
                out_layout=LAYOUT_NCHW, out_cstride=None, out_coffset=0, gn_stats=None, gn_groups=4, out_dtype=torch.float32,
-               gate_cstride=0, arith=None):
+               gate_cstride=0, arith=None, tune=None):
         """gn_stats: zeroed float64 [B*gn_groups*2] tensor that receives the GroupNorm statistics of
         the (pre-activation) output, for a following groupnorm_apply().  out_dtype (channel-last outputs only): bf16 / fp16
         feature storage, rounded to nearest even in the epilogue.  arith: ARITH_F32 | ARITH_BF16 (default: this binding's
@@ -255,14 +283,14 @@ class Ops:
             kh=kh, kw=kw, stride=pc.stride, pad_h=pc.pad[0], pad_w=pc.pad[1], in_mode=in_mode, act=act,
             res_mode=res_mode, res_after_act=int(res_after_act), out_layout=out_layout, out_cstride=out_cstride,
             out_coffset=out_coffset, post_scale=post_scale, gate_cstride=gate_cstride,
-            arith=(self.conv_arith if arith is None else arith))
+            arith=(self.conv_arith if arith is None else arith), tune=(self.tune["conv2d"] if tune is None else tune))
         self._call("dmvs_conv2d_f32", C.byref(d), self.stream())
         if self.timers is not None and "dmvs_conv2d_f32" in self.timers:      # bench: MFMA roofline over every conv launch
             self.timers.setdefault("_conv2d_flops", []).append(2.0 * B * Hout * Wout * pc.cout * pc.cin * kh * kw)
             self.timers.setdefault("_conv2d_shape", []).append((B, pc.cin, pc.cout, kh, kw, pc.stride, Hout, Wout, in_mode, int(mul0 is not None)))
         return out
 
-    def featurenet_stem(self, pc0: PackedConv, pc1: PackedConv, x):
+    def featurenet_stem(self, pc0: PackedConv, pc1: PackedConv, x, tune=None):
         """relu(bn(conv0.1(relu(bn(conv0.0(x)))))) of FeatureNet in one kernel: x [N,3,H,W] -> [N,8,H,W].
         x may be a LIST of V tensors [B,3,H,W] (the views of a batch): one launch per view into consecutive slices of one
         [V*B,8,H,W] output -- the view stack is never concatenated"""
@@ -271,36 +299,22 @@ class Ops:
             Bv, cin, H, W = x[0].shape
             y = self.empty(len(x) * Bv, 8, H, W)
             for v, xv in enumerate(x):
-                self._stem_launch(pc0, pc1, xv, y[v * Bv:(v + 1) * Bv])
+                self._stem_launch(pc0, pc1, xv, y[v * Bv:(v + 1) * Bv], tune)
             return y
         self._chk(x)
         N, cin, H, W = x.shape
         y = self.empty(N, 8, H, W)
-        self._stem_launch(pc0, pc1, x, y)
+        self._stem_launch(pc0, pc1, x, y, tune)
         return y
 
-    def _stem_launch(self, pc0: PackedConv, pc1: PackedConv, x, y):
+    def _stem_launch(self, pc0: PackedConv, pc1: PackedConv, x, y, tune=None):
         N, cin, H, W = x.shape
         if not (cin == 3 and pc0.cin == 3 and pc0.cout == 8 and pc1.cin == 8 and pc1.cout == 8 and pc0.k == (3, 3) and
                 pc1.k == (3, 3) and pc0.stride == 1 and pc1.stride == 1 and pc0.pad == (1, 1) and pc1.pad == (1, 1) and
                 pc0.cout_pad == 8 and pc1.cout_pad == 8):
             raise _lib.DmvsError("featurenet_stem: expects the 3->8->8 3x3 stem of FeatureNet")
         self._call("dmvs_featurenet_stem_f32", _ptr(x), _ptr(pc0.weight), _ptr(pc0.scale), _ptr(pc0.shift), _ptr(pc1.weight),
-                   _ptr(pc1.scale), _ptr(pc1.shift), _ptr(y), N, H, W, self.stream())
-
-    def conv3x3_pair16(self, pca: PackedConv, pcb: PackedConv, x):
-        """relu(bn(conv_b(relu(bn(conv_a(x)))))) for two 16 -> 16 channel 3x3 layers in one kernel (FeatureNet conv1.1 + conv1.2):
-        x [N,16,H,W] -> [N,16,H,W]; the intermediate stays in LDS"""
-        self._chk(x)
-        N, cin, H, W = x.shape
-        for pc in (pca, pcb):
-            if not (cin == 16 and pc.cin == 16 and pc.cout == 16 and pc.cout_pad == 16 and pc.k == (3, 3) and pc.stride == 1 and
-                    pc.pad == (1, 1)):
-                raise _lib.DmvsError("conv3x3_pair16: expects two 16->16 3x3 stride-1 layers")
-        y = self.empty(N, 16, H, W)
-        self._call("dmvs_conv3x3_pair16_f32", _ptr(x), _ptr(pca.weight), _ptr(pca.scale), _ptr(pca.shift), _ptr(pcb.weight),
-                   _ptr(pcb.scale), _ptr(pcb.shift), _ptr(y), N, H, W, self.stream())
-        return y
+                   _ptr(pc1.scale), _ptr(pc1.shift), _ptr(y), N, H, W, self.tune["stem"] if tune is None else tune, self.stream())
 
     def conv2d_wgrad(self, pc: PackedConv, x0, grad_out, x1=None, *, mul0=None, in_mode=IN_PLAIN, want_bias=False):
         """Weight gradient of conv2d(pc, x0, x1, mul0=..., in_mode=...) in torch layout [cout, cin, kh, kw]
@@ -331,7 +345,7 @@ class Ops:
         return (gw, gb) if want_bias else gw
 
     # ------------------------------------------------------------------ conv3d
-    def conv3d(self, pc: PackedConv, x, *, act=ACT_NONE, residual=None, out=None):
+    def conv3d(self, pc: PackedConv, x, *, act=ACT_NONE, residual=None, out=None, tune=None):
         self._chk(x, residual, out)
         B, cin, Din, Hin, Win = x.shape
         assert cin == pc.cin
@@ -345,7 +359,7 @@ class Ops:
         d = _lib.Conv3dDesc(in_=_ptr(x), weight=_ptr(pc.weight), scale=_ptr(pc.scale), shift=_ptr(pc.shift),
                             residual=_ptr(residual), out=_ptr(out), B=B, cin=cin, cout=pc.cout, cout_pad=pc.cout_pad,
                             Din=Din, Hin=Hin, Win=Win, Dout=Dout, Hout=Hout, Wout=Wout, stride=pc.stride,
-                            transposed=int(pc.transposed), act=act)
+                            transposed=int(pc.transposed), act=act, tune=(self.tune["conv3d"] if tune is None else tune))
         self._call("dmvs_conv3d_f32", C.byref(d), self.stream())
         return out
 
@@ -384,7 +398,7 @@ class Ops:
                    _ptr(disp_min), _ptr(disp_max), _ptr(out), B, S, Cc, G, D, H, W, Hs, Ws, self.stream())
         return out
 
-    def warp_corr_init_quad(self, ref, src, rt, disp_min, disp_max, D, G=4):
+    def warp_corr_init_quad(self, ref, src, rt, disp_min, disp_max, D, G=4, tune=None):
         """quad-per-pixel plane sweep: ref [B,H,W,C], src [S,B,Hs,Ws,C] in the NHWC-g4 channel order (fp32) or plain NHWC
         (bf16 / fp16 feature storage) -> [B,S,G,D,H,W] fp32"""
         self._chk(rt, disp_min, disp_max)
@@ -393,7 +407,7 @@ class Ops:
         S, _, Hs, Ws, _ = src.shape
         out = self.empty(B, S, G, D, H, W)
         self._call("dmvs_warp_corr_init_quad_f32", _ptr(ref), _ptr(src), _ptr(rt), _ptr(disp_min), _ptr(disp_max), _ptr(out),
-                   B, S, Cc, G, D, H, W, Hs, Ws, fdt, self.stream())
+                   B, S, Cc, G, D, H, W, Hs, Ws, fdt, self.tune["sweep"] if tune is None else tune, self.stream())
         if self.timers is not None and "dmvs_warp_corr_init_quad_f32" in self.timers:
             self.timers.setdefault("_warp_init_bytes", []).append(B * H * W * (ref.element_size() * (Cc + S * Cc) + 4 * S * G * D))
         return out

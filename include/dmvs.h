@@ -8,7 +8,9 @@
  *
  * Conventions:
  *   - every pointer is a DEVICE pointer owned by the caller; nothing is allocated, freed or
- *     retained by the library; no global state  => re-entrant, graph-capturable;
+ *     retained by the library; no global state, no environment variables: every choice a caller can make is an argument
+ *     or a descriptor field (the `tune` fields: 0 = the measured-best path; the other values exist for A/B measurements
+ *     and for tests that pin a code path)  => re-entrant, graph-capturable;
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing syncs;
  *   - the return value is 0 on success, a hipError_t otherwise, or DMVS_EINVAL for a
  *     descriptor the library cannot run (unsupported kernel size, channel tile, ...);
@@ -24,7 +26,11 @@
 extern "C" {
 #endif
 
-#define DMVS_ABI_VERSION 1
+/* 2 (round 4): dmvs_conv2d_desc gained `arith` (round 3, without a bump) and `tune`; dmvs_conv3d_desc gained `tune`;
+ * dmvs_featurenet_stem_f32 and dmvs_warp_corr_init_quad_f32 take a trailing `tune` argument; dmvs_conv3x3_pair16_f32 is gone;
+ * the library no longer reads any environment variable.  A caller built against version 1 passes shorter descriptors:
+ * check dmvs_abi_version() == DMVS_ABI_VERSION before the first call. */
+#define DMVS_ABI_VERSION 2
 #define DMVS_EINVAL (-22)
 
 /* activation codes for the fused epilogues */
@@ -65,6 +71,15 @@ int dmvs_abi_version(void);
 #define DMVS_ARITH_F32 0
 #define DMVS_ARITH_BF16 1
 
+/* dmvs_conv2d_desc.tune: 0 = the library's own choice (measured best on the MI355X); the bits force a code path for A/B runs.
+ * Results do not depend on them (bit-identical kernels), except DMVS_TUNE_1X1_WIDE whose summation order is the direct kernel's. */
+#define DMVS_TUNE_TILE_WX(n) ((n) & 3)           /* 1 | 2: 16- / 32-pixel-wide workgroup tiles for the 3x3 / 5x5 layers           */
+#define DMVS_TUNE_NO_WALK 0x4                     /* one tile per workgroup everywhere (no resident tile-walking workgroups)        */
+#define DMVS_TUNE_PIECES4 0x8                     /* input halo staged in 4-byte LDS-DMA pieces even where 16-byte ones apply        */
+#define DMVS_TUNE_TILE_MT(n) (((n) & 7) << 4)     /* 1 | 2 | 4: tile height in units of 4 rows                                       */
+#define DMVS_TUNE_1X1_WIDE 0x80                   /* direct (no LDS input tile) 1x1 kernel also for 2..9 output n-tiles              */
+#define DMVS_TUNE_NO_LEAN 0x100                   /* plain layers on the generic kernel (every fused path resolved at run time)     */
+
 typedef struct dmvs_conv2d_desc {
     const float* in0;       /* [B,c0,*,*] physical tensor                                   */
     const float* in1;       /* [B,c1,Hin,Win] or NULL; only with DMVS_IN_PLAIN               */
@@ -102,6 +117,7 @@ typedef struct dmvs_conv2d_desc {
                                BASELINE.json (configs[2], [4]); tensors in memory stay fp32.  Honoured by stride-1 layers with
                                more than one tap, >= 24 input channels and an NCHW output (where it is faster); every other
                                layer computes in fp32 in either mode.                                                     */
+    int32_t tune;           /* DMVS_TUNE_* bits, 0 = automatic                                                              */
 } dmvs_conv2d_desc;
 
 /* Size limits (DMVS_EINVAL beyond them; the kernels address one batch item with 32-bit element offsets):
@@ -113,16 +129,11 @@ int dmvs_conv2d_f32(const dmvs_conv2d_desc* d, void* stream);
  *   x [N,3,H,W], y [N,8,H,W] NCHW;  w0 [3][3][3][8], w1 [8][3][3][8] in the kernel weight layout of dmvs_conv2d_f32
  *   (cout_pad = 8); scale / shift [8] = folded eval BatchNorm (NULL = 1 / 0).  Agrees with the two dmvs_conv2d_f32
  *   launches it replaces to the last bits (different summation grouping of conv0.0's 27 products). */
+/* tune: 0 = automatic (input halo in 16-byte LDS-DMA pieces when W % 4 == 0 and x is 16-byte aligned: 1094 -> 938 us per 96
+ * images on the MI355X, profiles/r4_optins_ab.jsonl); DMVS_TUNE_PIECES4 = 4-byte pieces (bit-identical results). */
 int dmvs_featurenet_stem_f32(const float* x, const float* w0, const float* scale0, const float* shift0, const float* w1,
-                             const float* scale1, const float* shift1, float* y, int32_t N, int32_t H, int32_t W, void* stream);
-
-/* Two 16 -> 16 channel 3x3 convolutions, each followed by folded eval BatchNorm + ReLU, in one kernel:
- *   y = relu(bn_b(conv3x3_b(relu(bn_a(conv3x3_a(x))))))       FeatureNet conv1.1 + conv1.2 (models/module.py:368-371, :400)
- * x, y [N,16,H,W] NCHW, padding 1; wa, wb [16][9][16] in the kernel weight layout of dmvs_conv2d_f32 (cout_pad = 16); scale / shift
- * [16] (NULL = 1 / 0).  The 16-channel intermediate never leaves LDS: half the HBM traffic of the two dmvs_conv2d_f32 launches
- * it replaces, whose results it reproduces (same products, same summation order). */
-int dmvs_conv3x3_pair16_f32(const float* x, const float* wa, const float* scale_a, const float* shift_a, const float* wb,
-                            const float* scale_b, const float* shift_b, float* y, int32_t N, int32_t H, int32_t W, void* stream);
+                             const float* scale1, const float* shift1, float* y, int32_t N, int32_t H, int32_t W, int32_t tune,
+                             void* stream);
 
 /* Weight (and bias) gradient of the convolution described by `d` (its input side: in0 / in1 / mul0 / in_mode / kh /
  * kw / stride / pad / cout / cout_pad / B / Hin / Win / Hout / Wout; epilogue fields are ignored):
@@ -158,7 +169,11 @@ typedef struct dmvs_conv3d_desc {
     int32_t stride;         /* 1 or 2                                                       */
     int32_t transposed;     /* 0 | 1 (stride must be 2)                                     */
     int32_t act;
+    int32_t tune;           /* 0 = automatic; DMVS_TUNE3D_* bits force a code path (A/B runs; bit-identical results except
+                               DMVS_TUNE3D_S2_DIRECT, whose summation order is the direct kernel's)                        */
 } dmvs_conv3d_desc;
+#define DMVS_TUNE3D_PIECES4 0x1       /* stride-1 MFMA kernels: halo tile in 4-byte LDS-DMA pieces even where 16-byte ones apply  */
+#define DMVS_TUNE3D_S2_DIRECT 0x2     /* stride-2 layers on the direct (VALU) kernels of round 1 instead of the matrix cores      */
 
 /* Size limit of the stride-1 layers (DMVS_EINVAL beyond): cin * Din*Hin*Win < 2^31 and cout * Dout*Hout*Wout < 2^31
  * (one batch item is addressed with 32-bit element offsets). */
@@ -266,11 +281,14 @@ int dmvs_getcost_gather_f32(const dmvs_getcost_desc* d, void* stream);
  * Reduced-precision feature storage (BASELINE.json's bf16 / fp16 configurations): feat_dtype = DMVS_DTYPE_BF16 | _F16 reads ref /
  * src as 16-bit elements in PLAIN NHWC order (a group's C/4 channels are then contiguous already: 8 / 16 / 24 bytes per lane);
  * values are widened to fp32 on arrival, projection, hypotheses, correlation and accumulation stay fp32. */
+/* tune (plane sweep): 0 = the source band of a 16 x 4 pixel tile is staged in LDS (warp_init_band_kernel);
+ * DMVS_TUNE_SWEEP_GLOBAL = every texel from global memory (warp_init_quad_kernel, the round-2 form; bit-identical results). */
+#define DMVS_TUNE_SWEEP_GLOBAL 0x1
 int dmvs_getcost_quad_f32(const dmvs_getcost_desc* d, void* stream);
 int dmvs_warp_corr_init_quad_f32(const void* ref, const void* src, const float* rt,
                                  const float* disp_min, const float* disp_max, float* out,
                                  int32_t B, int32_t S, int32_t C, int32_t G, int32_t D,
-                                 int32_t H, int32_t W, int32_t Hs, int32_t Ws, int32_t feat_dtype, void* stream);
+                                 int32_t H, int32_t W, int32_t Hs, int32_t Ws, int32_t feat_dtype, int32_t tune, void* stream);
 
 /* Stand-alone differentiable_warping (models/module.py:181-218) in the reference's layouts:
  * src [B,C,Hs,Ws] NCHW, rt [B,12] (rot row-major, trans) = src_proj * inverse(ref_proj),

@@ -23,8 +23,7 @@ def build_emu(force=False):
         objs.append(o)
         procs.append(subprocess.Popen(
             ["g++", "-O2", "-std=c++17", "-fPIC", "-x", "c++", "-c", s, "-o", o,
-             "-I", HERE, "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wno-unknown-pragmas", "-Wno-attributes",
-             "-DDMVS_CONV_SKIP_PAD_PASS"]))      # conv2d_tiled.h: logic verified here (poisoned LDS) before the GPU build adopts it
+             "-I", HERE, "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wno-unknown-pragmas", "-Wno-attributes"]))
     for p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipemu compile failed")

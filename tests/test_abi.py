@@ -49,6 +49,24 @@ def test_descriptor_structs_match_header_field_order():
         assert got == fields, (cname, got, fields)
 
 
+def test_abi_version_pins_the_descriptor_sizes():
+    """a change of a descriptor's size or of an entry point's argument list must come with a DMVS_ABI_VERSION bump (ADVICE round 3:
+    `arith` was appended under version 1): the sizes and arities of version 2 are pinned here, header and binding alike"""
+    src = open(os.path.join(ROOT, "include", "dmvs.h")).read()
+    assert int(re.search(r"#define DMVS_ABI_VERSION (\d+)", src).group(1)) == _lib.ABI_VERSION == 2
+    assert (ctypes.sizeof(_lib.Conv2dDesc), ctypes.sizeof(_lib.Conv3dDesc), ctypes.sizeof(_lib.GetCostDesc)) == (192, 104, 152)
+    assert len(_lib.SIGNATURES["dmvs_featurenet_stem_f32"]) == 13 and len(_lib.SIGNATURES["dmvs_warp_corr_init_quad_f32"]) == 18
+    assert "dmvs_conv3x3_pair16_f32" not in _lib.SIGNATURES
+
+
+def test_library_reads_no_environment_variable():
+    """include/dmvs.h: no global state, no environment variables -- knobs are `tune` arguments, read from the environment (if at
+    all) by the Python layer"""
+    csrc = os.path.join(ROOT, "diffmvs_amd", "csrc")
+    for f in os.listdir(csrc):
+        assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+
+
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(_lib.DmvsError):
         _lib.Lib(str(tmp_path / "nope.so"))

@@ -164,12 +164,11 @@ def test_conv2d_16_byte_staging_pieces_fused_inputs(ops):
 
 
 @pytest.mark.parametrize("c0,cout,H,W,res", [(32, 64, 10, 16, "up"), (64, 144, 7, 8, None), (48, 32, 5, 44, "same"), (6, 36, 33, 36, None), (64, 96, 16, 64, "up")])
-def test_conv2d_1x1_direct_wide_variants(c0, cout, H, W, res, monkeypatch):
-    """the 2..9 n-tile instantiations of the direct 1x1 kernel, dispatched only under DMVS_CONV1X1_WIDE=1 (kept for tuning:
+def test_conv2d_1x1_direct_wide_variants(c0, cout, H, W, res):
+    """the 2..9 n-tile instantiations of the direct 1x1 kernel, dispatched only under tune = DMVS_TUNE_1X1_WIDE (kept for tuning:
     they are not faster than the tiled kernel yet) -- host-emulated"""
     from conftest import emu_ops
     ops = emu_ops()
-    monkeypatch.setenv("DMVS_CONV1X1_WIDE", "1")
     B = 2
     x = rnd(B, c0, H, W, seed=1)
     w, bias = rnd(cout, c0, 1, 1, seed=3) * 0.3, rnd(cout, seed=4)
@@ -181,7 +180,8 @@ def test_conv2d_1x1_direct_wide_variants(c0, cout, H, W, res, monkeypatch):
     elif res == "up":
         r = rnd(B, cout, H // 2, W // 2, seed=5)
         ref = ref + F.interpolate(r, scale_factor=2, mode="nearest")
-    out = ops.conv2d(K.pack_conv2d(w, bias), x, residual=r, res_mode=K.IN_UPSAMPLE2 if res == "up" else K.IN_PLAIN, act=K.ACT_RELU)
+    out = ops.conv2d(K.pack_conv2d(w, bias), x, residual=r, res_mode=K.IN_UPSAMPLE2 if res == "up" else K.IN_PLAIN, act=K.ACT_RELU,
+                     tune=K._lib.TUNE_1X1_WIDE)
     close(out, F.relu(ref), 2e-5)
 
 
@@ -715,24 +715,6 @@ def test_conv2d_tile_walking_workgroups(ops, cin, cout, k, stride, HW, with_res)
     close(out, ref, 2e-5)
 
 
-@pytest.mark.parametrize("N,H,W", [(2, 16, 16), (3, 37, 50), (1, 5, 7), (2, 64, 96)])
-def test_conv3x3_pair16(ops, N, H, W):
-    """FeatureNet conv1.1 + conv1.2 in one kernel (intermediate in LDS): against torch and BIT FOR BIT against the two
-    dmvs_conv2d_f32 launches it replaces; several tiles per workgroup, ragged tiles, images smaller than a tile"""
-    x = rnd(N, 16, H, W, seed=1)
-    ws = [rnd(16, 16, 3, 3, seed=2 + i) * 0.2 for i in range(2)]
-    bns = [{"weight": rnd(16, seed=4 + i, lo=0.5, hi=1.5), "bias": rnd(16, seed=6 + i), "running_mean": rnd(16, seed=8 + i),
-            "running_var": rnd(16, seed=10 + i, lo=0.5, hi=1.5)} for i in range(2)]
-    ref = x
-    for w, bn in zip(ws, bns):
-        ref = F.relu(F.batch_norm(F.conv2d(ref, w, None, 1, 1), bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"], False, 0.0, 1e-5))
-    pcs = [K.pack_conv2d(dev(ops, w), bn={k_: v.to(ops.device) for k_, v in bn.items()}, pad=1) for w, bn in zip(ws, bns)]
-    out = ops.conv3x3_pair16(pcs[0], pcs[1], dev(ops, x))
-    close(out, ref, 2e-5)
-    two = ops.conv2d(pcs[1], ops.conv2d(pcs[0], dev(ops, x), act=K.ACT_RELU), act=K.ACT_RELU)
-    assert torch.equal(out.cpu(), two.cpu())
-
-
 @pytest.mark.parametrize("bad", [float("nan"), float("inf"), 3.0e7])
 def test_groupnorm_stats_propagate_non_finite_and_out_of_range(ops, bad):
     """the fixed-point statistics slots (dmvs_common.h): a NaN / Inf activation -- or one beyond the documented magnitude
@@ -994,20 +976,18 @@ def test_featurenet_stem_fused(ops, N, H, W):
 
 
 @pytest.mark.parametrize("N,H,W", [(2, 37, 52), (1, 64, 96), (2, 9, 12)])
-def test_featurenet_stem_16_byte_pieces(N, H, W, monkeypatch):
-    """DMVS_STEM_V16=1 (experiment, not yet timed and not yet run on a GPU: host-emulated only, like the wide 1x1 variants): the
-    stem's input halo staged in 16-byte pieces, BIT FOR BIT the default kernel; several tiles per workgroup, all four borders"""
-    from conftest import emu_ops
-    ops = emu_ops()
-    x = rnd(N, 3, H, W, seed=1)
+def test_featurenet_stem_16_byte_pieces(ops, N, H, W):
+    """the stem's input halo staged in 16-byte pieces (the default wherever rows are 16-byte multiples: 1094 -> 938 us per 96 images on
+    the MI355X), BIT FOR BIT the 4-byte form (tune = DMVS_TUNE_PIECES4); several tiles per workgroup, all four borders"""
+    x = dev(ops, rnd(N, 3, H, W, seed=1))
     w0, w1 = rnd(8, 3, 3, 3, seed=2) * 0.4, rnd(8, 8, 3, 3, seed=3) * 0.3
-    pc0, pc1 = K.pack_conv2d(w0, rnd(8, seed=4), pad=1), K.pack_conv2d(w1, rnd(8, seed=5), pad=1)
-    a = ops.featurenet_stem(pc0, pc1, x)
-    monkeypatch.setenv("DMVS_STEM_V16", "1")
+    pc0, pc1 = K.pack_conv2d(*dev(ops, w0, rnd(8, seed=4)), pad=1), K.pack_conv2d(*dev(ops, w1, rnd(8, seed=5)), pad=1)
+    a = ops.featurenet_stem(pc0, pc1, x, tune=K._lib.TUNE_PIECES4)
     b = ops.featurenet_stem(pc0, pc1, x)
+    x = x.cpu()
     ref = F.relu(F.conv2d(F.relu(F.conv2d(x, w0, rnd(8, seed=4), 1, 1)), w1, rnd(8, seed=5), 1, 1))
     close(b, ref, 2e-5)
-    assert torch.equal(a, b)
+    assert torch.equal(a.cpu(), b.cpu())
 
 
 @pytest.mark.parametrize("cin,cout,with_res", [(4, 8, False), (3, 8, True)])
@@ -1031,17 +1011,17 @@ def test_conv3d_streamed_tiles(ops, cin, cout, with_res):
 @pytest.mark.parametrize("cin,cout,B,D,H,W", [(4, 8, 2, 23, 62, 100),      # pair kernel (4 -> 8, two depth slices per MFMA), >= 512 tiles
                                               (3, 16, 2, 23, 62, 100),     # streamed kernel (cin <= 4, one n-tile)
                                               (8, 8, 1, 9, 14, 36), (16, 16, 2, 6, 10, 20), (8, 32, 1, 5, 6, 44)])      # generic kernel, one / two n-tiles
-def test_conv3d_16_byte_halo_pieces(ops, monkeypatch, cin, cout, B, D, H, W):
-    """DMVS_CONV3D_V16=1 (experiment, not yet timed): the halo tile of the stride-1 MFMA kernels staged in 16-byte pieces -- against
-    torch and BIT FOR BIT against the default 4-byte form; ragged volumes, pieces outside the volume on every face"""
+def test_conv3d_16_byte_halo_pieces(ops, cin, cout, B, D, H, W):
+    """the halo tile of the stride-1 MFMA kernels staged in 16-byte pieces (the default wherever rows are 16-byte multiples: 2-6 %
+    per layer on the MI355X) -- against torch and BIT FOR BIT against the 4-byte form (tune = DMVS_TUNE3D_PIECES4); ragged volumes,
+    pieces outside the volume on every face"""
     x = rnd(B, cin, D, H, W, seed=1)
     w = rnd(cout, cin, 3, 3, 3, seed=2) * 0.2
     bias = rnd(cout, seed=3)
     res = rnd(B, cout, D, H, W, seed=4)
     ref = F.relu(F.conv3d(x, w, bias, 1, 1)) + res
     pc = K.pack_conv3d(*dev(ops, w, bias))
-    a = ops.conv3d(pc, dev(ops, x), act=K.ACT_RELU, residual=dev(ops, res))
-    monkeypatch.setenv("DMVS_CONV3D_V16", "1")
+    a = ops.conv3d(pc, dev(ops, x), act=K.ACT_RELU, residual=dev(ops, res), tune=K._lib.TUNE3D_PIECES4)
     b = ops.conv3d(pc, dev(ops, x), act=K.ACT_RELU, residual=dev(ops, res))
     close(b, ref, 2e-5)
     assert torch.equal(a.cpu(), b.cpu())

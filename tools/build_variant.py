@@ -1,9 +1,9 @@
 """Build a macro variant of the GPU library next to the default one, for A/B runs of compile-time experiments:
 
-    python tools/build_variant.py padskip -DDMVS_CONV_SKIP_PAD_PASS          # -> tools/calib/libdmvs_hip_padskip.so
+    python tools/build_variant.py nopipe -DDMVS_QUAD_PIPE=0 --only warp_quad.hip   # -> tools/calib/libdmvs_hip_nopipe.so
     python tools/build_variant.py kyrolled -DDMVS_CONV_KY_ROLLED
     python tools/build_variant.py gcexp1 -DDMVS_GC_EXP=1 --only warp_quad.hip     # one translation unit, the rest from build/obj
-    gpurun -- 'CONV_2D_ONLY=1 python tools/conv_bench.py > a.jsonl; CONV_2D_ONLY=1 CONV_LIB=tools/calib/libdmvs_hip_padskip.so python tools/conv_bench.py > b.jsonl'
+    gpurun -- 'CONV_2D_ONLY=1 python tools/conv_bench.py > a.jsonl; CONV_2D_ONLY=1 CONV_LIB=tools/calib/libdmvs_hip_kyrolled.so python tools/conv_bench.py > b.jsonl'
 
 Runs in the build container (hipcc cross-compiles gfx950); the .so is git-ignored and travels to the GPU box with the snapshot.
 The whole library is rebuilt with the extra flags (objects under build/variant_<name>/), the default library is not touched."""

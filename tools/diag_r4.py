@@ -60,9 +60,10 @@ def getcost_inputs(o, B, geometry, conf):
             0.25, 4.0, gi["vw_shift"])
 
 
-def getcost(B=96):
+def getcost(B=None):
+    B = B or int(os.environ.get("DIAG_B", "96"))
     base = Ops.for_device("cuda:0")
-    libs = [("product", None)] + [(n, os.path.join(ROOT, "tools", "calib", "libdmvs_hip_%s.so" % n)) for n in ("gcexp1", "gcexp2", "gcexp3")]
+    libs = [("product", None)] + [(n, os.path.join(ROOT, "tools", "calib", "libdmvs_hip_%s.so" % n)) for n in ("nopipe", "gcexp1", "gcexp2", "gcexp3")]
     alg = 4.0 * B * 128 * 160 * (32 + 5 * 32 + 6 + 5 + 24)
     for geometry, conf in (("noise", None), ("noise", "random"), ("scene", 0.5)):
         args = getcost_inputs(base, B, geometry, conf)
@@ -70,9 +71,13 @@ def getcost(B=96):
             if path is not None and not os.path.exists(path):
                 continue
             o = base if path is None else Ops(_lib.Lib(path), "cuda:0")
+            out = o.getcost_quad(*args)[0]
+            if name == "product":
+                ref_out = out.clone()
             us = timeit(lambda: o.getcost_quad(*args))
             print(json.dumps({"diag": "getcost", "B": B, "geometry": geometry, "conf": conf, "build": name, "us": round(us, 1),
-                              "frac_of_8TBs": round(alg / (us * 1e-6) / 8e12, 4)}), flush=True)
+                              "frac_of_8TBs": round(alg / (us * 1e-6) / 8e12, 4),
+                              "bit_identical_to_product": bool(torch.equal(out, ref_out)) if name in ("product", "nopipe") else None}), flush=True)
 
 
 def warp_init(B=96):
@@ -118,12 +123,10 @@ def optins():
     b0, b1 = torch.randn(8, generator=g, device="cuda"), torch.randn(8, generator=g, device="cuda")
     pc0, pc1 = K.pack_conv2d(w0, b0, pad=1), K.pack_conv2d(w1, b1, pad=1)
     ref = o.featurenet_stem(pc0, pc1, x)
-    for knob in ("0", "1"):
-        os.environ["DMVS_STEM_V16"] = knob
-        same = bool(torch.equal(ref, o.featurenet_stem(pc0, pc1, x)))
-        us = timeit(lambda: o.featurenet_stem(pc0, pc1, x), iters=10)
+    for knob, tune in (("0", _lib.TUNE_PIECES4), ("1", 0)):      # (round 4, first session: the knob was an environment variable of the library)
+        same = bool(torch.equal(ref, o.featurenet_stem(pc0, pc1, x, tune=tune)))
+        us = timeit(lambda: o.featurenet_stem(pc0, pc1, x, tune=tune), iters=10)
         print(json.dumps({"diag": "stem", "DMVS_STEM_V16": knob, "us_per_96_images": round(us, 1), "bit_identical": same}), flush=True)
-    os.environ.pop("DMVS_STEM_V16", None)
     del x, ref
     # 3-D MFMA kernels: PixelViewWeight conv0 (480 volumes), CostRegNet conv0 / conv1 (96 volumes), stride 1
     for name, N, cin, cout in (("pvw conv0 4->8 x480", 480, 4, 8), ("costreg conv0 4->8 x96", 96, 4, 8), ("costreg conv1 8->8 x96", 96, 8, 8),
@@ -132,14 +135,11 @@ def optins():
         v = torch.randn(N, cin, D, H, W, generator=g, device="cuda")
         w3 = torch.randn(cout, cin, 3, 3, 3, generator=g, device="cuda") * 0.2
         pc3 = K.pack_conv3d(w3, None)
-        os.environ.pop("DMVS_CONV3D_V16", None)
         r3 = o.conv3d(pc3, v, act=K.ACT_RELU)
-        for knob in ("0", "1"):
-            os.environ["DMVS_CONV3D_V16"] = knob
-            same = bool(torch.equal(r3, o.conv3d(pc3, v, act=K.ACT_RELU)))
-            us = timeit(lambda: o.conv3d(pc3, v, act=K.ACT_RELU), iters=10)
+        for knob, tune in (("0", _lib.TUNE3D_PIECES4), ("1", 0)):
+            same = bool(torch.equal(r3, o.conv3d(pc3, v, act=K.ACT_RELU, tune=tune)))
+            us = timeit(lambda: o.conv3d(pc3, v, act=K.ACT_RELU, tune=tune), iters=10)
             print(json.dumps({"diag": "conv3d", "layer": name, "DMVS_CONV3D_V16": knob, "us": round(us, 1), "bit_identical": same}), flush=True)
-        os.environ.pop("DMVS_CONV3D_V16", None)
         del v, r3
     # padding-pass skip (variant build) on the 16-channel layers it targets and two controls
     path = os.path.join(ROOT, "tools", "calib", "libdmvs_hip_padskip.so")
