@@ -9,7 +9,7 @@ views shard across GPUs with no data-path collective (inference is embarrassingl
 SURVEY section 8e) => weak scaling; value = all ranks' depth maps / max-over-ranks time.
 
 Also reported on the same JSON line:
-  roofline      the homography-warp kernel (getcost_win_kernel, launched stage_iters[1]=4 times per
+  roofline      the homography-warp kernel (getcost_quad_kernel, launched stage_iters[1]=4 times per
                 step): algorithmic bytes per launch (SURVEY section 8d formula) / mean launch
                 duration from HIP events recorded on the launch stream inside the timed region
   cpu_baseline  oracle/diffmvs_oracle.py (CPU restatement pinned to the reference) timed on this
@@ -41,8 +41,7 @@ def scene_geometry_getcost(ops, B, H, W, S, n, iters=20):
     """The GetCost kernel on the geometry a TRAINED network produces from its second GRU iteration on: hypotheses centred on the
     synthetic scene's true depth (sigma 0.01 of the normalised inverse-depth range), confidence 0.5.  The timed model above runs
     random-init weights, whose depth maps are noise (as is the first iteration of every diffusion stage of any network:
-    scale * randn, update.py:472).  Untimed side measurement, same stage-2 shapes; the round-1 per-pixel gather kernel on the
-    same inputs beside it."""
+    scale * randn, update.py:472).  Untimed side measurement, same stage-2 shapes."""
     from diffmvs_amd.ops import Ops, g4_channels
     o = Ops(ops.lib, ops.device)
     dev = ops.device
@@ -53,7 +52,7 @@ def scene_geometry_getcost(ops, B, H, W, S, n, iters=20):
     ref4, src4 = t["ref"][..., perm].contiguous(), t["src"][..., perm].contiguous()
     tail = (rt, t["inv"], t["conf"], t["view_w"], t["disp_min"], t["disp_max"], n, t["interval"], 0.25, 4.0, t["vw_shift"])
     out = {}
-    for name, fn in (("quad", lambda: o.getcost_quad(ref4, src4, *tail)), ("gather", lambda: o.getcost(t["ref"], t["src"], *tail, gather=True))):
+    for name, fn in (("quad", lambda: o.getcost_quad(ref4, src4, *tail)),):
         for _ in range(5):
             fn()
         torch.cuda.synchronize()
@@ -69,8 +68,7 @@ def scene_geometry_getcost(ops, B, H, W, S, n, iters=20):
     return {"kernel": "getcost_quad_kernel<32,6> (hypotheses around the scene's true depth, sigma 0.01, confidence 0.5)",
             "bound": "hbm", "achieved": round(alg / out["quad"] / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(alg / out["quad"] / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": alg,
-            "avg_launch_us": round(out["quad"] * 1e6, 2), "round1_gather_kernel_same_inputs_us": round(out["gather"] * 1e6, 2),
-            "round1_gather_kernel_frac": round(alg / out["gather"] / 1e9 / HBM_PEAK_GBS, 4)}
+            "avg_launch_us": round(out["quad"] * 1e6, 2)}
 
 
 def batch_sweep(model, make_batch, batches=(1, 2, 4, 8, 16, 32, 64), iters=6):
@@ -359,8 +357,7 @@ def main():
     with torch.no_grad():
         for _ in range(a.warmup):
             model(imgs, proj, dv)
-        eng.ops.timers = {"dmvs_getcost_f32": [], "dmvs_getcost_gather_f32": [], "dmvs_getcost_quad_f32": [],
-                          "dmvs_warp_corr_init_f32": [], "dmvs_warp_corr_init_quad_f32": []}
+        eng.ops.timers = {"dmvs_getcost_quad_f32": [], "dmvs_warp_corr_init_quad_f32": []}
         elapsed = timed_steps(lambda: model(imgs, proj, dv), a.steps, 0, barrier)
     timers, eng.ops.timers = eng.ops.timers, None
     elapsed = shard.barrier_and_max(elapsed, dev)      # whole-job time = slowest rank
@@ -388,15 +385,13 @@ def main():
         print("B cin cout kh kw s Hout Wout mode gated | launches  ms/step  TFLOP/s  frac", file=sys.stderr)
         for shp, (n, ms, fl) in sorted(by.items(), key=lambda kv: -kv[1][1]):
             print(*shp, "|", n, round(ms, 3), round(fl / ms / 1e9, 1), round(fl / ms / 1e9 / FP32_MFMA_PEAK_TFS, 3), file=sys.stderr)
-    gather_tiles = eng.ops.getcost_tiles or (None, None)      # last lazily read-back probe of the hybrid launch
-    scene = scene_geometry_getcost(eng.ops, B, H, W, S, args.CostNum[1]) if (rank == 0 and a.config == "cfg2" and eng.quad) else None
+    scene = scene_geometry_getcost(eng.ops, B, H, W, S, args.CostNum[1]) if (rank == 0 and a.config == "cfg2") else None
 
     sweep = batch_sweep(model, make_batch) if (rank == 0 and world == 1 and not a.no_batch_sweep and a.config == "cfg2") else None
     maps = B * a.steps * world
     value = maps / elapsed
-    gc_ms = [s.elapsed_time(e) for s, e in timers["dmvs_getcost_f32"] + timers["dmvs_getcost_gather_f32"] + timers["dmvs_getcost_quad_f32"]]
-    n_hybrid, n_plain, n_quad = len(timers["dmvs_getcost_f32"]), len(timers["dmvs_getcost_gather_f32"]), len(timers["dmvs_getcost_quad_f32"])
-    wi_ms = [s.elapsed_time(e) for s, e in timers["dmvs_warp_corr_init_f32"] + timers["dmvs_warp_corr_init_quad_f32"]]
+    gc_ms = [s.elapsed_time(e) for s, e in timers["dmvs_getcost_quad_f32"]]
+    wi_ms = [s.elapsed_time(e) for s, e in timers["dmvs_warp_corr_init_quad_f32"]]
     gc_avg_s = sum(gc_ms) / max(1, len(gc_ms)) * 1e-3
     # the launches of a step in order = the GRU iterations of the diffusion stage(s): iteration 1 samples around pure noise
     # (scale * randn, update.py:472), iterations 2.. around the network's own estimate
@@ -426,8 +421,8 @@ def main():
     # HBM traffic per getcost launch from the PMC passes (rocprofv3 cannot run inside the timed process); only
     # quoted when the committed measurement was taken at this batch size
     traffic, traffic_note = None, None
-    tj = os.path.join(ROOT, "profiles", "r3_getcost_traffic.json")
-    if eng.quad and os.path.exists(tj):
+    tj = os.path.join(ROOT, "profiles", "r4_getcost_traffic.json")
+    if os.path.exists(tj):
         with open(tj) as f:
             tinfo = json.load(f)
         if tinfo.get("kernel_source_sha") != kernel_source_hash():
@@ -446,19 +441,15 @@ def main():
                    "weights": "seeded random init (no checkpoint offline)",
                    "launch": "captured HIP graph of the forward" if a.graphs else "eager launch sequence (~350 kernels per step)"},
         "batch_sweep_ms_per_map": sweep,
-        "roofline": {"kernel": ("GetCost: getcost_quad_kernel<32,6> (quad per pixel, software-pipelined texel loop, one launch for any geometry)" if eng.quad else
-                                "GetCost: getcost_win_kernel<32,6> (LDS-staged source windows) / getcost_kernel<32,4,6> (per-pixel gather), picked per launch"),
+        "roofline": {"kernel": "GetCost: getcost_quad_kernel<32,6> (quad per pixel, one launch for any geometry)",
                      "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "traffic_source": traffic_note,
                      "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(gc_avg_s * 1e6, 2),
-                     "launches_timed": len(gc_ms), "per_gru_iteration": by_iter,
-                     "launches_quad": n_quad, "launches_hybrid": n_hybrid, "launches_plain_gather": n_plain,
-                     "tiles_on_gather_path": gather_tiles[0], "tiles_total": gather_tiles[1]},
-        "roofline_warp_init": {"kernel": (("warp_init_quad_kernel<48> (stage-1 plane sweep, quad per pixel, texels from global memory: tune DMVS_TUNE_SWEEP_GLOBAL)"
-                                           if eng.ops.tune["sweep"] else
-                                           "warp_init_band_kernel<48> (stage-1 plane sweep, quad per pixel, source band of a 16x4 pixel tile staged in LDS)")
-                                          if eng.quad else "warp_init_win_kernel<48> (stage-1 plane sweep, LDS-staged source windows)"), "bound": "hbm",
+                     "launches_timed": len(gc_ms), "per_gru_iteration": by_iter},
+        "roofline_warp_init": {"kernel": ("warp_init_quad_kernel<48> (stage-1 plane sweep, quad per pixel, texels from global memory: tune DMVS_TUNE_SWEEP_GLOBAL)"
+                                          if eng.ops.tune["sweep"] else
+                                          "warp_init_band_kernel<48> (stage-1 plane sweep, quad per pixel, source band of a 16x4 pixel tile staged in LDS)"), "bound": "hbm",
                                "achieved": round(alg_init / wi_avg_s / 1e9, 2) if wi_avg_s > 0 else 0.0,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(alg_init / wi_avg_s / 1e9 / HBM_PEAK_GBS, 4) if wi_avg_s > 0 else 0.0,

@@ -15,7 +15,7 @@ HIP_LIB_PATH = os.path.join(PKG, "libdmvs_hip.so")
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_SILU = range(5)
 IN_PLAIN, IN_UPSAMPLE2, IN_UNSHUFFLE2, IN_ZEROINSERT2 = range(4)
 LAYOUT_NCHW, LAYOUT_NHWC, LAYOUT_NHWC_BF16, LAYOUT_NHWC_F16 = 0, 1, 2, 3
-DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
+DTYPE_F32, DTYPE_BF16, DTYPE_F16, DTYPE_F32_PLAIN = 0, 1, 2, 3
 ARITH_F32, ARITH_BF16 = 0, 1
 EW_DEPTH_TO_DISP, EW_DISP_TO_DEPTH = 0, 1
 
@@ -67,11 +67,7 @@ SIGNATURES = {
     "dmvs_conv3d_wgrad_workspace_f32": [C.POINTER(Conv3dDesc), C.POINTER(C.c_int64)],
     "dmvs_conv3d_wgrad_f32": [C.POINTER(Conv3dDesc), _P, _P, _P, _P, C.c_int64, _P],
     "dmvs_compose_proj_f32": [_P, _P, _I, _I, _P],
-    "dmvs_warp_corr_init_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "dmvs_warp_corr_init_gather_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "dmvs_warp_volume_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    "dmvs_getcost_f32": [C.POINTER(GetCostDesc), _P],
-    "dmvs_getcost_gather_f32": [C.POINTER(GetCostDesc), _P],
     "dmvs_getcost_quad_f32": [C.POINTER(GetCostDesc), _P],
     "dmvs_warp_corr_init_quad_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "dmvs_warp_corr_init_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -104,7 +104,7 @@ class _WarpCorrInitFn(torch.autograd.Function):
     def forward(ctx, ref, src, rt, disp_min, disp_max, ops: Ops, D, G):
         ctx.save_for_backward(ref, src, rt, disp_min, disp_max)
         ctx.ops = ops
-        return ops.warp_corr_init(ref, src, rt, disp_min, disp_max, D, G)
+        return ops.warp_corr_init_quad(ref, src, rt, disp_min, disp_max, D, G, plain=True)      # plain NHWC fp32: the order the backward kernels read
 
     @staticmethod
     def backward(ctx, g):
@@ -120,12 +120,11 @@ def warp_corr_init(ops: Ops, ref, src, rt, disp_min, disp_max, D, G=4):
 
 class _GetCostFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, ops: Ops, n, interval, rmin, rmax, shift, key, G):
-        cost, samples = ops.getcost(ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, rmin, rmax, shift,
-                                    G=G, policy_key=key)
+    def forward(ctx, ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, ops: Ops, n, interval, rmin, rmax, shift, G):
+        cost, samples = ops.getcost_quad(ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, rmin, rmax,
+                                         shift, G=G, plain=True)
         ctx.save_for_backward(ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max)
         ctx.ops, ctx.meta = ops, (n, interval, rmin, rmax, shift, G)
-        ctx.plain = ops.last_getcost_plain      # same geometry in the backward: same device path
         ctx.mark_non_differentiable(samples)
         return cost, samples
 
@@ -134,15 +133,14 @@ class _GetCostFn(torch.autograd.Function):
         ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max = ctx.saved_tensors
         n, interval, rmin, rmax, shift, G = ctx.meta
         gref, gsrc = ctx.ops.getcost_bwd(ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, rmin,
-                                         rmax, shift, g.contiguous(), G=G, gather=ctx.plain)
-        return (gref, gsrc) + (None,) * 14
+                                         rmax, shift, g.contiguous(), G=G)
+        return (gref, gsrc) + (None,) * 13
 
 
-def getcost(ops: Ops, ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, rmin, rmax, vw_shift,
-            policy_key=None, G=4):
+def getcost(ops: Ops, ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, rmin, rmax, vw_shift, G=4):
     """GetCost with gradients to the image features only (hypotheses / view weights are detached in the reference)."""
     return _GetCostFn.apply(ref.contiguous(), src.contiguous(), rt, inv_depth, confidence, view_w, disp_min, disp_max, ops, n,
-                            interval, rmin, rmax, vw_shift, policy_key, G)
+                            interval, rmin, rmax, vw_shift, G)
 
 
 class _ViewAggregateFn(torch.autograd.Function):

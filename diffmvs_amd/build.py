@@ -15,7 +15,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libdmvs_hip.so")
-SOURCES = ["conv2d_k33.hip", "conv2d_k55.hip", "conv2d_k77.hip", "conv2d_k15.hip", "conv2d.hip", "stem.hip", "conv3d.hip", "warp.hip", "warp_win.hip", "warp_init_win.hip", "warp_quad.hip", "warp_bwd.hip", "warp_bwd_win.hip", "warp_init_bwd_win.hip", "misc.hip", "optim.hip", "norm.hip", "fusion.hip"]
+SOURCES = ["conv2d_k33.hip", "conv2d_k55.hip", "conv2d_k77.hip", "conv2d_k15.hip", "conv2d.hip", "stem.hip", "conv3d.hip", "warp_quad.hip", "warp_bwd.hip", "warp_bwd_win.hip", "warp_init_bwd_win.hip", "misc.hip", "optim.hip", "norm.hip", "fusion.hip"]
 
 
 def _stale() -> bool:

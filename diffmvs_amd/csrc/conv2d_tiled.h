@@ -704,7 +704,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
         if (tid < 8) {
             const float tot = gn_scratch[tid] + gn_scratch[8 + tid] + gn_scratch[16 + tid] + gn_scratch[24 + tid];
             const int gi = tid & 3, which = tid >> 2;
-            if (tot != 0.0f) dmvs_gn_accumulate(&d.gn_stats[((size_t)b * 4 + gi) * 2 + which], (double)tot);
+            if (tot != 0.0f) dmvs_gn_accumulate(&d.gn_stats[((size_t)b * 4 + gi) * 2], which, (double)tot);
         }
     }
     if constexpr (!WALK) break;

@@ -63,29 +63,38 @@ __device__ __forceinline__ float dmvs_act(float v, int act) {
 // units): integer addition is associative, so the statistics -- and with them the whole forward -- are bit-reproducible
 // run to run.  Resolution 1.5e-5 per contribution (a workgroup's partial sum, magnitude 1e2..1e6).
 // Magnitude contract: statistics up to 3.5e13 (|fixed| < 2^61; a random-weight network's pre-normalisation planes reach
-// 1e12).  A contribution that is not finite, or whose magnitude reaches 2^44 (1.8e13), POISONS the slot -- it is overwritten
-// with 3 * 2^61, which in-range contributions do not bring back below 2^61 -- and dmvs_gn_read returns NaN for any slot at
-// or beyond +-2^61: a NaN / Inf / out-of-range activation makes its group's outputs NaN, like the floating-point statistics
-// of the reference would, instead of finite garbage or a silent wrap.
+// 1e12).  A contribution that is not finite, or whose magnitude reaches 2^44 (1.8e13), POISONS the (sum, sum of squares) PAIR:
+// bits 61 and 62 of the sum-of-squares slot -- which only ever receives non-negative adds -- are set with an atomic OR, and
+// dmvs_gn_read_pair returns NaN for both statistics when that slot is at or beyond 2^61 (or the sum is beyond +-2^61).  The mark is
+// sticky: an OR cannot be undone by later in-range adds (round 3 overwrote the slot with a sentinel VALUE, which enough later adds
+// could carry back into range -- ADVICE round 3); only further in-range contributions summing past 2^63 units (1.4e14, four times
+// the contract) could wrap it.  A NaN / Inf / out-of-range activation makes its group's outputs NaN, like the floating-point
+// statistics of the reference would, instead of finite garbage or a silent wrap.
 // Callers keep treating the buffer as opaque zero-initialised 8-byte slots (all-zero bits = 0 in either reading).
 #define DMVS_GN_FIX 65536.0
 #define DMVS_GN_POISON 0x6000000000000000ull
-__device__ __forceinline__ void dmvs_gn_accumulate(double* slot, double v) {
-    unsigned long long* p = reinterpret_cast<unsigned long long*>(slot);
+// pair = &stats[2 * (b * groups + g)]; which = 0: sum, 1: sum of squares
+__device__ __forceinline__ void dmvs_gn_accumulate(double* pair, int which, double v) {
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(pair);
     if (!(fabs(v) < 17592186044416.0)) {         // 2^44; false for NaN as well
 #ifdef DMVS_HOST_EMULATION
-        __atomic_store_n(p, DMVS_GN_POISON, __ATOMIC_RELAXED);
+        __atomic_fetch_or(p + 1, DMVS_GN_POISON, __ATOMIC_RELAXED);
 #else
-        atomicExch(p, DMVS_GN_POISON);
+        atomicOr(p + 1, DMVS_GN_POISON);
 #endif
         return;
     }
-    atomicAdd(p, (unsigned long long)(long long)llrint(v * DMVS_GN_FIX));
+    atomicAdd(p + which, (unsigned long long)(long long)llrint(v * DMVS_GN_FIX));
 }
-__device__ __forceinline__ double dmvs_gn_read(const double* slot) {
-    const long long f = *reinterpret_cast<const long long*>(slot);
-    if (f >= (1ll << 61) || f <= -(1ll << 61)) return __builtin_nan("");
-    return (double)f * (1.0 / DMVS_GN_FIX);
+__device__ __forceinline__ void dmvs_gn_read_pair(const double* pair, double& sum, double& sumsq) {
+    const long long f0 = reinterpret_cast<const long long*>(pair)[0];
+    const unsigned long long f1 = reinterpret_cast<const unsigned long long*>(pair)[1];
+    if (f1 >= (1ull << 61) || f0 >= (1ll << 61) || f0 <= -(1ll << 61)) {
+        sum = sumsq = __builtin_nan("");
+        return;
+    }
+    sum = (double)f0 * (1.0 / DMVS_GN_FIX);
+    sumsq = (double)(long long)f1 * (1.0 / DMVS_GN_FIX);
 }
 
 // 16-bit feature storage (DMVS_DTYPE_BF16 / DMVS_DTYPE_F16): round-to-nearest-even conversions; arithmetic stays fp32.

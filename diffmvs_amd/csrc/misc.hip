@@ -87,10 +87,51 @@ view_aggregate_kernel(const float* __restrict__ cor, const float* __restrict__ w
     out[i] = a / wsum;
 }
 
+// The same with 16-byte accesses and the view weights held in registers: a lane owns 4 consecutive pixels of one batch item and
+// walks a strip of GDS (group, depth) planes; w (read S x GD times per pixel by the kernel above, if from cache) is read once per
+// strip.  Same operations in the same order per output: bit-identical.  (Round 4: 0.67 ms per B = 96 step at 3.4 TB/s before.)
+template <int S>
+__global__ void __launch_bounds__(DMVS_BLOCK)
+view_aggregate_vec_kernel(const float* __restrict__ cor, const float* __restrict__ w, float* __restrict__ out, int GD, int HW, int GDS) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int p4 = blockIdx.x * DMVS_BLOCK + threadIdx.x;              // pixel quad
+    if (p4 * 4 >= HW) return;
+    const int b = blockIdx.z, gd0 = blockIdx.y * GDS, gd1 = min(gd0 + GDS, GD);
+    f32x4 ws[S], wsum = {1e-8f, 1e-8f, 1e-8f, 1e-8f};
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        ws[s] = *reinterpret_cast<const f32x4*>(w + ((long)b * S + s) * HW + p4 * 4);
+        wsum += ws[s];
+    }
+    for (int gd = gd0; gd < gd1; ++gd) {
+        f32x4 a = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const f32x4 c = *reinterpret_cast<const f32x4*>(cor + (((long)b * S + s) * GD + gd) * (long)HW + p4 * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = fmaf(ws[s][r], c[r], a[r]);
+        }
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = a[r] / wsum[r];
+        *reinterpret_cast<f32x4*>(out + ((long)b * GD + gd) * (long)HW + p4 * 4) = o;
+    }
+}
+
 extern "C" int dmvs_view_aggregate_f32(const float* cor, const float* w, float* out, int32_t B, int32_t S, int32_t GD,
                                        int32_t HW, void* stream) {
+    if (!cor || !w || !out) return DMVS_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if ((HW & 3) == 0 && ((((uintptr_t)cor | (uintptr_t)w | (uintptr_t)out) & 15) == 0) && B <= 65535 && S >= 2 && S <= 11) {
+        const int GDS = 16;
+        dim3 grid(dmvs_ceil_div(HW / 4, DMVS_BLOCK), (unsigned)((GD + GDS - 1) / GDS), (unsigned)B), block(DMVS_BLOCK);
+#define DMVS_VA(SV) case SV: hipLaunchKernelGGL(view_aggregate_vec_kernel<SV>, grid, block, 0, st, cor, w, out, GD, HW, GDS); break
+        switch (S) { DMVS_VA(2); DMVS_VA(3); DMVS_VA(4); DMVS_VA(5); DMVS_VA(6); DMVS_VA(7); DMVS_VA(8); DMVS_VA(9); DMVS_VA(10); DMVS_VA(11); }
+#undef DMVS_VA
+        return dmvs_launch_status();
+    }
     hipLaunchKernelGGL(view_aggregate_kernel, dim3(dmvs_ceil_div((long)B * GD * HW, DMVS_BLOCK)), dim3(DMVS_BLOCK), 0,
-                       (hipStream_t)stream, cor, w, out, B, S, GD, HW);
+                       st, cor, w, out, B, S, GD, HW);
     return dmvs_launch_status();
 }
 
@@ -225,8 +266,8 @@ gn_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, long pe
             a += (double)red[0][w];
             c += (double)red[1][w];
         }
-        dmvs_gn_accumulate(&stats[2 * bg], a);
-        dmvs_gn_accumulate(&stats[2 * bg + 1], c);
+        dmvs_gn_accumulate(&stats[2 * bg], 0, a);
+        dmvs_gn_accumulate(&stats[2 * bg], 1, c);
     }
 }
 
@@ -248,8 +289,10 @@ gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma, co
         const int cg = C / groups;
         const int g = c / cg;
         const double n = (double)cg * HW;
-        const double mean = dmvs_gn_read(&stats[2 * (b * groups + g)]) / n;
-        double var = dmvs_gn_read(&stats[2 * (b * groups + g) + 1]) / n - mean * mean;
+        double s1, s2;
+        dmvs_gn_read_pair(&stats[2 * (b * groups + g)], s1, s2);
+        const double mean = s1 / n;
+        double var = s2 / n - mean * mean;
         var = var < 0.0 ? 0.0 : var;
         const float rstd = (float)(1.0 / sqrt(var + (double)eps));
         // y = ((x - mean) * rstd * gamma + beta) * (scale + 1) + shift  ==  x * A + Bc

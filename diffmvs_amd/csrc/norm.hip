@@ -298,8 +298,10 @@ __device__ __forceinline__ void gn_row_consts(const double* stats, int b, int c,
                                               float& rstd) {
     const int cg = C / groups, g = c / cg;
     const double n = (double)cg * HW;
-    const double m = dmvs_gn_read(&stats[2 * (b * groups + g)]) / n;
-    double var = dmvs_gn_read(&stats[2 * (b * groups + g) + 1]) / n - m * m;
+    double s1, s2;
+    dmvs_gn_read_pair(&stats[2 * (b * groups + g)], s1, s2);
+    const double m = s1 / n;
+    double var = s2 / n - m * m;
     var = var < 0.0 ? 0.0 : var;
     mean = (float)m;
     rstd = (float)(1.0 / sqrt(var + (double)eps));

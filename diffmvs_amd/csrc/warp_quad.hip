@@ -141,21 +141,26 @@ template <typename V, typename P> __device__ __forceinline__ V ldv(P p) {
 //   fp32   : NHWC-g4, C/16 units of 64 bytes, the lane reads 16 bytes of each (4 channels)
 //   16-bit : plain NHWC -- a group's C/4 channels are already contiguous (8 / 16 / 24 bytes per lane), the quad still reads one
 //            contiguous run of 2*C bytes; converted to fp32 on arrival, all arithmetic stays fp32
+//   fp32 plain (DMVS_DTYPE_F32_PLAIN): plain NHWC fp32 -- the lane's C/4 channels are C bytes contiguous (C/16 loads of 16 bytes
+//            at a C-byte lane pitch instead of one 64-byte run per quad and unit); the training graph's features, whose backward
+//            kernels (warp_bwd*.hip) read the same tensors in that order
 template <int C, int FT> struct Feat {
     static constexpr int E = C / 4;                                          // channels per lane
-    static constexpr int ESIZE = FT == DMVS_DTYPE_F32 ? 4 : 2;
+    static constexpr bool F32 = FT == DMVS_DTYPE_F32 || FT == DMVS_DTYPE_F32_PLAIN;
+    static constexpr int ESIZE = F32 ? 4 : 2;
     static constexpr int TEXEL_BYTES = C * ESIZE;
-    static constexpr int NW = FT == DMVS_DTYPE_F32 ? E : E / 2;              // 32-bit words per lane and texel
+    static constexpr int NW = F32 ? E : E / 2;              // 32-bit words per lane and texel
     uint32_t w[NW];
 
-    static __device__ __forceinline__ unsigned lane_bytes(int q) { return FT == DMVS_DTYPE_F32 ? (unsigned)q * 16u : (unsigned)q * (E * 2); }
+    static __device__ __forceinline__ unsigned lane_bytes(int q) { return FT == DMVS_DTYPE_F32 ? (unsigned)q * 16u : (unsigned)q * (E * ESIZE); }
 
     // P = const char* (global memory) or lds_cptr (the workgroup's staged band: ds_read_b128 / _b64)
     template <typename P> __device__ __forceinline__ void load(P p) {
-        if constexpr (FT == DMVS_DTYPE_F32) {
+        if constexpr (F32) {
+            constexpr int PITCH = FT == DMVS_DTYPE_F32 ? 64 : 16;      // g4: one 16-byte piece per 64-byte unit; plain: consecutive pieces
 #pragma unroll
             for (int j = 0; j < C / 16; ++j) {
-                const u32x4 v = ldv<u32x4>(p + ((DMVS_GC_EXP == 3) ? 0 : j * 64));
+                const u32x4 v = ldv<u32x4>(p + ((DMVS_GC_EXP == 3) ? 0 : j * PITCH));
                 w[4 * j] = v[0]; w[4 * j + 1] = v[1]; w[4 * j + 2] = v[2]; w[4 * j + 3] = v[3];
             }
         } else if constexpr (NW == 6) {
@@ -174,7 +179,7 @@ template <int C, int FT> struct Feat {
         }
     }
     __device__ __forceinline__ float get(int i) const {      // channel i of the lane's group
-        if constexpr (FT == DMVS_DTYPE_F32) return __uint_as_float(w[i]);
+        if constexpr (F32) return __uint_as_float(w[i]);
         else if constexpr (FT == DMVS_DTYPE_BF16) return __uint_as_float((i & 1) ? (w[i >> 1] & 0xffff0000u) : (w[i >> 1] << 16));
         else return dmvs_f16_to_f32((uint16_t)((i & 1) ? (w[i >> 1] >> 16) : (w[i >> 1] & 0xffffu)));
     }
@@ -465,6 +470,24 @@ __global__ void __launch_bounds__(DMVS_BLOCK) getcost_quad_kernel(const dmvs_get
     }
 }
 
+// the NB plane values of a chunk -> out[b, s, q, d0 + k, pixel]: a wave-uniform 64-bit plane base (scalar registers, advanced by one
+// plane per store) + the lane's 32-bit byte offset, so that a store costs no vector address arithmetic (the per-store 64-bit
+// multiply-adds and predicates this replaces were ~80 of a chunk's ~600 vector instructions); whole chunks take the unpredicated path
+template <int NB>
+__device__ __forceinline__ void store_planes(float* view_out, unsigned lane_off, int d0, int D, long hw, bool live, const float (&acc)[NB]) {
+    if (!live) return;
+    char* pl = reinterpret_cast<char*>(view_out + (long)d0 * hw);      // wave-uniform
+    const long step = hw * 4;
+    if (d0 + NB <= D) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k, pl += step) *reinterpret_cast<float*>(pl + lane_off) = acc[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < NB; ++k, pl += step)
+            if (d0 + k < D) *reinterpret_cast<float*>(pl + lane_off) = acc[k];
+    }
+}
+
 // ------------------------------------------------------------------------------------------ stage-1 plane sweep
 // grid = (pixel blocks, S); planes in chunks of 8 (lane q projects planes d0 + q and d0 + q + 4).  out [B,S,4,D,H,W].
 template <int C, int TPT, int FT>
@@ -496,7 +519,8 @@ warp_init_quad_kernel(const void* __restrict__ ref_f, const void* __restrict__ s
     __shared__ float depth_tab[TAB];
     if ((int)threadIdx.x < min(D, TAB)) depth_tab[threadIdx.x] = dmvs_disp_to_depth((float)threadIdx.x / dm1, dmin, dmax);
     __syncthreads();
-    float* op = out + ((((long)b * S + s) * 4 + q) * D) * (long)hw + yx;
+    float* const view_out = out + (((long)b * S + s) * 4 * D) * (long)hw;                  // [4][D][hw] of this (batch item, view): uniform
+    const unsigned lane_off = (unsigned)(((long)q * D * hw + yx) * 4);                      // group plane + pixel (one view's volumes < 4 GiB: entry point)
     for (int d0 = 0; d0 < D; d0 += NB) {
         HypQ own[HPL];
 #pragma unroll
@@ -510,11 +534,7 @@ warp_init_quad_kernel(const void* __restrict__ ref_f, const void* __restrict__ s
 #pragma unroll
         for (int k = 0; k < NB; ++k) acc[k] = 0.0f;
         quad_accumulate<C, FT, NB, TPT>(base, view_off, Ws, own, Hs, Ws, ref, 1.0f, acc);
-        if (live) {
-#pragma unroll
-            for (int k = 0; k < NB; ++k)
-                if (d0 + k < D) op[(long)(d0 + k) * (long)hw] = acc[k];
-        }
+        store_planes<NB>(view_out, lane_off, d0, D, hw, live, acc);
     }
 }
 
@@ -613,7 +633,8 @@ warp_init_band_kernel(const void* __restrict__ ref_f, const void* __restrict__ s
         return bad == 0;
     };
 
-    float* op = out + ((((long)b * S + s) * 4 + q) * D) * (long)hw + yx;
+    float* const view_out = out + (((long)b * S + s) * 4 * D) * (long)hw;                  // [4][D][hw] of this (batch item, view): uniform
+    const unsigned lane_off = (unsigned)(((long)q * D * hw + yx) * 4);
     const int nchunk = (D + NB - 1) / NB;
     int cpg = nchunk;                                          // chunks per group: halved until a group's band fits
     for (int c0 = 0; c0 < nchunk;) {
@@ -659,11 +680,7 @@ warp_init_band_kernel(const void* __restrict__ ref_f, const void* __restrict__ s
             for (int k = 0; k < NB; ++k) acc[k] = 0.0f;
             if (staged) quad_accumulate<C, FT, NB, TPT>((lds_cptr)band, band_off, ncols, own, Hs, Ws, ref, 1.0f, acc);
             else quad_accumulate<C, FT, NB, TPT>(gbase, view_off, Ws, own, Hs, Ws, ref, 1.0f, acc);
-            if (live) {
-#pragma unroll
-                for (int k = 0; k < NB; ++k)
-                    if (d0 + k < D) op[(long)(d0 + k) * (long)hw] = acc[k];
-            }
+            store_planes<NB>(view_out, lane_off, d0, D, hw, live, acc);
         }
         c0 += cnt;
     }
@@ -693,7 +710,7 @@ extern "C" int dmvs_getcost_quad_f32(const dmvs_getcost_desc* dp, void* stream) 
     if (!dp) return DMVS_EINVAL;
     const dmvs_getcost_desc& d = *dp;
     if (d.G != 4 || !d.ref || !d.src || !d.rt || !d.inv_depth || !d.view_w || !d.out_cost || !d.out_samples) return DMVS_EINVAL;
-    if (d.feat_dtype < DMVS_DTYPE_F32 || d.feat_dtype > DMVS_DTYPE_F16) return DMVS_EINVAL;
+    if (d.feat_dtype < DMVS_DTYPE_F32 || d.feat_dtype > DMVS_DTYPE_F32_PLAIN) return DMVS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     // 24-bit row multiplies and 32-bit byte offsets inside ONE view's image (2^24 texels x <= 192 bytes < 2^32); the source
     // stack as a whole may be any size (64-bit per-view bases); grid.y
@@ -701,6 +718,7 @@ extern "C" int dmvs_getcost_quad_f32(const dmvs_getcost_desc* dp, void* stream) 
     dim3 grid(dmvs_ceil_div((long)d.H * d.W, DMVS_BLOCK / 4), (unsigned)d.B), block(DMVS_BLOCK);
     if (d.feat_dtype == DMVS_DTYPE_BF16) return launch_getcost_quad<DMVS_DTYPE_BF16>(d, grid, block, st);
     if (d.feat_dtype == DMVS_DTYPE_F16) return launch_getcost_quad<DMVS_DTYPE_F16>(d, grid, block, st);
+    if (d.feat_dtype == DMVS_DTYPE_F32_PLAIN) return launch_getcost_quad<DMVS_DTYPE_F32_PLAIN>(d, grid, block, st);
     return launch_getcost_quad<DMVS_DTYPE_F32>(d, grid, block, st);
 }
 
@@ -738,16 +756,19 @@ extern "C" int dmvs_warp_corr_init_quad_f32(const void* ref, const void* src, co
                                             int32_t D, int32_t H, int32_t W, int32_t Hs, int32_t Ws, int32_t feat_dtype, int32_t tune,
                                             void* stream) {
     if (G != 4 || D < 2 || !ref || !src || !rt || !out) return DMVS_EINVAL;
-    if (feat_dtype < DMVS_DTYPE_F32 || feat_dtype > DMVS_DTYPE_F16) return DMVS_EINVAL;
+    if (feat_dtype < DMVS_DTYPE_F32 || feat_dtype > DMVS_DTYPE_F32_PLAIN) return DMVS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if ((long)H * W >= (1L << 24) || (long)Hs * Ws >= (1L << 24) || (long)B * S > 65535) return DMVS_EINVAL;
+    if (16L * D * H * W >= (1L << 32)) return DMVS_EINVAL;      // one (batch item, view)'s [4][D][H*W] volumes are addressed with 32-bit byte offsets
     if (!(tune & DMVS_TUNE_SWEEP_GLOBAL)) {      // default: the LDS-band kernel; the flag: the round-2 kernel (every texel from global memory / L1), A/B runs
         if (feat_dtype == DMVS_DTYPE_BF16) return launch_warp_init_band<DMVS_DTYPE_BF16>(ref, src, rt, disp_min, disp_max, out, B, S, C, D, H, W, Hs, Ws, st);
         if (feat_dtype == DMVS_DTYPE_F16) return launch_warp_init_band<DMVS_DTYPE_F16>(ref, src, rt, disp_min, disp_max, out, B, S, C, D, H, W, Hs, Ws, st);
+        if (feat_dtype == DMVS_DTYPE_F32_PLAIN) return launch_warp_init_band<DMVS_DTYPE_F32_PLAIN>(ref, src, rt, disp_min, disp_max, out, B, S, C, D, H, W, Hs, Ws, st);
         return launch_warp_init_band<DMVS_DTYPE_F32>(ref, src, rt, disp_min, disp_max, out, B, S, C, D, H, W, Hs, Ws, st);
     }
     dim3 grid(dmvs_ceil_div((long)H * W, DMVS_BLOCK / 4), (unsigned)(B * S)), block(DMVS_BLOCK);
     if (feat_dtype == DMVS_DTYPE_BF16) return launch_warp_init_quad<DMVS_DTYPE_BF16>(ref, src, rt, disp_min, disp_max, out, B, S, C, D, H, W, Hs, Ws, grid, block, st);
     if (feat_dtype == DMVS_DTYPE_F16) return launch_warp_init_quad<DMVS_DTYPE_F16>(ref, src, rt, disp_min, disp_max, out, B, S, C, D, H, W, Hs, Ws, grid, block, st);
+    if (feat_dtype == DMVS_DTYPE_F32_PLAIN) return launch_warp_init_quad<DMVS_DTYPE_F32_PLAIN>(ref, src, rt, disp_min, disp_max, out, B, S, C, D, H, W, Hs, Ws, grid, block, st);
     return launch_warp_init_quad<DMVS_DTYPE_F32>(ref, src, rt, disp_min, disp_max, out, B, S, C, D, H, W, Hs, Ws, grid, block, st);
 }

@@ -398,9 +398,6 @@ class Engine:
         self.up_ratio = 2 if self.cas else 4
         self.G = args.cost_dim_stage[0]
         self.G_cost = args.cost_dim_stage[1]
-        # warp kernels: "quad" = quad-per-pixel kernels on NHWC-g4 features (warp_quad.hip, one launch for any geometry);
-        # "legacy" = the LDS-window / per-pixel-gather pair of round 1 on plain NHWC features (kept for A/B runs)
-        self.quad = os.environ.get("DMVS_WARP", "quad") != "legacy"
         # feature storage precision: args.precision / DMVS_PRECISION in {"fp32", "bf16", "fp16"} (BASELINE.json configs[2] /
         # [4]).  The image features FeatureNet hands to the warp kernels are stored in 16 bits (half the bytes of the path's
         # dominant gather traffic); projection, hypotheses, correlation, every convolution and all accumulators stay fp32
@@ -419,9 +416,7 @@ class Engine:
         self.conv_arith = arith
         if K.CONV_ARITH[arith] != self.ops.conv_arith:
             self.ops = self.ops.with_conv_arith(K.CONV_ARITH[arith])
-        if self.feat_dtype != torch.float32 and not self.quad:
-            raise K._lib.DmvsError("16-bit feature storage needs the quad-per-pixel warp kernels (unset DMVS_WARP=legacy)")
-        self.feat = pack_feature(sd, "feature", g4=self.quad, feat_dtype=self.feat_dtype)
+        self.feat = pack_feature(sd, "feature", g4=True, feat_dtype=self.feat_dtype)      # (the quad warp kernels' channel order)
         self.ctx = pack_context_trunk(sd, "context")
         # ContextNet output heads split into their hidden | context halves (diffusion.py:223-231): the
         # context half is written straight into the Unet input buffer, the hidden half feeds hidden_init
@@ -465,8 +460,7 @@ class Engine:
         o = self.ops
         B, H, W, _ = ref.shape
         S = src.shape[0]
-        warp_init = o.warp_corr_init_quad if self.quad else o.warp_corr_init
-        cor = warp_init(ref, src, rt, disp_min, disp_max, D, self.G)                    # [B,S,G,D,H,W]
+        cor = o.warp_corr_init_quad(ref, src, rt, disp_min, disp_max, D, self.G)        # [B,S,G,D,H,W]
         vw = run_pvw(o, self.pvw, cor.view(B * S, self.G, D, H, W)).view(B, S, H, W)
         agg = o.view_aggregate(cor, vw)
         logits = run_costreg(o, self.reg, agg)                                          # [B,1,D,H,W]
@@ -475,18 +469,16 @@ class Engine:
         return mask, nd, depth, vw, conf
 
     # ------------------------------------------------------------------ stages 2, 3
-    def update_block(self, ub: _UpdateBlock, feats_ref, feats_src, rt, inv_depth, hidden, X, view_w, vw_shift,
+    def update_block(self, ub: _UpdateBlock, feats_ref, feats_src, rt, inv_depth, hidden, context, view_w, vw_shift,
                      disp_min, disp_max, interval, noise_fn):
         """DiffusionUpdateBlockDepth.forward eval branch (update.py:466-521).
-        X: [B,2cd,H,W] whose first cd channels hold relu(context) (the rest is unused: the encoder output lives in its own
-        [B,cd,H,W] tensor, see run_unet)."""
+        context: [B,cd,H,W] = relu(context half of the ContextNet head); the encoder output lives in its own [B,cd,H,W] tensor
+        (run_unet: the Unet's input concatenation is never materialised)."""
         o = self.ops
         a = self.args
         B, _, H, W = inv_depth.shape
         cd, n = ub.cd, ub.n
         noise = noise_fn((B, 1, H, W), o.device).float().contiguous()
-        # mask head reads relu(context) = X[:, :cd]; for B > 1 that slice is strided, so give it its own copy
-        context = o.act_slice(X, K.ACT_NONE, 0, cd)
         mask = run_mask(o, ub.mask, context)
         ctx_part = o.conv2d(ub.init_ctx, context)             # the context half of the Unet's 7x7 init_conv, once per stage
         E = o.empty(B, cd, H, W)                              # encoder output (cd - 1 channels) + current inverse depth
@@ -501,13 +493,8 @@ class Engine:
             img, img_scale = delta, 1.0
             cur_hidden, confidence = hidden, None
             for it in range(ub.iters):
-                if self.quad:
-                    cost, samples = o.getcost_quad(feats_ref, feats_src, rt, new, confidence, view_w, disp_min, disp_max, n,
-                                                   interval, a.min_radius, a.max_radius, vw_shift, G=self.G_cost)
-                else:
-                    cost, samples = o.getcost(feats_ref, feats_src, rt, new, confidence, view_w, disp_min, disp_max, n,
-                                              interval, a.min_radius, a.max_radius, vw_shift, G=self.G_cost,
-                                              policy_key=(vw_shift, it))
+                cost, samples = o.getcost_quad(feats_ref, feats_src, rt, new, confidence, view_w, disp_min, disp_max, n,
+                                               interval, a.min_radius, a.max_radius, vw_shift, G=self.G_cost)
                 run_encoder(o, ub.enc, cost, samples, out=E, out_cstride=cd, out_coffset=0)
                 cur_hidden, upd, conf = run_unet(o, self.arena, ub, E, ctx_part, cur_hidden, ss_of)
                 confidence = conf.view(B, H, W)
@@ -587,10 +574,9 @@ class Engine:
                 for pc in hi[:-1]:
                     hidden = o.conv2d(pc, hidden, act=K.ACT_RELU)
                 hidden = o.conv2d(hi[-1], hidden, act=K.ACT_TANH)
-                X = o.empty(B, 2 * cd, h, w)
-                o.conv2d(ctx_pc, trunk[s], act=K.ACT_RELU, out=X, out_cstride=2 * cd, out_coffset=0)
+                context = o.conv2d(ctx_pc, trunk[s], act=K.ACT_RELU)
                 mask, hidden, inv_seq, conf_seq = self.update_block(
-                    ub, ref, src, rt, inv_cur, hidden, X, view_w, s, disp_min, disp_max,
+                    ub, ref, src, rt, inv_cur, hidden, context, view_w, s, disp_min, disp_max,
                     interval * _RATIOS[s], noise_fn)
                 if test:
                     depths.append(o.depth_convert(inv_seq[-1], disp_min, disp_max, K._lib.EW_DISP_TO_DEPTH).view(B, h, w))

@@ -167,10 +167,6 @@ class Ops:
         # optional per-entry-point HIP-event timing on the launch stream (bench.py roofline leg):
         # {"dmvs_getcost_f32": [(start_event, end_event), ...]}
         self.timers = None
-        self.last_getcost_plain = False
-        self._getcost_state = {}     # per launch shape: which GetCost device path the last probe favoured (see getcost)
-        self.getcost_tiles = None
-        self.last_getcost_worklist = None
         self.conv_arith = ARITH_F32      # matrix arithmetic of the multi-tap 2-D convolutions (with_conv_arith)
 
     def with_conv_arith(self, arith: int) -> "Ops":
@@ -388,21 +384,13 @@ class Ops:
         self._call("dmvs_compose_proj_f32", _ptr(proj), _ptr(out), B, V, self.stream())
         return out
 
-    def warp_corr_init(self, ref, src, rt, disp_min, disp_max, D, G=4, gather=False):
-        """ref [B,H,W,C], src [S,B,Hs,Ws,C] (NHWC) -> [B,S,G,D,H,W].  gather=True: per-pixel kernel (A/B measurements)."""
-        self._chk(ref, src, rt, disp_min, disp_max)
-        B, H, W, Cc = ref.shape
-        S, _, Hs, Ws, _ = src.shape
-        out = self.empty(B, S, G, D, H, W)
-        self._call("dmvs_warp_corr_init_gather_f32" if gather else "dmvs_warp_corr_init_f32", _ptr(ref), _ptr(src), _ptr(rt),
-                   _ptr(disp_min), _ptr(disp_max), _ptr(out), B, S, Cc, G, D, H, W, Hs, Ws, self.stream())
-        return out
-
-    def warp_corr_init_quad(self, ref, src, rt, disp_min, disp_max, D, G=4, tune=None):
+    def warp_corr_init_quad(self, ref, src, rt, disp_min, disp_max, D, G=4, tune=None, plain=False):
         """quad-per-pixel plane sweep: ref [B,H,W,C], src [S,B,Hs,Ws,C] in the NHWC-g4 channel order (fp32) or plain NHWC
-        (bf16 / fp16 feature storage) -> [B,S,G,D,H,W] fp32"""
+        (bf16 / fp16 feature storage; fp32 with plain=True: the training graph's features) -> [B,S,G,D,H,W] fp32"""
         self._chk(rt, disp_min, disp_max)
         fdt = self._chk_feat(ref, src)
+        if plain and fdt == DTYPE_F32:
+            fdt = _lib.DTYPE_F32_PLAIN
         B, H, W, Cc = ref.shape
         S, _, Hs, Ws, _ = src.shape
         out = self.empty(B, S, G, D, H, W)
@@ -414,11 +402,13 @@ class Ops:
 
     def getcost_quad(self, ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, min_radius,
                      max_radius, vw_shift, out_cost=None, cost_cstride=None, cost_coffset=0, out_samples=None,
-                     samp_cstride=None, samp_coffset=0, G=4):
+                     samp_cstride=None, samp_coffset=0, G=4, plain=False):
         """quad-per-pixel GetCost, one launch for any geometry; ref / src in the NHWC-g4 channel order (fp32) or plain NHWC
-        (bf16 / fp16 feature storage)"""
+        (bf16 / fp16 feature storage; fp32 with plain=True: the training graph's features)"""
         self._chk(rt, inv_depth, confidence, view_w, disp_min, disp_max, out_cost, out_samples)
         fdt = self._chk_feat(ref, src)
+        if plain and fdt == DTYPE_F32:
+            fdt = _lib.DTYPE_F32_PLAIN
         B, H, W, Cc = ref.shape
         S = src.shape[0]
         if out_cost is None:
@@ -448,56 +438,6 @@ class Ops:
         self._call("dmvs_warp_volume_f32", _ptr(src), _ptr(rt), _ptr(depth), _ptr(out), B, Cc, D, H, W, Hs, Ws,
                    self.stream())
         return out
-
-    def getcost(self, ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, min_radius,
-                max_radius, vw_shift, out_cost=None, cost_cstride=None, cost_coffset=0, out_samples=None,
-                samp_cstride=None, samp_coffset=0, G=4, gather=False, policy_key=None):
-        """gather=True forces the per-pixel gather kernel (A/B measurements; also DMVS_GETCOST=gather in the environment);
-        default = LDS-window kernel for C 32|16 with the gather kernel behind it for the tiles that do not fit"""
-        gather = gather or os.environ.get("DMVS_GETCOST") == "gather"
-        # policy_key: the caller's name for this call site (e.g. (stage, iteration)): the first iteration of a diffusion
-        # stage starts from white noise (scale * randn, update.py:472) and never fits the windows, the later ones do
-        self._chk(ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, out_cost, out_samples)
-        B, H, W, Cc = ref.shape
-        S = src.shape[0]
-        if out_cost is None:
-            cost_cstride = G * n
-            out_cost = self.empty(B, G * n, H, W)
-        if out_samples is None:
-            samp_cstride = n
-            out_samples = self.empty(B, n, H, W)
-        # Which device path: the hybrid launch (LDS windows + gather for the tiles that do not fit) costs ~35 us of
-        # pre-pass and extra launches, which only pays off while the windows carry the work.  The verdict of the last
-        # hybrid launch of the same shape is read back lazily (async copy + event, never a sync): if most tiles went
-        # to the gather path -- a depth map that is noise, e.g. an untrained network -- later calls launch the plain
-        # gather kernel alone and re-probe every 64th call.
-        ntiles = B * ((H + 15) // 16) * ((W + 15) // 16)
-        st = self._getcost_state.setdefault((B, H, W, Cc, n, policy_key), {"gather": False, "pending": None, "calls": 0})
-        if st["pending"] is not None and st["pending"][0].query():
-            host = st["pending"][1]
-            st["gather"] = bool(host[1]) or int(host[0]) * 2 > ntiles
-            st["last"] = (ntiles if bool(host[1]) else int(host[0]), ntiles)
-            st["pending"] = None
-        st["calls"] += 1
-        plain = gather or Cc == 48 or S > MAX_WINDOW_VIEWS or (st["gather"] and st["calls"] % 64 != 0)
-        wl = None if plain else torch.empty(4 + 66 * ntiles, dtype=torch.int32, device=self.device)
-        d = _lib.GetCostDesc(ref=_ptr(ref), src=_ptr(src), rt=_ptr(rt), inv_depth=_ptr(inv_depth),
-                             confidence=_ptr(confidence), view_w=_ptr(view_w), disp_min=_ptr(disp_min),
-                             disp_max=_ptr(disp_max), out_cost=_ptr(out_cost), out_samples=_ptr(out_samples),
-                             worklist=_ptr(wl), B=B, S=S, C=Cc, G=G, n=n, H=H, W=W, vw_shift=vw_shift, cost_cstride=cost_cstride,
-                             cost_coffset=cost_coffset, samp_cstride=samp_cstride, samp_coffset=samp_coffset,
-                             interval=interval, min_radius=min_radius, max_radius=max_radius)
-        self._call("dmvs_getcost_gather_f32" if plain else "dmvs_getcost_f32", C.byref(d), self.stream())
-        if wl is not None and self.device.type == "cuda" and st["pending"] is None and not torch.cuda.is_current_stream_capturing():
-            host = torch.empty(2, dtype=torch.int32, pin_memory=True)
-            host.copy_(wl[:2], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            st["pending"] = (ev, host)
-        self.last_getcost_plain = plain
-        self.getcost_tiles = st.get("last")      # diagnostics: (tiles on the gather path, tiles) of the last probe read back
-        self.last_getcost_worklist = wl      # diagnostics: [0] tiles handed to the gather path, [1] = 1: all of them (pre-pass)
-        return out_cost, out_samples
 
     # ------------------------------------------------------------------ backward (training step)
     def warp_corr_init_bwd(self, ref, src, rt, disp_min, disp_max, gcor, gsrc=None, gather=True):

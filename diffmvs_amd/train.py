@@ -309,13 +309,9 @@ def forward_train(model, imgs, proj_matrices, depth_values, depth_gt_ms, ops: Op
         ref, src = _nhwc(fs, B)
         nsamp = a.CostNum[s]
 
-        calls = [0]
-
-        def cost_fn(inv, confidence, ref=ref, src=src, rt=rt, vw=vw, nsamp=nsamp, s=s, calls=calls):
-            calls[0] += 1
+        def cost_fn(inv, confidence, ref=ref, src=src, rt=rt, vw=vw, nsamp=nsamp, s=s):
             return A.getcost(o, ref, src, rt, inv.contiguous(), None if confidence is None else confidence.contiguous(), vw,
-                             kmin, kmax, nsamp, interval * _RATIOS[s], a.min_radius, a.max_radius, s,
-                             policy_key=("train", s, calls[0]), G=a.cost_dim_stage[1])
+                             kmin, kmax, nsamp, interval * _RATIOS[s], a.min_radius, a.max_radius, s, G=a.cost_dim_stage[1])
 
         ub = f"update_block_depth{s + 1}"
         t = t_source(B, a.timesteps[s], dev)

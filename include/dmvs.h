@@ -43,7 +43,8 @@ enum { DMVS_LAYOUT_NCHW = 0, DMVS_LAYOUT_NHWC = 1,
           BASELINE.json's bf16 / fp16 configurations; `out` then points at uint16 elements, strides / offsets count elements */
        DMVS_LAYOUT_NHWC_BF16 = 2, DMVS_LAYOUT_NHWC_F16 = 3 };
 /* element type of the image-feature tensors handed to the quad warp kernels */
-enum { DMVS_DTYPE_F32 = 0, DMVS_DTYPE_BF16 = 1, DMVS_DTYPE_F16 = 2 };
+enum { DMVS_DTYPE_F32 = 0 /* fp32 in the NHWC-g4 channel order (see dmvs_getcost_quad_f32) */, DMVS_DTYPE_BF16 = 1, DMVS_DTYPE_F16 = 2 /* 16-bit, plain NHWC */,
+       DMVS_DTYPE_F32_PLAIN = 3 /* fp32, plain NHWC: the training graph's features (its backward kernels read the same order) */ };
 
 int dmvs_abi_version(void);
 
@@ -199,54 +200,34 @@ int dmvs_conv3d_wgrad_f32(const dmvs_conv3d_desc* d, const float* grad_out, floa
 int dmvs_compose_proj_f32(const float* proj, float* out, int32_t B, int32_t V, void* stream);
 
 /* ---------------------------------------------------------------------------------------
- * Plane-sweep group-wise correlation volumes for depth initialisation.
- * Fuses differentiable_warping (models/module.py:181-218) with the group-wise correlation of
- * InitialCost.forward (:514-531) for ALL source views in one launch; the hypotheses are
- * uniform in normalised inverse depth (models/diffusion.py:187-192), so they are generated
- * in-kernel:  depth_d = 1 / clamp(1/dmax + (1/dmin - 1/dmax) * d/(D-1), 1e-6).
- *   ref  [B,H,W,C]  NHWC        src  [S][B,Hs,Ws,C] NHWC, contiguous over S
- *   rt   [B,S,12]   from dmvs_compose_proj_f32
- *   disp_min/disp_max [B]       (= depth_values[:,0], depth_values[:,-1])
- *   out  [B,S,G,D,H,W]          cor[g] = mean over the C/G channels of group g
- * C in {16,32,48}, G = 4.
- */
-int dmvs_warp_corr_init_f32(const float* ref, const float* src, const float* rt,
-                            const float* disp_min, const float* disp_max, float* out,
-                            int32_t B, int32_t S, int32_t C, int32_t G, int32_t D,
-                            int32_t H, int32_t W, int32_t Hs, int32_t Ws, void* stream);
-/* Same contract on the per-pixel gather kernel (dmvs_warp_corr_init_f32 stages source windows through LDS for C = 48,
- * the model's stage 1).  Kept public for A/B measurements. */
-int dmvs_warp_corr_init_gather_f32(const float* ref, const float* src, const float* rt,
-                                   const float* disp_min, const float* disp_max, float* out,
-                                   int32_t B, int32_t S, int32_t C, int32_t G, int32_t D,
-                                   int32_t H, int32_t W, int32_t Hs, int32_t Ws, void* stream);
-
-/* ---------------------------------------------------------------------------------------
- * GetCost.forward (models/module.py:583-667) in ONE kernel: hypothesis generation
- * (get_cur_depth_range_samples :250-277 + disp_to_depth :220-227), S homography warps,
- * group-wise correlation and view-weighted aggregation  sum_s w_s cor_s / (1e-8 + sum_s w_s).
- *   inv_depth  [B,1,H,W] normalised inverse depth      confidence [B,H,W] or NULL
- *   view_w     [B,S,H>>vw_shift,W>>vw_shift]  (nearest-upsampled on the fly,
- *              models/diffusion.py:219-221)
- *   out_cost   [B,G*n,H,W]  written at channel offset cost_coffset of a tensor with
- *              cost_cstride channels;   out_samples [B,n,H,W] likewise
- * n in {4,6}; interval = depth_interval * ratio (models/diffusion.py:246).
+ * The two fused warp kernels ("quad per pixel", warp_quad.hip): any geometry in ONE launch.
  *
- * Two device paths share the arithmetic.  (1) "window": a 16x16 pixel tile stages the source texels its hypotheses
- * can touch through LDS once per view (C = 32 | 16; needs every view's footprint of the tile to fit a 24 x 22|24
- * texel window -- true where the depth map is locally smooth) -- the fast path.  (2) "gather": every pixel fetches its
- * own 2x2 taps through the texture path; any geometry, any C.  dmvs_getcost_f32 runs (1) and lets the tiles that do
- * not fit fall through to (2) via `worklist`: caller-owned int32 scratch of DMVS_GETCOST_WORKLIST_INTS(B,H,W)
- * elements (contents irrelevant on entry; holds per-tile fit flags, the list of flagged tiles and the per-view window
- * boxes).  A pre-pass counts the tiles that would fall through; above 75 % the window kernel stands down and (2)
- * takes everything.  worklist == NULL, or C == 48: path (2) for everything.
+ * dmvs_warp_corr_init_quad_f32 -- plane-sweep group-wise correlation volumes for depth initialisation: differentiable_warping
+ * (models/module.py:181-218) + the group-wise correlation of InitialCost.forward (:514-531) for ALL source views; the hypotheses
+ * are uniform in normalised inverse depth (models/diffusion.py:187-192) and generated in-kernel:
+ *   depth_d = 1 / clamp(1/dmax + (1/dmin - 1/dmax) * d/(D-1), 1e-6).
+ *   ref  [B,H,W,C]   src  [S][B,Hs,Ws,C] channel-last, contiguous over S     rt [B,S,12] from dmvs_compose_proj_f32
+ *   disp_min/disp_max [B] (= depth_values[:,0], depth_values[:,-1])           out [B,S,G,D,H,W], cor[g] = mean over the group's channels
+ *   C in {16,32,48}, G = 4.
+ *
+ * dmvs_getcost_quad_f32 -- GetCost.forward (models/module.py:583-667): hypothesis generation (get_cur_depth_range_samples :250-277 +
+ * disp_to_depth :220-227), S homography warps, group-wise correlation and view-weighted aggregation
+ * sum_s w_s cor_s / (1e-8 + sum_s w_s).
+ *   inv_depth  [B,1,H,W] normalised inverse depth      confidence [B,H,W] or NULL
+ *   view_w     [B,S,H>>vw_shift,W>>vw_shift]  (nearest-upsampled on the fly, models/diffusion.py:219-221)
+ *   out_cost   [B,G*n,H,W]  written at channel offset cost_coffset of a tensor with cost_cstride channels; out_samples [B,n,H,W] likewise
+ *   n in {4,6}; interval = depth_interval * ratio (models/diffusion.py:246).
+ *
+ * (Round 1's LDS-window / per-pixel-gather forward kernels -- dmvs_getcost_f32, dmvs_getcost_gather_f32, dmvs_warp_corr_init_f32,
+ * dmvs_warp_corr_init_gather_f32 -- were retired in round 4 / ABI 2: the training graph runs the quad kernels too, on
+ * DMVS_DTYPE_F32_PLAIN features.  `worklist` remains for the BACKWARD's hybrid window / per-pixel launch, dmvs_getcost_bwd_f32.)
  */
 #define DMVS_GETCOST_TILE 16
-#define DMVS_GETCOST_MAX_WINDOW_VIEWS 16      /* more source views than this: dmvs_getcost_f32 / _bwd_f32 take the per-pixel path */
+#define DMVS_GETCOST_MAX_WINDOW_VIEWS 16      /* more source views than this: dmvs_getcost_bwd_f32 takes the per-pixel path */
 #define DMVS_GETCOST_WORKLIST_INTS(B, H, W) \
     (4 + 66 * (B) * (((H) + DMVS_GETCOST_TILE - 1) / DMVS_GETCOST_TILE) * (((W) + DMVS_GETCOST_TILE - 1) / DMVS_GETCOST_TILE))
 typedef struct dmvs_getcost_desc {
-    const float* ref;       /* [B,H,W,C] NHWC (16-bit elements behind the pointer for dmvs_getcost_quad_f32 with feat_dtype != 0) */
+    const float* ref;       /* [B,H,W,C] channel-last (16-bit elements behind the pointer for feat_dtype BF16 / F16) */
     const float* src;       /* [S][B,H,W,C] NHWC */
     const float* rt;        /* [B,S,12] */
     const float* inv_depth;
@@ -256,22 +237,17 @@ typedef struct dmvs_getcost_desc {
     const float* disp_max;  /* [B] */
     float* out_cost;
     float* out_samples;
-    int32_t* worklist;      /* scratch, DMVS_GETCOST_WORKLIST_INTS(B,H,W) ints, or NULL */
+    int32_t* worklist;      /* dmvs_getcost_bwd_f32 only: scratch of DMVS_GETCOST_WORKLIST_INTS(B,H,W) ints (per-tile fit flags, the list of
+                               tiles left to the per-pixel kernel, per-view window boxes), or NULL = per-pixel kernel everywhere */
     int32_t B, S, C, G, n, H, W;
     int32_t vw_shift;
     int32_t cost_cstride, cost_coffset, samp_cstride, samp_coffset;
     float interval, min_radius, max_radius;
-    int32_t feat_dtype;     /* DMVS_DTYPE_*: element type of ref / src; honoured by dmvs_getcost_quad_f32 only (the others: fp32) */
+    int32_t feat_dtype;     /* DMVS_DTYPE_*: element type / channel order of ref / src (the backward reads plain fp32 NHWC) */
 } dmvs_getcost_desc;
 
-int dmvs_getcost_f32(const dmvs_getcost_desc* d, void* stream);
-/* Same contract, everything on path (2) regardless of `worklist`.  Kept public for A/B measurements. */
-int dmvs_getcost_gather_f32(const dmvs_getcost_desc* d, void* stream);
-
 /* ---------------------------------------------------------------------------------------
- * "Quad per pixel" variants of the two fused warp kernels (warp_quad.hip): same arithmetic contracts as
- * dmvs_getcost_f32 / dmvs_warp_corr_init_f32, any geometry in ONE launch (no LDS windows, no pre-pass, `worklist`
- * ignored), C in {16,32,48}.  The feature tensors `ref` / `src` are read in the GROUP-INTERLEAVED channel-last layout
+ * Feature layouts of the quad kernels.  feat_dtype = DMVS_DTYPE_F32: `ref` / `src` are read in the GROUP-INTERLEAVED channel-last layout
  * "NHWC-g4": a texel is C/16 units of 16 floats, unit j = [ch 4j..4j+3 of group 0 | of group 1 | of group 2 | of group 3]
  * (group g = channels g*C/4 .. (g+1)*C/4 - 1 of the reference's NCHW tensor), i.e.
  *     position p of a texel holds channel  c(p) = ((p / 4) % 4) * (C / 4) + (p / 16) * 4 + p % 4,
@@ -280,7 +256,8 @@ int dmvs_getcost_gather_f32(const dmvs_getcost_desc* d, void* stream);
  * their weights); diffmvs_amd.ops.g4_channels(C) is the permutation for callers that hold plain NHWC tensors.
  * Reduced-precision feature storage (BASELINE.json's bf16 / fp16 configurations): feat_dtype = DMVS_DTYPE_BF16 | _F16 reads ref /
  * src as 16-bit elements in PLAIN NHWC order (a group's C/4 channels are then contiguous already: 8 / 16 / 24 bytes per lane);
- * values are widened to fp32 on arrival, projection, hypotheses, correlation and accumulation stay fp32. */
+ * values are widened to fp32 on arrival, projection, hypotheses, correlation and accumulation stay fp32.
+ * DMVS_DTYPE_F32_PLAIN: fp32 in plain NHWC order (what the training graph holds and its backward kernels read). */
 /* tune (plane sweep): 0 = the source band of a 16 x 4 pixel tile is staged in LDS (warp_init_band_kernel);
  * DMVS_TUNE_SWEEP_GLOBAL = every texel from global memory (warp_init_quad_kernel, the round-2 form; bit-identical results). */
 #define DMVS_TUNE_SWEEP_GLOBAL 0x1
@@ -309,7 +286,8 @@ int dmvs_warp_corr_init_bwd_f32(const float* ref, const float* src, const float*
                                 const float* disp_min, const float* disp_max, const float* gcor,
                                 float* gref, float* gsrc, int32_t B, int32_t S, int32_t C, int32_t G,
                                 int32_t D, int32_t H, int32_t W, int32_t Hs, int32_t Ws, int32_t gather, void* stream);
-/* gcost [B,G*n,H,W] contiguous; d->out_cost / out_samples are ignored */
+/* gcost [B,G*n,H,W] contiguous; d->out_cost / out_samples / feat_dtype are ignored (features: plain fp32 NHWC).  With d->worklist the
+ * LDS-window kernel takes the 16x16 tiles whose source footprints fit its windows (C = 32 | 16) and the per-pixel kernel the rest. */
 int dmvs_getcost_bwd_f32(const dmvs_getcost_desc* d, const float* gcost, float* gref, float* gsrc, void* stream);
 /* backward of dmvs_view_aggregate_f32 (InitialCost, where the view weights DO require grad, :539-548):
  * gcor [B,S,GD,HW], gw [B,S,HW] are written */

@@ -253,7 +253,7 @@ class InitialCost(HipModule):       # reference models/module.py:465-573
         disp_min = (1.0 / dv[:, 0, 0, 0]).contiguous()     # plane 0 is the farthest (normalised inverse depth 0)
         disp_max = (1.0 / dv[:, -1, 0, 0]).contiguous()
         rt = o.compose_proj(_dev(o, proj_matrices))
-        cor = o.warp_corr_init(ref, src, rt, disp_min, disp_max, D, G)
+        cor = o.warp_corr_init_quad(ref, src, rt, disp_min, disp_max, D, G, plain=True)
         vw = E.run_pvw(o, pvw, cor.view(B * S, G, D, H, W)).view(B, S, H, W)
         logits = E.run_costreg(o, reg, o.view_aggregate(cor, vw))
         nd, depth, conf = o.depth_regress(logits.view(B, D, H, W), disp_min, disp_max)
@@ -275,9 +275,9 @@ class GetCost(HipModule):           # reference models/module.py:575-667 (no par
         rt = o.compose_proj(_dev(o, proj_matrices))
         dmax = torch.as_tensor(depth_max, dtype=torch.float32, device=o.device).reshape(-1).expand(B)
         dmin = torch.as_tensor(depth_min, dtype=torch.float32, device=o.device).reshape(-1).expand(B)
-        return o.getcost(ref, src, rt, _dev(o, inverse_depth), _dev(o, confidence), _dev(o, view_weights),
-                         (1.0 / dmax).contiguous(), (1.0 / dmin).contiguous(), CostNum, float(depth_interval),
-                         self.min_radius, self.max_radius, vw_shift=0, G=self.group_dim)
+        return o.getcost_quad(ref, src, rt, _dev(o, inverse_depth), _dev(o, confidence), _dev(o, view_weights),
+                              (1.0 / dmax).contiguous(), (1.0 / dmin).contiguous(), CostNum, float(depth_interval),
+                              self.min_radius, self.max_radius, vw_shift=0, G=self.group_dim, plain=True)
 
 
 class SepConvGRU(HipModule):        # reference models/module.py:152-179

@@ -118,13 +118,14 @@ def test_invalid_descriptors_are_rejected_before_any_launch():
                              samp_cstride=6, samp_coffset=0, interval=0.04, min_radius=0.125, max_radius=8.0)
         for k, v in kw.items():
             setattr(d, k, v)
-        return lib.dll.dmvs_getcost_f32(ctypes.byref(d), None)
+        return lib.dll.dmvs_getcost_quad_f32(ctypes.byref(d), None)
 
     assert getcost(n=5) == -22                                     # the reference uses 4 or 6 hypotheses
     assert getcost(C=24) == -22
     assert getcost(G=3) == -22
     assert getcost(ref=None) == -22
-    assert getcost(B=64, S=16, H=1024, W=1024) == -22              # source stack >= 4 GiB: 32-bit byte offsets
+    assert getcost(feat_dtype=4) == -22                            # DMVS_DTYPE_* 0..3
+    assert getcost(H=8192, W=8192) == -22                          # plane >= 2^24 texels: 24-bit row multiplies
     assert lib.dll.dmvs_conv2d_f32(None, None) == -22 and lib.dll.dmvs_conv3d_f32(None, None) == -22
 
 

@@ -34,7 +34,7 @@ def short(name):
 
 def main():
     fetch_dir, write_dir, tag, batch = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
-    kname = sys.argv[5] if len(sys.argv) > 5 else "getcost_quad_kernel<32, 6>"
+    kname = sys.argv[5] if len(sys.argv) > 5 else "getcost_quad_kernel<32, 6,"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     fe, wr = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
     rows = []

@@ -1,8 +1,8 @@
-"""A/B timing of the homography-warp kernels on cuda:0: GetCost (LDS-window hybrid / per-pixel gather / quad-per-pixel) on
-scene geometry (hypotheses around the synthetic scene's true depth) and on noise geometry (hypotheses centred on
+"""Timing of the homography-warp kernels on cuda:0: GetCost (quad per pixel; NHWC-g4 features and the training graph's plain NHWC
+features) on scene geometry (hypotheses around the synthetic scene's true depth) and on noise geometry (hypotheses centred on
 clamp(inv + 0.5 * randn), what the first GRU iteration of every diffusion stage and any untrained network feed the kernel),
-and the stage-1 plane sweep (LDS-window / gather / quad).  One JSON line per case; every variant is also compared with the
-per-pixel gather kernel's result."""
+and the stage-1 plane sweep (LDS band / texels from global memory).  One JSON line per case.  (Round 1's LDS-window and per-pixel
+kernels, which this script used to time beside them, were retired in round 4: their numbers are in profiles/r2_warp_ab_b16.json.)"""
 import argparse
 import json
 import os
@@ -51,15 +51,12 @@ def getcost_case(o, a, stage, C, n, geometry, conf):
     alg = 4.0 * a.batch * hw * (C + a.src * C + n + a.src + 4 * n)          # bench.py's formula
     res = {"case": "getcost", "stage": stage, "C": C, "n": n, "geometry": geometry, "conf": conf, "B": a.batch, "hw": [h, w],
            "algorithmic_MB": round(alg / 1e6, 2)}
-    oo = Ops(o.lib, dev)
-    t_g, out_g = timeit(lambda: oo.getcost(ref, src, *tail, gather=True), a.iters)
-    t_w, out_w = timeit(lambda: oo.getcost(ref, src, *tail), a.iters)
-    t_q, out_q = timeit(lambda: oo.getcost_quad(ref4, src4, *tail), a.iters)
-    for name, t, out in (("gather", t_g, out_g), ("hybrid", t_w, out_w), ("quad", t_q, out_q)):
+    t_q, out_q = timeit(lambda: o.getcost_quad(ref4, src4, *tail), a.iters)
+    t_p, out_p = timeit(lambda: o.getcost_quad(ref.contiguous(), src.contiguous(), *tail, plain=True), a.iters)
+    for name, t, out in (("quad_g4", t_q, out_q), ("quad_plain", t_p, out_p)):
         res[name + "_us"] = round(t, 2)
         res[name + "_frac"] = round(alg / (t * 1e-6) / 8e12, 4)
-        res[name + "_maxrel_vs_gather"] = float((out[0] - out_g[0]).abs().max() / out_g[0].abs().max())
-    res["hybrid_tiles_on_gather"] = oo.getcost_tiles
+    res["plain_bit_identical_to_g4"] = bool(torch.equal(out_q[0], out_p[0]))
     print(json.dumps(res), flush=True)
 
 
@@ -76,13 +73,13 @@ def init_case(o, a, C, D):
     kmin, kmax = dv[:, 0].contiguous().to(dev), dv[:, -1].contiguous().to(dev)
     alg = 4.0 * a.batch * h * w * (C + a.src * C + a.src * 4 * D)
     res = {"case": "warp_init", "C": C, "D": D, "B": a.batch, "hw": [h, w], "algorithmic_MB": round(alg / 1e6, 2)}
-    t_g, out_g = timeit(lambda: o.warp_corr_init(ref, src, rt, kmin, kmax, D, gather=True), a.iters)
-    t_w, out_w = timeit(lambda: o.warp_corr_init(ref, src, rt, kmin, kmax, D), a.iters)
-    t_q, out_q = timeit(lambda: o.warp_corr_init_quad(ref4, src4, rt, kmin, kmax, D), a.iters)
-    for name, t, out in (("gather", t_g, out_g), ("window", t_w, out_w), ("quad", t_q, out_q)):
+    from diffmvs_amd import _lib
+    t_b, out_b = timeit(lambda: o.warp_corr_init_quad(ref4, src4, rt, kmin, kmax, D), a.iters)
+    t_q, out_q = timeit(lambda: o.warp_corr_init_quad(ref4, src4, rt, kmin, kmax, D, tune=_lib.TUNE_SWEEP_GLOBAL), a.iters)
+    for name, t in (("band", t_b), ("global", t_q)):
         res[name + "_us"] = round(t, 2)
         res[name + "_frac"] = round(alg / (t * 1e-6) / 8e12, 4)
-        res[name + "_maxrel_vs_gather"] = float((out - out_g).abs().max() / out_g.abs().max())
+    res["bit_identical"] = bool(torch.equal(out_b, out_q))
     print(json.dumps(res), flush=True)
 
 
@@ -96,7 +93,7 @@ def main():
     ap.add_argument("--min-radius", type=float, default=0.25)
     ap.add_argument("--max-radius", type=float, default=4.0)
     ap.add_argument("--quick", action="store_true")
-    ap.add_argument("--init-only", action="store_true", help="only the stage-1 plane sweep (DMVS_PLANE_SWEEP=quad: the round-2 kernel)")
+    ap.add_argument("--init-only", action="store_true", help="only the stage-1 plane sweep")
     a = ap.parse_args()
     o = Ops.for_device("cuda:0")
     if a.init_only:
