@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.path.join(PKG, "libdmvs_hip.so")
+# DMVS_LIB: another build of the same sources (tools/build_variant.py) for A/B runs; default: the in-tree product library
+HIP_LIB_PATH = os.environ.get("DMVS_LIB") or os.path.join(PKG, "libdmvs_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_SILU = range(5)
 IN_PLAIN, IN_UPSAMPLE2, IN_UNSHUFFLE2, IN_ZEROINSERT2 = range(4)
@@ -27,12 +28,12 @@ _F = C.c_float
 class Conv2dDesc(C.Structure):
     _fields_ = [
         ("in0", _P), ("in1", _P), ("mul0", _P), ("weight", _P), ("scale", _P), ("shift", _P),
-        ("residual", _P), ("gru_z", _P), ("gru_h", _P), ("out", _P), ("gn_stats", _P),
+        ("residual", _P), ("gru_z", _P), ("gru_h", _P), ("out", _P), ("gn_stats", _P), ("out_mul", _P),
         ("B", _I), ("c0", _I), ("c1", _I), ("Hin", _I), ("Win", _I), ("Hout", _I), ("Wout", _I),
         ("cout", _I), ("cout_pad", _I), ("kh", _I), ("kw", _I), ("stride", _I), ("pad_h", _I), ("pad_w", _I),
         ("in_mode", _I), ("act", _I), ("res_mode", _I), ("res_after_act", _I),
         ("out_layout", _I), ("out_cstride", _I), ("out_coffset", _I), ("gn_groups", _I), ("post_scale", _F),
-        ("gate_cstride", _I), ("arith", _I), ("tune", _I),
+        ("gate_cstride", _I), ("arith", _I), ("tune", _I), ("out_mul_c0", _I), ("in0_cstride", _I),
     ]
 
 
@@ -95,7 +96,7 @@ SIGNATURES = {
 }
 ABI_VERSION = 2
 # dmvs.h: DMVS_TUNE_* (dmvs_conv2d_desc.tune, dmvs_featurenet_stem_f32), DMVS_TUNE3D_* (dmvs_conv3d_desc.tune), DMVS_TUNE_SWEEP_GLOBAL
-TUNE_NO_WALK, TUNE_PIECES4, TUNE_1X1_WIDE, TUNE_NO_LEAN = 0x4, 0x8, 0x80, 0x100
+TUNE_NO_WALK, TUNE_PIECES4, TUNE_NO_LEAN, TUNE_1X1_TILED = 0x4, 0x8, 0x100, 0x200
 TUNE3D_PIECES4, TUNE3D_S2_DIRECT = 0x1, 0x2
 TUNE_SWEEP_GLOBAL = 0x1
 

@@ -30,164 +30,208 @@ namespace {
 // 1x1 convolutions without the LDS input tile.  A 1x1 layer has no halo and no spatial structure: it is the GEMM
 // out[cout][p] = W[cout][ci] X[ci][p] over the flat pixel index p, and at 16..64 input channels it is bound by memory and by the
 // per-tile fixed costs of the tiled kernel (input DMA + barrier per 8 channels, 16 x 16 tiles of 64-byte rows), which ran
-// these layers at 0.12-0.27 of the MFMA peak and ~2 TB/s.  Here a wave owns MT x 16 consecutive pixels and every output
-// channel: the pixels are the A operand, loaded straight from global memory (lane = pixel m, channel 4c + kq: four 64-byte
-// segments per load), the weights the B operand from an LDS copy made once per workgroup; no barrier in the channel loop,
-// loads of the next channel groups in flight under the MFMAs.  Accumulators are in the transposed form (4 consecutive
-// pixels of one channel per lane): 16-byte stores and residual reads.  The k order equals the tiled kernel's, so the
-// values are identical bit for bit.  Covers plain / concatenated inputs, BN / bias, activation, post-scale, residual
-// (same size or nearest-x2), NCHW output with channel offset; anything else takes the tiled kernel.  Instantiated for
-// one 16-channel n-tile (the narrow layers, where it wins: see conv1x1_direct_ok).
+// these layers at 0.12-0.27 of the MFMA peak and ~2 TB/s.  Round 2's direct kernel (a wave = 64 pixels as the A operand, one float
+// per lane and load; it won for one n-tile only) was replaced in round 4 by the 16-byte form below.
 constexpr int kC11MaxCin = 64;
 
-template <int NT, int MT>
-__global__ void __launch_bounds__(DMVS_BLOCK) conv1x1_direct_kernel(const dmvs_conv2d_desc d, int tiles_per_item) {
+// ------------------------------------------------------------------------------------------
+// 1x1 layers with 16-BYTE accesses on both sides (round 4).  Round 2's direct kernel fed the matrix cores one float per lane and load
+// (lane = pixel m, channel 4c + kq: 256 bytes per wave-level load), which is why its wide instantiations were no faster than the tiled
+// kernel.  Here the PIXELS are the B operand and a lane loads FOUR consecutive pixels of its channel (global_load_dwordx4: lane
+// (n, kq) holds pixels 4n .. 4n+3 of channel 4c + kq); the four values feed four MFMAs, MFMA r computing the strided pixel set
+// {4n + r}.  D[cout][n] then leaves lane (n, kq) with output channels 4kq .. 4kq+3 of pixels 4n .. 4n+3 -- one 16-byte NCHW store per
+// channel (acc[0..3][nt][j]), or one 16-byte channel-last store per pixel (acc[r][nt]).  Per 4 input channels and 64 pixels: one load,
+// NT weight reads (LDS), 4 NT MFMAs.  Same products in the same k order as the other forms: bit-identical results.
+// A wave owns 64 consecutive pixels and every output channel; 3 channel groups of loads in flight.
+// ACTX: sigmoid / tanh / SiLU epilogues (inlined transcendental code per value: its own instantiation, one n-tile only)
+template <int NT, int OT, bool ACTX = false>
+__global__ void __launch_bounds__(DMVS_BLOCK) conv1x1_px4_kernel(const dmvs_conv2d_desc d, int tiles_per_item) {
     constexpr int NW = NT * 16, WS = (NW % 32 == 0) ? NW + 16 : NW;      // weight row stride: the four k-groups on disjoint banks
     __shared__ float s_w[kC11MaxCin * WS];
     DMVS_LDS_POISON(s_w);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m = lane & 15, kq = lane >> 4;
+    const int n = lane & 15, kq = lane >> 4;
     const int cin = d.c0 + d.c1, cin4 = (cin + 3) >> 2;
     const int HW = d.Hout * d.Wout;
+    const int nbase = blockIdx.y * NW;                                   // output channels of this workgroup: nbase .. nbase + NW - 1
     for (int e = tid; e < cin4 * 4 * NW; e += DMVS_BLOCK) {
         const int k = e / NW, co = e - k * NW;
-        s_w[k * WS + co] = (k < cin && co < d.cout_pad) ? d.weight[k * d.cout_pad + co] : 0.0f;
+        s_w[k * WS + co] = (k < cin && nbase + co < d.cout_pad) ? d.weight[k * d.cout_pad + nbase + co] : 0.0f;
     }
     const int b = blockIdx.x / tiles_per_item, t = blockIdx.x - b * tiles_per_item;
-    const int p0 = (t * 4 + wave) * (16 * MT);
+    const int p = (t * 4 + wave) * 64 + 4 * n;                           // this lane's four pixels (HW % 4 == 0: together or not at all)
+    const bool pok = p < HW;
+    const int pcl = pok ? p : HW - 4;
     const float* in0b = d.in0 + (size_t)b * d.c0 * HW;
     const float* in1b = d.in1 ? d.in1 + (size_t)b * d.c1 * HW : d.in0;
     __syncthreads();
 
-    f32x4 acc[MT][NT];
+    f32x4 acc[4][NT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    // Two channel groups ahead: the loads of groups c+1, c+2 are in flight while group c goes through the matrix cores.  The
-    // loads are UNCONDITIONAL (channel and pixel clamped into the tensor, the value zeroed when it is consumed): predicated
-    // loads sit in their own basic blocks, and hipcc then waits vmcnt(0) -- i.e. also for the prefetch -- before the MFMAs.
-    int pc[MT];
-    bool pok[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int p = p0 + 16 * mt + m;
-        pok[mt] = p < HW;
-        pc[mt] = pok[mt] ? p : HW - 1;
-    }
-    auto load = [&](int c, float (&a)[MT]) {
+        for (int j = 0; j < NT; ++j) acc[r][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    // Two channel groups ahead: the loads of groups c+1, c+2 are in flight while group c goes through the matrix cores.  The loads are
+    // UNCONDITIONAL (channel and pixel clamped into the tensor, the value zeroed when it is consumed): predicated loads sit in their own
+    // basic blocks, and hipcc then waits vmcnt(0) -- i.e. also for the prefetch -- before the MFMAs.  Three register sets in rotation
+    // (renamed, not moved); the scheduling barrier keeps each prefetch in front of the current group's MFMAs.
+    auto load = [&](int c) -> f32x4 {
         int ci = 4 * c + kq;
         ci = ci < cin ? ci : cin - 1;
         const float* src = ci < d.c0 ? in0b + (size_t)ci * HW : in1b + (size_t)(ci - d.c0) * HW;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt] = src[pc[mt]];
+        return *reinterpret_cast<const f32x4*>(src + pcl);
     };
-    auto mma = [&](int c, const float (&a)[MT]) {
-        const bool cok = 4 * c + kq < cin;
-        const float* wp = s_w + (4 * c + kq) * WS + m;
+    auto mma = [&](int c, const f32x4& x) {
+        const bool ok = pok && 4 * c + kq < cin;
+        const float* wp = s_w + (4 * c + kq) * WS + n;                   // A operand: weights [cout = lane & 15][k = lane >> 4]
+        float xv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xv[r] = ok ? x[r] : 0.0f;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const float bw = wp[nt * 16];
+            const float aw = wp[nt * 16];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32((cok && pok[mt]) ? a[mt] : 0.0f, bw, acc[mt][nt], 0, 0, 0);
+            for (int r = 0; r < 4; ++r) acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, xv[r], acc[r][nt], 0, 0, 0);
         }
     };
-    // three register sets in rotation (renamed, not moved: a move of the prefetched value would wait for it);
-    // the scheduling barrier keeps each prefetch in front of the current group's MFMAs (hipcc sinks it behind them otherwise)
-    float a0[MT], a1[MT], a2[MT];
-    load(0, a0);
-    load(1, a1);
+    f32x4 a0 = load(0), a1 = load(1), a2;
     for (int c = 0;;) {
-        load(c + 2, a2);
+        a2 = load(c + 2);
         __builtin_amdgcn_sched_barrier(0);
         mma(c, a0);
         if (++c >= cin4) break;
-        load(c + 2, a0);
+        a0 = load(c + 2);
         __builtin_amdgcn_sched_barrier(0);
         mma(c, a1);
         if (++c >= cin4) break;
-        load(c + 2, a1);
+        a1 = load(c + 2);
         __builtin_amdgcn_sched_barrier(0);
         mma(c, a2);
         if (++c >= cin4) break;
     }
+    if (!pok) return;
 
-    // epilogue: this lane holds channel nt*16 + m of pixels p0 + 16*mt + 4*kq + r (HW and Wout are multiples of 4: the four
-    // pixels exist together and lie in one image row)
+    // epilogue: this lane holds output channels nt*16 + 4*kq + j of pixels p .. p+3 (one image row: Wout % 4 == 0)
     const bool rup = d.res_mode == DMVS_IN_UPSAMPLE2;
     const int rW = rup ? (d.Wout >> 1) : d.Wout, rplane = rup ? (d.Hout >> 1) * rW : HW;
-    float* const outb = d.out + ((size_t)b * d.out_cstride + d.out_coffset) * HW;
     const float* const resb = d.residual ? d.residual + (size_t)b * d.cout * rplane : nullptr;
+    const int oy = rup ? p / d.Wout : 0, ox = rup ? p - oy * d.Wout : 0;
+    const int rpix = rup ? (oy >> 1) * rW + (ox >> 1) : p;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int cg = nt * 16 + m;
-        if (cg >= d.cout) continue;
-        const float sc = d.scale ? d.scale[cg] : 1.0f, sh = d.shift ? d.shift[cg] : 0.0f;
+        f32x4 y[4], res[4];                                               // [j] = channel 4kq + j: its four pixels
+        // the four residual loads of an n-tile are issued together, ahead of the arithmetic (one at a time, hipcc waits vmcnt(0) for
+        // each before its store: the epilogue then runs at one load latency per channel)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int p = p0 + 16 * mt + 4 * kq;
-            if (p >= HW) continue;
-            f32x4 y;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) y[r] = acc[mt][nt][r] * sc + sh;
-            f32x4 res = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (resb) {
+        for (int j = 0; j < 4; ++j) {
+            const int cg = nbase + nt * 16 + 4 * kq + j;
+            res[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (resb && cg < d.cout) {
                 if (rup) {
                     typedef float f32x2 __attribute__((ext_vector_type(2)));
-                    const int oy = p / d.Wout, ox = p - oy * d.Wout;
-                    const f32x2 rv = *reinterpret_cast<const f32x2*>(resb + (size_t)cg * rplane + (oy >> 1) * rW + (ox >> 1));
-                    res = f32x4{rv[0], rv[0], rv[1], rv[1]};
+                    const f32x2 rv = *reinterpret_cast<const f32x2*>(resb + (size_t)cg * rplane + rpix);
+                    res[j] = f32x4{rv[0], rv[0], rv[1], rv[1]};
                 } else {
-                    res = *reinterpret_cast<const f32x4*>(resb + (size_t)cg * HW + p);
+                    res[j] = *reinterpret_cast<const f32x4*>(resb + (size_t)cg * HW + p);
                 }
-                if (!d.res_after_act) y += res;
             }
-            if (d.act == DMVS_ACT_RELU) {
+        }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) y[r] = fmaxf(y[r], 0.0f);
-            } else if (d.act != DMVS_ACT_NONE) {
+        for (int j = 0; j < 4; ++j) {
+            const int cg = nbase + nt * 16 + 4 * kq + j;
+            const bool okc = cg < d.cout;
+            const float sc = d.scale ? d.scale[okc ? cg : 0] : 1.0f, sh = d.shift ? d.shift[okc ? cg : 0] : 0.0f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) y[r] = dmvs_act(y[r], d.act);
+            for (int r = 0; r < 4; ++r) y[j][r] = acc[r][nt][j] * sc + sh;
+            if (!d.res_after_act) y[j] += res[j];
+            if constexpr (ACTX) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[j][r] = dmvs_act(y[j][r], d.act);
+            } else if (d.act == DMVS_ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[j][r] = fmaxf(y[j][r], 0.0f);
             }
-            y *= d.post_scale;
-            if (resb && d.res_after_act) y += res;
-            *reinterpret_cast<f32x4*>(outb + (size_t)cg * HW + p) = y;
+            y[j] *= d.post_scale;
+            if (d.res_after_act) y[j] += res[j];
+        }
+        if constexpr (OT != DMVS_DTYPE_F32) {                             // channel-last, 16-bit elements: 8 bytes per pixel and lane
+            const int c0o = nbase + nt * 16 + 4 * kq;
+            uint16_t* const ob = reinterpret_cast<uint16_t*>(d.out) + ((size_t)b * HW + p) * d.out_cstride + d.out_coffset + c0o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c0o + j < d.cout) ob[(size_t)r * d.out_cstride + j] = dmvs_to_x16<OT>(y[j][r]);
+        } else if (d.out_layout == DMVS_LAYOUT_NCHW) {
+            float* const outb = d.out + ((size_t)b * d.out_cstride + d.out_coffset) * HW + p;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cg = nbase + nt * 16 + 4 * kq + j;
+                if (cg < d.cout) *reinterpret_cast<f32x4*>(outb + (size_t)cg * HW) = y[j];
+            }
+        } else {                                                          // channel-last fp32: 16 bytes (4 channels) per pixel and lane
+            const int c0o = nbase + nt * 16 + 4 * kq;
+            float* const ob = d.out + ((size_t)b * HW + p) * d.out_cstride + d.out_coffset + c0o;
+            const bool full = c0o + 3 < d.cout && ((d.out_cstride | d.out_coffset) & 3) == 0 && ((uintptr_t)d.out & 15) == 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (full) {
+                    *reinterpret_cast<f32x4*>(ob + (size_t)r * d.out_cstride) = f32x4{y[0][r], y[1][r], y[2][r], y[3][r]};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (c0o + j < d.cout) ob[(size_t)r * d.out_cstride + j] = y[j][r];
+                }
+            }
         }
     }
 }
 
-// the direct form applies: plain 1x1, <= 64 input channels, <= 16 output channels, fp32 NCHW output, rows of 16-byte multiples
-// on 16-byte aligned tensors, none of the GRU / GroupNorm fusions.  (Measured at B=96, 128x160, against the tiled kernel with
-// transposed accumulators: 32->16 95 -> 75 us = 5.0 TB/s; with wider N tiles the template is no better -- 32->64 on 576 images
-// 1379 -> 1350 us, 64->144 856 -> 892 us -- so those layers stay on the tiled kernel.)
-static bool conv1x1_direct_ok(const dmvs_conv2d_desc& d) {
+// the 16-byte form applies: plain 1x1 (optionally two concatenated inputs), <= 64 input channels, <= 144 output channels, planes of
+// 16-byte multiples on 16-byte aligned tensors, none of the GRU / GroupNorm fusions; NCHW or channel-last output (fp32 / 16-bit)
+static bool conv1x1_px4_ok(const dmvs_conv2d_desc& d) {
     if (d.kh != 1 || d.kw != 1 || d.stride != 1 || d.pad_h || d.pad_w || d.in_mode != DMVS_IN_PLAIN) return false;
-    if (d.mul0 || d.gru_z || d.gn_stats || d.out_layout != DMVS_LAYOUT_NCHW) return false;
-    // DMVS_TUNE_1X1_WIDE (experiments): also the 2..9 n-tile instantiations, which are not faster than the tiled kernel yet
-    const int max_cout_pad = (d.tune & DMVS_TUNE_1X1_WIDE) ? 144 : 16;
-    if (d.c0 + d.c1 > kC11MaxCin || d.cout_pad > max_cout_pad || (d.Wout & 3)) return false;
+    if (d.mul0 || d.gru_z || d.gn_stats || d.out_mul || d.in0_cstride || (d.tune & DMVS_TUNE_1X1_TILED)) return false;
+    if (d.act > DMVS_ACT_RELU && (d.cout_pad > 16 || d.out_layout != DMVS_LAYOUT_NCHW)) return false;      // (ACTX: one n-tile, planar output)
+    if (d.c0 + d.c1 > kC11MaxCin || d.cout_pad > 144 || (d.Wout & 3)) return false;
     if (d.res_mode == DMVS_IN_UPSAMPLE2 && ((d.Hout | d.Wout) & 1)) return false;
-    if ((((uintptr_t)d.in0 | (uintptr_t)d.in1 | (uintptr_t)d.out | (uintptr_t)d.residual) & 15) != 0) return false;
+    if ((((uintptr_t)d.in0 | (uintptr_t)d.in1 | (uintptr_t)d.residual) & 15) != 0) return false;
+    if (d.out_layout == DMVS_LAYOUT_NCHW && ((uintptr_t)d.out & 15)) return false;
     return true;
 }
 
-template <int NT, int MT>
-static int launch_conv1x1_direct(const dmvs_conv2d_desc& d, hipStream_t st) {
+template <int NT>
+static int launch_conv1x1_px4(const dmvs_conv2d_desc& d, hipStream_t st, int ngroups) {
     const int HW = d.Hout * d.Wout;
-    const int tiles = (HW + 64 * MT - 1) / (64 * MT);
-    hipLaunchKernelGGL((conv1x1_direct_kernel<NT, MT>), dim3((unsigned)(tiles * d.B)), dim3(DMVS_BLOCK), 0, st, d, tiles);
+    const int tiles = (HW + 255) / 256;
+    dim3 grid((unsigned)(tiles * d.B), (unsigned)ngroups), block(DMVS_BLOCK);
+    if (d.out_layout == DMVS_LAYOUT_NHWC_BF16) hipLaunchKernelGGL((conv1x1_px4_kernel<NT, DMVS_DTYPE_BF16>), grid, block, 0, st, d, tiles);
+    else if (d.out_layout == DMVS_LAYOUT_NHWC_F16) hipLaunchKernelGGL((conv1x1_px4_kernel<NT, DMVS_DTYPE_F16>), grid, block, 0, st, d, tiles);
+    else hipLaunchKernelGGL((conv1x1_px4_kernel<NT, DMVS_DTYPE_F32>), grid, block, 0, st, d, tiles);
     return dmvs_launch_status();
 }
 
-static int conv1x1_direct(const dmvs_conv2d_desc& d, hipStream_t st) {
-    switch ((d.cout_pad + 15) / 16) {      // n-tiles beyond 1 only under DMVS_TUNE_1X1_WIDE (conv1x1_direct_ok)
-        case 1: return launch_conv1x1_direct<1, 4>(d, st);
-        case 2: return launch_conv1x1_direct<2, 4>(d, st);
-        case 3: return launch_conv1x1_direct<3, 2>(d, st);
-        case 4: return launch_conv1x1_direct<4, 2>(d, st);
-        case 5: case 6: return launch_conv1x1_direct<6, 2>(d, st);
-        default: return launch_conv1x1_direct<9, 1>(d, st);
+// up to 4 n-tiles (64 output channels) per workgroup -- 90 VGPRs; wider layers split into groups that re-read the input (64 -> 144:
+// 3 groups of 3: the 64-channel input is read three times, a third of the output's bytes)
+static int conv1x1_px4(const dmvs_conv2d_desc& d, hipStream_t st) {
+    if (d.act > DMVS_ACT_RELU) {
+        const int HW = d.Hout * d.Wout, tiles = (HW + 255) / 256;
+        hipLaunchKernelGGL((conv1x1_px4_kernel<1, DMVS_DTYPE_F32, true>), dim3((unsigned)(tiles * d.B)), dim3(DMVS_BLOCK), 0, st, d, tiles);
+        return dmvs_launch_status();
+    }
+    const int ntiles = (d.cout_pad + 15) / 16;
+    // n-tiles per workgroup: 4 (3 for 5..6 and 9 tiles), but 2 with a residual -- its reads and the 64 accumulators of 4 n-tiles leave 3
+    // waves per SIMD; measured at B = 96 (profiles/r4_conv1x1_px4_ab.txt): FeatureNet inner1 (32 -> 64 + nearest-x2 residual, 576 images)
+    // 1.79 ms with 4 n-tiles, 1.44 with 2 x 2 although the 32-channel input is then read twice; without a residual the wide groups win
+    // (64 -> 144: 0.62 against 0.71 ms, 64 -> 48 channel-last: 0.30 against 0.46)
+    const int maxnt = d.residual ? 2 : 4;
+    const int ngroups = (ntiles + maxnt - 1) / maxnt;
+    const int nt = (ntiles + ngroups - 1) / ngroups;
+    switch (nt) {
+        case 1: return launch_conv1x1_px4<1>(d, st, ngroups);
+        case 2: return launch_conv1x1_px4<2>(d, st, ngroups);
+        case 3: return launch_conv1x1_px4<3>(d, st, ngroups);
+        default: return launch_conv1x1_px4<4>(d, st, ngroups);
     }
 }
 
@@ -428,6 +472,8 @@ extern "C" int dmvs_conv2d_f32(const dmvs_conv2d_desc* dp, void* stream) {
     if ((d.in_mode == DMVS_IN_UPSAMPLE2 || d.in_mode == DMVS_IN_ZEROINSERT2) && ((d.Hin | d.Win) & 1)) return DMVS_EINVAL;
     if (d.gru_z && (!d.gru_h || d.act != DMVS_ACT_TANH)) return DMVS_EINVAL;
     if (d.gate_cstride < 0 || (d.gate_cstride && d.in_mode != DMVS_IN_PLAIN)) return DMVS_EINVAL;
+    if (d.in0_cstride < 0 || (d.in0_cstride && (d.in_mode != DMVS_IN_PLAIN || d.in0_cstride < d.c0))) return DMVS_EINVAL;
+    if (d.out_mul && (d.out_mul_c0 < 0 || d.out_mul_c0 >= d.cout || d.gn_stats)) return DMVS_EINVAL;
     if (d.gn_stats && (d.gn_groups != 4 || d.cout % 4)) return DMVS_EINVAL;
     if (d.arith != DMVS_ARITH_F32 && d.arith != DMVS_ARITH_BF16) return DMVS_EINVAL;
     const int eh = (d.Hin + 2 * d.pad_h - d.kh) / d.stride + 1, ew = (d.Win + 2 * d.pad_w - d.kw) / d.stride + 1;
@@ -441,7 +487,8 @@ extern "C" int dmvs_conv2d_f32(const dmvs_conv2d_desc* dp, void* stream) {
     if ((long)d.Hout * d.Wout >= (1L << 24) || ocs >= (1 << 24) || (long)ocs * d.Hout * d.Wout >= (1L << 31)) return DMVS_EINVAL;
     const int key = d.kh * 100 + d.kw * 10 + d.stride;
     switch (key) {
-        case 111: return conv1x1_direct_ok(d) ? conv1x1_direct(d, st) : dmvs_detail::launch_conv2d_111(d, st);
+        case 111:
+            return conv1x1_px4_ok(d) ? conv1x1_px4(d, st) : dmvs_detail::launch_conv2d_111(d, st);
         case 331: return dmvs_detail::launch_conv2d_331(d, st);
         case 332: return dmvs_detail::launch_conv2d_332(d, st);
         case 552: return dmvs_detail::launch_conv2d_552(d, st);

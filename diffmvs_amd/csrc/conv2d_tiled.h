@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     const int pc0 = mode == DMVS_IN_UNSHUFFLE2 ? (d.c0 >> 2) : d.c0;
     const float *in0b, *mul0b, *in1b;      // per-batch-item input bases of the tile being staged
     auto set_bases = [&]() {
-        in0b = d.in0 + (size_t)s_b * pc0 * plane0;
+        in0b = d.in0 + (size_t)s_b * (d.in0_cstride ? d.in0_cstride : pc0) * plane0;
         mul0b = (!kLean && d.mul0) ? d.mul0 + (size_t)s_b * (d.gate_cstride ? d.gate_cstride : pc0) * plane0 : nullptr;
         in1b = (!WALK && d.in1) ? d.in1 + (size_t)s_b * d.c1 * plane1 : d.in0;
     };
@@ -480,7 +480,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
         // residual / GRU-gate read) per (row, n-tile) instead of four 4-byte ones, one bounds predicate and one offset
         // per four values.  NCHW fp32 outputs only; the values are those of the other form bit for bit.
         const int oxb = ox0 + wx * 16 + 4 * kq;
-        const bool vec = kLean || ((d.Wout & 3) == 0 && (((uintptr_t)d.out | (uintptr_t)d.residual | (uintptr_t)d.gru_z | (uintptr_t)d.gru_h) & 15) == 0 &&
+        const bool vec = kLean || ((d.Wout & 3) == 0 && (((uintptr_t)d.out | (uintptr_t)d.residual | (uintptr_t)d.gru_z | (uintptr_t)d.gru_h | (uintptr_t)d.out_mul) & 15) == 0 &&
                                    ((oplane * d.out_coffset) & 3) == 0);
         float sc[NT], sh[NT];
         int cgs[NT];
@@ -563,6 +563,15 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) y[r] = (1.0f - z[r]) * h[r] + z[r] * y[r];
+                }
+                if (!kLean && d.out_mul && cg >= d.out_mul_c0 && okl) {      // SepConvGRU: the r half of the merged gate conv leaves as r * h
+                    const float* mb = d.out_mul + ((size_t)b * (d.cout - d.out_mul_c0) + (cg - d.out_mul_c0)) * oplane + opix;
+                    if (fast) {
+                        y *= *reinterpret_cast<const f32x4*>(mb);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[r] *= mb[ok[r] ? r : 0];
+                    }
                 }
                 if (fast) {
                     *reinterpret_cast<f32x4*>(outb + o0) = y;
@@ -655,6 +664,16 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
                         y[nt][r] = (1.0f - z) * ghb[gi] + z * y[nt][r];
                     }
             }
+            if (d.out_mul) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int cg = nbase + nt * 16 + kq * 4 + r;
+                        if (okp && cg < d.cout && cg >= d.out_mul_c0)
+                            y[nt][r] *= d.out_mul[((size_t)b * (d.cout - d.out_mul_c0) + (cg - d.out_mul_c0)) * oplane + opix];
+                    }
+            }
             if constexpr (OT != DMVS_DTYPE_F32) {      // channel-last, 16-bit elements
                 uint16_t* const ob16 = reinterpret_cast<uint16_t*>(d.out) + (size_t)b * oplane * d.out_cstride + d.out_coffset;
 #pragma unroll
@@ -737,7 +756,7 @@ static int conv_tile_waves_x(const dmvs_conv2d_desc& d, long out_pixels, int nt)
 // no activation, no gating / GRU blend / GroupNorm statistics / post-scale, an optional same-size residual added before the
 // activation, rows of 16-byte multiples on 16-byte aligned tensors.  DMVS_TUNE_NO_WALK: one tile per workgroup everywhere (A/B).
 static bool conv_lean_ok(const dmvs_conv2d_desc& d) {
-    if ((d.tune & DMVS_TUNE_NO_LEAN) || d.arith != DMVS_ARITH_F32 || d.in_mode != DMVS_IN_PLAIN || d.mul0 || d.gru_z) return false;
+    if ((d.tune & DMVS_TUNE_NO_LEAN) || d.arith != DMVS_ARITH_F32 || d.in_mode != DMVS_IN_PLAIN || d.mul0 || d.gru_z || d.out_mul) return false;
     if ((d.act != DMVS_ACT_NONE && d.act != DMVS_ACT_RELU) || d.post_scale != 1.0f) return false;
     if (d.residual && (d.res_after_act || d.res_mode != DMVS_IN_PLAIN)) return false;
     if ((d.Wout & 3) || ((((uintptr_t)d.out | (uintptr_t)d.residual) & 15) != 0) || (((long)d.Hout * d.Wout * d.out_coffset) & 3)) return false;

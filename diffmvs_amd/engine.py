@@ -162,8 +162,10 @@ def run_gru(o: Ops, g, h, x):
     merged = os.environ.get("DMVS_GRU_MERGE", "1") != "0"      # A/B knob: 0 = z and r as two launches
     for n in ("1", "2"):     # horizontal then vertical pass (module.py:164-177)
         if merged:
-            zr = o.conv2d(g["zr" + n], h, x, act=K.ACT_SIGMOID)               # [B, 2*hd, H, W] = sigmoid([convz | convr]([h, x]))
-            h = o.conv2d(g["q" + n], h, x, mul0=zr[:, hd:], act=K.ACT_TANH, gru_z=zr[:, :hd], gru_h=h, gate_cstride=2 * hd)
+            # [B, 2*hd, H, W] = [z | r * h]: the r half of sigmoid([convz | convr]([h, x])) is multiplied by h in the epilogue (out_mul), so
+            # the candidate convolution reads a plain concatenated input instead of gating its staged tile in LDS per chunk
+            zr = o.conv2d(g["zr" + n], h, x, act=K.ACT_SIGMOID, out_mul=h, out_mul_c0=hd)
+            h = o.conv2d(g["q" + n], zr[:, hd:], x, in0_cstride=2 * hd, act=K.ACT_TANH, gru_z=zr[:, :hd], gru_h=h, gate_cstride=2 * hd)
         else:
             z = o.conv2d(g["z" + n], h, x, act=K.ACT_SIGMOID)
             r = o.conv2d(g["r" + n], h, x, act=K.ACT_SIGMOID)

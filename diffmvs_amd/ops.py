@@ -144,14 +144,14 @@ def bump_weights_generation() -> None:
 def _env_tune():
     """A/B knobs of the kernels' `tune` arguments (include/dmvs.h), read ONCE per binding in the Python layer -- the C library
     itself reads no environment variable.  All default to 0 = the library's measured-best path:
-      DMVS_CONV_WX=1|2, DMVS_CONV_MT=1|2|4, DMVS_CONV_WALK=0, DMVS_CONV_LEAN=0, DMVS_CONV_V16=0, DMVS_CONV1X1_WIDE=1   (dmvs_conv2d_desc.tune)
+      DMVS_CONV_WX=1|2, DMVS_CONV_MT=1|2|4, DMVS_CONV_WALK=0, DMVS_CONV_LEAN=0, DMVS_CONV_V16=0, DMVS_CONV1X1_PX4=0   (dmvs_conv2d_desc.tune)
       DMVS_CONV3D_V16=0, DMVS_CONV3D_S2=direct   (dmvs_conv3d_desc.tune)      DMVS_STEM_V16=0      DMVS_PLANE_SWEEP=quad"""
     e = os.environ.get
     t2 = _lib.tune_tile_wx(int(e("DMVS_CONV_WX", "0"))) | _lib.tune_tile_mt(int(e("DMVS_CONV_MT", "0")))
     t2 |= _lib.TUNE_NO_WALK if e("DMVS_CONV_WALK") == "0" else 0
     t2 |= _lib.TUNE_PIECES4 if e("DMVS_CONV_V16") == "0" else 0
-    t2 |= _lib.TUNE_1X1_WIDE if e("DMVS_CONV1X1_WIDE") == "1" else 0
     t2 |= _lib.TUNE_NO_LEAN if e("DMVS_CONV_LEAN") == "0" else 0
+    t2 |= _lib.TUNE_1X1_TILED if e("DMVS_CONV1X1_PX4") == "0" else 0
     t3 = (_lib.TUNE3D_PIECES4 if e("DMVS_CONV3D_V16") == "0" else 0) | (_lib.TUNE3D_S2_DIRECT if e("DMVS_CONV3D_S2") == "direct" else 0)
     return {"conv2d": t2, "conv3d": t3, "stem": _lib.TUNE_PIECES4 if e("DMVS_STEM_V16") == "0" else 0,
             "sweep": _lib.TUNE_SWEEP_GLOBAL if e("DMVS_PLANE_SWEEP") == "quad" else 0}
@@ -233,20 +233,25 @@ class Ops:
     def conv2d(self, pc: PackedConv, x0, x1=None, *, mul0=None, in_mode=IN_PLAIN, act=ACT_NONE, residual=None,
                res_mode=IN_PLAIN, res_after_act=False, post_scale=1.0, gru_z=None, gru_h=None, out=None,
                out_layout=LAYOUT_NCHW, out_cstride=None, out_coffset=0, gn_stats=None, gn_groups=4, out_dtype=torch.float32,
-               gate_cstride=0, arith=None, tune=None):
+               gate_cstride=0, arith=None, tune=None, out_mul=None, out_mul_c0=0, in0_cstride=0):
         """gn_stats: zeroed float64 [B*gn_groups*2] tensor that receives the GroupNorm statistics of
         the (pre-activation) output, for a following groupnorm_apply().  out_dtype (channel-last outputs only): bf16 / fp16
         feature storage, rounded to nearest even in the epilogue.  arith: ARITH_F32 | ARITH_BF16 (default: this binding's
         conv_arith) -- bf16 rounds inputs and weights as they enter the matrix cores (fp32 accumulation, fp32 tensors); layers
         with one tap and channel-last outputs always compute in fp32."""
+        if in0_cstride:       # x0 is a channel slice of a contiguous [B,in0_cstride,H,W] tensor (the r * h half of the merged gate conv's output)
+            if (x0.dtype != torch.float32 or x0.device != self.device or x0.stride(1) != x0.shape[2] * x0.shape[3] or
+                    x0.stride(0) != in0_cstride * x0.shape[2] * x0.shape[3] or x0.stride(3) != 1 or in_mode != IN_PLAIN):
+                raise _lib.DmvsError("in0_cstride: x0 must be a channel slice of a contiguous [B,in0_cstride,H,W] tensor, plain input mode")
+        self._chk(out_mul)
         if gate_cstride:      # mul0 / gru_z are channel slices of one [B,gate_cstride,H,W] tensor (merged z|r gate convolution)
-            self._chk(x0, x1, residual, gru_h)
+            self._chk(*(() if in0_cstride else (x0,)), x1, residual, gru_h)
             for t in (mul0, gru_z):
                 if t is not None and (t.dtype != torch.float32 or t.device != self.device or t.stride(1) != t.shape[2] * t.shape[3] or
                                       t.stride(0) != gate_cstride * t.shape[2] * t.shape[3] or t.stride(3) != 1):
                     raise _lib.DmvsError("gate_cstride: mul0 / gru_z must be channel slices of a contiguous [B,gate_cstride,H,W] tensor")
         else:
-            self._chk(x0, x1, mul0, residual, gru_z, gru_h)
+            self._chk(*(() if in0_cstride else (x0,)), x1, mul0, residual, gru_z, gru_h)
         if out_dtype != torch.float32:
             if out_layout != LAYOUT_NHWC or out is not None:
                 raise _lib.DmvsError("16-bit outputs are channel-last feature tensors allocated by conv2d")
@@ -279,7 +284,8 @@ class Ops:
             kh=kh, kw=kw, stride=pc.stride, pad_h=pc.pad[0], pad_w=pc.pad[1], in_mode=in_mode, act=act,
             res_mode=res_mode, res_after_act=int(res_after_act), out_layout=out_layout, out_cstride=out_cstride,
             out_coffset=out_coffset, post_scale=post_scale, gate_cstride=gate_cstride,
-            arith=(self.conv_arith if arith is None else arith), tune=(self.tune["conv2d"] if tune is None else tune))
+            arith=(self.conv_arith if arith is None else arith), tune=(self.tune["conv2d"] if tune is None else tune),
+            out_mul=_ptr(out_mul), out_mul_c0=out_mul_c0, in0_cstride=in0_cstride)
         self._call("dmvs_conv2d_f32", C.byref(d), self.stream())
         if self.timers is not None and "dmvs_conv2d_f32" in self.timers:      # bench: MFMA roofline over every conv launch
             self.timers.setdefault("_conv2d_flops", []).append(2.0 * B * Hout * Wout * pc.cout * pc.cin * kh * kw)

@@ -66,6 +66,7 @@ int dmvs_abi_version(void);
  *   y = act(y) * post_scale
  *   y += residual                           if residual &&  res_after_act
  *   y = (1 - gru_z) * gru_h + gru_z * y     if gru_z           (act must be TANH)
+ *   y *= out_mul[co - out_mul_c0]           if out_mul && co >= out_mul_c0
  * Output is written at channel offset out_coffset of a tensor with out_cstride channels
  * (so that concatenations never have to be materialised), NCHW or NHWC.
  */
@@ -73,12 +74,12 @@ int dmvs_abi_version(void);
 #define DMVS_ARITH_BF16 1
 
 /* dmvs_conv2d_desc.tune: 0 = the library's own choice (measured best on the MI355X); the bits force a code path for A/B runs.
- * Results do not depend on them (bit-identical kernels), except DMVS_TUNE_1X1_WIDE whose summation order is the direct kernel's. */
+ * Results do not depend on them (bit-identical kernels). */
 #define DMVS_TUNE_TILE_WX(n) ((n) & 3)           /* 1 | 2: 16- / 32-pixel-wide workgroup tiles for the 3x3 / 5x5 layers           */
 #define DMVS_TUNE_NO_WALK 0x4                     /* one tile per workgroup everywhere (no resident tile-walking workgroups)        */
 #define DMVS_TUNE_PIECES4 0x8                     /* input halo staged in 4-byte LDS-DMA pieces even where 16-byte ones apply        */
 #define DMVS_TUNE_TILE_MT(n) (((n) & 7) << 4)     /* 1 | 2 | 4: tile height in units of 4 rows                                       */
-#define DMVS_TUNE_1X1_WIDE 0x80                   /* direct (no LDS input tile) 1x1 kernel also for 2..9 output n-tiles              */
+#define DMVS_TUNE_1X1_TILED 0x200                 /* 1x1 layers on the LDS-tiled kernel instead of the 16-byte direct form                    */
 #define DMVS_TUNE_NO_LEAN 0x100                   /* plain layers on the generic kernel (every fused path resolved at run time)     */
 
 typedef struct dmvs_conv2d_desc {
@@ -98,6 +99,10 @@ typedef struct dmvs_conv2d_desc {
                                BEFORE the activation (GroupNorm statistics of the conv output, so
                                that Block.forward needs no separate reduction pass; the caller
                                zeroes the buffer).  gn_groups must be 4 and divide cout.       */
+    const float* out_mul;   /* [B, cout - out_mul_c0, Hout, Wout] dense, or NULL: output channels co >= out_mul_c0 are multiplied by
+                               out_mul[b, co - out_mul_c0] LAST (after activation, post-scale, residual).  SepConvGRU: the merged z|r
+                               gate convolution writes [z | r * h] directly, so that the candidate convolution reads a plain input
+                               instead of gating its staged tile (models/module.py:166-168)                                  */
     int32_t B, c0, c1;
     int32_t Hin, Win;       /* LOGICAL input size (after in_mode)                           */
     int32_t Hout, Wout;
@@ -119,6 +124,9 @@ typedef struct dmvs_conv2d_desc {
                                more than one tap, >= 24 input channels and an NCHW output (where it is faster); every other
                                layer computes in fp32 in either mode.                                                     */
     int32_t tune;           /* DMVS_TUNE_* bits, 0 = automatic                                                              */
+    int32_t out_mul_c0;     /* first output channel out_mul applies to                                                       */
+    int32_t in0_cstride;    /* 0: in0 is a dense [B,c0,..] tensor.  > 0 (DMVS_IN_PLAIN only): in0 is a channel slice (the pointer includes
+                               the channel offset) of a tensor with this many channels per batch item                         */
 } dmvs_conv2d_desc;
 
 /* Size limits (DMVS_EINVAL beyond them; the kernels address one batch item with 32-bit element offsets):

