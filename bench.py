@@ -440,6 +440,11 @@ def main():
                    "ref_views_per_gpu_per_step": B, "parallelism": f"ref-view sharding x{world}, no collective",
                    "weights": "seeded random init (no checkpoint offline)",
                    "launch": "captured HIP graph of the forward" if a.graphs else "eager launch sequence (~350 kernels per step)"},
+        # the second half of BASELINE.json's metric ("DTU abs-rel vs ref") cannot be measured here: no DTU scans and no trained checkpoint in
+        # the image.  What IS measured against the reference: depth maps on the reference's own inputs (goldens recorded by
+        # importing it) -- tests/test_model_gpu.py, final-depth relative L1 1e-7 .. 4e-7 against the 1e-3 bar
+        "dtu_abs_rel_vs_ref": None,
+        "accuracy_note": "DTU abs-rel unmeasurable offline (no dataset / checkpoint); depth parity vs the reference's recorded outputs: rel-L1 <= 4e-7 (GPU test suite)",
         "batch_sweep_ms_per_map": sweep,
         "roofline": {"kernel": "GetCost: getcost_quad_kernel<32,6> (quad per pixel, one launch for any geometry)",
                      "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
