@@ -174,6 +174,36 @@ def test_conv2d_16_byte_staging_pieces_fused_inputs(ops):
         assert torch.equal(a.cpu(), b.cpu())
 
 
+@pytest.mark.parametrize("hd,cx,H,W", [(12, 10, 21, 24), (32, 48, 9, 20), (6, 10, 10, 13)])
+def test_conv2d_gru_pass_with_the_gate_product_in_the_producer(ops, hd, cx, H, W):
+    """one SepConvGRU pass (module.py:164-177) the way the engine runs it since round 4: the merged z|r convolution writes [z | r * h]
+    (out_mul / out_mul_c0: channels >= hd multiplied by h after the sigmoid), the candidate convolution reads r * h as a plain
+    channel slice of that tensor (in0_cstride) -- against torch, and BIT FOR BIT against the form that gates the staged tile
+    (mul0): the same fp32 product, computed once in the producer"""
+    B = 2
+    h, x = rnd(B, hd, H, W, seed=1), rnd(B, cx, H, W, seed=2)
+    for k, pad in (((1, 5), (0, 2)), ((5, 1), (2, 0))):
+        wz, wr, wq = (rnd(hd, hd + cx, *k, seed=s) * 0.3 for s in (3, 4, 5))
+        bz, br, bq = (rnd(hd, seed=s) for s in (6, 7, 8))
+        hx = torch.cat([h, x], 1)
+        z, r = torch.sigmoid(F.conv2d(hx, wz, bz, 1, pad)), torch.sigmoid(F.conv2d(hx, wr, br, 1, pad))
+        q = torch.tanh(F.conv2d(torch.cat([r * h, x], 1), wq, bq, 1, pad))
+        ref = (1 - z) * h + z * q
+        pzr = K.pack_conv2d(*dev(ops, torch.cat([wz, wr]), torch.cat([bz, br])), pad=pad)
+        pq = K.pack_conv2d(*dev(ops, wq, bq), pad=pad)
+        hdv, xdv = dev(ops, h, x)
+        zr = ops.conv2d(pzr, hdv, xdv, act=K.ACT_SIGMOID, out_mul=hdv, out_mul_c0=hd)
+        close(zr[:, :hd], z, 2e-5)
+        close(zr[:, hd:], r * h, 2e-5)
+        out = ops.conv2d(pq, zr[:, hd:], xdv, in0_cstride=2 * hd, act=K.ACT_TANH, gru_z=zr[:, :hd], gru_h=hdv, gate_cstride=2 * hd)
+        close(out, ref, 2e-5)
+        zr0 = ops.conv2d(pzr, hdv, xdv, act=K.ACT_SIGMOID)
+        old = ops.conv2d(pq, hdv, xdv, mul0=zr0[:, hd:], act=K.ACT_TANH, gru_z=zr0[:, :hd], gru_h=hdv, gate_cstride=2 * hd)
+        assert torch.equal(zr[:, :hd].cpu(), zr0[:, :hd].cpu()) and torch.equal(out.cpu(), old.cpu())
+    with pytest.raises(K._lib.DmvsError):      # the slice must come from a [B, in0_cstride, H, W] tensor
+        ops.conv2d(pq, hdv, xdv, in0_cstride=2 * hd, act=K.ACT_TANH)
+
+
 @pytest.mark.parametrize("c0,cout,H,W,res", [(32, 64, 10, 16, "up"), (64, 144, 7, 8, None), (48, 32, 5, 44, "same"), (6, 36, 33, 36, None), (64, 96, 16, 64, "up")])
 def test_conv2d_1x1_16_byte_form_wide(c0, cout, H, W, res):
     """the 2..4 n-tile instantiations and the channel groups of the 16-byte 1x1 form (2 n-tiles per workgroup with a residual, up to 4
