@@ -14,15 +14,26 @@ from . import ops as K
 from .ops import Ops, PackedConv, pack_conv2d, pack_conv3d
 
 
+def _packed(cache, key, pins, make):
+    """per-step cache of packed weights, keyed by tensor identity; the entry pins the tensors so that an id is not reused"""
+    if cache is None:
+        return make()
+    hit = cache.get(key)
+    if hit is None:
+        hit = cache[key] = (make(), pins)
+    return hit[0]
+
+
 class _Conv2dFn(torch.autograd.Function):
     """conv2d(x, weight, bias) with stride 1|2 and the fused input modes of the forward kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, ops: Ops, stride, pad, in_mode):
-        pc = pack_conv2d(weight, bias, stride=stride, pad=pad)
+    def forward(ctx, x, weight, bias, ops: Ops, stride, pad, in_mode, cache):
+        pc = _packed(cache, ("fwd", id(weight), id(bias), stride, pad), (weight, bias),
+                     lambda: pack_conv2d(weight, bias, stride=stride, pad=pad))
         out = ops.conv2d(pc, x, in_mode=in_mode)
         ctx.save_for_backward(x, weight)
-        ctx.ops, ctx.pc, ctx.in_mode, ctx.has_bias = ops, pc, in_mode, bias is not None
+        ctx.ops, ctx.pc, ctx.in_mode, ctx.has_bias, ctx.cache = ops, pc, in_mode, bias is not None, cache
         return out
 
     @staticmethod
@@ -34,8 +45,10 @@ class _Conv2dFn(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             # dX = conv(dY (zero-inserted for stride 2), W flipped and cin<->cout transposed), pad' = k-1-pad
-            wb = weight.detach().flip(2, 3).permute(1, 0, 2, 3).contiguous()
-            pcb = pack_conv2d(wb, None, stride=1, pad=(kh - 1 - pc.pad[0], kw - 1 - pc.pad[1]))
+            def flipped():
+                wb = weight.detach().flip(2, 3).permute(1, 0, 2, 3).contiguous()
+                return pack_conv2d(wb, None, stride=1, pad=(kh - 1 - pc.pad[0], kw - 1 - pc.pad[1]))
+            pcb = _packed(ctx.cache, ("bwd", id(weight), pc.pad), (weight,), flipped)
             gl = ops.conv2d(pcb, g, in_mode=(K.IN_ZEROINSERT2 if pc.stride == 2 else K.IN_PLAIN))
             if in_mode == K.IN_UPSAMPLE2:
                 gx = F.avg_pool2d(gl, 2) * 4.0          # adjoint of nearest x2
@@ -50,12 +63,15 @@ class _Conv2dFn(torch.autograd.Function):
                 gw, gb = gw
         elif want_b:
             gb = g.sum((0, 2, 3))
-        return gx, gw, gb, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None
 
 
-def conv2d(ops: Ops, x, weight, bias=None, stride=1, pad=0, in_mode=K.IN_PLAIN):
+def conv2d(ops: Ops, x, weight, bias=None, stride=1, pad=0, in_mode=K.IN_PLAIN, cache=None):
+    """cache: a dict that lives for ONE training step (train._Net): the packed forward weights and the flipped / transposed
+    weights of the input gradient are built once per weight tensor and step instead of once per use -- the update block applies
+    the same layers in every GRU iteration (3 uses per step at cfg4: ~4 tiny permute / flip / copy kernels per use saved)."""
     pad = (pad, pad) if isinstance(pad, int) else tuple(pad)
-    return _Conv2dFn.apply(x.contiguous(), weight, bias, ops, stride, pad, in_mode)
+    return _Conv2dFn.apply(x.contiguous(), weight, bias, ops, stride, pad, in_mode, cache)
 
 
 class _Conv3dFn(torch.autograd.Function):

@@ -419,7 +419,9 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
             }
         } else {
         const int live_c = cin - c0 < CK ? cin - c0 : CK;
-        const int nc4 = (live_c + 3) >> 2;          // all-zero 4-channel groups of the last chunk are skipped
+        // all-zero 4-channel groups of the last chunk are skipped.  (A 4-channel chunk has one group: said at compile time for the
+        // tall-tile form, whose accumulators hipcc otherwise moves VGPR -> AGPR -> VGPR around the one-trip loop, 64 moves per chunk)
+        const int nc4 = (CK == 4 && MT == 8) ? 1 : (live_c + 3) >> 2;
 #pragma unroll 1
         for (int c4 = 0; c4 < nc4; ++c4) {
             const int ci = c4 * 4 + kq;
@@ -429,6 +431,10 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
             // of 4 MFMAs per trip runs the matrix pipe at 0.81 of the rate of 16 per trip (tools/calib/issue_probe.hip).  Measured per
             // layer (profiles/r3_conv_ky_unroll_ab.txt): -1...-9 % on the >= 32-channel layers, 16 -> 16 unchanged; the 5x5 / 7x7 layers
             // already have 10-40 per trip.  -DDMVS_CONV_KY_ROLLED restores one row per trip (A/B builds).  Same order of operations.
+            // Round 4 (profiles/r4_conv_tall_s2_ky_ab.jsonl, both removed again): all five rows of the one-n-tile 5x5 layers in one trip (50
+            // MFMAs instead of 10) -1.4 % on 8 -> 16 stride 2, nothing elsewhere; the stride-2 B operand read as 8-byte pairs (ds_read2_b64:
+            // a lane's taps kx, kx + 1 -- the 4-byte reads of lanes 2 floats apart meet two by two in the banks) +-1 %: LDS read
+            // bandwidth is not what separates the stride-2 layers from their stride-1 peers.
 #ifdef DMVS_CONV_KY_ROLLED
             constexpr int kKyUnroll = 1;
 #else
@@ -904,12 +910,47 @@ int launch_conv2d_mt(const dmvs_conv2d_desc& d, hipStream_t st, int nt, int ngro
     return dmvs_launch_status();
 }
 
+// 16 x 32-pixel tiles (MT = 8) for the plain 3x3 layers with one n-tile -- the 16 -> 16 layers that sat at 0.47-0.58 of the matrix peak.
+// Per MFMA a tall tile has half the tile decode / staging map / weight map, its 34 x 6 halo pieces fill 204 of the 256 lanes of ONE
+// DMA wave-instruction set per channel (the 16 x 16 tile's 108 pieces leave 148 lanes idle) and its 10 halo rows feed 8 output rows (6
+// feed 4).  The chunk drops to 4 channels (ConvCfg::CK: an 8-channel double buffer would be 61 KB) with the same 72 MFMAs per wave between
+// two barriers, 31 KB of LDS.  Measured at B = 96 (profiles/r4_conv_tall_s2_ky_ab.jsonl, bit-identical): 16 -> 16 at 576 x 256 x 320
+// 2479 -> 2350 us, at 96 x 256 x 320 420 -> 384, at 96 x 128 x 160 112 -> 101, at 96 x 64 x 80 37 -> 32; 32 -> 16 184 -> 177; 64 -> 16
+// unchanged (338 -> 339); the step 75.8 -> 75.0 ms (profiles/r4_tall_tiles_step_ab.json).  Default for <= 32 input channels when the
+// launch still has >= 4 tall tiles per CU (small batches keep the 16 x 16 / 16 x 4 tiles: more workgroups, shorter chunk chains).
+// DMVS_TUNE_TALL(1) = never, (2) = wherever the form applies (incl. the two-n-tile instantiation, an experiment).
+template <int KH, int KW, int S>
+static bool conv_tall_ok(const dmvs_conv2d_desc& d, int nt) {
+    if constexpr (KH == 3 && KW == 3 && S == 1) {
+        const int mode = (d.tune >> 10) & 3;
+        if (mode == 1 || nt > 2 || (nt == 2 && mode != 2)) return false;
+        if (d.out_layout != DMVS_LAYOUT_NCHW || !conv_lean_ok(d) || !conv_v16_ok<3>(d) || d.Hout < 32) return false;
+        if (mode == 2) return true;
+        const long tall_tiles = (long)((d.Wout + 15) / 16) * ((d.Hout + 31) / 32) * d.B;
+        return d.c0 + d.c1 <= 32 && tall_tiles >= 1024;
+    }
+    return false;
+}
+
 template <int KH, int KW, int S>
 int launch_conv2d(const dmvs_conv2d_desc& d, hipStream_t st) {
     const int ntiles = (d.cout_pad + 15) / 16;
     // output channels per workgroup: up to 4 MFMA n-tiles share one staged input tile
     const int nt = ntiles <= 4 ? ntiles : (ntiles % 3 == 0 ? 3 : 4);
     const int ngroups = (ntiles + nt - 1) / nt;
+    if constexpr (KH == 3 && KW == 3 && S == 1) {
+        if (conv_tall_ok<KH, KW, S>(d, nt)) {
+            const int tiles_x = (d.Wout + 15) / 16, tiles_y = (d.Hout + 31) / 32;
+            const dim3 grid((unsigned)(tiles_x * tiles_y * d.B), 1u);
+            if (nt == 1)
+                hipLaunchKernelGGL((conv2d_mfma_kernel<3, 3, 1, 1, 8, false, DMVS_DTYPE_F32, true, false, DMVS_ARITH_F32, 1, true, true>), grid,
+                                   dim3(DMVS_BLOCK), 0, st, d, tiles_x, tiles_y);
+            else
+                hipLaunchKernelGGL((conv2d_mfma_kernel<3, 3, 1, 2, 8, false, DMVS_DTYPE_F32, true, false, DMVS_ARITH_F32, 1, true, true>), grid,
+                                   dim3(DMVS_BLOCK), 0, st, d, tiles_x, tiles_y);
+            return dmvs_launch_status();
+        }
+    }
     if (d.in_mode == DMVS_IN_ZEROINSERT2) {        // training: input gradient of the 3x3 / 5x5 stride-2 layers
         if constexpr (S == 1 && ((KH == 3 && KW == 3) || (KH == 5 && KW == 5)))
             return launch_conv2d_mt<KH, KW, S, 2, true>(d, st, nt, ngroups);

@@ -152,6 +152,7 @@ def _env_tune():
     t2 |= _lib.TUNE_PIECES4 if e("DMVS_CONV_V16") == "0" else 0
     t2 |= _lib.TUNE_NO_LEAN if e("DMVS_CONV_LEAN") == "0" else 0
     t2 |= _lib.TUNE_1X1_TILED if e("DMVS_CONV1X1_PX4") == "0" else 0
+    t2 |= {"0": _lib.TUNE_NO_TALL, "1": _lib.TUNE_TALL}.get(e("DMVS_CONV_TALL"), 0)
     t3 = (_lib.TUNE3D_PIECES4 if e("DMVS_CONV3D_V16") == "0" else 0) | (_lib.TUNE3D_S2_DIRECT if e("DMVS_CONV3D_S2") == "direct" else 0)
     return {"conv2d": t2, "conv3d": t3, "stem": _lib.TUNE_PIECES4 if e("DMVS_STEM_V16") == "0" else 0,
             "sweep": _lib.TUNE_SWEEP_GLOBAL if e("DMVS_PLANE_SWEEP") == "quad" else 0}

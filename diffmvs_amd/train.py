@@ -38,13 +38,17 @@ class _Net:
         self.o = ops
         self.p = dict(model.named_parameters())
         self.b = dict(model.named_buffers())
+        # per-STEP cache (a _Net lives for one forward_train call and the backward of its graph): packed weights per weight tensor
+        # (autograd._packed), and the sub-graphs that do not depend on the GRU iteration -- standardised weights, time embeddings --
+        # built once and shared by the iterations (autograd sums their gradients before the shared node's backward runs once)
+        self.cache = {}
 
     def has(self, k):
         return k in self.p
 
     # ---- convolution flavours
     def conv2(self, x, k, stride=1, pad=0, in_mode=K.IN_PLAIN):
-        return A.conv2d(self.o, x, self.p[k + ".weight"], self.p.get(k + ".bias"), stride=stride, pad=pad, in_mode=in_mode)
+        return A.conv2d(self.o, x, self.p[k + ".weight"], self.p.get(k + ".bias"), stride=stride, pad=pad, in_mode=in_mode, cache=self.cache)
 
     def bn(self, x, k, relu, views=1, view_major=True):
         """BatchNorm in training mode (+ReLU): batch statistics, running stats updated in place (momentum 0.1).
@@ -56,7 +60,7 @@ class _Net:
 
     def cbr2(self, x, k, stride=1, pad=1, relu=True, views=1):
         """module.Conv2d / ConvBnReLU / ConvBn (module.py:24-58, :279-301)"""
-        y = A.conv2d(self.o, x, self.p[k + ".conv.weight"], None, stride=stride, pad=pad)
+        y = A.conv2d(self.o, x, self.p[k + ".conv.weight"], None, stride=stride, pad=pad, cache=self.cache)
         return self.bn(y, k + ".bn", relu, views)
 
     def cbr3(self, x, k, stride=1, transposed=False, views=1, view_major=True):
@@ -163,10 +167,13 @@ def initial_cost(n: _Net, feat, B, context, rt, disp_min, disp_max, dmin, dmax, 
 # ------------------------------------------------------------------ update block nets
 def _ws_conv(n: _Net, x, k):
     """WeightStandardizedConv2d (update.py:81-94); the standardisation is differentiated by autograd"""
-    w = n.p[k + ".weight"]
-    mean = w.mean(dim=(1, 2, 3), keepdim=True)
-    var = w.var(dim=(1, 2, 3), unbiased=False, keepdim=True)
-    return A.conv2d(n.o, x, (w - mean) * torch.rsqrt(var + 1e-5), n.p[k + ".bias"], pad=1)
+    ws = n.cache.get(("ws", k))
+    if ws is None:      # once per step: the GRU iterations share the standardised tensor (and its packed forms)
+        w = n.p[k + ".weight"]
+        mean = w.mean(dim=(1, 2, 3), keepdim=True)
+        var = w.var(dim=(1, 2, 3), unbiased=False, keepdim=True)
+        ws = n.cache[("ws", k)] = (w - mean) * torch.rsqrt(var + 1e-5)
+    return A.conv2d(n.o, x, ws, n.p[k + ".bias"], pad=1, cache=n.cache)
 
 
 def _block(n: _Net, x, k, scale_shift=None):
@@ -177,7 +184,10 @@ def _block(n: _Net, x, k, scale_shift=None):
 def resnet_block(n: _Net, x, k, t_emb=None):
     ss = None
     if t_emb is not None and n.has(k + ".mlp.1.weight"):
-        ss = F.linear(F.silu(t_emb), n.p[k + ".mlp.1.weight"], n.p[k + ".mlp.1.bias"])      # [B, 2C] = (scale | shift)
+        ss = n.cache.get(("ss", k, id(t_emb)))
+        if ss is None:      # [B, 2C] = (scale | shift): a function of the time embedding only, the same in every GRU iteration
+            ss = F.linear(F.silu(t_emb), n.p[k + ".mlp.1.weight"], n.p[k + ".mlp.1.bias"])
+            n.cache[("ss", k, id(t_emb))] = ss
     h = _block(n, _block(n, x, k + ".block1", ss), k + ".block2")
     res = n.conv2(x, k + ".res_conv") if n.has(k + ".res_conv.weight") else x
     return h + res
@@ -196,12 +206,16 @@ def sep_conv_gru(n: _Net, k, h, x):
 def unet(n: _Net, k, x, hidden, t, dim, L):
     x = n.conv2(x, k + ".init_conv", pad=3)
     r = x
-    half = dim // 2
-    freqs = torch.exp(torch.arange(half, device=x.device) * -(math.log(10000) / (half - 1)))
-    e = t[:, None] * freqs[None, :]
-    e = torch.cat((e.sin(), e.cos()), -1)
-    e = F.gelu(F.linear(e, n.p[k + ".time_mlp.1.weight"], n.p[k + ".time_mlp.1.bias"]))
-    te = F.linear(e, n.p[k + ".time_mlp.3.weight"], n.p[k + ".time_mlp.3.bias"])
+    te = n.cache.get(("te", k, id(t)))
+    if te is None:      # the time embedding of the stage's t (update.py:432: one draw per stage), shared by the GRU iterations
+        half = dim // 2
+        freqs = torch.exp(torch.arange(half, device=x.device) * -(math.log(10000) / (half - 1)))
+        e = t[:, None] * freqs[None, :]
+        e = torch.cat((e.sin(), e.cos()), -1)
+        e = F.gelu(F.linear(e, n.p[k + ".time_mlp.1.weight"], n.p[k + ".time_mlp.1.bias"]))
+        te = F.linear(e, n.p[k + ".time_mlp.3.weight"], n.p[k + ".time_mlp.3.bias"])
+        n.cache[("te", k, id(t))] = te
+        n.cache[("pin", id(t))] = t          # (keeps id(t) from being reused while the entry lives)
     skips = []
     for i in range(L):
         x = resnet_block(n, x, f"{k}.downs.{i}.0", te)

@@ -787,6 +787,33 @@ def test_conv2d_tile_walking_workgroups(ops, cin, cout, k, stride, HW, with_res)
     close(out, ref, 2e-5)
 
 
+@pytest.mark.parametrize("cin,c1,cout,HW,extra", [(16, 0, 16, (64, 48), "res"), (16, 0, 16, (40, 52), None), (12, 4, 16, (33, 36), "gn"), (32, 0, 13, (70, 20), None),
+                                                   (16, 0, 32, (64, 48), "res"), (24, 8, 32, (37, 36), "gn"), (32, 0, 31, (40, 20), None)])
+def test_conv2d_tall_tiles(ops, cin, c1, cout, HW, extra):
+    """DMVS_TUNE_TALL: the plain 3x3 layers on 16 x 32-pixel tiles (MT = 8, 4-channel chunks; one n-tile = the default at large
+    batches, two n-tiles = an experiment): ragged last tile rows, border tiles, a second concat input, the residual and the GroupNorm
+    statistics -- against torch and BIT FOR BIT the 16 x 16 / 16 x 4 tiles"""
+    B = 2
+    x0 = rnd(B, cin, *HW, seed=1)
+    x1 = rnd(B, c1, *HW, seed=2) if c1 else None
+    w, bias = rnd(cout, cin + c1, 3, 3, seed=3) * 0.2, rnd(cout, seed=4)
+    ref = F.conv2d(x0 if x1 is None else torch.cat([x0, x1], 1), w, bias, 1, 1)
+    res = rnd(*ref.shape, seed=5) if extra == "res" else None
+    pc = K.pack_conv2d(*dev(ops, w, bias), pad=1)
+    outs, sts = [], []
+    for tune in (K._lib.TUNE_NO_TALL, K._lib.TUNE_TALL):
+        stats = torch.zeros(B * 8, dtype=torch.float64, device=ops.device) if extra == "gn" else None
+        out = ops.conv2d(pc, dev(ops, x0), None if x1 is None else dev(ops, x1), residual=None if res is None else dev(ops, res),
+                         act=K.ACT_NONE if extra == "gn" else K.ACT_RELU, gn_stats=stats, tune=tune)
+        close(out, ref if extra == "gn" else F.relu(ref + res if res is not None else ref), 2e-5)
+        outs.append(out.cpu())
+        sts.append(None if stats is None else stats.cpu().view(torch.int64))
+    assert torch.equal(outs[0], outs[1])
+    if extra == "gn":      # fixed-point sums of float partials: the partials differ with the tile shape, the totals agree to rounding
+        a, b = sts[0].double() / 65536.0, sts[1].double() / 65536.0
+        assert float((a - b).abs().max()) <= 1e-3 * max(1.0, float(a.abs().max()))
+
+
 @pytest.mark.parametrize("bad", [float("nan"), float("inf"), 3.0e7])
 def test_groupnorm_stats_propagate_non_finite_and_out_of_range(ops, bad):
     """the fixed-point statistics slots (dmvs_common.h): a NaN / Inf activation -- or one beyond the documented magnitude

@@ -2,6 +2,7 @@
 
     python tools/diag_r4.py getcost     # which resource bounds getcost_quad_kernel<32,6> at the bench batch: the product build against
                                         # the DMVS_GC_EXP builds (tools/build_variant.py gcexp1..3: compute-only / memory-only / half requests)
+    python tools/diag_r4.py convexp     # tall tiles (tune bit) and the stride-2 / 5x5 variant builds, per layer
     python tools/diag_r4.py optins      # the opt-in experiments round 3 left untimed: 16-byte halo pieces in the 3-D MFMA kernels and the
                                         # fused stem (per-launch environment knobs), the padding-pass skip (variant build), per layer
 """
@@ -160,5 +161,74 @@ def optins():
             del xx, a, b
 
 
+def convexp():
+    """three convolution experiments at the bench batch, per layer (all bit-identical to the product, checked here):
+    tall = DMVS_TUNE_TALL (16 x 32-pixel tiles for the one-n-tile plain 3x3 layers); s2b64 / ky55 / s2b64ky55 = variant builds
+    (8-byte LDS reads of the stride-2 B operand; all five tap rows of a one-n-tile 5x5 layer in one loop trip)"""
+    o = Ops.for_device("cuda:0")
+    g = torch.Generator(device="cuda").manual_seed(0)
+    var = {}
+    for n in ("s2b64", "ky55", "s2b64ky55"):
+        path = os.path.join(ROOT, "tools", "calib", "libdmvs_hip_%s.so" % n)
+        if os.path.exists(path):
+            var[n] = Ops(_lib.Lib(path), "cuda:0")
+    layers = [  # name, N, cin, cout, k, stride, H, W (input)
+        ("16->16 3x3 256x320 x576", 576, 16, 16, 3, 1, 256, 320), ("16->16 3x3 128x160 x96", 96, 16, 16, 3, 1, 128, 160),
+        ("16->16 3x3 256x320 x96", 96, 16, 16, 3, 1, 256, 320), ("16->16 3x3 64x80 x96", 96, 16, 16, 3, 1, 64, 80),
+        ("32->16 3x3 128x160 x96", 96, 32, 16, 3, 1, 128, 160), ("64->16 3x3 128x160 x96", 96, 64, 16, 3, 1, 128, 160),
+        ("8->16 5x5 s2 512x640 x576", 576, 8, 16, 5, 2, 512, 640), ("16->32 5x5 s2 256x320 x576", 576, 16, 32, 5, 2, 256, 320),
+        ("32->64 5x5 s2 128x160 x576", 576, 32, 64, 5, 2, 128, 160), ("8->16 3x3 s2 512x640 x96", 96, 8, 16, 3, 2, 512, 640),
+        ("16->32 3x3 s2 256x320 x96", 96, 16, 32, 3, 2, 256, 320), ("32->48 3x3 s2 128x160 x96", 96, 32, 48, 3, 2, 128, 160)]
+    for name, N, cin, cout, k, s, H, W in layers:
+        xx = torch.randn(N, cin, H, W, generator=g, device="cuda")
+        ww = torch.randn(cout, cin, k, k, generator=g, device="cuda") * 0.1
+        pc = K.pack_conv2d(ww, None, stride=s, pad=k // 2)
+        ref = o.conv2d(pc, xx, act=K.ACT_RELU)
+        row = {"diag": "convexp", "layer": name, "product_us": round(timeit(lambda: o.conv2d(pc, xx, act=K.ACT_RELU), iters=10), 1)}
+        flops = 2.0 * N * (H // s) * (W // s) * cin * cout * k * k
+        row["product_frac"] = round(flops / (row["product_us"] * 1e-6) / 157.3e12, 3)
+        row["product_us"] = round(timeit(lambda: o.conv2d(pc, xx, act=K.ACT_RELU, tune=_lib.TUNE_NO_TALL), iters=10), 1) if s == 1 else row["product_us"]
+        if s == 1:
+            y = o.conv2d(pc, xx, act=K.ACT_RELU, tune=_lib.TUNE_TALL)
+            row["tall_bit_identical"] = bool(torch.equal(ref, y))
+            row["tall_us"] = round(timeit(lambda: o.conv2d(pc, xx, act=K.ACT_RELU, tune=_lib.TUNE_TALL), iters=10), 1)
+            del y
+        else:
+            for n, ov in var.items():
+                y = ov.conv2d(pc, xx, act=K.ACT_RELU)
+                row[n + "_bit_identical"] = bool(torch.equal(ref, y))
+                row[n + "_us"] = round(timeit(lambda: ov.conv2d(pc, xx, act=K.ACT_RELU), iters=10), 1)
+                del y
+        print(json.dumps(row), flush=True)
+        del xx, ref
+
+
+def convexp2():
+    """the tall-tile form with TWO n-tiles (DMVS_TUNE_TALL(2) on 17..32-output-channel plain 3x3 layers) against the product's choice
+    (walking / 32-wide / 16 x 16 tiles), as a plain ReLU layer and as a Unet block convolution (GroupNorm statistics: cannot walk)"""
+    o = Ops.for_device("cuda:0")
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for name, N, cin, cout, H, W in (("32->32 128x160 x96", 96, 32, 32, 128, 160), ("64->32 128x160 x576", 576, 64, 32, 128, 160),
+                                     ("32->32 128x160 x576", 576, 32, 32, 128, 160), ("64->31 128x160 x96", 96, 64, 31, 128, 160),
+                                     ("32->32 64x80 x96", 96, 32, 32, 64, 80), ("24->32 128x160 x96", 96, 24, 32, 128, 160),
+                                     ("48->32 64x80 x96", 96, 48, 32, 64, 80), ("16->32 64x80 x96", 96, 16, 32, 64, 80)):
+        xx = torch.randn(N, cin, H, W, generator=g, device="cuda")
+        ww = torch.randn(cout, cin, 3, 3, generator=g, device="cuda") * 0.1
+        pc = K.pack_conv2d(ww, None, pad=1)
+        row = {"diag": "convexp2", "layer": name}
+        for kind in ("relu", "gn"):
+            def call(tune):
+                if kind == "relu":
+                    return o.conv2d(pc, xx, act=K.ACT_RELU, tune=tune)
+                return o.conv2d(pc, xx, gn_stats=torch.zeros(N * 8, dtype=torch.float64, device="cuda"), tune=tune)
+            ref, y = call(0), call(_lib.TUNE_TALL)
+            row[kind + "_bit_identical"] = bool(torch.equal(ref, y))
+            del ref, y
+            row[kind + "_product_us"] = round(timeit(lambda: call(0), iters=10), 1)
+            row[kind + "_tall_us"] = round(timeit(lambda: call(_lib.TUNE_TALL), iters=10), 1)
+        print(json.dumps(row), flush=True)
+        del xx
+
+
 if __name__ == "__main__":
-    {"getcost": getcost, "warp_init": warp_init, "getcost_pmc": getcost_pmc, "optins": optins}[sys.argv[1]]()
+    {"getcost": getcost, "warp_init": warp_init, "getcost_pmc": getcost_pmc, "optins": optins, "convexp": convexp, "convexp2": convexp2}[sys.argv[1]]()
