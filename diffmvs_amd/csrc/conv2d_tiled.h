@@ -917,17 +917,22 @@ int launch_conv2d_mt(const dmvs_conv2d_desc& d, hipStream_t st, int nt, int ngro
 // two barriers, 31 KB of LDS.  Measured at B = 96 (profiles/r4_conv_tall_s2_ky_ab.jsonl, bit-identical): 16 -> 16 at 576 x 256 x 320
 // 2479 -> 2350 us, at 96 x 256 x 320 420 -> 384, at 96 x 128 x 160 112 -> 101, at 96 x 64 x 80 37 -> 32; 32 -> 16 184 -> 177; 64 -> 16
 // unchanged (338 -> 339); the step 75.8 -> 75.0 ms (profiles/r4_tall_tiles_step_ab.json).  Default for <= 32 input channels when the
-// launch still has >= 4 tall tiles per CU (small batches keep the 16 x 16 / 16 x 4 tiles: more workgroups, shorter chunk chains).
-// DMVS_TUNE_TALL(1) = never, (2) = wherever the form applies (incl. the two-n-tile instantiation, an experiment).
+// launch still has >= 3 tall tiles per CU (small batches keep the 16 x 16 / 16 x 4 tiles: more workgroups, shorter chunk chains).
+// Two n-tiles (96 VGPRs, 36 KB): per layer on random data 32 -> 32 at 96 x 128 x 160 387 -> 348 us, 64 -> 32 at 576 -5 % (profiles/
+// r4_conv_tall2_ab.jsonl); in the model's step, forced everywhere, the rows that gain are the >= 32-input-channel layers on the
+// 128 x 160 planes (64 -> 31 2.51 -> 2.24 ms, 32 -> 32 at 576 images 3.61 -> 3.49), the 6 / 16 / 24-channel and 64 x 80 ones lose a
+// little (profiles/r4_tall2_step_ab.json: 54.06 -> 53.90 ms of convolutions, the step unchanged within the box noise) -- so: >= 32
+// input channels on planes of >= 128 x 160 pixels.  DMVS_TUNE_TALL(1) = never, (2) = wherever the form applies.
 template <int KH, int KW, int S>
 static bool conv_tall_ok(const dmvs_conv2d_desc& d, int nt) {
     if constexpr (KH == 3 && KW == 3 && S == 1) {
         const int mode = (d.tune >> 10) & 3;
-        if (mode == 1 || nt > 2 || (nt == 2 && mode != 2)) return false;
+        if (mode == 1 || nt > 2) return false;
         if (d.out_layout != DMVS_LAYOUT_NCHW || !conv_lean_ok(d) || !conv_v16_ok<3>(d) || d.Hout < 32) return false;
         if (mode == 2) return true;
         const long tall_tiles = (long)((d.Wout + 15) / 16) * ((d.Hout + 31) / 32) * d.B;
-        return d.c0 + d.c1 <= 32 && tall_tiles >= 1024;
+        if (nt == 2) return d.c0 + d.c1 >= 32 && (long)d.Hout * d.Wout >= 128L * 160 && tall_tiles >= 1024;
+        return d.c0 + d.c1 <= 32 && tall_tiles >= 768;
     }
     return false;
 }

@@ -144,7 +144,7 @@ def bump_weights_generation() -> None:
 def _env_tune():
     """A/B knobs of the kernels' `tune` arguments (include/dmvs.h), read ONCE per binding in the Python layer -- the C library
     itself reads no environment variable.  All default to 0 = the library's measured-best path:
-      DMVS_CONV_WX=1|2, DMVS_CONV_MT=1|2|4, DMVS_CONV_WALK=0, DMVS_CONV_LEAN=0, DMVS_CONV_V16=0, DMVS_CONV1X1_PX4=0   (dmvs_conv2d_desc.tune)
+      DMVS_CONV_WX=1|2, DMVS_CONV_MT=1|2|4, DMVS_CONV_WALK=0, DMVS_CONV_LEAN=0, DMVS_CONV_V16=0, DMVS_CONV1X1_PX4=0, DMVS_CONV_TALL=0|1   (dmvs_conv2d_desc.tune)
       DMVS_CONV3D_V16=0, DMVS_CONV3D_S2=direct   (dmvs_conv3d_desc.tune)      DMVS_STEM_V16=0      DMVS_PLANE_SWEEP=quad"""
     e = os.environ.get
     t2 = _lib.tune_tile_wx(int(e("DMVS_CONV_WX", "0"))) | _lib.tune_tile_mt(int(e("DMVS_CONV_MT", "0")))
