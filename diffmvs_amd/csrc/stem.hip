@@ -4,8 +4,11 @@
 // 0.38 GB in, 1.0 GB out.
 //   * persistent workgroups walk 16x16 output tiles; the next tile's 3 x 20 x 20 input halo streams in by LDS-DMA
 //     while this tile computes;
-//   * conv0.0 on the 18x18 halo'd intermediate as an implicit GEMM with K = 27 (ci, tap) padded to 28:
-//     7 x v_mfma_f32_16x16x4_f32 per 16 pixels, B operand gathered from the LDS halo through per-lane k offsets;
+//   * conv0.0 on the 18x18 halo'd intermediate as an implicit GEMM, B operand gathered from the LDS halo through per-lane k
+//     offsets, with TWO INTERMEDIATE ROWS per MFMA like conv0.1 below (cout = 8 leaves half of the 16 A rows empty): K = (ci, input
+//     row j = 0..3, kx) = 36, A rows 0-7 = W[ky = j] for intermediate row 2q, rows 8-15 = W[ky = j-1] for row 2q+1 -- 9 MFMAs per 16
+//     pixel PAIRS (162 pair slots per tile = 11 groups = 99 MFMAs) instead of 7 per 16 pixels (21 groups = 147 MFMAs; round 4).  Each
+//     output still sums its 27 products in (ci, ky, kx) order, the interleaved zero-weight products add exact zeros;
 //     BN + ReLU, zeroed outside the image (it is conv0.1's zero padding), written to LDS [8][18x18];
 //   * conv0.1 from that LDS image, with TWO OUTPUT ROWS per MFMA: cout = 8 would leave half of the 16 A rows as zero padding, so
 //     rows 0-7 carry W[ky = j] (output row y) and rows 8-15 W[ky = j-1] (output row y+1) for input row y+j, j = 0..3 -- both
@@ -27,6 +30,7 @@ constexpr int MW = TS + 2, MP = MW * MW;          // intermediate tile 18 x 18 =
 constexpr int IW = TS + 4, IP = IW * IW;          // input tile 20 x 20 = 400
 constexpr int MPLANE = 336;                        // 324 padded to 16 mod 32 (bank spread over the 4 k-groups)
 constexpr int IN_FLOATS = 3 * IP;                  // 1200
+constexpr int K0 = 36, K0S = K0 / 4;               // conv0.0: (ci, input row j, kx) of a row PAIR; MFMA k-steps
 // V16 (the default where the alignment allows; 1094 -> 938 us per 96 images on the MI355X): the input halo in 16-byte LDS-DMA pieces (conv2d.hip, template V16).  An LDS row is
 // the 16-byte aligned 24-float cover of the 20-float halo row (it starts SLACK = 2 floats further left: tile origins are multiples
 // of 16 pixels, the halo starts 2 pixels left of them): 360 pieces instead of 1200 elements per tile, 6 instead of 19 wave-level DMA
@@ -47,11 +51,11 @@ featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0
     // be waited out immediately.
     constexpr int IWP = V16 ? IWL16 : IW, X0 = V16 ? SLACK16 : 0;      // LDS row pitch of the input halo, halo column 0 inside a row
     constexpr int IPL = IW * IWP, INF = 3 * IPL;                       // one channel plane / one input buffer in LDS
-    __shared__ __attribute__((aligned(16))) float lds[2 * INF + 8 * MPLANE + 28 * 16 + 8 * W1S];
+    __shared__ __attribute__((aligned(16))) float lds[2 * INF + 8 * MPLANE + K0 * 16 + 8 * W1S];
     DMVS_LDS_POISON(lds);
     float* const s_mid = lds + 2 * INF;
     float* const s_w0 = s_mid + 8 * MPLANE;
-    float* const s_w1 = s_w0 + 28 * 16;
+    float* const s_w1 = s_w0 + K0 * 16;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, kq = lane >> 4;
@@ -59,9 +63,11 @@ featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0
     const int ntiles = tiles_x * tiles_y * N;
 
     // weights -> LDS once per workgroup, output channels zero-padded to the 16 MFMA rows
-    for (int e = tid; e < 28 * 16; e += DMVS_BLOCK) {
-        const int k = e >> 4, co = e & 15;
-        s_w0[e] = (k < 27 && co < 8) ? w0[k * 8 + co] : 0.0f;
+    for (int e = tid; e < K0 * 16; e += DMVS_BLOCK) {      // paired slab: k = (ci, j, kx); rows 0-7 take tap row ky = j, rows 8-15 ky = j - 1
+        const int k = e >> 4, row = e & 15;
+        const int ci = k / 12, j = (k - ci * 12) / 3, kx = k % 3;
+        const int ky = row < 8 ? j : j - 1;
+        s_w0[e] = (ky >= 0 && ky <= 2) ? w0[(ci * 9 + ky * 3 + kx) * 8 + (row & 7)] : 0.0f;
     }
     for (int e = tid; e < 8 * W1S; e += DMVS_BLOCK) {
         const int ci = e / W1S, r = e - ci * W1S, jt = r >> 4, row = r & 15;
@@ -119,19 +125,18 @@ featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0
         }
     };
 
-    // this lane's conv0.0 operands: A = w0[k = 4j + kq][cout = m], B offsets of (ci, ky, kx) = k inside the input halo
-    float a0[7];
-    int koff[7];
+    // this lane's conv0.0 operands: A = paired w0[k = 4s + kq][row m], B offsets of k = (ci, j, kx) inside the input halo
+    float a0[K0S];
+    int koff[K0S];
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
-        const int k = 4 * j + kq;
-        a0[j] = s_w0[k * 16 + m];
-        const int kk = k < 27 ? k : 0;           // the 28th k has zero weights: any valid address
-        const int ci = kk / 9, t = kk - ci * 9;
-        koff[j] = ci * IPL + (t / 3) * IWP + (t % 3);
+    for (int s = 0; s < K0S; ++s) {
+        const int k = 4 * s + kq;
+        a0[s] = s_w0[k * 16 + m];
+        const int ci = k / 12, j = (k - ci * 12) / 3, kx = k % 3;
+        koff[s] = ci * IPL + j * IWP + kx;
     }
-    float sc0[4], sh0[4];       // conv0.0: this lane's output channels 4*kq + r (lanes with kq >= 2 hold padding)
+    float sc0[4], sh0[4];       // conv0.0: this lane's D rows 4*kq + r = channel (4*kq + r) & 7 of intermediate row 2q + (kq >> 1)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int co = (4 * kq + r) & 7;
@@ -182,21 +187,24 @@ featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0
         if (pn >= 0) store_tile(pend, pn, pox0, poy0);
         const float* in = lds + cur * INF;
 
-        // ---- conv0.0 -> s_mid: 21 groups of 16 intermediate pixels (row-major over 18 x 18), waves take groups round-robin
-        for (int gidx = wave; gidx < (MP + 15) / 16; gidx += DMVS_BLOCK / 64) {
-            const int p = min(gidx * 16 + m, MP - 1);
-            const int py = p / MW, px = p - py * MW;
-            const float* ip = in + py * IWP + X0 + px;
+        // ---- conv0.0 -> s_mid: 11 groups of 16 pair slots (slot = (row pair q, column), row-major over 9 x 18), waves take groups
+        // round-robin
+        constexpr int NSLOT = (MW / 2) * MW;
+        for (int gidx = wave; gidx < (NSLOT + 15) / 16; gidx += DMVS_BLOCK / 64) {
+            const int p = min(gidx * 16 + m, NSLOT - 1);
+            const int q = p / MW, px = p - q * MW;
+            const float* ip = in + (2 * q) * IWP + X0 + px;
             f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int j = 0; j < 7; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], ip[koff[j]], acc, 0, 0, 0);
-            // D[row = 4*kq + r][col = m]: this lane holds intermediate channels 4*kq + r of pixel p
+            for (int s = 0; s < K0S; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], ip[koff[s]], acc, 0, 0, 0);
+            // D[row = 4*kq + r][col = m]: rows 0-7 = the 8 channels of intermediate pixel (2q, px), rows 8-15 = those of (2q + 1, px)
+            const int py = 2 * q + (kq >> 1);
             const int gy = oy0 - 1 + py, gx = ox0 - 1 + px;
             const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
-            if (kq < 2 && gidx * 16 + m < MP) {
+            if (gidx * 16 + m < NSLOT) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    s_mid[(4 * kq + r) * MPLANE + p] = inside ? fmaxf(fmaf(acc[r], sc0[r], sh0[r]), 0.0f) : 0.0f;
+                    s_mid[(4 * (kq & 1) + r) * MPLANE + py * MW + px] = inside ? fmaxf(fmaf(acc[r], sc0[r], sh0[r]), 0.0f) : 0.0f;
             }
         }
         DMVS_LDS_BARRIER();     // s_mid complete (ds_writes only); the next tile's input DMA stays in flight
@@ -237,11 +245,18 @@ extern "C" int dmvs_featurenet_stem_f32(const float* x, const float* w0, const f
     const int tiles_x = (W + TS - 1) / TS, tiles_y = (H + TS - 1) / TS;
     const long ntiles = (long)tiles_x * tiles_y * N;
     if (ntiles >= (1L << 31)) return DMVS_EINVAL;
-    const unsigned grid = (unsigned)(ntiles < 256 * 6 ? ntiles : 256 * 6);      // persistent: ~6 workgroups per CU (22 KB LDS each)
+    // persistent workgroups: exactly as many as are resident at once (the occupancy query: 5 per CU with the 16-byte form's 31 KB of
+    // LDS, 7 with the 4-byte form's 22 KB).  Until round 4 this was a fixed 6 per CU -- with 31 KB the sixth workgroup of every CU started
+    // when the other five had walked all their tiles, and then walked its own share alone on an otherwise idle CU.
+    static const int resident16 = dmvs_resident_workgroups(reinterpret_cast<const void*>(featurenet_stem_kernel<true>));
+    static const int resident4 = dmvs_resident_workgroups(reinterpret_cast<const void*>(featurenet_stem_kernel<false>));
+    const bool v16 = !(tune & DMVS_TUNE_PIECES4) && (W & 3) == 0 && ((uintptr_t)x & 15) == 0;
+    const int resident = v16 ? resident16 : resident4;
+    const unsigned grid = (unsigned)(ntiles < resident ? ntiles : resident);
     // input halo in 16-byte LDS-DMA pieces wherever rows are 16-byte multiples on a 16-byte aligned tensor (6 instead of 19 wave-level
     // DMA instructions per tile, 84 instead of 96 VGPRs): 1094 -> 938 us per 96 images on the MI355X, bit-identical
     // (profiles/r4_optins_ab.jsonl); DMVS_TUNE_PIECES4 forces the 4-byte form
-    if (!(tune & DMVS_TUNE_PIECES4) && (W & 3) == 0 && ((uintptr_t)x & 15) == 0)
+    if (v16)
         hipLaunchKernelGGL(featurenet_stem_kernel<true>, dim3(grid), dim3(DMVS_BLOCK), 0, (hipStream_t)stream, x, w0, scale0, shift0, w1,
                            scale1, shift1, y, N, H, W, tiles_x, tiles_y);
     else

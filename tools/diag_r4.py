@@ -230,5 +230,18 @@ def convexp2():
         del xx
 
 
+def stem():
+    """the fused FeatureNet stem at the bench size (96 images of 512 x 640), 16-byte and 4-byte halo pieces"""
+    o = Ops.for_device("cuda:0")
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(96, 3, 512, 640, generator=g, device="cuda")
+    w0, w1 = torch.randn(8, 3, 3, 3, generator=g, device="cuda") * 0.4, torch.randn(8, 8, 3, 3, generator=g, device="cuda") * 0.3
+    b0, b1 = torch.randn(8, generator=g, device="cuda"), torch.randn(8, generator=g, device="cuda")
+    pc0, pc1 = K.pack_conv2d(w0, b0, pad=1), K.pack_conv2d(w1, b1, pad=1)
+    for name, tune in (("16-byte pieces", 0), ("4-byte pieces", _lib.TUNE_PIECES4)):
+        us = timeit(lambda: o.featurenet_stem(pc0, pc1, x, tune=tune), iters=10)
+        print(json.dumps({"diag": "stem", "form": name, "us_per_96_images": round(us, 1)}), flush=True)
+
+
 if __name__ == "__main__":
-    {"getcost": getcost, "warp_init": warp_init, "getcost_pmc": getcost_pmc, "optins": optins, "convexp": convexp, "convexp2": convexp2}[sys.argv[1]]()
+    {"getcost": getcost, "warp_init": warp_init, "getcost_pmc": getcost_pmc, "optins": optins, "convexp": convexp, "convexp2": convexp2, "stem": stem}[sys.argv[1]]()
