@@ -28,7 +28,7 @@ def test_design_quotes_the_committed_bench_line():
     rf = line["roofline"]
     assert rf["bound"] == "hbm" and abs(rf["achieved"] / rf["peak"] - rf["frac"]) < 1e-3
     assert abs(rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_us"] * 1e-6) / 1e9 - rf["achieved"]) < 1.0
-    # round 4: the closing run is the full default run (batch sweep and CPU leg included), so the two files are the same line
+    # the last bench run of the round skipped the batch sweep and the CPU leg (GPU budget); the last full default run carries them
     full = json.load(open(os.path.join(ROOT, "profiles", "r4_bench_full_line.json")))
     assert f"{round(full['value'])} depth-maps/s" in text and f"{full['ms_per_step']:.1f} ms" in text
     cb = full["cpu_baseline"]
