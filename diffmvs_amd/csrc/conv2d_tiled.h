@@ -975,9 +975,9 @@ int launch_conv2d(const dmvs_conv2d_desc& d, hipStream_t st) {
         return launch_conv2d_mt<KH, KW, S, 2, false>(d, st, nt, ngroups);
     const long wg16 = (long)((d.Wout + 15) / 16) * ((d.Hout + 15) / 16) * d.B * ngroups;
     const int force_mt = (d.tune >> 4) & 7;      // DMVS_TUNE_TILE_MT: experiments force the tile height
-    if constexpr (!heavy) {
-        if (force_mt == 4) return launch_conv2d_mt<KH, KW, S, 4, false>(d, st, nt, ngroups);
-    }
+    // (MT = 4 for the stride-2 / many-tap families is an experiment only -- 16 x 16-pixel tiles never chosen automatically there: the
+    // tall-tile result of the 3x3 layers suggests timing it on the 8 -> 16 5x5 stride-2 layer, 0.54 of the matrix peak at MT = 2)
+    if (force_mt == 4) return launch_conv2d_mt<KH, KW, S, 4, false>(d, st, nt, ngroups);
     if (force_mt == 2) return launch_conv2d_mt<KH, KW, S, 2, false>(d, st, nt, ngroups);
     if (force_mt == 1) return launch_conv2d_mt<KH, KW, S, 1, false>(d, st, nt, ngroups);
     if (wg16 * 2 < 1024) return launch_conv2d_mt<KH, KW, S, 1, false>(d, st, nt, ngroups);

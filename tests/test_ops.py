@@ -814,6 +814,21 @@ def test_conv2d_tall_tiles(ops, cin, c1, cout, HW, extra):
         assert float((a - b).abs().max()) <= 1e-3 * max(1.0, float(a.abs().max()))
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,HW", [(8, 16, 5, 2, (50, 72)), (16, 32, 5, 2, (44, 40)), (32, 16, 7, 1, (37, 36)), (8, 16, 3, 2, (40, 52)),
+                                                   (32, 64, 5, 2, (36, 40)), (16, 16, 3, 1, (33, 36))])
+def test_conv2d_forced_tile_heights(ops, cin, cout, k, stride, HW):
+    """DMVS_TUNE_TILE_MT(1 | 2 | 4): every tile height of a family gives the same bits -- incl. the 16 x 16-pixel tiles of the
+    stride-2 / 5x5 / 7x7 families, which the dispatcher never picks on its own (round-4 experiment instantiations)"""
+    B = 2
+    x = rnd(B, cin, *HW, seed=1)
+    w, bias = rnd(cout, cin, k, k, seed=2) * 0.2, rnd(cout, seed=3)
+    ref = F.relu(F.conv2d(x, w, bias, stride, k // 2))
+    pc = K.pack_conv2d(*dev(ops, w, bias), stride=stride, pad=k // 2)
+    outs = [ops.conv2d(pc, dev(ops, x), act=K.ACT_RELU, tune=K._lib.tune_tile_mt(mt) | K._lib.TUNE_NO_TALL).cpu() for mt in (1, 2, 4)]
+    close(outs[0], ref, 2e-5)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 @pytest.mark.parametrize("bad", [float("nan"), float("inf"), 3.0e7])
 def test_groupnorm_stats_propagate_non_finite_and_out_of_range(ops, bad):
     """the fixed-point statistics slots (dmvs_common.h): a NaN / Inf activation -- or one beyond the documented magnitude

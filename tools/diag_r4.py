@@ -230,6 +230,29 @@ def convexp2():
         del xx
 
 
+def heavymt():
+    """(not yet run: prepared for the next round) 16 x 16-pixel tiles (DMVS_TUNE_TILE_MT(4)) against the dispatcher's 16 x 8 on the
+    stride-2 / 5x5 / 7x7 layers of the B = 96 step, per layer, bit-identical"""
+    o = Ops.for_device("cuda:0")
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for name, N, cin, cout, k, s, H, W in (("8->16 5x5 s2 512x640 x576", 576, 8, 16, 5, 2, 512, 640), ("16->32 5x5 s2 256x320 x576", 576, 16, 32, 5, 2, 256, 320),
+                                           ("32->64 5x5 s2 128x160 x576", 576, 32, 64, 5, 2, 128, 160), ("8->16 3x3 s2 512x640 x96", 96, 8, 16, 3, 2, 512, 640),
+                                           ("16->32 3x3 s2 256x320 x96", 96, 16, 32, 3, 2, 256, 320), ("32->16 7x7 128x160 x96", 96, 32, 16, 7, 1, 128, 160),
+                                           ("64->64 1x5 64x80 x96", 96, 64, 64, (1, 5), 1, 64, 80), ("64->64 5x1 64x80 x96", 96, 64, 64, (5, 1), 1, 64, 80)):
+        kk = (k, k) if isinstance(k, int) else k
+        xx = torch.relu(torch.randn(N, cin, H, W, generator=g, device="cuda"))
+        ww = torch.randn(cout, cin, *kk, generator=g, device="cuda") * 0.1
+        pc = K.pack_conv2d(ww, None, stride=s, pad=(kk[0] // 2, kk[1] // 2))
+        ref = o.conv2d(pc, xx, act=K.ACT_RELU)
+        row = {"diag": "heavymt", "layer": name, "product_us": round(timeit(lambda: o.conv2d(pc, xx, act=K.ACT_RELU), iters=10), 1)}
+        for mt in (2, 4):
+            tune = _lib.tune_tile_mt(mt)
+            row["mt%d_bit_identical" % mt] = bool(torch.equal(ref, o.conv2d(pc, xx, act=K.ACT_RELU, tune=tune)))
+            row["mt%d_us" % mt] = round(timeit(lambda: o.conv2d(pc, xx, act=K.ACT_RELU, tune=tune), iters=10), 1)
+        print(json.dumps(row), flush=True)
+        del xx, ref
+
+
 def stem():
     """the fused FeatureNet stem at the bench size (96 images of 512 x 640), 16-byte and 4-byte halo pieces"""
     o = Ops.for_device("cuda:0")
@@ -244,4 +267,4 @@ def stem():
 
 
 if __name__ == "__main__":
-    {"getcost": getcost, "warp_init": warp_init, "getcost_pmc": getcost_pmc, "optins": optins, "convexp": convexp, "convexp2": convexp2, "stem": stem}[sys.argv[1]]()
+    {"getcost": getcost, "warp_init": warp_init, "getcost_pmc": getcost_pmc, "optins": optins, "convexp": convexp, "convexp2": convexp2, "stem": stem, "heavymt": heavymt}[sys.argv[1]]()
