@@ -356,8 +356,14 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_kernel(const dm
 // MFMAs per wave produce two slices instead of 2 x 108: 1.5x fewer MFMAs for the same result, bit-identical per output
 // (each output still sums its 27 x cin products in (kd, ky, kx) order).  Same resident, tile-pipelined structure as
 // conv3d_mfma_stream_kernel.
+//
+// WREG (round 4, an experiment: DMVS_TUNE3D_PAIR_WREG, not yet timed): the 36 paired weights a lane multiplies with -- (j, ky, kx) of its
+// input channel kq and MFMA row m, the same for every tile of the launch -- live in 36 registers (read from global memory once per
+// workgroup) instead of an LDS slab read again for every tile.  The kernel then holds only the two halo buffers in LDS: 46 KB instead
+// of 56 KB in the 16-byte form = THREE workgroups per CU instead of two, and 72 instead of 108 LDS reads per 144 MFMAs.  The price is
+// ~88 instead of 52 VGPRs (no occupancy cost at 3 waves per SIMD) and a fully unrolled tile body.  Same products, same order.
 constexpr int kPairWgsPerCu = 3;       // 45 KB of LDS each
-template <bool V16>
+template <bool V16, bool WREG = false>
 __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_pair_kernel(const dmvs_conv3d_desc d, int tiles_x, int tiles_y, int tiles_d) {
     constexpr int TX = 16, TY = 4, TD = 8, CK = 4;
     constexpr int IW = TX + 2, IH = TY + 2, ID = TD + 2;
@@ -365,7 +371,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_pair_kernel(con
     constexpr int PLANE = HS::PLANE, IWP = HS::PITCH;
     constexpr int WP = pad16mod32_3d(36 * 16);             // paired weights of one input channel: [j 4][ky 3][kx 3][16 rows]
     using Halo = typename HS::type;
-    __shared__ __attribute__((aligned(16))) float lds[2 * CK * PLANE + CK * WP];
+    __shared__ __attribute__((aligned(16))) float lds[2 * CK * PLANE + (WREG ? 0 : CK * WP)];
     DMVS_LDS_POISON(lds);
     float* const s_w = lds + 2 * CK * PLANE;
 
@@ -376,15 +382,22 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_pair_kernel(con
 
     Halo halo;
     halo.init(tid, d.Hin, d.Win);
-    // paired weight slab, built once per workgroup from the [cin][27][cout_pad = 8] weights
-    for (int e = tid; e < CK * 36 * 16; e += DMVS_BLOCK) {
-        const int ci = e / (36 * 16), rem = e - ci * (36 * 16);
-        const int jt = rem >> 4, row = rem & 15;
+    // paired weights of (input channel ci, slab position jt = (j, ky, kx), MFMA row): rows 0-7 take W[kd = j], rows 8-15 W[kd = j - 1]
+    auto paired = [&](int ci, int jt, int row) -> float {
         const int j = jt / 9, t9 = jt - j * 9;
-        const int kd = row < 8 ? j : j - 1, co = row & 7;
-        float v = 0.0f;
-        if (ci < d.cin && kd >= 0 && kd <= 2 && co < d.cout) v = d.weight[(ci * 27 + kd * 9 + t9) * d.cout_pad + co];
-        s_w[ci * WP + jt * 16 + row] = v;
+        const int kd = row < 8 ? j : j - 1, co_ = row & 7;
+        return (ci < d.cin && kd >= 0 && kd <= 2 && co_ < d.cout) ? d.weight[(ci * 27 + kd * 9 + t9) * d.cout_pad + co_] : 0.0f;
+    };
+    float wreg[WREG ? 36 : 1];
+    if constexpr (WREG) {
+#pragma unroll
+        for (int jt = 0; jt < 36; ++jt) wreg[jt] = paired(kq, jt, m);      // this lane's A operands: k = input channel kq, row m
+    } else {
+        // paired weight slab, built once per workgroup from the [cin][27][cout_pad = 8] weights
+        for (int e = tid; e < CK * 36 * 16; e += DMVS_BLOCK) {
+            const int ci = e / (36 * 16), rem = e - ci * (36 * 16);
+            s_w[ci * WP + (rem >> 4) * 16 + (rem & 15)] = paired(ci, rem >> 4, rem & 15);
+        }
     }
     // epilogue constants (transposed accumulators: A = input pixels, B = the paired weights): this lane holds output slice
     // 2w + (m >> 3), channel m & 7, of the 4 consecutive voxels tx*16 + 4*kq + r of a row -- 16-byte stores
@@ -453,13 +466,14 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_pair_kernel(con
         {
             const float* wp = s_w + kq * WP + m;                                   // k = input channel kq
             const float* ipb = s_in + kq * PLANE + (2 * wave) * (IH * IWP) + HS::X0 + m;      // halo slice 2w = input slice (2w - 1)
-#pragma unroll 1
+            constexpr int kJUnroll = WREG ? 4 : 1;      // (register-resident weights are indexed by compile-time constants)
+#pragma unroll kJUnroll
             for (int j = 0; j < 4; ++j) {
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
-                        const float av = wp[((j * 3 + ky) * 3 + kx) * 16];
+                        const float av = WREG ? wreg[WREG ? (j * 3 + ky) * 3 + kx : 0] : wp[((j * 3 + ky) * 3 + kx) * 16];
 #pragma unroll
                         for (int mt = 0; mt < 4; ++mt) {
                             const float bv = ipb[(j * IH + ky + mt) * IWP + kx];
@@ -1111,6 +1125,11 @@ extern "C" int dmvs_conv3d_f32(const dmvs_conv3d_desc* dp, void* stream) {
             const int tiles_d8 = (d.Dout + 7) / 8;
             if ((long)tiles_x * tiles_y * tiles_d8 * d.B >= 512) {
                 dim3 gs((unsigned)(256 * kPairWgsPerCu), 1);
+                if (v16 && (d.tune & DMVS_TUNE3D_PAIR_WREG)) {      // experiment: weights in registers, 46 KB of LDS, resident count from the occupancy query
+                    static const int resident = dmvs_resident_workgroups(reinterpret_cast<const void*>(conv3d_mfma_stream_pair_kernel<true, true>));
+                    hipLaunchKernelGGL((conv3d_mfma_stream_pair_kernel<true, true>), dim3((unsigned)resident, 1), block, 0, st, d, tiles_x, tiles_y, tiles_d8);
+                    return dmvs_launch_status();
+                }
                 if (v16) hipLaunchKernelGGL(conv3d_mfma_stream_pair_kernel<true>, dim3(256 * 2, 1), block, 0, st, d, tiles_x, tiles_y, tiles_d8);      // 56 KB of LDS each
                 else hipLaunchKernelGGL(conv3d_mfma_stream_pair_kernel<false>, gs, block, 0, st, d, tiles_x, tiles_y, tiles_d8);
                 return dmvs_launch_status();

@@ -184,6 +184,7 @@ typedef struct dmvs_conv3d_desc {
 } dmvs_conv3d_desc;
 #define DMVS_TUNE3D_PIECES4 0x1       /* stride-1 MFMA kernels: halo tile in 4-byte LDS-DMA pieces even where 16-byte ones apply  */
 #define DMVS_TUNE3D_S2_DIRECT 0x2     /* stride-2 layers on the direct (VALU) kernels of round 1 instead of the matrix cores      */
+#define DMVS_TUNE3D_PAIR_WREG 0x4     /* experiment: the 4 -> 8 paired kernel with its weights in registers (46 KB of LDS, 3 workgroups per CU) */
 
 /* Size limit of the stride-1 layers (DMVS_EINVAL beyond): cin * Din*Hin*Win < 2^31 and cout * Dout*Hout*Wout < 2^31
  * (one batch item is addressed with 32-bit element offsets). */

@@ -1141,6 +1141,21 @@ def test_conv3d_16_byte_halo_pieces(ops, cin, cout, B, D, H, W):
     assert torch.equal(a.cpu(), b.cpu())
 
 
+@pytest.mark.parametrize("cin,cout,B,D,H,W", [(4, 8, 2, 23, 62, 100), (3, 5, 2, 17, 64, 96)])
+def test_conv3d_paired_kernel_weights_in_registers(ops, cin, cout, B, D, H, W):
+    """DMVS_TUNE3D_PAIR_WREG (an experiment): the 4 -> 8 paired kernel with each lane's 36 paired weights in registers instead of an LDS
+    slab -- against torch and BIT FOR BIT the default form; ragged volumes, fewer than 4 input / 8 output channels"""
+    x = rnd(B, cin, D, H, W, seed=1)
+    w, bias = rnd(cout, cin, 3, 3, 3, seed=2) * 0.2, rnd(cout, seed=3)
+    res = rnd(B, cout, D, H, W, seed=4)
+    ref = F.relu(F.conv3d(x, w, bias, 1, 1)) + res
+    pc = K.pack_conv3d(*dev(ops, w, bias))
+    a = ops.conv3d(pc, dev(ops, x), act=K.ACT_RELU, residual=dev(ops, res))
+    b = ops.conv3d(pc, dev(ops, x), act=K.ACT_RELU, residual=dev(ops, res), tune=K._lib.TUNE3D_PAIR_WREG)
+    close(b, ref, 2e-5)
+    assert torch.equal(a.cpu(), b.cpu())
+
+
 @pytest.mark.parametrize("cin,cout,D,H,W,with_res", [(8, 16, 11, 18, 70, False), (16, 32, 8, 9, 33, True), (6, 12, 5, 7, 20, False)])
 def test_conv3d_stride2_matrix_core_form(ops, cin, cout, D, H, W, with_res):
     """CostRegNet_small's stride-2 layers (conv2 8 -> 16, conv4 16 -> 32) on the matrix cores: several output tiles per axis, odd and

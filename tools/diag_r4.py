@@ -253,6 +253,23 @@ def heavymt():
         del xx, ref
 
 
+def pairwreg():
+    """(not yet run: prepared for the next round) the 4 -> 8 paired 3-D kernel with its weights in registers (DMVS_TUNE3D_PAIR_WREG: 46 KB of
+    LDS, three workgroups per CU) against the default (56 KB, two), on the two launches of the B = 96 step"""
+    o = Ops.for_device("cuda:0")
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for name, N in (("pvw conv0 4->8 x480", 480), ("costreg conv0 4->8 x96", 96)):
+        v = torch.randn(N, 4, 48, 64, 80, generator=g, device="cuda")
+        pc3 = K.pack_conv3d(torch.randn(8, 4, 3, 3, 3, generator=g, device="cuda") * 0.2, None)
+        ref = o.conv3d(pc3, v, act=K.ACT_RELU)
+        same = bool(torch.equal(ref, o.conv3d(pc3, v, act=K.ACT_RELU, tune=_lib.TUNE3D_PAIR_WREG)))
+        del ref
+        print(json.dumps({"diag": "pairwreg", "layer": name, "default_us": round(timeit(lambda: o.conv3d(pc3, v, act=K.ACT_RELU), iters=10), 1),
+                          "wreg_us": round(timeit(lambda: o.conv3d(pc3, v, act=K.ACT_RELU, tune=_lib.TUNE3D_PAIR_WREG), iters=10), 1),
+                          "bit_identical": same}), flush=True)
+        del v
+
+
 def stem():
     """the fused FeatureNet stem at the bench size (96 images of 512 x 640), 16-byte and 4-byte halo pieces"""
     o = Ops.for_device("cuda:0")
@@ -267,4 +284,4 @@ def stem():
 
 
 if __name__ == "__main__":
-    {"getcost": getcost, "warp_init": warp_init, "getcost_pmc": getcost_pmc, "optins": optins, "convexp": convexp, "convexp2": convexp2, "stem": stem, "heavymt": heavymt}[sys.argv[1]]()
+    {"getcost": getcost, "warp_init": warp_init, "getcost_pmc": getcost_pmc, "optins": optins, "convexp": convexp, "convexp2": convexp2, "stem": stem, "heavymt": heavymt, "pairwreg": pairwreg}[sys.argv[1]]()
