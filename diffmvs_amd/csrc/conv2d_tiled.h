@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
         const int live_c = cin - c0 < CK ? cin - c0 : CK;
         // all-zero 4-channel groups of the last chunk are skipped.  (A 4-channel chunk has one group: said at compile time for the
         // tall-tile form, whose accumulators hipcc otherwise moves VGPR -> AGPR -> VGPR around the one-trip loop, 64 moves per chunk)
-        const int nc4 = (CK == 4 && MT == 8) ? 1 : (live_c + 3) >> 2;
+        const int nc4 = (CK == 4 && MT >= 8) ? 1 : (live_c + 3) >> 2;
 #pragma unroll 1
         for (int c4 = 0; c4 < nc4; ++c4) {
             const int ci = c4 * 4 + kq;
@@ -922,12 +922,13 @@ int launch_conv2d_mt(const dmvs_conv2d_desc& d, hipStream_t st, int nt, int ngro
 // r4_conv_tall2_ab.jsonl); in the model's step, forced everywhere, the rows that gain are the >= 32-input-channel layers on the
 // 128 x 160 planes (64 -> 31 2.51 -> 2.24 ms, 32 -> 32 at 576 images 3.61 -> 3.49), the 6 / 16 / 24-channel and 64 x 80 ones lose a
 // little (profiles/r4_tall2_step_ab.json: 54.06 -> 53.90 ms of convolutions, the step unchanged within the box noise) -- so: >= 32
-// input channels on planes of >= 128 x 160 pixels.  DMVS_TUNE_TALL(1) = never, (2) = wherever the form applies.
+// input channels on planes of >= 128 x 160 pixels.  DMVS_TUNE_TALL(1) = never, (2) = wherever the form applies, (3) = 16 x 64
+// tiles for the one-n-tile layers and the small tiles elsewhere (experiment).
 template <int KH, int KW, int S>
 static bool conv_tall_ok(const dmvs_conv2d_desc& d, int nt) {
     if constexpr (KH == 3 && KW == 3 && S == 1) {
         const int mode = (d.tune >> 10) & 3;
-        if (mode == 1 || nt > 2) return false;
+        if (mode == 1 || mode == 3 || nt > 2) return false;
         if (d.out_layout != DMVS_LAYOUT_NCHW || !conv_lean_ok(d) || !conv_v16_ok<3>(d) || d.Hout < 32) return false;
         if (mode == 2) return true;
         const long tall_tiles = (long)((d.Wout + 15) / 16) * ((d.Hout + 31) / 32) * d.B;
@@ -944,6 +945,15 @@ int launch_conv2d(const dmvs_conv2d_desc& d, hipStream_t st) {
     const int nt = ntiles <= 4 ? ntiles : (ntiles % 3 == 0 ? 3 : 4);
     const int ngroups = (ntiles + nt - 1) / nt;
     if constexpr (KH == 3 && KW == 3 && S == 1) {
+        if (nt == 1 && ((d.tune >> 10) & 3) == 3 && d.out_layout == DMVS_LAYOUT_NCHW && conv_lean_ok(d) && conv_v16_ok<3>(d) && d.Hout >= 64) {
+            // DMVS_TUNE_TALL(3), an experiment not yet timed: 16 x 64-pixel tiles (MT = 16) for the one-n-tile layers -- per MFMA half
+            // the per-tile work of the 16 x 32 form again, 396 halo pieces per channel (two DMA instruction sets at 77 % of their
+            // lanes), 64 accumulator registers, 60 KB of LDS = 2 workgroups per CU
+            const int tiles_x = (d.Wout + 15) / 16, tiles_y = (d.Hout + 63) / 64;
+            hipLaunchKernelGGL((conv2d_mfma_kernel<3, 3, 1, 1, 16, false, DMVS_DTYPE_F32, true, false, DMVS_ARITH_F32, 1, true, true>),
+                               dim3((unsigned)(tiles_x * tiles_y * d.B), 1u), dim3(DMVS_BLOCK), 0, st, d, tiles_x, tiles_y);
+            return dmvs_launch_status();
+        }
         if (conv_tall_ok<KH, KW, S>(d, nt)) {
             const int tiles_x = (d.Wout + 15) / 16, tiles_y = (d.Hout + 31) / 32;
             const dim3 grid((unsigned)(tiles_x * tiles_y * d.B), 1u);

@@ -81,7 +81,7 @@ int dmvs_abi_version(void);
 #define DMVS_TUNE_TILE_MT(n) (((n) & 7) << 4)     /* 1 | 2 | 4: tile height in units of 4 rows                                       */
 #define DMVS_TUNE_1X1_TILED 0x200                 /* 1x1 layers on the LDS-tiled kernel instead of the 16-byte direct form                    */
 #define DMVS_TUNE_NO_LEAN 0x100                   /* plain layers on the generic kernel (every fused path resolved at run time)     */
-#define DMVS_TUNE_TALL(n) (((n) & 3) << 10)      /* 16 x 32-pixel tiles for the plain 3x3 layers: 0 = where measured better, 1 = never, 2 = wherever they apply */
+#define DMVS_TUNE_TALL(n) (((n) & 3) << 10)      /* 16 x 32-pixel tiles for the plain 3x3 layers: 0 = where measured better, 1 = never, 2 = wherever they apply, 3 = 16 x 64 (experiment) */
 
 typedef struct dmvs_conv2d_desc {
     const float* in0;       /* [B,c0,*,*] physical tensor                                   */

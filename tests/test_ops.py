@@ -788,7 +788,7 @@ def test_conv2d_tile_walking_workgroups(ops, cin, cout, k, stride, HW, with_res)
 
 
 @pytest.mark.parametrize("cin,c1,cout,HW,extra", [(16, 0, 16, (64, 48), "res"), (16, 0, 16, (40, 52), None), (12, 4, 16, (33, 36), "gn"), (32, 0, 13, (70, 20), None),
-                                                   (16, 0, 32, (64, 48), "res"), (24, 8, 32, (37, 36), "gn"), (32, 0, 31, (40, 20), None)])
+                                                   (16, 0, 32, (64, 48), "res"), (24, 8, 32, (37, 36), "gn"), (32, 0, 31, (40, 20), None), (16, 0, 16, (130, 36), None)])
 def test_conv2d_tall_tiles(ops, cin, c1, cout, HW, extra):
     """DMVS_TUNE_TALL: the plain 3x3 layers on 16 x 32-pixel tiles (MT = 8, 4-channel chunks; one n-tile = the default at large
     batches, two n-tiles = an experiment): ragged last tile rows, border tiles, a second concat input, the residual and the GroupNorm
@@ -809,6 +809,10 @@ def test_conv2d_tall_tiles(ops, cin, c1, cout, HW, extra):
         outs.append(out.cpu())
         sts.append(None if stats is None else stats.cpu().view(torch.int64))
     assert torch.equal(outs[0], outs[1])
+    if cout <= 16 and HW[0] >= 64 and ops.device.type == "cpu":      # 16 x 64 tiles (experiment instantiation, not yet run on the GPU)
+        tall64 = ops.conv2d(pc, dev(ops, x0), None if x1 is None else dev(ops, x1), residual=None if res is None else dev(ops, res),
+                            act=K.ACT_NONE if extra == "gn" else K.ACT_RELU, tune=K._lib.TUNE_TALL64)
+        assert torch.equal(outs[0], tall64.cpu())
     if extra == "gn":      # fixed-point sums of float partials: the partials differ with the tile shape, the totals agree to rounding
         a, b = sts[0].double() / 65536.0, sts[1].double() / 65536.0
         assert float((a - b).abs().max()) <= 1e-3 * max(1.0, float(a.abs().max()))

@@ -193,6 +193,9 @@ def convexp():
             row["tall_bit_identical"] = bool(torch.equal(ref, y))
             row["tall_us"] = round(timeit(lambda: o.conv2d(pc, xx, act=K.ACT_RELU, tune=_lib.TUNE_TALL), iters=10), 1)
             del y
+            if cout <= 16 and H >= 64:      # 16 x 64 tiles (added after the run in profiles/r4_conv_tall_s2_ky_ab.jsonl)
+                row["tall64_bit_identical"] = bool(torch.equal(ref, o.conv2d(pc, xx, act=K.ACT_RELU, tune=_lib.TUNE_TALL64)))
+                row["tall64_us"] = round(timeit(lambda: o.conv2d(pc, xx, act=K.ACT_RELU, tune=_lib.TUNE_TALL64), iters=10), 1)
         else:
             for n, ov in var.items():
                 y = ov.conv2d(pc, xx, act=K.ACT_RELU)
