@@ -491,6 +491,127 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_pair_kernel(con
     if (pb >= 0) store(pend, pb, ptd, pty, ptx);
 }
 
+// 5..8 input channels, cout <= 8 (CostRegNet conv1, 8 -> 8 at full resolution): the paired kernel above over TWO 4-channel chunks per
+// tile.  (An experiment, DMVS_TUNE3D_PAIR8, not yet timed: the generic kernel that runs this layer today spends half of its MFMA rows
+// on padding -- 216 MFMAs per 64 voxels against 144 here.)  The pipeline item is a (tile, chunk) unit: while chunk c of a tile computes,
+// the next unit's 4-channel halo streams into the other LDS buffer; the accumulators live across a tile's two units and are stored one
+// unit late, after the next barrier.  Weights in registers (2 x 36 per lane, see WREG above): the kernel holds only the two halo
+// buffers in LDS (46 KB, three workgroups per CU).  Each output still sums its products in (ci, kd, ky, kx) order: bit-identical to the
+// generic kernel.
+__global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_pair8_kernel(const dmvs_conv3d_desc d, int tiles_x, int tiles_y, int tiles_d) {
+    constexpr int TX = 16, TY = 4, TD = 8, CK = 4, NCH = 2;
+    constexpr int IW = TX + 2, IH = TY + 2, ID = TD + 2;
+    using HS = HaloSel<true, ID, IH, IW>;
+    constexpr int PLANE = HS::PLANE, IWP = HS::PITCH;
+    using Halo = typename HS::type;
+    __shared__ __attribute__((aligned(16))) float lds[2 * CK * PLANE];
+    DMVS_LDS_POISON(lds);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, kq = lane >> 4;
+    const int vol = d.Din * d.Hin * d.Win, ovol = d.Dout * d.Hout * d.Wout;
+    const int ntiles = tiles_x * tiles_y * tiles_d * d.B;
+
+    Halo halo;
+    halo.init(tid, d.Hin, d.Win);
+    // this lane's A operands: input channel 4c + kq, MFMA row m: rows 0-7 take W[kd = j] (output slice 2w), rows 8-15 W[kd = j - 1] (2w + 1)
+    float wreg[NCH][36];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int jt = 0; jt < 36; ++jt) {
+            const int ci = 4 * c + kq, j = jt / 9, t9 = jt - j * 9;
+            const int kd = m < 8 ? j : j - 1, co_ = m & 7;
+            wreg[c][jt] = (ci < d.cin && kd >= 0 && kd <= 2 && co_ < d.cout) ? d.weight[(ci * 27 + kd * 9 + t9) * d.cout_pad + co_] : 0.0f;
+        }
+    const int co = m & 7, sl = m >> 3;
+    const float sc = d.scale ? d.scale[co < d.cout ? co : 0] : 1.0f, sh = d.shift ? d.shift[co < d.cout ? co : 0] : 0.0f;
+    const bool vec = (d.Wout & 3) == 0 && (((uintptr_t)d.out | (uintptr_t)d.residual) & 15) == 0;
+
+    auto stage = [&](int b, int td, int ty, int tx, int c, float* buf) {
+        const int gx0 = tx * TX - 1, gy0 = ty * TY - 1, gd0 = td * TD - 1;
+        unsigned lo, him1;
+        Halo::bounds(gd0, gy0, gx0, d.Din, d.Hin, d.Win, lo, him1);
+        const float* origin = d.in + ((size_t)b * d.cin + 4 * c) * vol + ((long)gd0 * d.Hin + gy0) * d.Win + gx0;
+#pragma unroll
+        for (int ci = 0; ci < CK; ++ci) halo.stage(origin + (long)ci * vol, 4 * c + ci < d.cin, lo, him1, buf + ci * PLANE, wave);
+    };
+    auto decode = [&](int tile, int& b, int& td, int& ty, int& tx) {
+        tx = tile % tiles_x; tile /= tiles_x;
+        ty = tile % tiles_y; tile /= tiles_y;
+        td = tile % tiles_d;
+        b = tile / tiles_d;
+    };
+    auto store = [&](const f32x4 (&a)[4], int sb, int std_, int sty, int stx) {
+        const int oxb = stx * TX + 4 * kq, od = std_ * TD + 2 * wave + sl;
+        if (oxb >= d.Wout || od >= d.Dout || co >= d.cout) return;
+        float* outb = d.out + (size_t)sb * d.cout * ovol;
+        const float* resb = d.residual ? d.residual + (size_t)sb * d.cout * ovol : nullptr;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int oy = sty * TY + mt;
+            if (oy >= d.Hout) continue;
+            const int o = co * ovol + (od * d.Hout + oy) * d.Wout + oxb;
+            f32x4 y;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = dmvs_act(a[mt][r] * sc + sh, d.act);
+            if (vec) {
+                if (resb) y += *reinterpret_cast<const f32x4*>(resb + o);
+                *reinterpret_cast<f32x4*>(outb + o) = y;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (oxb + r < d.Wout) outb[o + r] = resb ? y[r] + resb[o + r] : y[r];
+            }
+        }
+    };
+    auto chunk_mfmas = [&](const float* s_in, const float (&w)[36], f32x4 (&acc)[4]) __attribute__((always_inline)) {
+        const float* ipb = s_in + kq * PLANE + (2 * wave) * (IH * IWP) + HS::X0 + m;      // halo slice 2w = input slice (2w - 1)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ipb[(j * IH + ky + mt) * IWP + kx], w[(j * 3 + ky) * 3 + kx], acc[mt], 0, 0, 0);
+    };
+
+    int tile = blockIdx.x, cur = 0;
+    int b = 0, td = 0, ty = 0, tx = 0;
+    f32x4 acc[4], pend[4];              // this tile's accumulators (live across its two units); the previous tile's, not stored yet
+    int pb = -1, ptd = 0, pty = 0, ptx = 0;
+    if (tile < ntiles) {
+        decode(tile, b, td, ty, tx);
+        stage(b, td, ty, tx, 0, lds);
+    }
+    for (; tile < ntiles; tile += gridDim.x) {
+        // ---- unit (tile, chunk 0): chunk 1 of the same tile streams in meanwhile
+        __syncthreads();
+        stage(b, td, ty, tx, 1, lds + (cur ^ 1) * (CK * PLANE));
+        if (pb >= 0) store(pend, pb, ptd, pty, ptx);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        chunk_mfmas(lds + cur * (CK * PLANE), wreg[0], acc);
+        cur ^= 1;
+        // ---- unit (tile, chunk 1): chunk 0 of the workgroup's next tile streams in meanwhile
+        __syncthreads();
+        int nb = 0, ntd = 0, nty = 0, ntx = 0;
+        if (tile + (int)gridDim.x < ntiles) {
+            decode(tile + gridDim.x, nb, ntd, nty, ntx);
+            stage(nb, ntd, nty, ntx, 0, lds + (cur ^ 1) * (CK * PLANE));
+        }
+        chunk_mfmas(lds + cur * (CK * PLANE), wreg[1], acc);
+        cur ^= 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pend[i] = acc[i];
+        pb = b; ptd = td; pty = ty; ptx = tx;
+        b = nb; td = ntd; ty = nty; tx = ntx;
+    }
+    if (pb >= 0) store(pend, pb, ptd, pty, ptx);
+}
+
 // S = 2: the stride-2 layers of CostRegNet_small (conv2 8 -> 16, conv4 16 -> 32, reference module.py:428-433) as the same
 // implicit GEMM: a 16 x 4 x 4 tile of OUTPUT voxels reads a 33 x 9 x 9 input halo, the B operand walks it with stride 2.
 template <int NT, int S = 1, bool V16 = false>
@@ -1132,6 +1253,14 @@ extern "C" int dmvs_conv3d_f32(const dmvs_conv3d_desc* dp, void* stream) {
                 }
                 if (v16) hipLaunchKernelGGL(conv3d_mfma_stream_pair_kernel<true>, dim3(256 * 2, 1), block, 0, st, d, tiles_x, tiles_y, tiles_d8);      // 56 KB of LDS each
                 else hipLaunchKernelGGL(conv3d_mfma_stream_pair_kernel<false>, gs, block, 0, st, d, tiles_x, tiles_y, tiles_d8);
+                return dmvs_launch_status();
+            }
+        }
+        if ((d.tune & DMVS_TUNE3D_PAIR8) && v16 && d.cin > 4 && d.cin <= 8 && d.cout <= 8 && d.cout_pad == 8) {      // experiment: 8 -> 8 on the paired form
+            const int tiles_d8 = (d.Dout + 7) / 8;
+            if ((long)tiles_x * tiles_y * tiles_d8 * d.B >= 512) {
+                static const int resident = dmvs_resident_workgroups(reinterpret_cast<const void*>(conv3d_mfma_stream_pair8_kernel));
+                hipLaunchKernelGGL(conv3d_mfma_stream_pair8_kernel, dim3((unsigned)resident, 1), block, 0, st, d, tiles_x, tiles_y, tiles_d8);
                 return dmvs_launch_status();
             }
         }

@@ -78,7 +78,7 @@ int dmvs_abi_version(void);
 #define DMVS_TUNE_TILE_WX(n) ((n) & 3)           /* 1 | 2: 16- / 32-pixel-wide workgroup tiles for the 3x3 / 5x5 layers           */
 #define DMVS_TUNE_NO_WALK 0x4                     /* one tile per workgroup everywhere (no resident tile-walking workgroups)        */
 #define DMVS_TUNE_PIECES4 0x8                     /* input halo staged in 4-byte LDS-DMA pieces even where 16-byte ones apply        */
-#define DMVS_TUNE_TILE_MT(n) (((n) & 7) << 4)     /* 1 | 2 | 4: tile height in units of 4 rows                                       */
+#define DMVS_TUNE_TILE_MT(n) (((n) & 7) << 4)     /* 1 | 2 | 4: tile height in units of 4 rows (4 on the stride-2 / 5x5 / 7x7 families: experiment only) */
 #define DMVS_TUNE_1X1_TILED 0x200                 /* 1x1 layers on the LDS-tiled kernel instead of the 16-byte direct form                    */
 #define DMVS_TUNE_NO_LEAN 0x100                   /* plain layers on the generic kernel (every fused path resolved at run time)     */
 #define DMVS_TUNE_TALL(n) (((n) & 3) << 10)      /* 16 x 32-pixel tiles for the plain 3x3 layers: 0 = where measured better, 1 = never, 2 = wherever they apply, 3 = 16 x 64 (experiment) */
@@ -185,6 +185,7 @@ typedef struct dmvs_conv3d_desc {
 #define DMVS_TUNE3D_PIECES4 0x1       /* stride-1 MFMA kernels: halo tile in 4-byte LDS-DMA pieces even where 16-byte ones apply  */
 #define DMVS_TUNE3D_S2_DIRECT 0x2     /* stride-2 layers on the direct (VALU) kernels of round 1 instead of the matrix cores      */
 #define DMVS_TUNE3D_PAIR_WREG 0x4     /* experiment: the 4 -> 8 paired kernel with its weights in registers (46 KB of LDS, 3 workgroups per CU) */
+#define DMVS_TUNE3D_PAIR8 0x8         /* experiment: 5..8 -> <= 8 channel layers (CostRegNet conv1) on a two-chunk paired kernel instead of the generic one */
 
 /* Size limit of the stride-1 layers (DMVS_EINVAL beyond): cin * Din*Hin*Win < 2^31 and cout * Dout*Hout*Wout < 2^31
  * (one batch item is addressed with 32-bit element offsets). */

@@ -1166,6 +1166,24 @@ def test_conv3d_paired_kernel_weights_in_registers(cin, cout, B, D, H, W):
     assert torch.equal(a.cpu(), b.cpu())
 
 
+@pytest.mark.parametrize("cin,cout,B,D,H,W", [(8, 8, 2, 23, 62, 100), (6, 5, 2, 17, 64, 96), (5, 8, 3, 9, 30, 180)])
+def test_conv3d_two_chunk_paired_kernel(cin, cout, B, D, H, W):
+    """DMVS_TUNE3D_PAIR8 (an experiment): 5..8 -> <= 8 channel layers (CostRegNet conv1) on the paired kernel over two 4-channel chunks
+    per tile -- against torch and BIT FOR BIT the generic kernel that runs them by default; ragged volumes and channel counts (written
+    after the round's GPU budget was spent: host-emulated only until it has been timed on the GPU)"""
+    from conftest import emu_ops
+    ops = emu_ops()
+    x = rnd(B, cin, D, H, W, seed=1)
+    w, bias = rnd(cout, cin, 3, 3, 3, seed=2) * 0.2, rnd(cout, seed=3)
+    res = rnd(B, cout, D, H, W, seed=4)
+    ref = F.relu(F.conv3d(x, w, bias, 1, 1)) + res
+    pc = K.pack_conv3d(*dev(ops, w, bias))
+    a = ops.conv3d(pc, dev(ops, x), act=K.ACT_RELU, residual=dev(ops, res))
+    b = ops.conv3d(pc, dev(ops, x), act=K.ACT_RELU, residual=dev(ops, res), tune=K._lib.TUNE3D_PAIR8)
+    close(b, ref, 2e-5)
+    assert torch.equal(a.cpu(), b.cpu())
+
+
 @pytest.mark.parametrize("cin,cout,D,H,W,with_res", [(8, 16, 11, 18, 70, False), (16, 32, 8, 9, 33, True), (6, 12, 5, 7, 20, False)])
 def test_conv3d_stride2_matrix_core_form(ops, cin, cout, D, H, W, with_res):
     """CostRegNet_small's stride-2 layers (conv2 8 -> 16, conv4 16 -> 32) on the matrix cores: several output tiles per axis, odd and

@@ -273,6 +273,20 @@ def pairwreg():
         del v
 
 
+def pair8():
+    """(not yet run: prepared for the next round) CostRegNet conv1 (8 -> 8, 96 volumes of 48 x 64 x 80) on the two-chunk paired kernel
+    (DMVS_TUNE3D_PAIR8: 144 instead of 216 MFMAs per 64 voxels) against the generic kernel"""
+    o = Ops.for_device("cuda:0")
+    g = torch.Generator(device="cuda").manual_seed(0)
+    v = torch.relu(torch.randn(96, 8, 48, 64, 80, generator=g, device="cuda"))
+    pc3 = K.pack_conv3d(torch.randn(8, 8, 3, 3, 3, generator=g, device="cuda") * 0.2, None)
+    ref = o.conv3d(pc3, v, act=K.ACT_RELU)
+    same = bool(torch.equal(ref, o.conv3d(pc3, v, act=K.ACT_RELU, tune=_lib.TUNE3D_PAIR8)))
+    del ref
+    print(json.dumps({"diag": "pair8", "layer": "costreg conv1 8->8 x96", "default_us": round(timeit(lambda: o.conv3d(pc3, v, act=K.ACT_RELU), iters=10), 1),
+                      "pair8_us": round(timeit(lambda: o.conv3d(pc3, v, act=K.ACT_RELU, tune=_lib.TUNE3D_PAIR8), iters=10), 1), "bit_identical": same}), flush=True)
+
+
 def stem():
     """the fused FeatureNet stem at the bench size (96 images of 512 x 640), 16-byte and 4-byte halo pieces"""
     o = Ops.for_device("cuda:0")
@@ -287,4 +301,4 @@ def stem():
 
 
 if __name__ == "__main__":
-    {"getcost": getcost, "warp_init": warp_init, "getcost_pmc": getcost_pmc, "optins": optins, "convexp": convexp, "convexp2": convexp2, "stem": stem, "heavymt": heavymt, "pairwreg": pairwreg}[sys.argv[1]]()
+    {"getcost": getcost, "warp_init": warp_init, "getcost_pmc": getcost_pmc, "optins": optins, "convexp": convexp, "convexp2": convexp2, "stem": stem, "heavymt": heavymt, "pairwreg": pairwreg, "pair8": pair8}[sys.argv[1]]()
