@@ -19,7 +19,39 @@ from diffmvs_amd import ops as K  # noqa: E402
 from diffmvs_amd.ops import Ops, g4_channels  # noqa: E402
 
 
+# DIAG_DEVICE=cpu runs a mode on the host emulation of the kernel sources (tests/hipemu) with every shape shrunk: a dry run of the script
+# itself in the build container (no GPU), so that a typo does not cost a GPU session
+DEV = os.environ.get("DIAG_DEVICE", "cuda:0")
+DRY = DEV == "cpu"
+
+
+def _ops():
+    if not DRY:
+        return Ops.for_device(DEV)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from hipemu.build import build_emu
+    return Ops(_lib.Lib(build_emu()), "cpu")
+
+
+def _gen(seed=0):
+    return torch.Generator(device=DEV).manual_seed(seed)
+
+
+def _n(n, lo=1):       # batch-like extents shrink to `lo` in a dry run
+    return lo if DRY else n
+
+
+def _hw(v, div=8):     # spatial extents shrink by `div` in a dry run (kept multiples of 4)
+    return max(8, (v // div) // 4 * 4) if DRY else v
+
+
 def timeit(fn, iters=20, warm=3):
+    if DRY:
+        import time
+        fn()
+        t0 = time.perf_counter()
+        fn()
+        return (time.perf_counter() - t0) * 1e6
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -165,8 +197,8 @@ def convexp():
     """three convolution experiments at the bench batch, per layer (all bit-identical to the product, checked here):
     tall = DMVS_TUNE_TALL (16 x 32-pixel tiles for the one-n-tile plain 3x3 layers); s2b64 / ky55 / s2b64ky55 = variant builds
     (8-byte LDS reads of the stride-2 B operand; all five tap rows of a one-n-tile 5x5 layer in one loop trip)"""
-    o = Ops.for_device("cuda:0")
-    g = torch.Generator(device="cuda").manual_seed(0)
+    o = _ops()
+    g = _gen()
     var = {}
     for n in ("s2b64", "ky55", "s2b64ky55"):
         path = os.path.join(ROOT, "tools", "calib", "libdmvs_hip_%s.so" % n)
@@ -180,8 +212,9 @@ def convexp():
         ("32->64 5x5 s2 128x160 x576", 576, 32, 64, 5, 2, 128, 160), ("8->16 3x3 s2 512x640 x96", 96, 8, 16, 3, 2, 512, 640),
         ("16->32 3x3 s2 256x320 x96", 96, 16, 32, 3, 2, 256, 320), ("32->48 3x3 s2 128x160 x96", 96, 32, 48, 3, 2, 128, 160)]
     for name, N, cin, cout, k, s, H, W in layers:
-        xx = torch.randn(N, cin, H, W, generator=g, device="cuda")
-        ww = torch.randn(cout, cin, k, k, generator=g, device="cuda") * 0.1
+        N, H, W = _n(N, 2), (H if not DRY else max(64, H // 4)), _hw(W)
+        xx = torch.randn(N, cin, H, W, generator=g, device=DEV)
+        ww = torch.randn(cout, cin, k, k, generator=g, device=DEV) * 0.1
         pc = K.pack_conv2d(ww, None, stride=s, pad=k // 2)
         ref = o.conv2d(pc, xx, act=K.ACT_RELU)
         row = {"diag": "convexp", "layer": name, "product_us": round(timeit(lambda: o.conv2d(pc, xx, act=K.ACT_RELU), iters=10), 1)}
@@ -236,15 +269,16 @@ def convexp2():
 def heavymt():
     """(not yet run: prepared for the next round) 16 x 16-pixel tiles (DMVS_TUNE_TILE_MT(4)) against the dispatcher's 16 x 8 on the
     stride-2 / 5x5 / 7x7 layers of the B = 96 step, per layer, bit-identical"""
-    o = Ops.for_device("cuda:0")
-    g = torch.Generator(device="cuda").manual_seed(0)
+    o = _ops()
+    g = _gen()
     for name, N, cin, cout, k, s, H, W in (("8->16 5x5 s2 512x640 x576", 576, 8, 16, 5, 2, 512, 640), ("16->32 5x5 s2 256x320 x576", 576, 16, 32, 5, 2, 256, 320),
                                            ("32->64 5x5 s2 128x160 x576", 576, 32, 64, 5, 2, 128, 160), ("8->16 3x3 s2 512x640 x96", 96, 8, 16, 3, 2, 512, 640),
                                            ("16->32 3x3 s2 256x320 x96", 96, 16, 32, 3, 2, 256, 320), ("32->16 7x7 128x160 x96", 96, 32, 16, 7, 1, 128, 160),
                                            ("64->64 1x5 64x80 x96", 96, 64, 64, (1, 5), 1, 64, 80), ("64->64 5x1 64x80 x96", 96, 64, 64, (5, 1), 1, 64, 80)):
         kk = (k, k) if isinstance(k, int) else k
-        xx = torch.relu(torch.randn(N, cin, H, W, generator=g, device="cuda"))
-        ww = torch.randn(cout, cin, *kk, generator=g, device="cuda") * 0.1
+        N, H, W = _n(N, 2), _hw(H), _hw(W)
+        xx = torch.relu(torch.randn(N, cin, H, W, generator=g, device=DEV))
+        ww = torch.randn(cout, cin, *kk, generator=g, device=DEV) * 0.1
         pc = K.pack_conv2d(ww, None, stride=s, pad=(kk[0] // 2, kk[1] // 2))
         ref = o.conv2d(pc, xx, act=K.ACT_RELU)
         row = {"diag": "heavymt", "layer": name, "product_us": round(timeit(lambda: o.conv2d(pc, xx, act=K.ACT_RELU), iters=10), 1)}
@@ -259,11 +293,12 @@ def heavymt():
 def pairwreg():
     """(not yet run: prepared for the next round) the 4 -> 8 paired 3-D kernel with its weights in registers (DMVS_TUNE3D_PAIR_WREG: 46 KB of
     LDS, three workgroups per CU) against the default (56 KB, two), on the two launches of the B = 96 step"""
-    o = Ops.for_device("cuda:0")
-    g = torch.Generator(device="cuda").manual_seed(0)
+    o = _ops()
+    g = _gen()
     for name, N in (("pvw conv0 4->8 x480", 480), ("costreg conv0 4->8 x96", 96)):
-        v = torch.randn(N, 4, 48, 64, 80, generator=g, device="cuda")
-        pc3 = K.pack_conv3d(torch.randn(8, 4, 3, 3, 3, generator=g, device="cuda") * 0.2, None)
+        N = _n(N, 8)
+        v = torch.randn(N, 4, 48, 64, 80, generator=g, device=DEV) if not DRY else torch.randn(N, 4, 16, 32, 80, generator=g, device=DEV)
+        pc3 = K.pack_conv3d(torch.randn(8, 4, 3, 3, 3, generator=g, device=DEV) * 0.2, None)
         ref = o.conv3d(pc3, v, act=K.ACT_RELU)
         same = bool(torch.equal(ref, o.conv3d(pc3, v, act=K.ACT_RELU, tune=_lib.TUNE3D_PAIR_WREG)))
         del ref
@@ -276,10 +311,10 @@ def pairwreg():
 def pair8():
     """(not yet run: prepared for the next round) CostRegNet conv1 (8 -> 8, 96 volumes of 48 x 64 x 80) on the two-chunk paired kernel
     (DMVS_TUNE3D_PAIR8: 144 instead of 216 MFMAs per 64 voxels) against the generic kernel"""
-    o = Ops.for_device("cuda:0")
-    g = torch.Generator(device="cuda").manual_seed(0)
-    v = torch.relu(torch.randn(96, 8, 48, 64, 80, generator=g, device="cuda"))
-    pc3 = K.pack_conv3d(torch.randn(8, 8, 3, 3, 3, generator=g, device="cuda") * 0.2, None)
+    o = _ops()
+    g = _gen()
+    v = torch.relu(torch.randn(96, 8, 48, 64, 80, generator=g, device=DEV)) if not DRY else torch.relu(torch.randn(8, 8, 16, 32, 80, generator=g, device=DEV))
+    pc3 = K.pack_conv3d(torch.randn(8, 8, 3, 3, 3, generator=g, device=DEV) * 0.2, None)
     ref = o.conv3d(pc3, v, act=K.ACT_RELU)
     same = bool(torch.equal(ref, o.conv3d(pc3, v, act=K.ACT_RELU, tune=_lib.TUNE3D_PAIR8)))
     del ref
@@ -287,13 +322,53 @@ def pair8():
                       "pair8_us": round(timeit(lambda: o.conv3d(pc3, v, act=K.ACT_RELU, tune=_lib.TUNE3D_PAIR8), iters=10), 1), "bit_identical": same}), flush=True)
 
 
+def mtsweep():
+    """(not yet run: prepared for the next round) every multi-tap conv2d shape of the B = 96 step (profiles/r4_conv2d_layers_b96_final.txt)
+    with each tile shape forced -- 16 x 4 / 16 x 8 / 16 x 16 (DMVS_TUNE_TILE_MT), 16 x 32 (DMVS_TUNE_TALL(2)), 32-wide (DMVS_TUNE_TILE_WX(2))
+    -- against the dispatcher's choice: the thresholds in launch_conv2d were set at B = 16 in round 2.  ReLU'd random inputs, plain
+    ReLU layers (the fused variants of a shape share its tile shape)."""
+    o = _ops()
+    g = _gen()
+    shapes = []
+    for line in open(os.path.join(ROOT, "profiles", "r4_conv2d_layers_b96_final.txt")):
+        if "|" not in line or line.startswith("B"):
+            continue
+        a, b = line.split("|")
+        B, cin, cout, kh, kw, s, Ho, Wo, mode, gated = map(int, a.split())
+        if kh * kw > 1 and mode == 0:
+            shapes.append((B, cin, cout, kh, kw, s, Ho, Wo, int(b.split()[0])))
+    variants = [("auto", 0), ("mt1", _lib.tune_tile_mt(1) | _lib.TUNE_NO_TALL), ("mt2", _lib.tune_tile_mt(2) | _lib.TUNE_NO_TALL),
+                ("mt4", _lib.tune_tile_mt(4) | _lib.TUNE_NO_TALL), ("tall", _lib.TUNE_TALL), ("wx2", _lib.tune_tile_wx(2) | _lib.TUNE_NO_TALL),
+                ("wx1", _lib.tune_tile_wx(1) | _lib.TUNE_NO_TALL), ("nowalk", _lib.TUNE_NO_WALK | _lib.TUNE_NO_TALL)]
+    for B, cin, cout, kh, kw, s, Ho, Wo, launches in (shapes[::6] if DRY else shapes):
+        B, Ho, Wo = _n(B, 2), _hw(Ho, 4), _hw(Wo, 4)
+        xx = torch.relu(torch.randn(B, cin, Ho * s, Wo * s, generator=g, device=DEV))
+        ww = torch.randn(cout, cin, kh, kw, generator=g, device=DEV) * 0.1
+        pc = K.pack_conv2d(ww, None, stride=s, pad=(kh // 2, kw // 2))
+        ref = o.conv2d(pc, xx, act=K.ACT_RELU)
+        row = {"diag": "mtsweep", "shape": [B, cin, cout, kh, kw, s, Ho, Wo], "launches_per_step": launches}
+        for name, tune in variants:
+            try:
+                y = o.conv2d(pc, xx, act=K.ACT_RELU, tune=tune)
+            except _lib.DmvsError:
+                continue
+            if not torch.equal(ref, y):
+                row[name + "_differs"] = True
+            del y
+            row[name + "_us"] = round(timeit(lambda: o.conv2d(pc, xx, act=K.ACT_RELU, tune=tune), iters=8, warm=2), 1)
+        best = min((v, k) for k, v in row.items() if k.endswith("_us"))
+        row["best"], row["gain_ms_per_step"] = best[1][:-3], round((row["auto_us"] - best[0]) * launches / 1e3, 3)
+        print(json.dumps(row), flush=True)
+        del xx, ref
+
+
 def stem():
     """the fused FeatureNet stem at the bench size (96 images of 512 x 640), 16-byte and 4-byte halo pieces"""
-    o = Ops.for_device("cuda:0")
-    g = torch.Generator(device="cuda").manual_seed(0)
-    x = torch.randn(96, 3, 512, 640, generator=g, device="cuda")
-    w0, w1 = torch.randn(8, 3, 3, 3, generator=g, device="cuda") * 0.4, torch.randn(8, 8, 3, 3, generator=g, device="cuda") * 0.3
-    b0, b1 = torch.randn(8, generator=g, device="cuda"), torch.randn(8, generator=g, device="cuda")
+    o = _ops()
+    g = _gen()
+    x = torch.randn(_n(96, 2), 3, _hw(512), _hw(640), generator=g, device=DEV)
+    w0, w1 = torch.randn(8, 3, 3, 3, generator=g, device=DEV) * 0.4, torch.randn(8, 8, 3, 3, generator=g, device=DEV) * 0.3
+    b0, b1 = torch.randn(8, generator=g, device=DEV), torch.randn(8, generator=g, device=DEV)
     pc0, pc1 = K.pack_conv2d(w0, b0, pad=1), K.pack_conv2d(w1, b1, pad=1)
     for name, tune in (("16-byte pieces", 0), ("4-byte pieces", _lib.TUNE_PIECES4)):
         us = timeit(lambda: o.featurenet_stem(pc0, pc1, x, tune=tune), iters=10)
@@ -301,4 +376,4 @@ def stem():
 
 
 if __name__ == "__main__":
-    {"getcost": getcost, "warp_init": warp_init, "getcost_pmc": getcost_pmc, "optins": optins, "convexp": convexp, "convexp2": convexp2, "stem": stem, "heavymt": heavymt, "pairwreg": pairwreg, "pair8": pair8}[sys.argv[1]]()
+    {"getcost": getcost, "warp_init": warp_init, "getcost_pmc": getcost_pmc, "optins": optins, "convexp": convexp, "convexp2": convexp2, "stem": stem, "heavymt": heavymt, "pairwreg": pairwreg, "pair8": pair8, "mtsweep": mtsweep}[sys.argv[1]]()
