@@ -171,6 +171,10 @@ class Ops:
         # {"dmvs_getcost_f32": [(start_event, end_event), ...]}
         self.timers = None
         self.conv_arith = ARITH_F32      # matrix arithmetic of the multi-tap 2-D convolutions (with_conv_arith)
+        # debugging aid (tools/determinism.py, tests): a float every freshly allocated kernel output is filled with before the launch, so
+        # that a kernel that leaves part of its output unwritten -- or reads scratch it never wrote -- shows up as NaN instead of whatever the
+        # allocator handed back.  None (the product default): plain torch.empty
+        self.debug_fill = None
 
     def with_conv_arith(self, arith: int) -> "Ops":
         """a binding of the same library whose conv2d() computes in `arith` (ARITH_F32 | ARITH_BF16) by default"""
@@ -214,7 +218,16 @@ class Ops:
         return None
 
     def empty(self, *shape, dtype=torch.float32):
-        return torch.empty(*shape, dtype=dtype, device=self.device)
+        t = torch.empty(*shape, dtype=dtype, device=self.device)
+        if self.debug_fill is not None and t.is_floating_point():      # tools/determinism.py: every kernel output starts as NaN / garbage
+            t.fill_(self.debug_fill)
+        return t
+
+    def empty_like(self, x):
+        t = torch.empty_like(x)
+        if self.debug_fill is not None and t.is_floating_point():
+            t.fill_(self.debug_fill)
+        return t
 
     def _chk_feat(self, *ts):
         dt = ts[0].dtype
@@ -457,7 +470,7 @@ class Ops:
         B, H, W, Cc = ref.shape
         S, _, Hs, Ws, _ = src.shape
         G, D = gcor.shape[2], gcor.shape[3]
-        gref = torch.empty_like(ref)
+        gref = self.empty_like(ref)
         if gsrc is None:
             gsrc = torch.zeros_like(src)
         self._call("dmvs_warp_corr_init_bwd_f32", _ptr(ref), _ptr(src), _ptr(rt), _ptr(disp_min), _ptr(disp_max), _ptr(gcor),
@@ -469,7 +482,7 @@ class Ops:
         self._chk(ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, gcost, gsrc)
         B, H, W, Cc = ref.shape
         S = src.shape[0]
-        gref = torch.empty_like(ref)
+        gref = self.empty_like(ref)
         if gsrc is None:
             gsrc = torch.zeros_like(src)
         ntiles = B * ((H + 15) // 16) * ((W + 15) // 16)
@@ -485,7 +498,7 @@ class Ops:
     def view_aggregate_bwd(self, cor, w, out, gout):
         self._chk(cor, w, out, gout)
         B, S, G, D, H, W = cor.shape
-        gcor, gw = torch.empty_like(cor), torch.empty_like(w)
+        gcor, gw = self.empty_like(cor), self.empty_like(w)
         self._call("dmvs_view_aggregate_bwd_f32", _ptr(cor), _ptr(w), _ptr(out), _ptr(gout), _ptr(gcor), _ptr(gw), B, S,
                    G * D, H * W, self.stream())
         return gcor, gw
@@ -549,7 +562,7 @@ class Ops:
     def groupnorm_silu_bwd(self, x, dy, gamma, beta, groups, stats, scale_shift=None, eps=1e-5):
         self._chk(x, dy, gamma, beta, scale_shift)
         B, Cc, H, W = x.shape
-        dx = torch.empty_like(x)
+        dx = self.empty_like(x)
         dgamma, dbeta = self.empty(Cc), self.empty(Cc)
         dss = self.empty(B, 2 * Cc) if scale_shift is not None else None
         n = C.c_int64(0)
@@ -574,8 +587,8 @@ class Ops:
         self._chk(inv, delta_in, update, new2)
         B = inv.shape[0]
         HW = inv.numel() // B
-        delta_out = torch.empty_like(inv)
-        new_inv = torch.empty_like(inv)
+        delta_out = self.empty_like(inv)
+        new_inv = self.empty_like(inv)
         self._call("dmvs_delta_update_f32", _ptr(inv), _ptr(delta_in), _ptr(update), delta_in_scale,
                       _ptr(delta_out), _ptr(new_inv), _ptr(new2), new2_cstride, new2_coffset, B, HW, self.stream())
         return delta_out, new_inv
@@ -583,7 +596,7 @@ class Ops:
     def depth_convert(self, x, disp_min, disp_max, mode):
         self._chk(x, disp_min, disp_max)
         B = x.shape[0]
-        out = torch.empty_like(x)
+        out = self.empty_like(x)
         self._call("dmvs_depth_convert_f32", _ptr(x), _ptr(disp_min), _ptr(disp_max), _ptr(out), mode, B,
                       x.numel() // B, self.stream())
         return out
@@ -626,7 +639,7 @@ class Ops:
         self._chk(x, gamma, beta, running_mean, running_var)
         B, Cc = x.shape[0], x.shape[1]
         S = x.numel() // (B * Cc)
-        y = torch.empty_like(x)
+        y = self.empty_like(x)
         mean, rstd = self.empty(views, Cc), self.empty(views, Cc)
         ws, nb = self._bn_ws(B, Cc, S, views)
         bump_weights_generation()         # running_mean / running_var are rewritten in place
@@ -638,7 +651,7 @@ class Ops:
         self._chk(x, dy, gamma, beta, mean, rstd)
         B, Cc = x.shape[0], x.shape[1]
         S = x.numel() // (B * Cc)
-        dx = torch.empty_like(x)
+        dx = self.empty_like(x)
         dgamma, dbeta = self.empty(Cc), self.empty(Cc)
         ws, nb = self._bn_ws(B, Cc, S, views)
         self._call("dmvs_batchnorm_train_bwd_f32", _ptr(x), _ptr(dy), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dx),

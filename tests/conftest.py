@@ -16,8 +16,26 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Collection order: the per-kernel parity tests first, then the module / training-step parity, then the end-to-end goldens, and the
+# full-size oracle comparisons and property tests LAST -- under `pytest -x` a red full-size test must not hide the kernel rows
+# (round 4: one failing property test at collected position 31 left 273 op-level tests unrun).
+_FILE_ORDER = ["test_abi.py", "test_docs.py", "test_oracle_golden.py", "test_formats.py", "test_loss.py", "test_ops.py", "test_modules.py",
+               "test_train.py", "test_trainer.py", "test_shard_gloo.py", "test_fusion.py", "test_model_cpu.py", "test_eval_gpu.py",
+               "test_scene.py", "test_model_gpu.py"]
+_LATE = ("full_size", "size_properties", "cfg4_full_size", "hip_graph")
+
+
+def _order_key(item):
+    fname = os.path.basename(str(item.fspath))
+    rank = _FILE_ORDER.index(fname) if fname in _FILE_ORDER else len(_FILE_ORDER) - 1
+    late = any(tag in item.name for tag in _LATE)
+    return (2 * len(_FILE_ORDER) if late else 0) + rank
+
+
 def pytest_collection_modifyitems(config, items):
-    """A plain `pytest` in a container without a HIP device skips the gpu-marked tests instead of erroring."""
+    """Orders the suite (see _FILE_ORDER); a plain `pytest` in a container without a HIP device skips the gpu-marked tests instead
+    of erroring."""
+    items.sort(key=_order_key)          # stable: the order inside a file is kept
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason="needs a HIP device (MI355X)")

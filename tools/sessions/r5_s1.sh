@@ -1,19 +1,17 @@
 #!/bin/bash
-# Prepared at the end of round 4 (no GPU budget left) for the first GPU session of the next round: the experiment instantiations that
-# exist but have never been timed, each per layer with its bit-identity check, and the two same-box step A/Bs they point at.
-#   mtsweep   every multi-tap conv2d shape of the step with each tile shape forced, against the dispatcher's choice
-#   heavymt   16 x 16 tiles for the stride-2 / 5x5 / 7x7 conv families (DMVS_TUNE_TILE_MT(4))
-#   pairwreg  the 4 -> 8 paired 3-D kernel with its weights in registers (DMVS_TUNE3D_PAIR_WREG)
-#   pair8     CostRegNet conv1 (8 -> 8) on a two-chunk paired kernel (DMVS_TUNE3D_PAIR8)
-#   convexp   tall tiles again, now with the 16 x 64 form beside them (DMVS_TUNE_TALL(3))
-#   stem      16-byte against 4-byte halo pieces, on random data and inside the model's step (open)
+# Round 5, GPU session 1: (1) where the cfg5 run-to-run difference of the round-4 driver run comes from (tools/determinism.py), (2) the
+# whole GPU suite in its new order, WITHOUT -x, so that every red test is seen at once, (3) the opt-in kernel instantiations round 4 left
+# untimed, each per layer with its bit-identity check (they become the default or are deleted after this session).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r5_s1
 mkdir -p $O
 cd $R
-for m in mtsweep heavymt pairwreg pair8 convexp stem; do timeout 300 python tools/diag_r4.py $m > $O/$m.jsonl 2> $O/$m.err; done
-timeout 300 python bench.py --no-batch-sweep --no-cpu-baseline --steps 10 --warmup 2 --conv-table > $O/bench_default.json 2> $O/bench_default.err
-DMVS_STEM_V16=0 timeout 300 python bench.py --no-batch-sweep --no-cpu-baseline --steps 10 --warmup 2 > $O/bench_stem4.json 2> $O/bench_stem4.err
-DMVS_CONV3D_PAIR_WREG=1 DMVS_CONV3D_PAIR8=1 timeout 300 python bench.py --no-batch-sweep --no-cpu-baseline --steps 10 --warmup 2 > $O/bench_pairwreg.json 2> $O/bench_pairwreg.err
+timeout 420 python tools/determinism.py cfg5 --runs 4 > $O/determinism_cfg5.jsonl 2> $O/determinism_cfg5.err
+timeout 200 python tools/determinism.py cfg3 --runs 3 > $O/determinism_cfg3.jsonl 2> $O/determinism_cfg3.err
+timeout 600 python -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1
+echo "pytest rc=$?" >> $O/pytest_gpu.log
+for m in heavymt pairwreg pair8 convexp; do timeout 100 python tools/diag_r4.py $m > $O/$m.jsonl 2> $O/$m.err; done
+DMVS_CONV3D_PAIR_WREG=1 DMVS_CONV3D_PAIR8=1 timeout 150 python bench.py --no-batch-sweep --no-cpu-baseline --steps 10 --warmup 2 > $O/bench_pairwreg.json 2> $O/bench_pairwreg.err
+timeout 150 python bench.py --no-batch-sweep --no-cpu-baseline --steps 10 --warmup 2 --conv-table > $O/bench_default.json 2> $O/bench_default.err
 echo done > $O/finished
