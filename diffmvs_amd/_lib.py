@@ -96,8 +96,8 @@ SIGNATURES = {
 }
 ABI_VERSION = 2
 # dmvs.h: DMVS_TUNE_* (dmvs_conv2d_desc.tune, dmvs_featurenet_stem_f32), DMVS_TUNE3D_* (dmvs_conv3d_desc.tune), DMVS_TUNE_SWEEP_GLOBAL
-TUNE_NO_WALK, TUNE_PIECES4, TUNE_NO_LEAN, TUNE_1X1_TILED, TUNE_NO_TALL, TUNE_TALL, TUNE_TALL64 = 0x4, 0x8, 0x100, 0x200, 0x400, 0x800, 0xC00
-TUNE3D_PIECES4, TUNE3D_S2_DIRECT, TUNE3D_PAIR_WREG, TUNE3D_PAIR8 = 0x1, 0x2, 0x4, 0x8
+TUNE_NO_WALK, TUNE_PIECES4, TUNE_NO_LEAN, TUNE_1X1_TILED, TUNE_NO_TALL, TUNE_TALL = 0x4, 0x8, 0x100, 0x200, 0x400, 0x800
+TUNE3D_PIECES4, TUNE3D_S2_DIRECT, TUNE3D_NO_PAIR = 0x1, 0x2, 0x4
 TUNE_SWEEP_GLOBAL = 0x1
 
 

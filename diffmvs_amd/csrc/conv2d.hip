@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_wgrad_kernel(const dmvs_con
                 __builtin_amdgcn_global_load_lds(src, DMVS_LDS(s_g + i * DMVS_BLOCK + wave * 64), 4, 0, 0);
             }
         }
-        __syncthreads();
+        DMVS_DMA_BARRIER();
         if (mul0b) {                                   // r*h gating (GRU candidate conv): X = in0 * mul0 on the in0 channels
             for (int i = 0; i < IN_IT; ++i) {
                 const int e = i * DMVS_BLOCK + tid;
@@ -504,6 +504,10 @@ static int wgrad_check(const dmvs_conv2d_desc& d) {
     if (d.cout_pad % 8 || d.cout > d.cout_pad || d.B <= 0 || !d.in0) return DMVS_EINVAL;
     if (d.c1 > 0 && (!d.in1 || d.in_mode != DMVS_IN_PLAIN)) return DMVS_EINVAL;
     if (d.mul0 && d.in_mode != DMVS_IN_PLAIN) return DMVS_EINVAL;
+    // the weight-gradient kernels read dense [B,c0,..] / [B,c1,..] inputs and dense [B,c0,..] gates only: a channel-slice in0
+    // (in0_cstride), a gate slice (gate_cstride) or a producer-side output product (out_mul changes what the forward's consumer read)
+    // would be read from the wrong memory -- refused, not ignored
+    if (d.in0_cstride || d.gate_cstride || d.out_mul) return DMVS_EINVAL;
     const int eh = (d.Hin + 2 * d.pad_h - d.kh) / d.stride + 1, ew = (d.Win + 2 * d.pad_w - d.kw) / d.stride + 1;
     if (eh != d.Hout || ew != d.Wout) return DMVS_EINVAL;
     return 0;

@@ -360,9 +360,9 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     for (int c0 = 0; c0 < cin; c0 += CK, cur ^= 1) {
         float* s_in = lds + cur * BUF;
         float* s_w = s_in + CK * PLANE;
-        // __syncthreads() drains this wave's LDS-DMA (vmcnt) and orders it against everyone's ds_reads:
+        // drains this wave's LDS-DMA (explicit vmcnt(0), dmvs_common.h) and orders it against everyone's ds_reads:
         // after it, chunk c0 is complete in `cur` and the other buffer is free for the next chunk
-        __syncthreads();
+        DMVS_DMA_BARRIER();
         if (!kLean && mul0b) {   // r*h gating of the GRU candidate conv: scale the staged in0 channels in place
             for (int i = 0; i < IN_IT; ++i) {
                 const int e = i * DMVS_BLOCK + tid;
@@ -922,13 +922,14 @@ int launch_conv2d_mt(const dmvs_conv2d_desc& d, hipStream_t st, int nt, int ngro
 // r4_conv_tall2_ab.jsonl); in the model's step, forced everywhere, the rows that gain are the >= 32-input-channel layers on the
 // 128 x 160 planes (64 -> 31 2.51 -> 2.24 ms, 32 -> 32 at 576 images 3.61 -> 3.49), the 6 / 16 / 24-channel and 64 x 80 ones lose a
 // little (profiles/r4_tall2_step_ab.json: 54.06 -> 53.90 ms of convolutions, the step unchanged within the box noise) -- so: >= 32
-// input channels on planes of >= 128 x 160 pixels.  DMVS_TUNE_TALL(1) = never, (2) = wherever the form applies, (3) = 16 x 64
-// tiles for the one-n-tile layers and the small tiles elsewhere (experiment).
+// input channels on planes of >= 128 x 160 pixels.  DMVS_TUNE_TALL(1) = never, (2) = wherever the form applies.
+// (16 x 64 tiles, round 5 on the MI355X: 2562 vs 2385 us on 16 -> 16 at 576 x 256 x 320, 118 vs 98 us at 96 x 128 x 160 -- two workgroups
+// per CU lose more than the halo saves; removed, profiles/r5_optins.jsonl.)
 template <int KH, int KW, int S>
 static bool conv_tall_ok(const dmvs_conv2d_desc& d, int nt) {
     if constexpr (KH == 3 && KW == 3 && S == 1) {
         const int mode = (d.tune >> 10) & 3;
-        if (mode == 1 || mode == 3 || nt > 2) return false;
+        if (mode == 1 || nt > 2) return false;
         if (d.out_layout != DMVS_LAYOUT_NCHW || !conv_lean_ok(d) || !conv_v16_ok<3>(d) || d.Hout < 32) return false;
         if (mode == 2) return true;
         const long tall_tiles = (long)((d.Wout + 15) / 16) * ((d.Hout + 31) / 32) * d.B;
@@ -945,15 +946,6 @@ int launch_conv2d(const dmvs_conv2d_desc& d, hipStream_t st) {
     const int nt = ntiles <= 4 ? ntiles : (ntiles % 3 == 0 ? 3 : 4);
     const int ngroups = (ntiles + nt - 1) / nt;
     if constexpr (KH == 3 && KW == 3 && S == 1) {
-        if (nt == 1 && ((d.tune >> 10) & 3) == 3 && d.out_layout == DMVS_LAYOUT_NCHW && conv_lean_ok(d) && conv_v16_ok<3>(d) && d.Hout >= 64) {
-            // DMVS_TUNE_TALL(3), an experiment not yet timed: 16 x 64-pixel tiles (MT = 16) for the one-n-tile layers -- per MFMA half
-            // the per-tile work of the 16 x 32 form again, 396 halo pieces per channel (two DMA instruction sets at 77 % of their
-            // lanes), 64 accumulator registers, 60 KB of LDS = 2 workgroups per CU
-            const int tiles_x = (d.Wout + 15) / 16, tiles_y = (d.Hout + 63) / 64;
-            hipLaunchKernelGGL((conv2d_mfma_kernel<3, 3, 1, 1, 16, false, DMVS_DTYPE_F32, true, false, DMVS_ARITH_F32, 1, true, true>),
-                               dim3((unsigned)(tiles_x * tiles_y * d.B), 1u), dim3(DMVS_BLOCK), 0, st, d, tiles_x, tiles_y);
-            return dmvs_launch_status();
-        }
         if (conv_tall_ok<KH, KW, S>(d, nt)) {
             const int tiles_x = (d.Wout + 15) / 16, tiles_y = (d.Hout + 31) / 32;
             const dim3 grid((unsigned)(tiles_x * tiles_y * d.B), 1u);
@@ -985,9 +977,11 @@ int launch_conv2d(const dmvs_conv2d_desc& d, hipStream_t st) {
         return launch_conv2d_mt<KH, KW, S, 2, false>(d, st, nt, ngroups);
     const long wg16 = (long)((d.Wout + 15) / 16) * ((d.Hout + 15) / 16) * d.B * ngroups;
     const int force_mt = (d.tune >> 4) & 7;      // DMVS_TUNE_TILE_MT: experiments force the tile height
-    // (MT = 4 for the stride-2 / many-tap families is an experiment only -- 16 x 16-pixel tiles never chosen automatically there: the
-    // tall-tile result of the 3x3 layers suggests timing it on the 8 -> 16 5x5 stride-2 layer, 0.54 of the matrix peak at MT = 2)
-    if (force_mt == 4) return launch_conv2d_mt<KH, KW, S, 4, false>(d, st, nt, ngroups);
+    // (16 x 16-pixel tiles for the stride-2 / many-tap families, timed per layer in round 5: within +-2 % of the 16 x 8 tiles on the 5x5
+    // stride-2 layers, -5 % on the 7x7 and +10 % on the 1x5 / 5x1 ones -- not worth their LDS; the instantiations are gone, profiles/r5_optins.jsonl)
+    if constexpr (!heavy) {
+        if (force_mt == 4) return launch_conv2d_mt<KH, KW, S, 4, false>(d, st, nt, ngroups);
+    }
     if (force_mt == 2) return launch_conv2d_mt<KH, KW, S, 2, false>(d, st, nt, ngroups);
     if (force_mt == 1) return launch_conv2d_mt<KH, KW, S, 1, false>(d, st, nt, ngroups);
     if (wg16 * 2 < 1024) return launch_conv2d_mt<KH, KW, S, 1, false>(d, st, nt, ngroups);

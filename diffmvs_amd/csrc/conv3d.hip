@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_kernel(const dm
         stage(b, td, ty, tx, lds);
     }
     for (; tile < ntiles; tile += gridDim.x, cur ^= 1) {
-        __syncthreads();            // this tile's halo (and, first time, the weights) landed; the other buffer is free
+        DMVS_DMA_BARRIER();            // this tile's halo (and, first time, the weights) landed; the other buffer is free
         int nb = 0, ntd = 0, nty = 0, ntx = 0;
         if (tile + (int)gridDim.x < ntiles) {
             decode(tile + gridDim.x, nb, ntd, nty, ntx);
@@ -357,7 +357,8 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_kernel(const dm
 // (each output still sums its 27 x cin products in (kd, ky, kx) order).  Same resident, tile-pipelined structure as
 // conv3d_mfma_stream_kernel.
 //
-// WREG (round 4, an experiment: DMVS_TUNE3D_PAIR_WREG, not yet timed): the 36 paired weights a lane multiplies with -- (j, ky, kx) of its
+// WREG (the 16-byte form; round 5: 3270 -> 3091 us on PixelViewWeight conv0 x480, 650 -> 611 us on CostRegNet conv0 x96, bit-identical,
+// profiles/r5_optins.jsonl): the 36 paired weights a lane multiplies with -- (j, ky, kx) of its
 // input channel kq and MFMA row m, the same for every tile of the launch -- live in 36 registers (read from global memory once per
 // workgroup) instead of an LDS slab read again for every tile.  The kernel then holds only the two halo buffers in LDS: 46 KB instead
 // of 56 KB in the 16-byte form = THREE workgroups per CU instead of two, and 72 instead of 108 LDS reads per 144 MFMAs.  The price is
@@ -452,7 +453,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_pair_kernel(con
         stage(b, td, ty, tx, lds);
     }
     for (; tile < ntiles; tile += gridDim.x, cur ^= 1) {
-        __syncthreads();            // this tile's halo (and, first time, the paired weights) landed; the other buffer is free
+        DMVS_DMA_BARRIER();            // this tile's halo (and, first time, the paired weights) landed; the other buffer is free
         int nb = 0, ntd = 0, nty = 0, ntx = 0;
         if (tile + (int)gridDim.x < ntiles) {
             decode(tile + gridDim.x, nb, ntd, nty, ntx);
@@ -588,7 +589,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_pair8_kernel(co
     }
     for (; tile < ntiles; tile += gridDim.x) {
         // ---- unit (tile, chunk 0): chunk 1 of the same tile streams in meanwhile
-        __syncthreads();
+        DMVS_DMA_BARRIER();
         stage(b, td, ty, tx, 1, lds + (cur ^ 1) * (CK * PLANE));
         if (pb >= 0) store(pend, pb, ptd, pty, ptx);
 #pragma unroll
@@ -596,7 +597,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_pair8_kernel(co
         chunk_mfmas(lds + cur * (CK * PLANE), wreg[0], acc);
         cur ^= 1;
         // ---- unit (tile, chunk 1): chunk 0 of the workgroup's next tile streams in meanwhile
-        __syncthreads();
+        DMVS_DMA_BARRIER();
         int nb = 0, ntd = 0, nty = 0, ntx = 0;
         if (tile + (int)gridDim.x < ntiles) {
             decode(tile + gridDim.x, nb, ntd, nty, ntx);
@@ -671,7 +672,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_kernel(const dmvs_conv
     for (int c0 = 0; c0 < d.cin; c0 += kCK, cur ^= 1) {
         const float* s_in = lds + cur * BUF;
         const float* s_w = s_in + kCK * PLANE;
-        __syncthreads();     // drains this wave's LDS-DMA; chunk c0 complete, other buffer free
+        DMVS_DMA_BARRIER();     // drains this wave's LDS-DMA; chunk c0 complete, other buffer free
         if (c0 + kCK < d.cin) stage(c0 + kCK, lds + (cur ^ 1) * BUF);
         const int live_c = d.cin - c0 < kCK ? d.cin - c0 : kCK;
         const int nc4 = (live_c + 3) >> 2;
@@ -748,7 +749,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_c1_kernel(const dmvs_conv3d
     int cur = 0;
     for (int ci = 0; ci < d.cin; ++ci, cur ^= 1) {
         const float* s_in = lds + cur * PLANE + (ld * IH + ly) * IW + lx;
-        __syncthreads();     // channel ci landed (DMA drained); the other buffer is free
+        DMVS_DMA_BARRIER();     // channel ci landed (DMA drained); the other buffer is free
         if (ci + 1 < d.cin) halo.stage(origin + (long)(ci + 1) * vol, true, lo, him1, lds + (cur ^ 1) * PLANE, wave);
         // constant address space + wave-uniform index = s_load (lgkmcnt): a vector load here would put a vmcnt(0) -- and with it
         // the wait for the NEXT channel's LDS-DMA -- in front of this channel's arithmetic
@@ -876,7 +877,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_c1_rows_kernel(const dmvs_c
     int cur = 0;
     for (int ci = 0; ci < d.cin; ++ci, cur ^= 1) {
         const float* s_in = lds + cur * plane + lbase;
-        __syncthreads();     // channel ci landed (DMA drained); the other buffer is free
+        DMVS_DMA_BARRIER();     // channel ci landed (DMA drained); the other buffer is free
         if (ci + 1 < d.cin) stage(ci + 1, lds + (cur ^ 1) * plane);
         if (!active) continue;
         typedef const __attribute__((address_space(4))) float* cfloat_p;      // wave-uniform weights: scalar loads (see conv3d_c1_kernel)
@@ -1121,7 +1122,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) deconv3d_mfma_kernel(const dmvs_co
         if (c0 + ci < d.cin && kx >= 0 && co < d.cout) v = d.weight[((c0 + ci) * 27 + (kd * 3 + ky) * 3 + kx) * d.cout_pad + co];
         s_w[ci * WP + sidx * 16 + row] = v;
     }
-    __syncthreads();                    // halo (LDS-DMA) and slabs (ds_write) landed
+    DMVS_DMA_BARRIER();                    // halo (LDS-DMA) and slabs (ds_write) landed
 
     const int live_c = d.cin - c0 < CK ? d.cin - c0 : CK;
     const int ngroups = (live_c + 3) >> 2;
@@ -1242,21 +1243,19 @@ extern "C" int dmvs_conv3d_f32(const dmvs_conv3d_desc* dp, void* stream) {
         dim3 g((unsigned)(tiles_x * tiles_y * tiles_d * d.B), (unsigned)((ntiles + 1) / 2));
         const long vtiles = (long)tiles_x * tiles_y * tiles_d * d.B;
         const bool v16 = conv3d_v16_ok(d);
-        if (d.cin <= 4 && d.cout <= 8 && d.cout_pad == 8) {      // 4 -> 8 layers: two output depth slices share the 16 MFMA rows
+        if (!(d.tune & DMVS_TUNE3D_NO_PAIR) && d.cin <= 4 && d.cout <= 8 && d.cout_pad == 8) {      // 4 -> 8 layers: two output depth slices share the 16 MFMA rows
             const int tiles_d8 = (d.Dout + 7) / 8;
             if ((long)tiles_x * tiles_y * tiles_d8 * d.B >= 512) {
-                dim3 gs((unsigned)(256 * kPairWgsPerCu), 1);
-                if (v16 && (d.tune & DMVS_TUNE3D_PAIR_WREG)) {      // experiment: weights in registers, 46 KB of LDS, resident count from the occupancy query
+                if (v16) {      // 16-byte halo pieces, the lane's 36 paired weights in registers: 46 KB of LDS, resident count from the occupancy query
                     static const int resident = dmvs_resident_workgroups(reinterpret_cast<const void*>(conv3d_mfma_stream_pair_kernel<true, true>));
                     hipLaunchKernelGGL((conv3d_mfma_stream_pair_kernel<true, true>), dim3((unsigned)resident, 1), block, 0, st, d, tiles_x, tiles_y, tiles_d8);
-                    return dmvs_launch_status();
+                } else {
+                    hipLaunchKernelGGL((conv3d_mfma_stream_pair_kernel<false, false>), dim3((unsigned)(256 * kPairWgsPerCu), 1), block, 0, st, d, tiles_x, tiles_y, tiles_d8);
                 }
-                if (v16) hipLaunchKernelGGL(conv3d_mfma_stream_pair_kernel<true>, dim3(256 * 2, 1), block, 0, st, d, tiles_x, tiles_y, tiles_d8);      // 56 KB of LDS each
-                else hipLaunchKernelGGL(conv3d_mfma_stream_pair_kernel<false>, gs, block, 0, st, d, tiles_x, tiles_y, tiles_d8);
                 return dmvs_launch_status();
             }
         }
-        if ((d.tune & DMVS_TUNE3D_PAIR8) && v16 && d.cin > 4 && d.cin <= 8 && d.cout <= 8 && d.cout_pad == 8) {      // experiment: 8 -> 8 on the paired form
+        if (!(d.tune & DMVS_TUNE3D_NO_PAIR) && v16 && d.cin > 4 && d.cin <= 8 && d.cout <= 8 && d.cout_pad == 8) {      // 5..8 -> <= 8 channels (CostRegNet conv1): the paired form over two chunks
             const int tiles_d8 = (d.Dout + 7) / 8;
             if ((long)tiles_x * tiles_y * tiles_d8 * d.B >= 512) {
                 static const int resident = dmvs_resident_workgroups(reinterpret_cast<const void*>(conv3d_mfma_stream_pair8_kernel));
@@ -1365,7 +1364,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_wgrad_kernel(const dmvs_con
                 __builtin_amdgcn_global_load_lds(src, DMVS_LDS(s_g + i * DMVS_BLOCK + wave * 64), 4, 0, 0);
             }
         }
-        __syncthreads();
+        DMVS_DMA_BARRIER();
 #pragma unroll 1
         for (int yy = 0; yy < 4; ++yy) {
 #pragma unroll

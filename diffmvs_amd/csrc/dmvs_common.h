@@ -15,10 +15,27 @@
 #endif
 
 // Workgroup barrier that publishes LDS writes (ds_write: lgkmcnt) but does NOT drain this wave's outstanding vector-memory
-// operations: __syncthreads() waits vmcnt(0), which would wait out an LDS-DMA prefetch that is meant to stay in flight
-// across the barrier.  Only for barriers whose producers are ds_writes.  (The host emulation predefines it as a plain barrier.)
+// operations, so that an LDS-DMA prefetch stays in flight across it.  Only for barriers whose producers are ds_writes.
+// (The host emulation predefines it as a plain barrier.)
 #ifndef DMVS_LDS_BARRIER
 #define DMVS_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
+// Workgroup barrier that PUBLISHES LDS-DMA DATA (global_load_lds_*): every wave first drains its own outstanding vector-memory
+// operations (s_waitcnt vmcnt(0): the LDS-DMA it issued has written LDS), then the barrier.  The wait is EXPLICIT on purpose.
+// Rounds 2-4 relied on "__syncthreads() waits vmcnt(0)" -- it does not: on gfx950 hipcc emits no vmcnt wait for the
+// workgroup-scope fence of __syncthreads() (the waves of a workgroup share a CU), and its wait-count pass does not tie an
+// LDS-DMA to the later ds_reads of the staged bytes in these kernels; where a vmcnt(0) did sit in front of such a barrier it
+// was there for an unrelated register dependency.  The round-4 stem kernel lost that accident: its tile loop had its only
+// vmcnt(0) in front of the loop, so from the second tile of a workgroup on, conv0.0 could read a halo that was still landing
+// -- the run-to-run differences the round-4 driver run found (tools/determinism.py, tools/isa_dma_audit.py).
+// EVERY barrier that follows an LDS-DMA whose data is read after it must be this one.  (Plain barrier under the host emulation.)
+#ifndef DMVS_DMA_BARRIER
+#define DMVS_DMA_BARRIER()                               \
+    do {                                                 \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        __syncthreads();                                 \
+    } while (0)
 #endif
 
 static inline int dmvs_launch_status() {

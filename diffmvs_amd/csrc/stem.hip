@@ -182,7 +182,7 @@ featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0
         const int ty = tq % tiles_y;
         const int n = tq / tiles_y;
         const int ox0 = tx * TS, oy0 = ty * TS;
-        __syncthreads();        // this tile's halo has landed; everyone is done with s_mid and the other input buffer
+        DMVS_DMA_BARRIER();     // this tile's halo has landed; everyone is done with s_mid and the other input buffer
         if (tile + (int)gridDim.x < ntiles) stage(tile + gridDim.x, lds + (cur ^ 1) * INF);
         if (pn >= 0) store_tile(pend, pn, pox0, poy0);
         const float* in = lds + cur * INF;

@@ -85,7 +85,7 @@ getcost_bwd_win_kernel(const dmvs_getcost_desc d, const float* __restrict__ gcos
                 }
             }
         }
-        __syncthreads();        // source window resident
+        DMVS_DMA_BARRIER();        // source window resident
 
         // both passes walk the hypotheses once and act per distinct footprint with the accumulated tap weights.
         // A rolled loop with ONE emit site (the emit bodies are 4*C LDS reads / atomics): hypothesis k's depth and

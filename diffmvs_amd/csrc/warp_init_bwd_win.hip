@@ -176,7 +176,7 @@ warp_init_bwd_win_kernel(const float* __restrict__ ref, const float* __restrict_
                     }
                 }
             }
-            __syncthreads();        // source half-window resident
+            DMVS_DMA_BARRIER();        // source half-window resident
 
             // ---- pass A: grad_ref
             walk([&](int fx, int fy, const float (&Wt)[4][2]) {

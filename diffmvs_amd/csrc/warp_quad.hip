@@ -31,7 +31,10 @@
 // DMVS_GC_EXP (diagnostic builds only, tools/build_variant.py; 0 = the product): which resource bounds the quad kernels?
 //   1: every texel address replaced by the pixel's own position in the view (coalesced, L1-friendly) -- same instructions, no
 //      scattered memory traffic: the VALU / issue floor;   2: hat weights + scatter removed (loads + dots stay): the memory
-//      floor;   3: only the first 64-byte unit of a texel is loaded: half the requests, the same lines.
+//      floor;   3: only the first 64-byte unit of a texel is loaded: half the requests, the same lines;
+//   4: the CEILING PROBE (round 5): projection, texel masks, bit scans, addresses and every load exactly as in the product -- the same
+//      line-request stream from the same quads -- but the loaded registers are only waited for (no dot, no hat weights, no scatter;
+//      the outputs are zeros): the time of this build is what the memory system alone delivers for this address stream.
 #ifndef DMVS_GC_EXP
 #define DMVS_GC_EXP 0
 #endif
@@ -376,6 +379,14 @@ __device__ __forceinline__ void quad_accumulate(P base, unsigned view_off, int p
             // every load of the trip is issued before anything waits on one: without this fence the scheduler, chasing one
             // more wave of occupancy, re-uses one texel's registers and serialises load -> wait -> FMAs per texel
             __builtin_amdgcn_sched_barrier(0);
+#if DMVS_GC_EXP == 4
+#pragma unroll
+            for (int i = 0; i < TPT; ++i)
+#pragma unroll
+                for (int j = 0; j < Feat<C, FT>::NW; ++j) asm volatile("" ::"v"(t[i].w[j]));      // the loads must land; nothing is computed from them
+            (void)ur; (void)vr; (void)fc; (void)fr; (void)has;
+            continue;
+#endif
             float dd[TPT], w[TPT][HPL];
             dot_texels<C, FT, TPT>(t, ref, dd);
 #if DMVS_GC_EXP == 2
@@ -664,7 +675,7 @@ warp_init_band_kernel(const void* __restrict__ ref_f, const void* __restrict__ s
                     __builtin_amdgcn_global_load_lds(srcp, (__attribute__((address_space(3))) void*)(band + (size_t)i0 * 16), 16, 0, 0);
                 }
             }
-            __syncthreads();                                   // (waits out this wave's LDS-DMA, then the barrier)
+            DMVS_DMA_BARRIER();                                   // (waits out this wave's LDS-DMA, then the barrier)
         }
         const unsigned band_off = Feat<C, FT>::lane_bytes(q) - (unsigned)(__mul24(by0, ncols) + bx0) * (unsigned)TB;
         for (int ch = c0; ch < c0 + cnt; ++ch) {
@@ -690,7 +701,10 @@ warp_init_band_kernel(const void* __restrict__ ref_f, const void* __restrict__ s
 
 // texels per trip of the texel loop: 2 (4 measured 8-10 % slower on the MI355X: one wave per SIMD less, more idle slots when a
 // pixel's texel count is not a multiple of the trip)
-constexpr int QUAD_TPT = 2;
+#ifndef DMVS_QUAD_TPT       // (diagnostic builds: the ceiling probe is also timed with 4 texels in flight per trip)
+#define DMVS_QUAD_TPT 2
+#endif
+constexpr int QUAD_TPT = DMVS_QUAD_TPT;
 
 template <int FT>
 static int launch_getcost_quad(const dmvs_getcost_desc& d, dim3 grid, dim3 block, hipStream_t st) {

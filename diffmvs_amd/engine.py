@@ -343,6 +343,27 @@ class _UpdateBlock:
         return table
 
 
+class SceneFeatureStore:
+    """FeatureNet outputs of every image of a scene, computed ONCE: {stage: [N,h,w,C]} in the layout the warp kernels read.
+    The reference's harness (test.py:92-127) -- and a per-sample forward here -- runs FeatureNet on all V images of every reference
+    view, so an image that is a source view of ~V-1 neighbours is pushed through the network ~V times per scene; 288 GB of HBM hold
+    every view's features of any scene (DTU, 49 views at 1600x1152: 2.4 GB), so the scene loop keeps them resident and each
+    reference view only gathers its rows.  `gather` returns the view-major [V*B,h,w,C] stack Engine.forward(feats=...) consumes:
+    plain device copies of rows, bit-identical to what a per-sample forward computes."""
+
+    def __init__(self, engine: "Engine", images: torch.Tensor, chunk: int = 64):
+        o = engine.ops
+        images = images.to(o.device).float().contiguous()
+        parts = [run_feature(o, engine.feat, images[i:i + chunk], feat_dtype=engine.feat_dtype) for i in range(0, images.shape[0], chunk)]
+        self.feats = {k: (parts[0][k] if len(parts) == 1 else torch.cat([p[k] for p in parts], 0)) for k in parts[0]}
+        self.n_views = images.shape[0]
+
+    def gather(self, view_ids: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """view_ids [B,V] (column 0 = the reference view) -> {stage: [V*B,h,w,C]}, row v*B + b = features of view_ids[b, v]"""
+        idx = view_ids.to(next(iter(self.feats.values())).device).long().t().reshape(-1)
+        return {k: f.index_select(0, idx) for k, f in self.feats.items()}
+
+
 class GraphedForward:
     """One HIP graph of the whole eval forward for fixed input shapes: ~350 kernel launches replayed by a single
     hipGraphLaunch.  Small batches are launch-bound in eager mode (the reference's own harness runs batch 1,
@@ -351,21 +372,22 @@ class GraphedForward:
     the next call.  The diffusion noise must come from the device (default torch.randn, whose generator torch keeps
     graph-safe) or from a source that returns the same device tensors every call."""
 
-    def __init__(self, engine, imgs, proj, dv, noise_fn, test):
+    def __init__(self, engine, imgs, proj, dv, noise_fn, test, feats=None):
         self.s_imgs = [i.detach().clone() for i in imgs]
         self.s_proj = {k: v.detach().clone() for k, v in proj.items()}
         self.s_dv = dv.detach().clone()
+        self.s_feats = None if feats is None else {k: v.detach().clone() for k, v in feats.items()}      # (scene mode: gathered rows of the store)
         side = torch.cuda.Stream(device=engine.ops.device)
         side.wait_stream(torch.cuda.current_stream(engine.ops.device))
         with torch.cuda.stream(side):                  # warm-up outside the capture: weight-side caches, allocator pools
             for _ in range(2):
                 self._rewind(noise_fn)
-                engine.forward(self.s_imgs, self.s_proj, self.s_dv, noise_fn=noise_fn, test=test)
+                engine.forward(self.s_imgs, self.s_proj, self.s_dv, noise_fn=noise_fn, test=test, feats=self.s_feats)
         torch.cuda.current_stream(engine.ops.device).wait_stream(side)
         self._rewind(noise_fn)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.out = engine.forward(self.s_imgs, self.s_proj, self.s_dv, noise_fn=noise_fn, test=test)
+            self.out = engine.forward(self.s_imgs, self.s_proj, self.s_dv, noise_fn=noise_fn, test=test, feats=self.s_feats)
 
     @staticmethod
     def _rewind(noise_fn):
@@ -377,9 +399,12 @@ class GraphedForward:
         if src.data_ptr() != dst.data_ptr():
             dst.copy_(src, non_blocking=True)
 
-    def __call__(self, imgs, proj, dv):
+    def __call__(self, imgs, proj, dv, feats=None):
         for d, s in zip(self.s_imgs, imgs):
             self._refresh(d, s)
+        if self.s_feats is not None:
+            for k, d in self.s_feats.items():
+                self._refresh(d, feats[k])
         for k, d in self.s_proj.items():
             self._refresh(d, proj[k])
         self._refresh(self.s_dv, dv)
@@ -517,36 +542,42 @@ class Engine:
 
     # ------------------------------------------------------------------ whole forward
     @torch.no_grad()
-    def forward_graphed(self, imgs, proj_matrices, depth_values, noise_fn: Optional[Callable] = None, test: bool = True):
+    def forward_graphed(self, imgs, proj_matrices, depth_values, noise_fn: Optional[Callable] = None, test: bool = True, feats=None):
         """forward() through a captured HIP graph (one per input geometry); see GraphedForward for the contract"""
         dev = self.ops.device
         imgs = [i.to(dev).float() for i in imgs]
         proj = {k: v.to(dev).float().contiguous() for k, v in proj_matrices.items()}
         dv = depth_values.to(dev).float()
-        key = (len(imgs), tuple(imgs[0].shape), tuple(dv.shape), bool(test), id(noise_fn))
+        nrows = None if feats is None else next(iter(feats.values())).shape[0]
+        key = (len(imgs), tuple(imgs[0].shape), tuple(dv.shape), bool(test), id(noise_fn), nrows)
         g = self._graphs.get(key)
         if g is None:
-            g = self._graphs[key] = GraphedForward(self, imgs, proj, dv, noise_fn, test)
-        return g(imgs, proj, dv)
+            g = self._graphs[key] = GraphedForward(self, imgs, proj, dv, noise_fn, test, feats)
+        return g(imgs, proj, dv, feats)
 
     @torch.no_grad()
-    def forward(self, imgs, proj_matrices, depth_values, noise_fn: Optional[Callable] = None, test: bool = True):
+    def forward(self, imgs, proj_matrices, depth_values, noise_fn: Optional[Callable] = None, test: bool = True, feats=None):
         """CasDiffMVS.forward in eval mode (models/diffusion.py:139-295).  test=True: the final iterate of each
         refinement stage and its confidence at full resolution (test.py); test=False: every iterate in "depth" and
-        the Unet confidences in "conf" (diffusion.py:264-270, what train.py's validation loop feeds the loss)."""
+        the Unet confidences in "conf" (diffusion.py:264-270, what train.py's validation loop feeds the loss).
+        feats: {stage: [V*B,h,w,C]} from SceneFeatureStore.gather -- the image features are taken from the scene's store instead of
+        running FeatureNet on `imgs` (of which only imgs[0], the reference views ContextNet reads, is then used)."""
         o, a = self.ops, self.args
         if noise_fn is None:
             noise_fn = lambda shape, device: torch.randn(shape, device=device)  # noqa: E731
-        V = len(imgs)
         B = imgs[0].shape[0]
+        V = len(imgs) if feats is None else next(iter(feats.values())).shape[0] // B
         self.arena.reset(B)
         dv = depth_values.to(o.device).float()
         depth_max_, depth_min_ = 1.0 / dv[:, 0], 1.0 / dv[:, -1]
         disp_min, disp_max = (1.0 / depth_max_).contiguous(), (1.0 / depth_min_).contiguous()   # module.py:222-223
         interval = 1.0 / depth_values.size(1)
 
-        views = [im.to(o.device).float().contiguous() for im in imgs]       # V x [B,3,H,W]: FeatureNet's stem reads them in place
-        feats = run_feature(o, self.feat, views, feat_dtype=self.feat_dtype)
+        if feats is None:
+            views = [im.to(o.device).float().contiguous() for im in imgs]       # V x [B,3,H,W]: FeatureNet's stem reads them in place
+            feats = run_feature(o, self.feat, views, feat_dtype=self.feat_dtype)
+        else:
+            views = [imgs[0].to(o.device).float().contiguous()]
         trunk = run_context_trunk(o, self.ctx, views[0])
         depths, confs_full, confs_seq = [], [], []
         view_w = None

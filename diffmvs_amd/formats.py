@@ -217,28 +217,38 @@ class MVSDataset:
         intr[1, :] *= new_h / h
         return resize_bilinear(img, (int(new_w), int(new_h))), intr
 
-    def __getitem__(self, idx):
-        scan, ref_view, src_views = self.metas[idx]
-        view_ids = [ref_view] + src_views[:self.n_views - 1]
+    def view_ids(self, idx) -> List[int]:
+        """[reference view, source views ...] of sample idx (datasets/mvs.py:131-134)"""
+        _, ref_view, src_views = self.metas[idx]
+        return [ref_view] + src_views[:self.n_views - 1]
+
+    def load_view(self, scan: str, vid: int):
+        """one view as EVERY sample that contains it sees it: image [H,W,3] resized / cropped, intrinsics scaled with it, extrinsics,
+        depth range (datasets/mvs.py:136-156).  Depends on the view alone -- which is what lets a scene loop load, decode and
+        encode each image once (diffmvs_amd.eval: scene cache)."""
         root = os.path.join(self.datapath, scan) if self.dataset != "general" else self.datapath
-        imgs, ks, es = [], [], []
-        dmin = dmax = None
-        for i, vid in enumerate(view_ids):
-            img, oh, ow = read_img(os.path.join(root, f"images/{vid:08d}.jpg"))
-            k, e, d0, d1 = read_cam_file(os.path.join(root, self.cam_folder, f"{vid:08d}_cam.txt"))
-            if self.dataset != "general":
-                img = resize_bilinear(img, self.img_wh)
-                k[0] *= self.img_wh[0] / ow
-                k[1] *= self.img_wh[1] / oh
-            else:
-                img, k = self._adaptive(img, k)
-            imgs.append(img)
-            ks.append(k)
-            es.append(e)
-            if i == 0:
-                dmin, dmax = d0, d1
+        img, oh, ow = read_img(os.path.join(root, f"images/{vid:08d}.jpg"))
+        k, e, d0, d1 = read_cam_file(os.path.join(root, self.cam_folder, f"{vid:08d}_cam.txt"))
+        if self.dataset != "general":
+            img = resize_bilinear(img, self.img_wh)
+            k[0] *= self.img_wh[0] / ow
+            k[1] *= self.img_wh[1] / oh
+        else:
+            img, k = self._adaptive(img, k)
+        return img, k, e, d0, d1
+
+    def sample_from_views(self, idx, views: dict):
+        """the sample of __getitem__(idx) assembled from already loaded views {view id: load_view(...)}"""
+        scan = self.metas[idx][0]
+        ids = self.view_ids(idx)
+        loaded = [views[v] for v in ids]
         prefix = (scan + "/") if self.dataset != "general" else ""
-        return make_sample(imgs, ks, es, dmin, dmax, self.numdepth, prefix + "{}/" + f"{view_ids[0]:0>8}" + "{}")
+        return make_sample([x[0] for x in loaded], [x[1] for x in loaded], [x[2] for x in loaded], loaded[0][3], loaded[0][4], self.numdepth,
+                           prefix + "{}/" + f"{ids[0]:0>8}" + "{}")
+
+    def __getitem__(self, idx):
+        scan = self.metas[idx][0]
+        return self.sample_from_views(idx, {v: self.load_view(scan, v) for v in self.view_ids(idx)})
 
 
 # ------------------------------------------------------------------------------------------ what test.py writes

@@ -281,3 +281,67 @@ def synth_cameras(H: int, W: int, n_src: int, B: int = 1, numdepth: int = 384, d
                 proj[sname][b, v, 1, :3, :3] = Ks.astype(np.float32)
     dv = np.tile(np.linspace(1.0 / depth_max, 1.0 / depth_min, numdepth, dtype=np.float32)[None], (B, 1))
     return {k: torch.from_numpy(p) for k, p in proj.items()}, torch.from_numpy(dv)
+
+
+# --------------------------------------------------------------------------- a whole synthetic SCENE (scene-mode evaluation)
+def synth_scene(H: int, W: int, n_views: int = 49, n_src: int = 5, seed: int = 0, numdepth: int = 384, depth_min: float = 425.0,
+                depth_max: float = 935.0, grid_w: int = 7):
+    """A DTU-shaped scene: n_views cameras on a grid_w-wide grid (30 mm spacing, each turned 0.05 rad per grid step towards the
+    scene, like synth_inputs' rig between neighbours) looking at ONE slanted textured plane, and a pair table like the datasets'
+    pair.txt (datasets/mvs.py:33-47): for every reference view its n_src nearest grid neighbours, nearest first.
+    -> {"images": [N,3,H,W], "K": [N,3,3], "E": [N,4,4], "pairs": int64 [N,n_src], "depth_values": [numdepth]}"""
+    rs = np.random.RandomState(1000003 * seed + 101)
+    d0 = rs.uniform(560.0, 760.0)
+    a, c = rs.uniform(-0.25, 0.25, 2)
+    tex_seed = rs.randint(0, 2 ** 31 - 1)
+    K = np.array([[1.2 * W, 0, W / 2.0], [0, 1.2 * W, H / 2.0], [0, 0, 1.0]], np.float64)
+    Kinv = np.linalg.inv(K)
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    pix = np.stack([xs.ravel(), ys.ravel(), np.ones(H * W)])
+    imgs = np.zeros((n_views, 3, H, W), np.float32)
+    Es = np.zeros((n_views, 4, 4), np.float32)
+    grid = np.array([(v % grid_w, v // grid_w) for v in range(n_views)], np.float64)
+    centre = grid.mean(0)
+    n = np.array([-a, -c, 1.0])
+    for v in range(n_views):
+        gx, gy = grid[v] - centre
+        ay, ax = 0.05 * gx, -0.02 * gy
+        Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
+        Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+        R = Rx @ Ry
+        t = np.array([-30.0 * gx, -30.0 * gy, 0.0])
+        E = np.eye(4)
+        E[:3, :3], E[:3, 3] = R, t
+        o = -R.T @ t
+        d = R.T @ (Kinv @ pix)
+        s = (d0 - n @ o) / (n @ d)
+        Xw = o[:, None] + s[None, :] * d
+        tex = _texture(Xw[0].reshape(H, W), Xw[1].reshape(H, W), np.random.RandomState(tex_seed))
+        imgs[v] = np.clip(tex + rs.uniform(-0.03, 0.03, size=(3, H, W)), 0.0, 1.0).astype(np.float32)
+        Es[v] = E.astype(np.float32)
+    pairs = np.zeros((n_views, n_src), np.int64)
+    for v in range(n_views):
+        dist = np.abs(grid - grid[v]).sum(1) + 1e-3 * np.arange(n_views)      # (ties: lower view id first)
+        dist[v] = 1e9
+        order = np.argsort(dist, kind="stable")
+        pairs[v] = order[np.arange(n_src) % max(1, n_views - 1)]
+    return {"images": torch.from_numpy(imgs), "K": torch.from_numpy(K.astype(np.float32))[None].repeat(n_views, 1, 1), "E": torch.from_numpy(Es),
+            "pairs": torch.from_numpy(pairs), "depth_values": torch.from_numpy(np.linspace(1.0 / depth_max, 1.0 / depth_min, numdepth, dtype=np.float32))}
+
+
+def scene_batch(scene: dict, ref_ids):
+    """the model inputs of reference views `ref_ids` of a synth_scene (what the dataset + collate would hand over):
+    -> imgs (V tensors [B,3,H,W]), proj {stage1..4: [B,V,2,4,4]}, depth_values [B,numdepth], view_ids int64 [B,V] (column 0 = ref)"""
+    ref_ids = torch.as_tensor(ref_ids, dtype=torch.int64)
+    view_ids = torch.cat([ref_ids[:, None], scene["pairs"][ref_ids]], 1)
+    B, V = view_ids.shape
+    imgs = [scene["images"][view_ids[:, v]] for v in range(V)]
+    proj = {}
+    for sname, sc in (("stage1", 0.125), ("stage2", 0.25), ("stage3", 0.5), ("stage4", 1.0)):
+        p = torch.zeros(B, V, 2, 4, 4)
+        p[:, :, 0] = scene["E"][view_ids]
+        Ks = scene["K"][view_ids].clone()
+        Ks[:, :, :2, :] *= sc
+        p[:, :, 1, :3, :3] = Ks
+        proj[sname] = p
+    return imgs, proj, scene["depth_values"][None].repeat(B, 1), view_ids

@@ -28,7 +28,9 @@ extern "C" {
 
 /* 2 (round 4): dmvs_conv2d_desc gained `arith` (round 3, without a bump) and `tune`; dmvs_conv3d_desc gained `tune`;
  * dmvs_featurenet_stem_f32 and dmvs_warp_corr_init_quad_f32 take a trailing `tune` argument; dmvs_conv3x3_pair16_f32 is gone;
- * the library no longer reads any environment variable.  A caller built against version 1 passes shorter descriptors:
+ * the library no longer reads any environment variable; dmvs_conv2d_desc also gained `out_mul`, `out_mul_c0` (producer-side output
+ * product, SepConvGRU's r * h) and `in0_cstride` (in0 as a channel slice) -- honoured by dmvs_conv2d_f32 only: the weight-gradient entry
+ * points return DMVS_EINVAL when any of in0_cstride / gate_cstride / out_mul is set.  A caller built against version 1 passes shorter descriptors:
  * check dmvs_abi_version() == DMVS_ABI_VERSION before the first call. */
 #define DMVS_ABI_VERSION 2
 #define DMVS_EINVAL (-22)
@@ -78,10 +80,10 @@ int dmvs_abi_version(void);
 #define DMVS_TUNE_TILE_WX(n) ((n) & 3)           /* 1 | 2: 16- / 32-pixel-wide workgroup tiles for the 3x3 / 5x5 layers           */
 #define DMVS_TUNE_NO_WALK 0x4                     /* one tile per workgroup everywhere (no resident tile-walking workgroups)        */
 #define DMVS_TUNE_PIECES4 0x8                     /* input halo staged in 4-byte LDS-DMA pieces even where 16-byte ones apply        */
-#define DMVS_TUNE_TILE_MT(n) (((n) & 7) << 4)     /* 1 | 2 | 4: tile height in units of 4 rows (4 on the stride-2 / 5x5 / 7x7 families: experiment only) */
+#define DMVS_TUNE_TILE_MT(n) (((n) & 7) << 4)     /* A/B: 1 | 2 | 4 = tile height in units of 4 rows (4: plain 3x3 / 1xk families only; timed on the stride-2 / 5x5 / 7x7 ones in round 5: +-2 %, removed) */
 #define DMVS_TUNE_1X1_TILED 0x200                 /* 1x1 layers on the LDS-tiled kernel instead of the 16-byte direct form                    */
 #define DMVS_TUNE_NO_LEAN 0x100                   /* plain layers on the generic kernel (every fused path resolved at run time)     */
-#define DMVS_TUNE_TALL(n) (((n) & 3) << 10)      /* 16 x 32-pixel tiles for the plain 3x3 layers: 0 = where measured better, 1 = never, 2 = wherever they apply, 3 = 16 x 64 (experiment) */
+#define DMVS_TUNE_TALL(n) (((n) & 3) << 10)      /* 16 x 32-pixel tiles for the plain 3x3 layers: 0 = where measured better, 1 = never, 2 = wherever they apply (16 x 64 tiles: timed in round 5, 6-8 % slower, removed) */
 
 typedef struct dmvs_conv2d_desc {
     const float* in0;       /* [B,c0,*,*] physical tensor                                   */
@@ -146,7 +148,8 @@ int dmvs_featurenet_stem_f32(const float* x, const float* w0, const float* scale
                              void* stream);
 
 /* Weight (and bias) gradient of the convolution described by `d` (its input side: in0 / in1 / mul0 / in_mode / kh /
- * kw / stride / pad / cout / cout_pad / B / Hin / Win / Hout / Wout; epilogue fields are ignored):
+ * kw / stride / pad / cout / cout_pad / B / Hin / Win / Hout / Wout; epilogue fields are ignored; in0 / in1 / mul0 must be DENSE tensors:
+ * DMVS_EINVAL when in0_cstride, gate_cstride or out_mul is set):
  *   gw[co][ci][ky][kx] = sum_{b,y,x} grad_out[b,co,y,x] * X[b,ci,y*stride+ky-pad,x*stride+kx-pad]     (torch layout)
  *   gb[co]             = sum_{b,y,x} grad_out[b,co,y,x]                                               (gb may be NULL)
  * grad_out [B,cout,Hout,Wout] NCHW.  Every element of gw / gb is written exactly once (no pre-zeroing) and the
@@ -184,8 +187,8 @@ typedef struct dmvs_conv3d_desc {
 } dmvs_conv3d_desc;
 #define DMVS_TUNE3D_PIECES4 0x1       /* stride-1 MFMA kernels: halo tile in 4-byte LDS-DMA pieces even where 16-byte ones apply  */
 #define DMVS_TUNE3D_S2_DIRECT 0x2     /* stride-2 layers on the direct (VALU) kernels of round 1 instead of the matrix cores      */
-#define DMVS_TUNE3D_PAIR_WREG 0x4     /* experiment: the 4 -> 8 paired kernel with its weights in registers (46 KB of LDS, 3 workgroups per CU) */
-#define DMVS_TUNE3D_PAIR8 0x8         /* experiment: 5..8 -> <= 8 channel layers (CostRegNet conv1) on a two-chunk paired kernel instead of the generic one */
+#define DMVS_TUNE3D_NO_PAIR 0x4       /* A/B: the <= 8 -> <= 8 channel stride-1 layers on the generic / streamed kernels instead of the paired ones (two output depth
+                                         slices per MFMA; bit-identical results; round 5: PixelViewWeight conv0 -5 %, CostRegNet conv1 1517 -> 983 us per 96 volumes) */
 
 /* Size limit of the stride-1 layers (DMVS_EINVAL beyond): cin * Din*Hin*Win < 2^31 and cout * Dout*Hout*Wout < 2^31
  * (one batch item is addressed with 32-bit element offsets). */

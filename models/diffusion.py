@@ -104,7 +104,13 @@ class CasDiffMVS(nn.Module):
             self._engine_key = key
         return self._engine
 
-    def forward(self, imgs, proj_matrices, depth_values, depth_gt_ms=None):
+    def scene_features(self, images, chunk: int = 64):
+        """FeatureNet over all N images [N,3,H,W] of a scene, once -> diffmvs_amd.engine.SceneFeatureStore; pass
+        `feats=store.gather(view_ids)` to forward() (view_ids [B,V], column 0 = the reference view).  Eval mode only."""
+        from diffmvs_amd.engine import SceneFeatureStore
+        return SceneFeatureStore(self.engine(), images, chunk)
+
+    def forward(self, imgs, proj_matrices, depth_values, depth_gt_ms=None, feats=None):
         if self.training:
             # train branch (reference diffusion.py:167-172, update.py:423-464): an autograd graph whose convolution /
             # warp / cost-volume nodes are libdmvs_hip.so kernels in both directions (diffmvs_amd/train.py)
@@ -115,5 +121,5 @@ class CasDiffMVS(nn.Module):
             return forward_train(self, imgs, proj_matrices, depth_values, depth_gt_ms, ops)
         eng = self.engine()
         if self.hip_graphs:
-            return eng.forward_graphed(imgs, proj_matrices, depth_values, noise_fn=self.noise_source, test=self.test)
-        return eng.forward(imgs, proj_matrices, depth_values, noise_fn=self.noise_source, test=self.test)
+            return eng.forward_graphed(imgs, proj_matrices, depth_values, noise_fn=self.noise_source, test=self.test, feats=feats)
+        return eng.forward(imgs, proj_matrices, depth_values, noise_fn=self.noise_source, test=self.test, feats=feats)

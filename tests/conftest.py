@@ -19,7 +19,7 @@ def pytest_configure(config):
 # Collection order: the per-kernel parity tests first, then the module / training-step parity, then the end-to-end goldens, and the
 # full-size oracle comparisons and property tests LAST -- under `pytest -x` a red full-size test must not hide the kernel rows
 # (round 4: one failing property test at collected position 31 left 273 op-level tests unrun).
-_FILE_ORDER = ["test_abi.py", "test_docs.py", "test_oracle_golden.py", "test_formats.py", "test_loss.py", "test_ops.py", "test_modules.py",
+_FILE_ORDER = ["test_abi.py", "test_isa_audit.py", "test_docs.py", "test_oracle_golden.py", "test_formats.py", "test_loss.py", "test_ops.py", "test_modules.py",
                "test_train.py", "test_trainer.py", "test_shard_gloo.py", "test_fusion.py", "test_model_cpu.py", "test_eval_gpu.py",
                "test_scene.py", "test_model_gpu.py"]
 _LATE = ("full_size", "size_properties", "cfg4_full_size", "hip_graph")

@@ -451,3 +451,4 @@ static inline float __int_as_float(int v) { float f; memcpy(&f, &v, 4); return f
 static inline int __float_as_int(float f) { int v; memcpy(&v, &f, 4); return v; }
 #define DMVS_ORDER_AFTER(var, dep) ((void)0)
 #define DMVS_LDS_BARRIER() __syncthreads()
+#define DMVS_DMA_BARRIER() __syncthreads()

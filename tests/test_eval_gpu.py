@@ -97,3 +97,22 @@ def test_eval_tank_layout_uses_the_scene_tables(tmp_path):
                             photo_thres=fusion.TANK_PHOTO_THRES["Horse"], method="casdiffmvs", dataset="tank", scan="Horse")
     assert n == res["fused_points"]["intermediate/Horse"]
     assert open(ply, "rb").read() == open(tmp_path / "direct.ply", "rb").read()
+
+
+def test_scene_cache_writes_the_same_files(tmp_path):
+    """--scene_cache 1 (every image through FeatureNet once per scene, the default) and --scene_cache 0 (the reference's per-sample order
+    of work, test.py:92-127) write byte-identical depth / confidence PFMs"""
+    from diffmvs_amd import eval as EV
+    root = tmp_path / "scene"
+    _write_scene(root, 64, 96, 5, seed=8, with_gt=False)
+    outs = []
+    for flag in ("1", "0"):
+        out = tmp_path / ("out" + flag)
+        res = EV.main(["--testpath", str(root), "--dataset", "general", "--outdir", str(out), "--method", "casdiffmvs", "--num_view", "4",
+                       "--numdepth_initial", "16", "--batch_size", "2", "--noise_seed", "5", "--scene_cache", flag])
+        assert res["views"] == 3 and (len(res["feature_store_s"]) == 1) == (flag == "1")
+        outs.append(out)
+    for v in range(5):
+        for sub in ("depth_est", "conf0", "conf1", "conf2"):
+            a, b = outs[0] / sub / f"{v:08d}.pfm", outs[1] / sub / f"{v:08d}.pfm"
+            assert open(a, "rb").read() == open(b, "rb").read(), (sub, v)

@@ -96,7 +96,7 @@ def getcost_inputs(o, B, geometry, conf):
 def getcost(B=None):
     B = B or int(os.environ.get("DIAG_B", "96"))
     base = Ops.for_device("cuda:0")
-    libs = [("product", None)] + [(n, os.path.join(ROOT, "tools", "calib", "libdmvs_hip_%s.so" % n)) for n in ("nopipe", "gcexp1", "gcexp2", "gcexp3")]
+    libs = [("product", None)] + [(n, os.path.join(ROOT, "tools", "calib", "libdmvs_hip_%s.so" % n)) for n in ("nopipe", "gcexp1", "gcexp2", "gcexp3", "gcexp4", "gcexp4t4", "gcexp4t1")]
     alg = 4.0 * B * 128 * 160 * (32 + 5 * 32 + 6 + 5 + 24)
     for geometry, conf in (("noise", None), ("noise", "random"), ("scene", 0.5)):
         args = getcost_inputs(base, B, geometry, conf)
@@ -226,9 +226,6 @@ def convexp():
             row["tall_bit_identical"] = bool(torch.equal(ref, y))
             row["tall_us"] = round(timeit(lambda: o.conv2d(pc, xx, act=K.ACT_RELU, tune=_lib.TUNE_TALL), iters=10), 1)
             del y
-            if cout <= 16 and H >= 64:      # 16 x 64 tiles (added after the run in profiles/r4_conv_tall_s2_ky_ab.jsonl)
-                row["tall64_bit_identical"] = bool(torch.equal(ref, o.conv2d(pc, xx, act=K.ACT_RELU, tune=_lib.TUNE_TALL64)))
-                row["tall64_us"] = round(timeit(lambda: o.conv2d(pc, xx, act=K.ACT_RELU, tune=_lib.TUNE_TALL64), iters=10), 1)
         else:
             for n, ov in var.items():
                 y = ov.conv2d(pc, xx, act=K.ACT_RELU)
@@ -266,60 +263,22 @@ def convexp2():
         del xx
 
 
-def heavymt():
-    """(not yet run: prepared for the next round) 16 x 16-pixel tiles (DMVS_TUNE_TILE_MT(4)) against the dispatcher's 16 x 8 on the
-    stride-2 / 5x5 / 7x7 layers of the B = 96 step, per layer, bit-identical"""
+def pair3d():
+    """the paired 3-D kernels (the default since round 5) against the kernels that ran these layers before (DMVS_TUNE3D_NO_PAIR): PixelViewWeight
+    conv0 / CostRegNet conv0 (4 -> 8) and CostRegNet conv1 (8 -> 8) of the B = 96 step, per layer, bit-identical"""
     o = _ops()
     g = _gen()
-    for name, N, cin, cout, k, s, H, W in (("8->16 5x5 s2 512x640 x576", 576, 8, 16, 5, 2, 512, 640), ("16->32 5x5 s2 256x320 x576", 576, 16, 32, 5, 2, 256, 320),
-                                           ("32->64 5x5 s2 128x160 x576", 576, 32, 64, 5, 2, 128, 160), ("8->16 3x3 s2 512x640 x96", 96, 8, 16, 3, 2, 512, 640),
-                                           ("16->32 3x3 s2 256x320 x96", 96, 16, 32, 3, 2, 256, 320), ("32->16 7x7 128x160 x96", 96, 32, 16, 7, 1, 128, 160),
-                                           ("64->64 1x5 64x80 x96", 96, 64, 64, (1, 5), 1, 64, 80), ("64->64 5x1 64x80 x96", 96, 64, 64, (5, 1), 1, 64, 80)):
-        kk = (k, k) if isinstance(k, int) else k
-        N, H, W = _n(N, 2), _hw(H), _hw(W)
-        xx = torch.relu(torch.randn(N, cin, H, W, generator=g, device=DEV))
-        ww = torch.randn(cout, cin, *kk, generator=g, device=DEV) * 0.1
-        pc = K.pack_conv2d(ww, None, stride=s, pad=(kk[0] // 2, kk[1] // 2))
-        ref = o.conv2d(pc, xx, act=K.ACT_RELU)
-        row = {"diag": "heavymt", "layer": name, "product_us": round(timeit(lambda: o.conv2d(pc, xx, act=K.ACT_RELU), iters=10), 1)}
-        for mt in (2, 4):
-            tune = _lib.tune_tile_mt(mt)
-            row["mt%d_bit_identical" % mt] = bool(torch.equal(ref, o.conv2d(pc, xx, act=K.ACT_RELU, tune=tune)))
-            row["mt%d_us" % mt] = round(timeit(lambda: o.conv2d(pc, xx, act=K.ACT_RELU, tune=tune), iters=10), 1)
-        print(json.dumps(row), flush=True)
-        del xx, ref
-
-
-def pairwreg():
-    """(not yet run: prepared for the next round) the 4 -> 8 paired 3-D kernel with its weights in registers (DMVS_TUNE3D_PAIR_WREG: 46 KB of
-    LDS, three workgroups per CU) against the default (56 KB, two), on the two launches of the B = 96 step"""
-    o = _ops()
-    g = _gen()
-    for name, N in (("pvw conv0 4->8 x480", 480), ("costreg conv0 4->8 x96", 96)):
+    for name, N, cin in (("pvw conv0 4->8 x480", 480, 4), ("costreg conv0 4->8 x96", 96, 4), ("costreg conv1 8->8 x96", 96, 8)):
         N = _n(N, 8)
-        v = torch.randn(N, 4, 48, 64, 80, generator=g, device=DEV) if not DRY else torch.randn(N, 4, 16, 32, 80, generator=g, device=DEV)
-        pc3 = K.pack_conv3d(torch.randn(8, 4, 3, 3, 3, generator=g, device=DEV) * 0.2, None)
+        v = torch.randn(N, cin, 48, 64, 80, generator=g, device=DEV) if not DRY else torch.randn(N, cin, 16, 32, 80, generator=g, device=DEV)
+        pc3 = K.pack_conv3d(torch.randn(8, cin, 3, 3, 3, generator=g, device=DEV) * 0.2, None)
         ref = o.conv3d(pc3, v, act=K.ACT_RELU)
-        same = bool(torch.equal(ref, o.conv3d(pc3, v, act=K.ACT_RELU, tune=_lib.TUNE3D_PAIR_WREG)))
+        same = bool(torch.equal(ref, o.conv3d(pc3, v, act=K.ACT_RELU, tune=_lib.TUNE3D_NO_PAIR)))
         del ref
-        print(json.dumps({"diag": "pairwreg", "layer": name, "default_us": round(timeit(lambda: o.conv3d(pc3, v, act=K.ACT_RELU), iters=10), 1),
-                          "wreg_us": round(timeit(lambda: o.conv3d(pc3, v, act=K.ACT_RELU, tune=_lib.TUNE3D_PAIR_WREG), iters=10), 1),
+        print(json.dumps({"diag": "pair3d", "layer": name, "paired_us": round(timeit(lambda: o.conv3d(pc3, v, act=K.ACT_RELU), iters=10), 1),
+                          "no_pair_us": round(timeit(lambda: o.conv3d(pc3, v, act=K.ACT_RELU, tune=_lib.TUNE3D_NO_PAIR), iters=10), 1),
                           "bit_identical": same}), flush=True)
         del v
-
-
-def pair8():
-    """(not yet run: prepared for the next round) CostRegNet conv1 (8 -> 8, 96 volumes of 48 x 64 x 80) on the two-chunk paired kernel
-    (DMVS_TUNE3D_PAIR8: 144 instead of 216 MFMAs per 64 voxels) against the generic kernel"""
-    o = _ops()
-    g = _gen()
-    v = torch.relu(torch.randn(96, 8, 48, 64, 80, generator=g, device=DEV)) if not DRY else torch.relu(torch.randn(8, 8, 16, 32, 80, generator=g, device=DEV))
-    pc3 = K.pack_conv3d(torch.randn(8, 8, 3, 3, 3, generator=g, device=DEV) * 0.2, None)
-    ref = o.conv3d(pc3, v, act=K.ACT_RELU)
-    same = bool(torch.equal(ref, o.conv3d(pc3, v, act=K.ACT_RELU, tune=_lib.TUNE3D_PAIR8)))
-    del ref
-    print(json.dumps({"diag": "pair8", "layer": "costreg conv1 8->8 x96", "default_us": round(timeit(lambda: o.conv3d(pc3, v, act=K.ACT_RELU), iters=10), 1),
-                      "pair8_us": round(timeit(lambda: o.conv3d(pc3, v, act=K.ACT_RELU, tune=_lib.TUNE3D_PAIR8), iters=10), 1), "bit_identical": same}), flush=True)
 
 
 def mtsweep():
@@ -376,4 +335,4 @@ def stem():
 
 
 if __name__ == "__main__":
-    {"getcost": getcost, "warp_init": warp_init, "getcost_pmc": getcost_pmc, "optins": optins, "convexp": convexp, "convexp2": convexp2, "stem": stem, "heavymt": heavymt, "pairwreg": pairwreg, "pair8": pair8, "mtsweep": mtsweep}[sys.argv[1]]()
+    {"getcost": getcost, "warp_init": warp_init, "getcost_pmc": getcost_pmc, "optins": optins, "convexp": convexp, "convexp2": convexp2, "stem": stem, "pair3d": pair3d, "mtsweep": mtsweep}[sys.argv[1]]()
