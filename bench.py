@@ -495,7 +495,7 @@ def main():
     # HBM traffic per getcost launch from the PMC passes (rocprofv3 cannot run inside the timed process); only
     # quoted when the committed measurement was taken at this batch size
     traffic, traffic_note = None, None
-    tj = os.path.join(ROOT, "profiles", "r4_getcost_traffic.json")
+    tj = os.path.join(ROOT, "profiles", "r5_getcost_traffic.json")
     if os.path.exists(tj):
         with open(tj) as f:
             tinfo = json.load(f)
@@ -505,6 +505,25 @@ def main():
             traffic = tinfo["traffic_bytes_per_launch"]
             traffic_note = (os.path.relpath(tj, ROOT) + " (rocprofv3 PMC passes of this command on this kernel source, counters scaled by the "
                             "factors of profiles/r3_traffic_calibration.json; not measured by this process)")
+
+    # the measured memory-system ceiling of GetCost's address stream (tools/diag_r4.py getcost with the DMVS_GC_EXP=4 builds: the product
+    # kernel's projection, masks, addresses and loads, nothing computed from the loaded registers) -- a committed measurement of another
+    # run of this kernel source at this batch, quoted next to the live number, never in place of it
+    ceiling = None
+    cj = os.path.join(ROOT, "profiles", "r5_getcost_ceiling_probe.json")
+    if os.path.exists(cj) and (H, W, S) == (512, 640, 5):
+        with open(cj) as f:
+            cinfo = json.load(f)
+        if cinfo.get("batch") == B:
+            pr, pc = cinfo["noise_no_confidence"], cinfo["noise_random_confidence"]
+            ceiling = {"source": os.path.relpath(cj, ROOT), "gate_0p60_us": cinfo["gate_0p60_us"],
+                       "noise_geometry": {"probe_us": pr["probe_us"], "product_us_same_session": pr["product_us"],
+                                          "probe_frac_of_hbm_peak": round(cinfo["algorithmic_bytes_per_launch"] / (pr["probe_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                          "product_over_probe": round(pr["probe_us"] / pr["product_us"], 3)},
+                       "noise_geometry_random_confidence": {"probe_us": pc["probe_us"], "product_us_same_session": pc["product_us"],
+                                                            "product_over_probe": round(pc["probe_us"] / pc["product_us"], 3)},
+                       "reading": "the kernel's own line-request stream with NO arithmetic takes longer than the 0.60 mark allows: the 0.60 gate is above "
+                                  "what the memory system delivers for this access pattern; the product kernel runs at 0.85-0.87 of that ceiling"}
 
     result = {
         "metric": "depth-maps/sec (640x512, 5 src views)", "value": round(value, 3), "unit": "depth-maps/s",
@@ -525,7 +544,8 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "traffic_source": traffic_note,
                      "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(gc_avg_s * 1e6, 2),
-                     "launches_timed": len(gc_ms), "per_gru_iteration": by_iter},
+                     "launches_timed": len(gc_ms), "per_gru_iteration": by_iter,
+                     "ceiling_probe_us": ceiling["noise_geometry"]["probe_us"] if ceiling else None, "ceiling_probe": ceiling},
         "roofline_warp_init": {"kernel": ("warp_init_quad_kernel<48> (stage-1 plane sweep, quad per pixel, texels from global memory: tune DMVS_TUNE_SWEEP_GLOBAL)"
                                           if eng.ops.tune["sweep"] else
                                           "warp_init_band_kernel<48> (stage-1 plane sweep, quad per pixel, source band of a 16x4 pixel tile staged in LDS)"), "bound": "hbm",

@@ -158,7 +158,9 @@ def _env_tune():
     t3 = (_lib.TUNE3D_PIECES4 if e("DMVS_CONV3D_V16") == "0" else 0) | (_lib.TUNE3D_S2_DIRECT if e("DMVS_CONV3D_S2") == "direct" else 0)
     t3 |= _lib.TUNE3D_NO_PAIR if e("DMVS_CONV3D_PAIR") == "0" else 0
     return {"conv2d": t2, "conv3d": t3, "stem": _lib.TUNE_PIECES4 if e("DMVS_STEM_V16") == "0" else 0,
-            "sweep": _lib.TUNE_SWEEP_GLOBAL if e("DMVS_PLANE_SWEEP") == "quad" else 0}
+            "sweep": _lib.TUNE_SWEEP_GLOBAL if e("DMVS_PLANE_SWEEP") == "quad" else 0,
+            # training: GetCost backward through the per-pixel gather kernel only (no tile pre-pass / LDS-window worklist): DMVS_GETCOST_BWD=gather
+            "bwd_gather": e("DMVS_GETCOST_BWD") == "gather"}
 
 
 class Ops:
@@ -479,7 +481,8 @@ class Ops:
         return gref, gsrc
 
     def getcost_bwd(self, ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, min_radius,
-                    max_radius, vw_shift, gcost, gsrc=None, G=4, gather=False):
+                    max_radius, vw_shift, gcost, gsrc=None, G=4, gather=None):
+        gather = self.tune.get("bwd_gather", False) if gather is None else gather
         self._chk(ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, gcost, gsrc)
         B, H, W, Cc = ref.shape
         S = src.shape[0]
