@@ -13,7 +13,7 @@ def _design():
 
 
 def test_design_quotes_the_committed_bench_line():
-    line = json.load(open(os.path.join(ROOT, "profiles", "r4_bench_line.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r5_bench_line.json")))
     text = _design()
     text = text[text.index("End-of-round numbers"):]
     text = text[:text.index("**Batch 1**")]
@@ -28,8 +28,8 @@ def test_design_quotes_the_committed_bench_line():
     rf = line["roofline"]
     assert rf["bound"] == "hbm" and abs(rf["achieved"] / rf["peak"] - rf["frac"]) < 1e-3
     assert abs(rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_us"] * 1e-6) / 1e9 - rf["achieved"]) < 1.0
-    # the last bench run of the round skipped the batch sweep and the CPU leg (GPU budget); the last full default run carries them
-    full = json.load(open(os.path.join(ROOT, "profiles", "r4_bench_full_line.json")))
+    # the full default run (batch sweep, CPU leg) is its own committed line
+    full = json.load(open(os.path.join(ROOT, "profiles", "r5_bench_full_line.json")))
     assert f"{round(full['value'])} depth-maps/s" in text and f"{full['ms_per_step']:.1f} ms" in text
     cb = full["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
@@ -38,8 +38,8 @@ def test_design_quotes_the_committed_bench_line():
 
 def test_kernel_stats_agree_with_the_bench_line():
     """the rocprof average of the plane-sweep kernel and the event-timed figure on the bench line of the same run agree"""
-    line = json.load(open(os.path.join(ROOT, "profiles", "r4_bench_b96_profiled_line.json")))
-    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r4_bench_b96_kernel_stats.csv"))))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r5_bench_b96_profiled_line.json")))
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r5_bench_b96_kernel_stats.csv"))))
     wi = [r for r in rows if "warp_init_band_kernel" in r["Name"]]
     assert len(wi) == 1
     prof_us = float(wi[0]["AverageNs"]) / 1e3
@@ -65,10 +65,10 @@ def test_design_test_counts_match_the_suite():
 
 
 def test_traffic_file_matches_the_kernel_source():
-    """profiles/r4_getcost_traffic.json was measured on the committed warp kernels (bench.py refuses it otherwise)"""
+    """profiles/r5_getcost_traffic.json was measured on the committed warp kernels (bench.py refuses it otherwise)"""
     import sys
     sys.path.insert(0, ROOT)
     import bench
-    t = json.load(open(os.path.join(ROOT, "profiles", "r4_getcost_traffic.json")))
+    t = json.load(open(os.path.join(ROOT, "profiles", "r5_getcost_traffic.json")))
     assert t["kernel_source_sha"] == bench.kernel_source_hash()
     assert 0.8 < t["traffic_bytes_per_launch"] / 1785200640 < 1.2
