@@ -976,7 +976,7 @@ int launch_conv2d(const dmvs_conv2d_desc& d, hipStream_t st) {
     if (S == 1 && KH * KW > 1 && conv_bf16_honoured(d))      // and for the bf16 matrix arithmetic
         return launch_conv2d_mt<KH, KW, S, 2, false>(d, st, nt, ngroups);
     const long wg16 = (long)((d.Wout + 15) / 16) * ((d.Hout + 15) / 16) * d.B * ngroups;
-    const int force_mt = (d.tune >> 4) & 7;      // DMVS_TUNE_TILE_MT: experiments force the tile height
+    const int force_mt = (d.tune >> 4) & 7;      // DMVS_TUNE_TILE_MT: A/B runs force the tile height
     // (16 x 16-pixel tiles for the stride-2 / many-tap families, timed per layer in round 5: within +-2 % of the 16 x 8 tiles on the 5x5
     // stride-2 layers, -5 % on the 7x7 and +10 % on the 1x5 / 5x1 ones -- not worth their LDS; the instantiations are gone, profiles/r5_optins.jsonl)
     if constexpr (!heavy) {

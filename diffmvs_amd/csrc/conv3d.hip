@@ -493,8 +493,8 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_pair_kernel(con
 }
 
 // 5..8 input channels, cout <= 8 (CostRegNet conv1, 8 -> 8 at full resolution): the paired kernel above over TWO 4-channel chunks per
-// tile.  (An experiment, DMVS_TUNE3D_PAIR8, not yet timed: the generic kernel that runs this layer today spends half of its MFMA rows
-// on padding -- 216 MFMAs per 64 voxels against 144 here.)  The pipeline item is a (tile, chunk) unit: while chunk c of a tile computes,
+// tile.  (Default since round 5: 1517 -> 983 us per 96 volumes on the MI355X, profiles/r5_optins.jsonl -- the generic kernel spends half of
+// its MFMA rows on padding, 216 MFMAs per 64 voxels against 144 here; DMVS_TUNE3D_NO_PAIR selects it for A/B.)  The pipeline item is a (tile, chunk) unit: while chunk c of a tile computes,
 // the next unit's 4-channel halo streams into the other LDS buffer; the accumulators live across a tile's two units and are stored one
 // unit late, after the next barrier.  Weights in registers (2 x 36 per lane, see WREG above): the kernel holds only the two halo
 // buffers in LDS (46 KB, three workgroups per CU).  Each output still sums its products in (ci, kd, ky, kx) order: bit-identical to the

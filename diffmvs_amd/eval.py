@@ -153,7 +153,7 @@ def main(argv=None):
     mine = shard.shard_scenes(scenes, rank, world)
     times, report, store_s = run_scenes(model, a, mine, device)
     res = {"rank": rank, "scenes": mine, "views": len(times), "avg_time_s": float(np.mean(times)) if times else None, "errors": report,
-           "feature_store_s": store_s}
+           "feature_store_s": store_s, "hip_graphs": bool(model.hip_graphs)}
     if a.filter:
         from . import fusion
         for scene in mine:      # the per-dataset protocol of test.py:298-367

@@ -116,3 +116,20 @@ def test_scene_cache_writes_the_same_files(tmp_path):
         for sub in ("depth_est", "conf0", "conf1", "conf2"):
             a, b = outs[0] / sub / f"{v:08d}.pfm", outs[1] / sub / f"{v:08d}.pfm"
             assert open(a, "rb").read() == open(b, "rb").read(), (sub, v)
+
+
+def test_eval_defaults_replay_the_captured_graph(tmp_path):
+    """the driver's defaults at the reference's batch size 1 (test.py:101-104): device RNG, scene cache, the forward replayed from a
+    captured HIP graph (two input geometries = two graphs: 4 views here); outputs finite, inside the depth range, one file per view"""
+    from diffmvs_amd import eval as EV
+    root = tmp_path / "scene"
+    _write_scene(root, 64, 96, 4, seed=9, with_gt=False)
+    out = tmp_path / "out"
+    res = EV.main(["--testpath", str(root), "--dataset", "general", "--outdir", str(out), "--method", "diffmvs", "--num_view", "3",
+                   "--numdepth_initial", "16"])
+    assert res["hip_graphs"] and res["views"] == 4 and len(res["feature_store_s"]) == 1
+    for v in range(4):
+        d, _ = IO.read_pfm(str(out / f"depth_est/{v:08d}.pfm"))
+        assert d.shape == (64, 96) and np.isfinite(d).all() and d.min() >= 424.9 and d.max() <= 935.1
+    seen = {open(out / f"depth_est/{v:08d}.pfm", "rb").read() for v in range(4)}
+    assert len(seen) == 4          # (a replay that returned a stale static output would repeat a file)

@@ -1,6 +1,8 @@
 """Kernel-level parity: every C-ABI entry point against the oracle / the matching ATen op.
 Runs twice: on the host emulation of the kernel sources (CPU container) and, with -m gpu,
 through libdmvs_hip.so on the MI355X."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1474,7 +1476,7 @@ def test_deconv3d_matrix_core_form(ops, cin, cout, D, H, W, with_res):
 # for the host emulation, whose "resident" grid is 2 workgroups: on the MI355X their grids fit the chip and nothing walks).  The round-4
 # stem kernel read a halo whose LDS-DMA was still landing from the second tile of a workgroup on -- about one launch in ten at this size --
 # and no op-level test could see it.  Each kernel: REPS launches bit-identical, and right against ATen.
-_WALK_REPS = 24
+_WALK_REPS = int(os.environ.get("DMVS_WALK_REPS", "24"))      # (a soak run raises it)
 
 
 def _same_every_launch(fn, reps=_WALK_REPS):
