@@ -230,6 +230,25 @@ def train_main(a):
     elapsed = timed_steps(step, a.steps, 0, barrier)
     elapsed = shard.barrier_and_max(elapsed, dev)
     ar_ms = [s_.elapsed_time(e_) for s_, e_ in tr.allreduce_events]
+    # one extra, untimed step with an event pair around the backward's two dominant kernel families (kept out of the timed region)
+    from diffmvs_amd.ops import Ops
+    ops = Ops.for_device(dev)
+    ops.timers = {"dmvs_getcost_bwd_f32": [], "dmvs_conv2d_wgrad_f32": []}
+    step()
+    torch.cuda.synchronize()
+    tm, ops.timers = ops.timers, None
+    gb_ms = [s_.elapsed_time(e_) for s_, e_ in tm["dmvs_getcost_bwd_f32"]]
+    wg_ms = [s_.elapsed_time(e_) for s_, e_ in tm["dmvs_conv2d_wgrad_f32"]]
+    gb_bytes, wg_flops = sum(tm.get("_getcost_bwd_bytes", [])), sum(tm.get("_wgrad_flops", []))
+    roof = {"roofline_getcost_bwd": {"kernel": "getcost_bwd_kernel<*> (gradient scatter into the source features, hardware fp32 atomics)", "bound": "hbm",
+                                     "achieved": round(gb_bytes / (sum(gb_ms) * 1e-3) / 1e9, 2) if gb_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(gb_bytes / (sum(gb_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if gb_ms else None,
+                                     "launches": len(gb_ms), "ms_per_step": round(sum(gb_ms), 3),
+                                     "note": "bound in practice by the L2's fp32 atomic rate (one atomic per tap and channel), not by HBM: DESIGN.md 3.2"},
+            "roofline_conv2d_wgrad": {"kernel": "conv2d_wgrad_kernel<*> (all weight-gradient launches of the step)", "bound": "mfma",
+                                      "achieved": round(wg_flops / (sum(wg_ms) * 1e-3) / 1e12, 2) if wg_ms else None, "peak": FP32_MFMA_PEAK_TFS, "unit": "TFLOP/s",
+                                      "frac": round(wg_flops / (sum(wg_ms) * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFS, 4) if wg_ms else None,
+                                      "launches": len(wg_ms), "ms_per_step": round(sum(wg_ms), 3)}}
     if rank == 0:
         print(json.dumps({
             "metric": "training samples/sec (CasDiffMVS 768x576, 9 views)", "value": round(B * world * a.steps / elapsed, 3), "unit": "samples/s",
@@ -240,7 +259,7 @@ def train_main(a):
                        "batch_per_gpu": B, "parallelism": f"data parallel x{world}: one all-reduce (SUM) of the {tr.flat.numel * 4 / 1e6:.2f} MB flat fp32 gradient bucket per step",
                        "weights": "seeded random init"},
             "allreduce_ms_per_step": round(sum(ar_ms) / max(1, len(ar_ms)), 4) if ar_ms else None,
-            "allreduce_bytes": tr.flat.numel * 4, "loss": float(last["loss"]),
+            "allreduce_bytes": tr.flat.numel * 4, "loss": float(last["loss"]), **roof,
             "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}), flush=True)
     if td:
         td.destroy_process_group()

@@ -363,6 +363,8 @@ class Ops:
         self._call("dmvs_conv2d_wgrad_workspace_f32", C.byref(d), C.byref(nbytes))
         ws = self.empty(nbytes.value // 4)
         self._call("dmvs_conv2d_wgrad_f32", C.byref(d), _ptr(grad_out), _ptr(gw), _ptr(gb), _ptr(ws), nbytes.value, self.stream())
+        if self.timers is not None and "dmvs_conv2d_wgrad_f32" in self.timers:      # bench cfg4: MFMA roofline over every weight-gradient launch
+            self.timers.setdefault("_wgrad_flops", []).append(2.0 * B * Hout * Wout * pc.cout * pc.cin * kh * kw)
         return (gw, gb) if want_bias else gw
 
     # ------------------------------------------------------------------ conv3d
@@ -497,6 +499,9 @@ class Ops:
                              H=H, W=W, vw_shift=vw_shift, cost_cstride=G * n, cost_coffset=0, samp_cstride=n, samp_coffset=0,
                              interval=interval, min_radius=min_radius, max_radius=max_radius)
         self._call("dmvs_getcost_bwd_f32", C.byref(d), _ptr(gcost), _ptr(gref), _ptr(gsrc), self.stream())
+        if self.timers is not None and "dmvs_getcost_bwd_f32" in self.timers:
+            # bench cfg4, algorithmic bytes: read ref + src + grad_cost, write grad_ref, read-modify-write grad_src (the scatter target)
+            self.timers.setdefault("_getcost_bwd_bytes", []).append(4.0 * B * H * W * (Cc + S * Cc + G * n + Cc + 2 * S * Cc))
         return gref, gsrc
 
     def view_aggregate_bwd(self, cor, w, out, gout):
