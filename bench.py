@@ -90,29 +90,6 @@ def batch_sweep(model, make_batch, batches=(1, 2, 4, 8, 16, 32, 64), iters=6):
                     model(imgs, proj, dv)
                 torch.cuda.synchronize()
             row["graph_ms_per_map" if graphs else "eager_ms_per_map"] = round((time.perf_counter() - t0) / iters / B * 1e3, 4)
-        if B <= 8:      # the same through the graph with the independent launch chains as parallel branches (Engine.multistream)
-            eng = model.engine()
-            was_ms, eng.multistream, model.hip_graphs = eng.multistream, True, True
-            with torch.no_grad():
-                for _ in range(2):
-                    model(imgs, proj, dv)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(iters):
-                    model(imgs, proj, dv)
-                torch.cuda.synchronize()
-            row["graph_multistream_ms_per_map"] = round((time.perf_counter() - t0) / iters / B * 1e3, 4)
-            model.hip_graphs = False
-            with torch.no_grad():
-                for _ in range(2):
-                    model(imgs, proj, dv)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(iters):
-                    model(imgs, proj, dv)
-                torch.cuda.synchronize()
-            row["eager_multistream_ms_per_map"] = round((time.perf_counter() - t0) / iters / B * 1e3, 4)
-            eng.multistream = was_ms
         out[str(B)] = row
     model.hip_graphs = was
     return out

@@ -13,7 +13,6 @@ Reference call graph followed (models/diffusion.py:139-295):
 """
 from __future__ import annotations
 
-import contextlib
 import math
 import os
 from typing import Callable, Dict, List, Optional
@@ -180,15 +179,11 @@ def pack_encoder(sd, p):
             for n in ("convc1", "convc2", "convd1", "convd2", "output")}
 
 
-def run_encoder(o: Ops, enc, cost, samples, out=None, out_cstride=None, out_coffset=0, fork=None):
-    """-> relu(output(cat(c_feat, d_feat))): the first out_chs-1 channels of the encoder result.  fork: an Engine whose side stream takes
-    the samples tower (independent of the cost tower until `output`)."""
+def run_encoder(o: Ops, enc, cost, samples, out=None, out_cstride=None, out_coffset=0):
+    """-> relu(output(cat(c_feat, d_feat))): the first out_chs-1 channels of the encoder result."""
     R = K.ACT_RELU
-    with (fork.side() if fork is not None else contextlib.nullcontext()):
-        df = o.conv2d(enc["convd2"], o.conv2d(enc["convd1"], samples, act=R), act=R)
     cf = o.conv2d(enc["convc2"], o.conv2d(enc["convc1"], cost, act=R), act=R)
-    if fork is not None:
-        fork.join()
+    df = o.conv2d(enc["convd2"], o.conv2d(enc["convd1"], samples, act=R), act=R)
     return o.conv2d(enc["output"], cf, df, act=R, out=out, out_cstride=out_cstride, out_coffset=out_coffset)
 
 
@@ -421,11 +416,6 @@ class Engine:
     def __init__(self, sd: Dict[str, torch.Tensor], args, ops: Ops):
         self.ops = self.base_ops = ops       # (self.ops may become a copy bound to another conv arithmetic, see conv_arith)
         self._graphs = {}
-        # independent launch chains of the forward on a second HIP stream (ContextNet next to FeatureNet, the mask heads next to the cost
-        # volume, the encoder's samples tower next to its cost tower): at small batches a kernel fills a fraction of the 256 CUs and the
-        # chains overlap -- inside a captured graph they become parallel branches.  Same kernels, same inputs: bit-identical outputs.
-        self.multistream = os.environ.get("DMVS_MULTISTREAM", "0") == "1"
-        self._side = None
         self.args = args
         self.arena = GnArena(ops)
         self._ss_cache = {}
@@ -480,25 +470,6 @@ class Engine:
         if self.cas:
             self.ub[2] = _UpdateBlock(sd, "update_block_depth3", args, 2, self.up_ratio)
 
-    @contextlib.contextmanager
-    def side(self):
-        """launches inside run on the side stream, ordered after everything enqueued on the current stream so far (fork); join() makes the
-        current stream wait for them.  Tensors allocated inside belong to the side stream's pool: they are only handed to the main stream
-        after a join and only freed after their last use was enqueued, and every later fork waits on the main stream first -- so a
-        re-used block is never written while an earlier reader is still in flight."""
-        if not self.multistream or self.ops.device.type != "cuda":
-            yield
-            return
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.ops.device)
-        self._side.wait_stream(torch.cuda.current_stream(self.ops.device))
-        with torch.cuda.stream(self._side):
-            yield
-
-    def join(self):
-        if self.multistream and self._side is not None:
-            torch.cuda.current_stream(self.ops.device).wait_stream(self._side)
-
     def _ss_of(self, ss, B):
         """time-conditioned scale/shift rows of one DDIM step, expanded to the batch once and cached"""
         def get(rb):
@@ -516,14 +487,12 @@ class Engine:
         o = self.ops
         B, H, W, _ = ref.shape
         S = src.shape[0]
-        with self.side():
-            mask = run_mask(o, self.mask, context)
         cor = o.warp_corr_init_quad(ref, src, rt, disp_min, disp_max, D, self.G)        # [B,S,G,D,H,W]
         vw = run_pvw(o, self.pvw, cor.view(B * S, self.G, D, H, W)).view(B, S, H, W)
         agg = o.view_aggregate(cor, vw)
         logits = run_costreg(o, self.reg, agg)                                          # [B,1,D,H,W]
         nd, depth, conf = o.depth_regress(logits.view(B, D, H, W), disp_min, disp_max)
-        self.join()
+        mask = run_mask(o, self.mask, context)
         return mask, nd, depth, vw, conf
 
     # ------------------------------------------------------------------ stages 2, 3
@@ -537,10 +506,8 @@ class Engine:
         B, _, H, W = inv_depth.shape
         cd, n = ub.cd, ub.n
         noise = noise_fn((B, 1, H, W), o.device).float().contiguous()
-        with self.side():
-            mask = run_mask(o, ub.mask, context)
-            ctx_part = o.conv2d(ub.init_ctx, context)         # the context half of the Unet's 7x7 init_conv, once per stage
-        side_pending = True
+        mask = run_mask(o, ub.mask, context)
+        ctx_part = o.conv2d(ub.init_ctx, context)             # the context half of the Unet's 7x7 init_conv, once per stage
         E = o.empty(B, cd, H, W)                              # encoder output (cd - 1 channels) + current inverse depth
         img, img_scale = noise, float(ub.scale)
         inv_list: List[torch.Tensor] = []
@@ -555,10 +522,7 @@ class Engine:
             for it in range(ub.iters):
                 cost, samples = o.getcost_quad(feats_ref, feats_src, rt, new, confidence, view_w, disp_min, disp_max, n,
                                                interval, a.min_radius, a.max_radius, vw_shift, G=self.G_cost)
-                run_encoder(o, ub.enc, cost, samples, out=E, out_cstride=cd, out_coffset=0, fork=self)
-                if side_pending:          # (the encoder's own join already covered mask / ctx_part when the side stream is in use)
-                    self.join()
-                    side_pending = False
+                run_encoder(o, ub.enc, cost, samples, out=E, out_cstride=cd, out_coffset=0)
                 cur_hidden, upd, conf = run_unet(o, self.arena, ub, E, ctx_part, cur_hidden, ss_of)
                 confidence = conf.view(B, H, W)
                 delta, new = o.delta_update(inv_depth, delta, upd, 1.0, new2=E, new2_cstride=cd, new2_coffset=cd - 1)
@@ -585,7 +549,7 @@ class Engine:
         proj = {k: v.to(dev).float().contiguous() for k, v in proj_matrices.items()}
         dv = depth_values.to(dev).float()
         nrows = None if feats is None else next(iter(feats.values())).shape[0]
-        key = (len(imgs), tuple(imgs[0].shape), tuple(dv.shape), bool(test), id(noise_fn), nrows, bool(self.multistream))
+        key = (len(imgs), tuple(imgs[0].shape), tuple(dv.shape), bool(test), id(noise_fn), nrows)
         g = self._graphs.get(key)
         if g is None:
             g = self._graphs[key] = GraphedForward(self, imgs, proj, dv, noise_fn, test, feats)
@@ -609,12 +573,12 @@ class Engine:
         disp_min, disp_max = (1.0 / depth_max_).contiguous(), (1.0 / depth_min_).contiguous()   # module.py:222-223
         interval = 1.0 / depth_values.size(1)
 
-        views = [im.to(o.device).float().contiguous() for im in (imgs if feats is None else imgs[:1])]   # V x [B,3,H,W]: the stem reads them in place
-        with self.side():          # ContextNet and its per-stage heads read the reference images only: next to FeatureNet, not after it
-            heads = self._context_heads(run_context_trunk(o, self.ctx, views[0]))
         if feats is None:
+            views = [im.to(o.device).float().contiguous() for im in imgs]       # V x [B,3,H,W]: FeatureNet's stem reads them in place
             feats = run_feature(o, self.feat, views, feat_dtype=self.feat_dtype)
-        self.join()
+        else:
+            views = [imgs[0].to(o.device).float().contiguous()]
+        trunk = run_context_trunk(o, self.ctx, views[0])
         depths, confs_full, confs_seq = [], [], []
         view_w = None
         for s in range(3):
@@ -625,8 +589,9 @@ class Engine:
             h, w, C = fs.shape[1], fs.shape[2], fs.shape[3]
             ref, src = fs[:B], fs[B:].view(V - 1, B, h, w, C)
             rt = o.compose_proj(proj_matrices[name].to(o.device).float().contiguous())
-            hidden, context = heads[s]
+            hid_pc, ctx_pc = self.ctx_out[s]
             if s == 0:
+                context = o.conv2d(ctx_pc, trunk[0], act=K.ACT_RELU)
                 mask, nd, init_depth, view_w, conf = self.initial_cost(ref, src, rt, context, disp_min, disp_max,
                                                                        a.numdepth_initial)
                 depths.append(init_depth)
@@ -637,6 +602,12 @@ class Engine:
                 ub = self.ub[s]
                 cd = ub.cd
                 inv_cur = o.depth_convert(depths[-1].view(B, 1, h, w), disp_min, disp_max, K._lib.EW_DEPTH_TO_DISP)
+                hidden = o.conv2d(hid_pc, trunk[s])
+                hi = self.hidden_init[s]
+                for pc in hi[:-1]:
+                    hidden = o.conv2d(pc, hidden, act=K.ACT_RELU)
+                hidden = o.conv2d(hi[-1], hidden, act=K.ACT_TANH)
+                context = o.conv2d(ctx_pc, trunk[s], act=K.ACT_RELU)
                 mask, hidden, inv_seq, conf_seq = self.update_block(
                     ub, ref, src, rt, inv_cur, hidden, context, view_w, s, disp_min, disp_max,
                     interval * _RATIOS[s], noise_fn)
@@ -649,22 +620,4 @@ class Engine:
                     confs_seq.extend(conf_seq)
                 _, depth_up = o.convex_upsample(inv_seq[-1], mask, disp_min, disp_max, self.up_ratio, want_inv=False)
                 depths.append(depth_up)
-        self.join()
         return {"depth": depths, "conf": confs_seq, "photometric_confidence": confs_full}
-
-    def _context_heads(self, trunk):
-        """per active stage: (hidden state initialisation or None, relu(context half of the ContextNet head)) -- diffusion.py:194, :223-231"""
-        o, heads = self.ops, {}
-        for s in range(3):
-            if self.args.stage_iters[s] == 0:
-                continue
-            hid_pc, ctx_pc = self.ctx_out[s]
-            hidden = None
-            if s > 0:
-                hidden = o.conv2d(hid_pc, trunk[s])
-                hi = self.hidden_init[s]
-                for pc in hi[:-1]:
-                    hidden = o.conv2d(pc, hidden, act=K.ACT_RELU)
-                hidden = o.conv2d(hi[-1], hidden, act=K.ACT_TANH)
-            heads[s] = (hidden, o.conv2d(ctx_pc, trunk[s], act=K.ACT_RELU))
-        return heads

@@ -281,36 +281,6 @@ def test_hip_graph_forward_matches_eager(variant, B):
     assert rel_l1(outs[(False, 21)][-3].cpu(), outs[(False, 22)][-3].cpu()) > 1e-4      # the two inputs do differ
 
 
-@pytest.mark.parametrize("variant,B", [("diffmvs", 1), ("casdiffmvs", 2), ("casdiffmvs", 1)])
-def test_side_stream_forward_is_bit_identical(variant, B):
-    """Engine.multistream: ContextNet next to FeatureNet, the mask heads next to the cost volume, the encoder's samples tower next to its
-    cost tower on a second stream -- eager and as parallel branches of the captured graph.  The same kernels on the same inputs: every
-    output BIT-identical to the single-stream forward, eight times over (a missing dependency would be a race, i.e. intermittent)"""
-    model, _, _ = make_model(variant, 16)
-    noise = _FixedNoise(9)
-    model.noise_source = noise
-    imgs, proj, dv = synth.synth_inputs(128, 192, 3, B=B, seed=41)
-    args = ([i.cuda() for i in imgs], {k: v.cuda() for k, v in proj.items()}, dv.cuda())
-
-    def fwd(multi, graphs):
-        model.engine().multistream = multi
-        model.hip_graphs = graphs
-        noise.rewind()
-        with torch.no_grad():
-            o = model(*args)
-        torch.cuda.synchronize()
-        return [d.clone() for d in o["depth"]] + [c.clone() for c in o["photometric_confidence"]]
-    want = fwd(False, False)
-    try:
-        for rep in range(8):
-            for graphs in (False, True):
-                got = fwd(True, graphs)
-                for i, (a, b) in enumerate(zip(got, want)):
-                    assert torch.equal(a, b), (rep, graphs, i)
-    finally:
-        model.engine().multistream = False
-
-
 def test_hip_graphs_of_two_batch_sizes_share_an_engine():
     """An eval run with an odd view count replays a B=2 graph, captures a B=1 graph for the last batch, then replays B=2 on the
     next scene; eager forwards of the other size in between.  The GroupNorm statistics buffers the captured graphs point into
