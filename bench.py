@@ -533,7 +533,7 @@ def main():
     if os.path.exists(cj) and (H, W, S) == (512, 640, 5):
         with open(cj) as f:
             cinfo = json.load(f)
-        if cinfo.get("batch") == B:
+        if cinfo.get("batch") == B and cinfo.get("kernel_source_sha") == kernel_source_hash():      # (a probe of another kernel source is not quoted)
             pr, pc = cinfo["noise_no_confidence"], cinfo["noise_random_confidence"]
             ceiling = {"source": os.path.relpath(cj, ROOT), "gate_0p60_us": cinfo["gate_0p60_us"],
                        "noise_geometry": {"probe_us": pr["probe_us"], "product_us_same_session": pr["product_us"],

@@ -409,18 +409,37 @@ __device__ __forceinline__ void quad_accumulate(P base, unsigned view_off, int p
 }
 
 // ------------------------------------------------------------------------------------------ GetCost
+#ifndef DMVS_GC_BLOCK       // threads per GetCost workgroup = 4 x pixels of its tile; log2 of the tile width (diagnostic builds vary both)
+#define DMVS_GC_BLOCK DMVS_BLOCK
+#endif
+#ifndef DMVS_GC_TW_SHIFT
+#define DMVS_GC_TW_SHIFT 5
+#endif
 template <int C, int N, int TPT, int FT>
-__global__ void __launch_bounds__(DMVS_BLOCK) getcost_quad_kernel(const dmvs_getcost_desc d) {
-    constexpr int HPL = (N + 3) / 4, PPB = DMVS_BLOCK / 4;
+__global__ void __launch_bounds__(DMVS_GC_BLOCK) getcost_quad_kernel(const dmvs_getcost_desc d) {
+    constexpr int HPL = (N + 3) / 4, PPB = DMVS_GC_BLOCK / 4;
+    constexpr int tw_shift = DMVS_GC_TW_SHIFT;
     const int q = threadIdx.x & 3;
     const int H = d.H, W = d.W;
     const int hw = H * W;
-    // grid = (64-pixel blocks of one image, B): the batch item is workgroup-uniform, so cameras, depth range and every
+    // grid = (64-pixel tiles of one image, B): the batch item is workgroup-uniform, so cameras, depth range and every
     // tensor base are scalar registers / scalar loads
     const int b = blockIdx.y;
-    const int pix = (int)dmvs_xcd_contiguous_block(blockIdx.x, gridDim.x) * PPB + (threadIdx.x >> 2);
-    const bool live = pix < hw;
-    const int yx = live ? pix : hw - 1;
+    // The workgroup's 64 pixels are a 32 x 2 TILE, a wave = 16 consecutive pixels of one row; the tile width is a COMPILE-TIME constant.
+    // Until round 5 they were a 64-pixel row segment.  The tile shares source rows between its pixel rows as well as along them, which the
+    // L1 / L2 feel most when the hypotheses spread (wide confidence radii) or are smooth: per B=96 launch 569 -> 545 us on noise geometry,
+    // 639 -> 607 with random confidences, 558 -> 529 on scene geometry, bit-identical (profiles/r5_getcost_mapping_sweep_b96.jsonl: every
+    // tile width x workgroup size as a variant build; 16 x 4 tiles and 128- / 64-thread workgroups are within 2 % of this, 512 threads and
+    // 8 x 8 tiles slower).  With the width a kernel ARGUMENT the same mapping ran at the old speed (553 / 651 / 586): hipcc then keeps the row
+    // index and everything derived from it in vector registers instead of recognising it as wave-uniform.
+    const int tw_mask = (1 << tw_shift) - 1, th = PPB >> tw_shift;
+    const int tiles_x = (W + tw_mask) >> tw_shift;
+    const int tile = (int)dmvs_xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int p_in = threadIdx.x >> 2;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int xx = (tx << tw_shift) + (p_in & tw_mask), yy = ty * th + (p_in >> tw_shift);
+    const bool live = xx < W && yy < H;
+    const int yx = live ? yy * W + xx : hw - 1;
     const int y = yx / W, x = yx - y * W;
     const long pc = (long)b * hw + yx;
 
@@ -729,7 +748,10 @@ extern "C" int dmvs_getcost_quad_f32(const dmvs_getcost_desc* dp, void* stream) 
     // 24-bit row multiplies and 32-bit byte offsets inside ONE view's image (2^24 texels x <= 192 bytes < 2^32); the source
     // stack as a whole may be any size (64-bit per-view bases); grid.y
     if ((long)d.H * d.W >= (1L << 24) || d.B > 65535) return DMVS_EINVAL;
-    dim3 grid(dmvs_ceil_div((long)d.H * d.W, DMVS_BLOCK / 4), (unsigned)d.B), block(DMVS_BLOCK);
+    // 32 x 2-pixel tiles (a ragged last tile column idles its surplus lanes: every stage-2 / stage-3 width of the reference's datasets but
+    // DTU's 400 is a multiple of 32)
+    constexpr int tw = 1 << DMVS_GC_TW_SHIFT, th = (DMVS_GC_BLOCK / 4) >> DMVS_GC_TW_SHIFT;
+    dim3 grid((unsigned)(((d.W + tw - 1) / tw) * ((d.H + th - 1) / th)), (unsigned)d.B), block(DMVS_GC_BLOCK);
     if (d.feat_dtype == DMVS_DTYPE_BF16) return launch_getcost_quad<DMVS_DTYPE_BF16>(d, grid, block, st);
     if (d.feat_dtype == DMVS_DTYPE_F16) return launch_getcost_quad<DMVS_DTYPE_F16>(d, grid, block, st);
     if (d.feat_dtype == DMVS_DTYPE_F32_PLAIN) return launch_getcost_quad<DMVS_DTYPE_F32_PLAIN>(d, grid, block, st);
