@@ -425,13 +425,12 @@ __global__ void __launch_bounds__(DMVS_GC_BLOCK) getcost_quad_kernel(const dmvs_
     // grid = (64-pixel tiles of one image, B): the batch item is workgroup-uniform, so cameras, depth range and every
     // tensor base are scalar registers / scalar loads
     const int b = blockIdx.y;
-    // The workgroup's 64 pixels are a 32 x 2 TILE, a wave = 16 consecutive pixels of one row; the tile width is a COMPILE-TIME constant.
-    // Until round 5 they were a 64-pixel row segment.  The tile shares source rows between its pixel rows as well as along them, which the
-    // L1 / L2 feel most when the hypotheses spread (wide confidence radii) or are smooth: per B=96 launch 569 -> 545 us on noise geometry,
-    // 639 -> 607 with random confidences, 558 -> 529 on scene geometry, bit-identical (profiles/r5_getcost_mapping_sweep_b96.jsonl: every
-    // tile width x workgroup size as a variant build; 16 x 4 tiles and 128- / 64-thread workgroups are within 2 % of this, 512 threads and
-    // 8 x 8 tiles slower).  With the width a kernel ARGUMENT the same mapping ran at the old speed (553 / 651 / 586): hipcc then keeps the row
-    // index and everything derived from it in vector registers instead of recognising it as wave-uniform.
+    // The workgroup's 64 pixels are a 32 x 2 TILE, a wave = 16 consecutive pixels of one row (reference loads and cost stores stay 64-byte
+    // runs); until round 5 they were a 64-pixel row segment.  The two pixel rows of a tile read the same source rows.  Launched back to back
+    // on a warm GPU (profiles/r5_getcost_mapping_sweep_b96.jsonl: every tile width x workgroup size as a variant build, all bit-identical):
+    // 569 -> 545 us per B=96 launch on noise geometry, 639 -> 607 with random confidences, 558 -> 529 on scene geometry; 16 x 4 tiles and
+    // 128- / 64-thread workgroups are within 2 % of this, 512 threads and 8 x 8 tiles slower.  Inside the model's step, where the feature
+    // maps have just been evicted by the convolutions in between, it is 576 -> 570 us.  The tile width is a compile-time constant.
     const int tw_mask = (1 << tw_shift) - 1, th = PPB >> tw_shift;
     const int tiles_x = (W + tw_mask) >> tw_shift;
     const int tile = (int)dmvs_xcd_contiguous_block(blockIdx.x, gridDim.x);

@@ -17,8 +17,10 @@ def main():
     def us(geo, conf, build):
         return [r["us"] for r in rows if r["geometry"] == geo and r["conf"] == conf and r["build"] == build][0]
 
+    ref_build = "gcsame" if any(r["build"] == "gcsame" for r in rows) else "product"      # the product source built like the probes (see diag_r4.py)
+
     def pair(geo, conf):
-        return {"product_us": us(geo, conf, "product"), "probe_us": min(us(geo, conf, b) for b in probes)}
+        return {"product_us": us(geo, conf, ref_build), "probe_us": min(us(geo, conf, b) for b in probes)}
     sys.path.insert(0, ROOT)
     import bench
     out = {"what": "GetCost ceiling probe (tools/diag_r4.py getcost; builds of warp_quad.hip with -DDMVS_GC_EXP=4: the product kernel's own projection, "

@@ -45,7 +45,8 @@ def _hw(v, div=8):     # spatial extents shrink by `div` in a dry run (kept mult
     return max(8, (v // div) // 4 * 4) if DRY else v
 
 
-def timeit(fn, iters=20, warm=3):
+def timeit(fn, iters=20, warm=12):      # (warm: the first measurement after seconds of host-side input generation otherwise sees a GPU still
+    # ramping its clocks -- up to 8 % on a 0.6 ms kernel; round 5 mistook that for a property of the build measured first)
     if DRY:
         import time
         fn()
@@ -96,7 +97,7 @@ def getcost_inputs(o, B, geometry, conf):
 def getcost(B=None):
     B = B or int(os.environ.get("DIAG_B", "96"))
     base = Ops.for_device("cuda:0")
-    libs = [("product", None)] + [(n, os.path.join(ROOT, "tools", "calib", "libdmvs_hip_%s.so" % n)) for n in ("nopipe", "gcexp1", "gcexp2", "gcexp3", "gcexp4", "gcexp4t4", "gcexp4t1", "gcc256s6")]
+    libs = [("product", None)] + [(n, os.path.join(ROOT, "tools", "calib", "libdmvs_hip_%s.so" % n)) for n in ("nopipe", "gcexp1", "gcexp2", "gcexp3", "gcexp4", "gcexp4t4", "gcexp4t1", "gcc256s6", "gcsame")]      # gcsame = the product source built as a variant (no flags): variants are compared with variants
     alg = 4.0 * B * 128 * 160 * (32 + 5 * 32 + 6 + 5 + 24)
     for geometry, conf in (("noise", None), ("noise", "random"), ("scene", 0.5)):
         args = getcost_inputs(base, B, geometry, conf)
@@ -110,7 +111,7 @@ def getcost(B=None):
             us = timeit(lambda: o.getcost_quad(*args))
             print(json.dumps({"diag": "getcost", "B": B, "geometry": geometry, "conf": conf, "build": name, "us": round(us, 1),
                               "frac_of_8TBs": round(alg / (us * 1e-6) / 8e12, 4),
-                              "bit_identical_to_product": bool(torch.equal(out, ref_out)) if (name in ("product", "nopipe") or name.startswith("gcblk") or name.startswith("gcc")) else None}), flush=True)
+                              "bit_identical_to_product": bool(torch.equal(out, ref_out)) if (name in ("product", "nopipe") or name.startswith("gcblk") or name.startswith("gcc") or name == "gcsame") else None}), flush=True)
 
 
 def warp_init(B=96):
