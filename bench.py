@@ -542,7 +542,8 @@ def main():
                        "noise_geometry_random_confidence": {"probe_us": pc["probe_us"], "product_us_same_session": pc["product_us"],
                                                             "product_over_probe": round(pc["probe_us"] / pc["product_us"], 3)},
                        "reading": "the kernel's own line-request stream with NO arithmetic takes longer than the 0.60 mark allows: the 0.60 gate is above "
-                                  "what the memory system delivers for this access pattern; the product kernel runs at 0.85-0.87 of that ceiling"}
+                                  "what the memory system delivers for this access pattern (product_over_probe = how close the product runs to it; "
+                                  "both timed as variant builds in one session, isolated back-to-back launches)"}
 
     result = {
         "metric": "depth-maps/sec (640x512, 5 src views)", "value": round(value, 3), "unit": "depth-maps/s",
