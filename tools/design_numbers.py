@@ -16,10 +16,12 @@ def main():
     sw = full["batch_sweep_ms_per_map"]
     cb = full["cpu_baseline"]
     tr = rf["traffic"]
-    text = f"""End-of-round numbers (1 x MI355X, `profiles/r5_bench_line.json`: the bench run of the round's LAST GPU session, on the committed
-sources, in the same session as the green GPU suite and `smoke()`): **{round(line['value'])} depth-maps/s** at the default 96 reference views per
+    text = f"""End-of-round numbers (1 x MI355X, `profiles/r5_bench_line.json`: the default `python bench.py` on the HEAD kernels -- the round's last GPU sessions are
+`tools/sessions/r5_final2.sh` (the whole GPU suite with `-x` green, `smoke()`, this command at 1310 depth-maps/s, the rocprofv3 / PMC / probe
+passes) and `r5_final_b.sh` (`smoke()` + this line again, once the traffic and probe files measured on the HEAD kernel source were committed
+so that the line quotes them; no `csrc/` or `include/` change in between or after): **{round(line['value'])} depth-maps/s** at the default 96 reference views per
 step ({line['ms_per_step']:.1f} ms per step; round 4: 1294 / 1299 on the driver's run, round 3: 1200, round 2: 1118, round 1: 848 at B=16).
-`roofline.frac` {rf['frac']:.2f} ({rf['avg_launch_us']:.0f} us per launch; first GRU iteration {it[0]['frac']:.2f}, iterations 2-4 {min(x['frac'] for x in it[1:]):.2f}-{max(x['frac'] for x in it[1:]):.2f};
+`roofline.frac` {rf['frac']:.2f} ({rf['avg_launch_us']:.0f} us per launch; first GRU iteration {it[0]['frac']:.2f}, iterations 2-4 {min(x['frac'] for x in it[1:]):.3f}-{max(x['frac'] for x in it[1:]):.3f};
 `traffic` {('%.2f GB' % (tr / 1e9)) if tr else 'n/a'} per launch against {rf['algorithmic_bytes_per_launch'] / 1e9:.2f} GB algorithmic: no wasted re-reads; `ceiling_probe_us` {rf['ceiling_probe_us']}: the
 kernel's own address stream without arithmetic, section 3.1 -- the 0.60 mark would be 372 us), `roofline_scene_geometry.frac` {line['roofline_scene_geometry']['frac']:.2f},
 `roofline_warp_init.frac` {line['roofline_warp_init']['frac']:.2f}, `roofline_conv2d.frac` {line['roofline_conv2d']['frac']:.2f} over {100 * line['roofline_conv2d']['share_of_step_time']:.0f} % of the step.
