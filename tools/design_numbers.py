@@ -29,8 +29,8 @@ The FULL default run (`profiles/r5_bench_full_line.json`: 20 steps, batch sweep,
 by batch {sw['16']['eager_ms_per_map']:.2f} ms per map at B=16, {sw['32']['eager_ms_per_map']:.2f} at 32, {sw['64']['eager_ms_per_map']:.2f} at 64; CPU baseline {cb['value']:.2f} maps/s (oracle port, {cb['cores']}
 threads) => ~{round(full['value'] / cb['value'] / 10) * 10}x -- a reported baseline, not a kernel-quality figure.  The profiled run (`profiles/r5_bench_b96_profiled_line.json` +
 `r5_bench_b96_kernel_stats.csv`) agrees with its event timing on the plane sweep and on GetCost (`tests/test_docs.py`).  Kernel-time split per
-B=96 forward (`tools/kernel_families.py profiles/r5_bench_b96_kernel_stats.csv 8`): conv2d 53.5 ms, conv3d 9.10 (round 4: 9.77 -- the paired
-kernels of 4.1), fused stem 4.58, GetCost ~2.3 ms in the timed steps, plane sweep 1.06, GroupNorm apply 1.82, everything else 2.4.
+B=96 forward (`tools/kernel_families.py profiles/r5_bench_b96_kernel_stats.csv 8`): conv2d 53.2 ms, conv3d 9.10 (round 4: 9.77 -- the paired
+kernels of 4.1), fused stem 4.56, GetCost ~2.3 ms in the timed steps, plane sweep 1.06, GroupNorm apply 1.82, everything else 2.4.
 
 The gates of the previous review, as measured.  GREEN at HEAD: the GPU suite in its new order, the reproducibility assertion on all outputs
 of cfg2 / cfg3 / cfg5 three more runs each (5.1).  Opt-ins: timed, two made default, the rest deleted (4.1, `profiles/r5_optins.jsonl`).
