@@ -44,8 +44,8 @@ not built, section 11), cfg4 >= 36 samples/s ({cfg4['value']:.1f}).
     text += f"""**Batch 1** (the reference's harness, `test.py:101-104`): {sw['1']['eager_ms_per_map']:.2f} ms per map eager, **{sw['1']['graph_ms_per_map']:.2f} ms** through the captured HIP graph
 (`GraphedForward`; `python -m diffmvs_amd.eval` now replays the graph by default for `--batch_size` <= 8, also with the scene cache);
 {sw['2']['eager_ms_per_map']:.2f} at B=2, {sw['4']['eager_ms_per_map']:.2f} at B=4, {sw['8']['eager_ms_per_map']:.2f} at B=8.  The profile
-of the batch-1 forward (`profiles/r4_bench_b1_kernel_stats.csv`): 3.25 ms of kernel time over ~287 launches, the 2-D convolutions at
-14.5 us average.  The launch count is not what bounds it: a batch-1 convolution has 20-320 workgroups for 256 CUs and each workgroup
+of the batch-1 forward (`profiles/r5_bench_b1_kernel_stats.csv`): 3.0 ms of kernel time over 279 launches, the 2-D convolutions at
+~14 us average.  The launch count is not what bounds it: a batch-1 convolution has 20-320 workgroups for 256 CUs and each workgroup
 runs its cin/8 chunks as a dependent DMA -> wait -> MFMA chain of ~1.5 us per chunk with nothing else resident to overlap it.  With the
 scene cache a batch-1 forward no longer contains FeatureNet on its 6 images (~1/5 of its launches).
 
