@@ -280,8 +280,14 @@ def scene_main(a):
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     td = shard.init_distributed(a.backend, dev) if world > 1 else None
+    variant, nd_initial, prec, arith = "diffmvs", 48, a.precision or "fp32", a.conv_arith or "fp32"
+    if a.config == "cfg3":      # the same comparison on BASELINE.json configs[2]: CasDiffMVS 1152x864, 7 source views, bf16 storage + arithmetic
+        variant, prec, arith = "casdiffmvs", a.precision or "bf16", a.conv_arith or "bf16"
+        a.height, a.width, a.src_views = 864, 1152, 7
+        if "--scenes-per-step" not in sys.argv:
+            a.scenes_per_step = 1
     H, W, S, NV = a.height, a.width, a.src_views, a.scene_views
-    args = synth.make_args("diffmvs", numdepth_initial=48)
+    args = synth.make_args(variant, numdepth_initial=nd_initial, precision=prec, conv_arith=arith)
     model = CasDiffMVS(args, test=True).eval()
     model.load_state_dict(synth.synth_state_dict(model.state_dict(), 123))
     model = model.to(dev)
@@ -316,12 +322,12 @@ def scene_main(a):
     maps = NV * k
     if rank == 0:
         print(json.dumps({
-            "metric": "depth-maps/sec (640x512, 5 src views), scene mode", "value": round(maps * a.steps * world / elapsed, 3), "unit": "depth-maps/s",
+            "metric": f"depth-maps/sec ({W}x{H}, {S} src views), scene mode", "value": round(maps * a.steps * world / elapsed, 3), "unit": "depth-maps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if arith == "bf16" else "f32",
             "data": f"synthetic scenes of {NV} views (one rendered per rank, further scenes = horizontally shifted copies), pair table = {S} nearest grid neighbours",
-            "config": {"workload": f"DiffMVS DTU eval {W}x{H}, {S} src views, numdepth_initial=48, 1 DDIM step, fp32 -- NOT THE HEADLINE: whole scenes, "
-                                   f"each image through FeatureNet once per scene (feature store resident in HBM)",
+            "config": {"workload": f"{'DiffMVS' if variant == 'diffmvs' else 'CasDiffMVS'} eval {W}x{H}, {S} src views, numdepth_initial={nd_initial}, {prec} feature storage, "
+                                   f"{arith} conv arithmetic -- NOT THE HEADLINE: whole scenes, each image through FeatureNet once per scene (feature store resident in HBM)",
                        "scenes_per_step": k, "views_per_scene": NV, "ref_views_per_gpu_per_step": maps, "images_through_featurenet_per_step": maps,
                        "images_through_featurenet_per_step_per_sample_mode": maps * (S + 1),
                        "parallelism": f"scene sharding x{world}, no collective", "weights": "seeded random init"},

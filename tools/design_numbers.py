@@ -12,6 +12,7 @@ def main():
     line, full = P("r5_bench_line.json"), P("r5_bench_full_line.json")
     cfg3, cfg4, cfg5, cfg5b8, cfg5b16, scene = (P("r5_bench_cfg3_line.json"), P("r5_bench_cfg4_line.json"), P("r5_bench_cfg5_line.json"),
                                                 P("r5_bench_cfg5_b8_line.json"), P("r5_bench_cfg5_b16_line.json"), P("r5_bench_scene_line.json"))
+    sc3 = P("r5_bench_scene_cfg3_line.json")
     rf, it = line["roofline"], line["roofline"]["per_gru_iteration"]
     sw = full["batch_sweep_ms_per_map"]
     cb = full["cpu_baseline"]
@@ -52,7 +53,8 @@ scene cache a batch-1 forward no longer contains FeatureNet on its 6 images (~1/
 Second lines (never the headline):
 * `bench.py --scene-mode` (`profiles/r5_bench_scene_line.json`; the headline's network and geometry evaluated as whole 49-view scenes,
   every image through FeatureNet once per scene -- section 8): **{round(scene['value'])} depth-maps/s** ({scene['ms_per_step']:.1f} ms per {scene['config']['ref_views_per_gpu_per_step']}-view step) against
-  {round(scene['per_sample']['depth_maps_per_s'])} for the same scenes through the per-sample forward, same process: **{scene['speedup_vs_per_sample']:.2f}x**;
+  {round(scene['per_sample']['depth_maps_per_s'])} for the same scenes through the per-sample forward, same process: **{scene['speedup_vs_per_sample']:.2f}x**; `--scene-mode --config cfg3`
+  (`r5_bench_scene_cfg3_line.json`: one 49-view scene of 1152x864 images per step, CasDiffMVS, bf16): {sc3['value']:.0f} against {sc3['per_sample']['depth_maps_per_s']:.0f} depth-maps/s, {sc3['speedup_vs_per_sample']:.2f}x;
 * `bench.py --config cfg3` (CasDiffMVS 1152x864, 7 src views, 4 reference views per step, bf16 feature storage + bf16 matrix
   arithmetic, `dtype` "bf16"): **{cfg3['value']:.1f} depth-maps/s** ({cfg3['ms_per_step']:.1f} ms per step; round 4: 184.8);
 * `bench.py --config cfg4` (CasDiffMVS training step 768x576, 8 src views, batch 4 per GPU, fp32, `Trainer.train_sample`):
