@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of the run at commit 138e93a: the diag modes heavymt / pairwreg / pair8 were folded into `pair3d` afterwards, when the paired kernels became the default and the other opt-ins were deleted)
 # Round 5, GPU session 1: (1) where the cfg5 run-to-run difference of the round-4 driver run comes from (tools/determinism.py), (2) the
 # whole GPU suite in its new order, WITHOUT -x, so that every red test is seen at once, (3) the opt-in kernel instantiations round 4 left
 # untimed, each per layer with its bit-identity check (they become the default or are deleted after this session).

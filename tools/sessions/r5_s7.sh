@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record: at this commit the tile width was a kernel argument; gcblk* = `-DDMVS_GC_BLOCK=n` builds)
 # Round 5, GPU session 7: GetCost on 32 x 2-pixel tiles (now the product mapping): 512-thread workgroups (32 x 4 tiles) and 128-thread ones
 # (32 x 1) against the 256-thread product, and the ceiling probe in the new mapping; the getcost parity tests on the GPU
 cd /tmp && export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record: gcc<threads>s<shift> = `-DDMVS_GC_BLOCK=<threads> -DDMVS_GC_TW_SHIFT=<shift>` builds; results: profiles/r5_getcost_mapping_sweep_b96.jsonl)
 # Round 5, GPU session 8: GetCost pixel mapping x workgroup size, every combination as a variant build with a compile-time tile width
 # (gcc<threads>s<log2 tile width>; s6 at 256 threads = the old 64-pixel row segment) next to the product (runtime tile width)
 cd /tmp && export TMPDIR=/tmp
