@@ -1,10 +1,14 @@
-"""Round-4 diagnostics, one gpurun call (JSON lines on stdout):
+"""Kernel A/B diagnostics (rounds 4 and 5), one mode per gpurun call, JSON lines on stdout:
 
-    python tools/diag_r4.py getcost     # which resource bounds getcost_quad_kernel<32,6> at the bench batch: the product build against
-                                        # the DMVS_GC_EXP builds (tools/build_variant.py gcexp1..3: compute-only / memory-only / half requests)
-    python tools/diag_r4.py convexp     # tall tiles (tune bit) and the stride-2 / 5x5 variant builds, per layer
-    python tools/diag_r4.py optins      # the opt-in experiments round 3 left untimed: 16-byte halo pieces in the 3-D MFMA kernels and the
-                                        # fused stem (per-launch environment knobs), the padding-pass skip (variant build), per layer
+    python tools/diag_r4.py getcost     # GetCost at the bench batch on noise / random-confidence / scene geometry: the product library and
+                                        # every tools/calib/libdmvs_hip_<name>.so present (tools/build_variant.py): gcexp1 no scattered traffic,
+                                        # gcexp2 no hat / scatter, gcexp4[t1|t4] = the ceiling probe (loads only), gcc256s6 = the old 64-pixel
+                                        # row-segment mapping, gcsame = the product source built like the variants (compare variants with it)
+    python tools/diag_r4.py getcost_pmc # the product GetCost alone (for rocprofv3 --pmc passes)
+    python tools/diag_r4.py warp_init   # the plane sweep against its diagnostic builds
+    python tools/diag_r4.py pair3d      # the paired 3-D kernels against DMVS_TUNE3D_NO_PAIR, per layer
+    python tools/diag_r4.py convexp | convexp2 | mtsweep | optins | stem     # conv2d tile shapes / 16-byte pieces, per layer
+DIAG_DEVICE=cpu dry-runs a mode on the host emulation with every shape shrunk.
 """
 import json
 import os
