@@ -21,7 +21,8 @@ def main():
 `tools/sessions/r5_final2.sh` (the whole GPU suite with `-x` green, `smoke()`, this command at 1310 depth-maps/s, the rocprofv3 / PMC / probe
 passes) and `r5_final_b.sh` (`smoke()` + this line again, once the traffic and probe files measured on the HEAD kernel source were committed
 so that the line quotes them; no `csrc/` or `include/` change in between or after): **{round(line['value'])} depth-maps/s** at the default 96 reference views per
-step ({line['ms_per_step']:.1f} ms per step; round 4: 1294 / 1299 on the driver's run, round 3: 1200, round 2: 1118, round 1: 848 at B=16).
+step ({line['ms_per_step']:.1f} ms per step; the same command on the seven boxes of this round's sessions: 73.3 .. 75.0 ms, i.e. 1280 .. 1310 depth-maps/s --
+box-to-box variation is larger than the round's kernel gains; round 4: 1294 / 1299 on the driver's run, round 3: 1200, round 2: 1118, round 1: 848 at B=16).
 `roofline.frac` {rf['frac']:.2f} ({rf['avg_launch_us']:.0f} us per launch; first GRU iteration {it[0]['frac']:.2f}, iterations 2-4 {min(x['frac'] for x in it[1:]):.3f}-{max(x['frac'] for x in it[1:]):.3f};
 `traffic` {('%.2f GB' % (tr / 1e9)) if tr else 'n/a'} per launch against {rf['algorithmic_bytes_per_launch'] / 1e9:.2f} GB algorithmic: no wasted re-reads; `ceiling_probe_us` {rf['ceiling_probe_us']}: the
 kernel's own address stream without arithmetic, section 3.1 -- the 0.60 mark would be 372 us), `roofline_scene_geometry.frac` {line['roofline_scene_geometry']['frac']:.2f},

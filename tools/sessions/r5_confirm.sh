@@ -1,12 +1,13 @@
 #!/bin/bash
 # Round 5, confirmation on the tree that is HEAD (python / docs / profiles only changed since r5_final2.sh and r5_final_b.sh): exactly what the
 # driver runs at round end -- the GPU suite with -x, smoke(), the default bench
+# (as run, the suite had a 420 s limit of this script and was cut at 97 % on a slow box -- every test up to there passed; the limit here is now 900 s, the driver allows 1200)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r5_confirm
 mkdir -p $O
 cd $R
-timeout 420 python -m pytest tests/ -x -q -m gpu > $O/pytest_gpu.log 2>&1
+timeout 900 python -m pytest tests/ -x -q -m gpu > $O/pytest_gpu.log 2>&1
 echo "pytest rc=$?" >> $O/pytest_gpu.log
 timeout 60 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
 echo "smoke rc=$?" >> $O/smoke.log
