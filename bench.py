@@ -318,7 +318,6 @@ def scene_main(a):
         elapsed = timed_steps(step, a.steps, a.warmup, barrier)
         elapsed = shard.barrier_and_max(elapsed, dev)
         ps = timed_steps(step_per_sample, max(2, a.steps // 4), 1, barrier) / max(2, a.steps // 4)
-        same = all(torch.equal(x, y) for x, y in zip(step()["depth"], step_per_sample()["depth"])) if model.noise_source is not None else None
     maps = NV * k
     if rank == 0:
         print(json.dumps({

@@ -566,7 +566,19 @@ class Engine:
         if noise_fn is None:
             noise_fn = lambda shape, device: torch.randn(shape, device=device)  # noqa: E731
         B = imgs[0].shape[0]
-        V = len(imgs) if feats is None else next(iter(feats.values())).shape[0] // B
+        V = len(imgs)
+        if feats is not None:      # rows gathered from a scene's store: validate before any launch reads them
+            H, W = imgs[0].shape[-2:]
+            V = next(iter(feats.values())).shape[0] // max(B, 1)
+            for s in range(3):
+                if a.stage_iters[s] == 0:
+                    continue
+                f = feats.get(f"stage{s + 1}")
+                want = (V * B, H >> (3 - s), W >> (3 - s))
+                if f is None or f.dim() != 4 or tuple(f.shape[:3]) != want or f.dtype != self.feat_dtype or f.device != o.device or V < 2:
+                    raise K._lib.DmvsError(f"feats['stage{s + 1}']: expected a {self.feat_dtype} tensor [V*B={want[0]},{want[1]},{want[2]},C] on {o.device} "
+                                           f"(SceneFeatureStore.gather of view ids [B,V], V >= 2), got "
+                                           f"{None if f is None else (tuple(f.shape), f.dtype, str(f.device))}")
         self.arena.reset(B)
         dv = depth_values.to(o.device).float()
         depth_max_, depth_min_ = 1.0 / dv[:, 0], 1.0 / dv[:, -1]

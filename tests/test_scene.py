@@ -50,6 +50,26 @@ def test_scene_store_reproduces_the_per_sample_forward(ops, variant):
         assert max(errs) < 1e-3, errs
 
 
+def test_scene_features_are_validated(ops):
+    """a feature stack that does not belong to the batch (wrong row count, wrong stage size, a missing stage) is refused before any launch"""
+    from diffmvs_amd import _lib
+    dev = ops.device
+    model, _, _ = _model("diffmvs", dev)
+    scene = synth.synth_scene(64, 96, n_views=4, n_src=2, seed=1, grid_w=2)
+    imgs, proj, dv, ids = synth.scene_batch(scene, [0, 1])
+    imgs, proj, dv = [i.to(dev) for i in imgs], {k: v.to(dev) for k, v in proj.items()}, dv.to(dev)
+    store = model.scene_features(scene["images"].to(dev))
+    good = store.gather(ids)
+    bad = [{k: v[:-1] for k, v in good.items()}, {"stage1": good["stage1"]}, {"stage1": good["stage1"], "stage2": good["stage1"]},
+           {k: v.double() for k, v in good.items()}]
+    for feats in bad:
+        with pytest.raises(_lib.DmvsError, match="feats"):
+            with torch.no_grad():
+                model(imgs[:1], proj, dv, feats=feats)
+    with torch.no_grad():
+        model(imgs[:1], proj, dv, feats=good)
+
+
 @pytest.mark.gpu
 def test_scene_mode_full_size_bit_identical():
     """BASELINE.json configs[1] geometry: a 49-view scene at 640x512, 12 reference views of it through the store == per sample"""
