@@ -71,6 +71,128 @@ def scene_geometry_getcost(ops, B, H, W, S, n, iters=20):
             "avg_launch_us": round(out["quad"] * 1e6, 2)}
 
 
+class ProbeLib:
+    """ctypes binding of diffmvs_amd/libdmvs_probe.so (include/dmvs_probe.h): bench-only measurement kernels, loaded here and nowhere in
+    the depth-estimation path.  Absent library => the probe legs are skipped and the line says so."""
+    PATH = os.path.join(ROOT, "diffmvs_amd", "libdmvs_probe.so")
+
+    def __init__(self):
+        import ctypes as C
+        from diffmvs_amd import _lib
+        self.dll = C.CDLL(self.PATH)
+        self.dll.dmvs_probe_abi_version.restype = C.c_int
+        if self.dll.dmvs_probe_abi_version() != 1:
+            raise RuntimeError("libdmvs_probe.so: unexpected ABI version")
+        self.dll.dmvs_probe_getcost_loads_f32.argtypes = [C.POINTER(_lib.GetCostDesc), C.c_void_p]
+        self.dll.dmvs_probe_getcost_loads_f32.restype = C.c_int
+        self.dll.dmvs_probe_random_line_gather.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p]
+        self.dll.dmvs_probe_random_line_gather.restype = C.c_int
+        self._C = C
+
+    def getcost_loads(self, desc, stream):
+        rc = self.dll.dmvs_probe_getcost_loads_f32(self._C.byref(desc), stream)
+        if rc:
+            raise RuntimeError(f"dmvs_probe_getcost_loads_f32 -> {rc}")
+
+    def random_line_gather(self, table, n_lines, n_quads, lines_per_quad, mode, window, seed, stream):
+        rc = self.dll.dmvs_probe_random_line_gather(self._C.c_void_p(table.data_ptr()), n_lines, n_quads, lines_per_quad, mode, window, seed, stream)
+        if rc:
+            raise RuntimeError(f"dmvs_probe_random_line_gather -> {rc}")
+
+
+def _event_us(fn, iters):
+    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st.record()
+    for _ in range(iters):
+        fn()
+    en.record()
+    torch.cuda.synchronize()
+    return st.elapsed_time(en) * 1e3 / iters
+
+
+def getcost_ceiling_probe(model, eng, imgs, proj, dv, alg_bytes):
+    """The memory-system ceiling of GetCost's address stream, measured BY THIS PROCESS (untimed legs, after the timed steps):
+      in_step   one extra forward in which dmvs_probe_getcost_loads_f32 -- the product kernel's own hypotheses, projection, texel masks,
+                addresses and loads with nothing computed from the loaded registers (csrc/probe/getcost_probe.hip) -- is launched right
+                BEFORE each product GetCost launch, on the same stream, with the same descriptor: it sees the caches exactly as the product
+                launch of a timed step does (the feature maps evicted by the convolutions since the last GRU iteration);
+      isolated  the four launches of that step replayed from their recorded inputs, 12 warm-up launches, then product and probe in
+                alternating blocks of back-to-back launches (warm caches, warm clocks: the figure round 5 quoted from a builder session);
+      random_line_gather   the calibration kernel: 128-byte lines of a table of GetCost's source footprint requested as two 64-byte
+                quad-coalesced pieces from 8 waves per SIMD with no arithmetic -- every line once in scrambled order (what the memory system
+                retires for independent missing lines), uniformly random with repeats, and from overlapping 48-line bands (each line asked
+                for by ~8 neighbouring quads close in time, the locality of texels scattered along epipolar segments)."""
+    import ctypes as C
+    from diffmvs_amd import _lib
+    probe = ProbeLib()
+    ops = eng.ops
+    stream = lambda: C.c_void_p(torch.cuda.current_stream(ops.device).cuda_stream)  # noqa: E731
+    captured, in_step = [], []
+
+    def hook(d, t):
+        st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        st.record()
+        probe.getcost_loads(d, stream())
+        en.record()
+        in_step.append((st, en))
+        keep = {k: (v.clone() if (v is not None and k in ("rt", "inv_depth", "confidence", "view_w", "disp_min", "disp_max")) else v) for k, v in t.items()}
+        keep["out_cost"], keep["out_samples"] = torch.empty_like(t["out_cost"]), torch.empty_like(t["out_samples"])
+        d2 = _lib.GetCostDesc()
+        C.memmove(C.byref(d2), C.byref(d), C.sizeof(d))
+        for k in ("rt", "inv_depth", "confidence", "view_w", "disp_min", "disp_max", "out_cost", "out_samples"):
+            setattr(d2, k, None if keep[k] is None else keep[k].data_ptr())
+        captured.append((d2, keep))
+
+    with torch.no_grad():
+        ops.getcost_hook = hook
+        try:
+            model(imgs, proj, dv)
+            torch.cuda.synchronize()
+        finally:
+            ops.getcost_hook = None
+    in_step_us = [round(s_.elapsed_time(e_) * 1e3, 2) for s_, e_ in in_step]
+    iso = []
+    for d2, keep in captured:
+        prod = lambda: ops.lib.call("dmvs_getcost_quad_f32", C.byref(d2), stream())  # noqa: E731
+        prb = lambda: probe.getcost_loads(d2, stream())  # noqa: E731
+        for _ in range(12):
+            prod()
+        torch.cuda.synchronize()
+        pu, qu = [], []
+        for _ in range(2):
+            pu.append(_event_us(prod, 8))
+            qu.append(_event_us(prb, 8))
+        iso.append({"product_us": round(sum(pu) / len(pu), 2), "probe_us": round(sum(qu) / len(qu), 2)})
+    del captured
+    # ---- calibration: plain random 128-byte-line gather over GetCost's source footprint (B x S views of h2 x w2 texels of 128 bytes)
+    gather = None
+    try:
+        n_lines = int(alg_bytes["src_texels"])
+        table = torch.zeros(n_lines * 128, dtype=torch.uint8, device=ops.device)
+        rows = {}
+        for name, mode, quads, lpq, win in (("every_line_once", 0, n_lines // 8, 8, 0), ("uniform_8_per_quad", 1, n_lines, 8, 0),
+                                            ("band48_8_per_quad", 2, n_lines, 8, 48)):
+            fn = lambda: probe.random_line_gather(table, n_lines, quads, lpq, mode, win, 12345, stream())  # noqa: E731
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            us = _event_us(fn, 6)
+            req_bytes = quads * lpq * 128
+            rows[name] = {"us": round(us, 2), "lines_requested": quads * lpq, "requested_GBs": round(req_bytes / us / 1e3, 1)}
+        rows["every_line_once"]["hbm_frac_of_peak"] = round(rows["every_line_once"]["requested_GBs"] / HBM_PEAK_GBS, 4)
+        gather = {"table_bytes": n_lines * 128, "request_shape": "two 64-byte quad-coalesced pieces per 128-byte line, 2 lines in flight per lane, 8 waves per SIMD, no arithmetic", **rows}
+        del table
+    except Exception as e:      # the calibration must never cost the headline line
+        gather = {"error": repr(e)[:200]}
+    gate_us = alg_bytes["getcost"] / (0.60 * HBM_PEAK_GBS * 1e9) * 1e6
+    avg = lambda xs: round(sum(xs) / max(1, len(xs)), 2)  # noqa: E731
+    return {"measured_by": "this process", "library": "diffmvs_amd/libdmvs_probe.so (csrc/probe/getcost_probe.hip: getcost_quad_body<QuadLoadsOnly>)",
+            "gate_0p60_us": round(gate_us, 1),
+            "in_step_probe_us": in_step_us, "in_step_probe_avg_us": avg(in_step_us),
+            "isolated_warm": iso, "isolated_probe_avg_us": avg([r["probe_us"] for r in iso]), "isolated_product_avg_us": avg([r["product_us"] for r in iso]),
+            "random_line_gather": gather}
+
+
 def batch_sweep(model, make_batch, batches=(1, 2, 4, 8, 16, 32, 64), iters=6):
     """Untimed side measurement: ms per depth map against the batch size (eager launch sequence; up to batch 8 also through the
     captured HIP graph of the same forward -- the reference's harness runs batch 1, test.py:101-127)."""
@@ -182,7 +304,7 @@ def kernel_source_hash():
     """sha256 (first 16 hex digits) of the warp kernels' source: PMC traffic files record it, a stale file is refused"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("warp_quad.hip", "dmvs_common.h"):
+    for f in ("warp_quad.hip", "warp_quad_core.h", "dmvs_common.h"):
         with open(os.path.join(ROOT, "diffmvs_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -366,6 +488,7 @@ def main():
     ap.add_argument("--no-batch-sweep", action="store_true")
     ap.add_argument("--conv-table", action="store_true", help="print the per-shape table of the step's conv2d launches to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probe", action="store_true", help="skip the GetCost ceiling-probe / random-line-gather legs (untimed; ~10 s)")
     ap.add_argument("--cpu-forwards", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=32, help="threads of the CPU baseline leg (more than ~32 is slower at batch 1)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -475,14 +598,25 @@ def main():
         conv_step_s = time.perf_counter() - t1
     timers.update(eng.ops.timers)
     eng.ops.timers = None
-    if a.conv_table and rank == 0:      # per-shape table of the step's conv2d launches (stderr): where the 0.54 comes from
+    # per-shape table of the step's conv2d launches: TFLOP/s against the fp32-MFMA peak AND algorithmic GB/s against the HBM peak; a
+    # row's binding resource is the larger of the two fractions (a 1x1 layer moves 4 bytes per 2 x cout flops: HBM; a 3x3 layer at 32+
+    # channels: the matrix pipe).  `sum` = (t_mfma + t_hbm) / t: near 1.0 the launch pays its matrix time PLUS its memory time (no overlap).
+    conv_rows = []
+    if timers.get("_conv2d_shape"):
         by = {}
-        for (st_, en_), fl, shp in zip(timers["dmvs_conv2d_f32"], timers["_conv2d_flops"], timers["_conv2d_shape"]):
-            e = by.setdefault(shp, [0, 0.0, 0.0])
-            e[0] += 1; e[1] += st_.elapsed_time(en_); e[2] += fl
-        print("B cin cout kh kw s Hout Wout mode gated | launches  ms/step  TFLOP/s  frac", file=sys.stderr)
-        for shp, (n, ms, fl) in sorted(by.items(), key=lambda kv: -kv[1][1]):
-            print(*shp, "|", n, round(ms, 3), round(fl / ms / 1e9, 1), round(fl / ms / 1e9 / FP32_MFMA_PEAK_TFS, 3), file=sys.stderr)
+        nb = timers.get("_conv2d_bytes") or [0.0] * len(timers["_conv2d_shape"])
+        for (st_, en_), fl, shp, bts in zip(timers["dmvs_conv2d_f32"], timers["_conv2d_flops"], timers["_conv2d_shape"], nb):
+            e = by.setdefault(shp, [0, 0.0, 0.0, 0.0])
+            e[0] += 1; e[1] += st_.elapsed_time(en_); e[2] += fl; e[3] += bts
+        for shp, (n, ms, fl, bts) in sorted(by.items(), key=lambda kv: -kv[1][1]):
+            f_m, f_h = fl / ms / 1e9 / FP32_MFMA_PEAK_TFS, bts / ms / 1e6 / HBM_PEAK_GBS
+            conv_rows.append({"shape": list(shp), "launches": n, "ms": round(ms, 3), "tflops": round(fl / ms / 1e9, 1), "frac_mfma": round(f_m, 3),
+                              "gbs": round(bts / ms / 1e6, 0), "frac_hbm": round(f_h, 3), "bound": "mfma" if f_m >= f_h else "hbm",
+                              "frac": round(max(f_m, f_h), 3), "sum": round(f_m + f_h, 3)})
+    if a.conv_table and rank == 0:
+        print("B cin cout kh kw s Hout Wout mode gated | launches  ms/step  TFLOP/s  frac_mfma  GB/s  frac_hbm  bound  sum", file=sys.stderr)
+        for r in conv_rows:
+            print(*r["shape"], "|", r["launches"], r["ms"], r["tflops"], r["frac_mfma"], int(r["gbs"]), r["frac_hbm"], r["bound"], r["sum"], file=sys.stderr)
     scene = scene_geometry_getcost(eng.ops, B, H, W, S, args.CostNum[1]) if (rank == 0 and a.config == "cfg2") else None
 
     sweep = batch_sweep(model, make_batch) if (rank == 0 and world == 1 and not a.no_batch_sweep and a.config == "cfg2") else None
@@ -519,7 +653,7 @@ def main():
     # HBM traffic per getcost launch from the PMC passes (rocprofv3 cannot run inside the timed process); only
     # quoted when the committed measurement was taken at this batch size
     traffic, traffic_note = None, None
-    tj = os.path.join(ROOT, "profiles", "r5_getcost_traffic.json")
+    tj = os.path.join(ROOT, "profiles", "r6_getcost_traffic.json")
     if os.path.exists(tj):
         with open(tj) as f:
             tinfo = json.load(f)
@@ -530,25 +664,19 @@ def main():
             traffic_note = (os.path.relpath(tj, ROOT) + " (rocprofv3 PMC passes of this command on this kernel source, counters scaled by the "
                             "factors of profiles/r3_traffic_calibration.json; not measured by this process)")
 
-    # the measured memory-system ceiling of GetCost's address stream (tools/diag_r4.py getcost with the DMVS_GC_EXP=4 builds: the product
-    # kernel's projection, masks, addresses and loads, nothing computed from the loaded registers) -- a committed measurement of another
-    # run of this kernel source at this batch, quoted next to the live number, never in place of it
+    # the memory-system ceiling of GetCost's address stream, measured by this process in untimed legs (see getcost_ceiling_probe)
     ceiling = None
-    cj = os.path.join(ROOT, "profiles", "r5_getcost_ceiling_probe.json")
-    if os.path.exists(cj) and (H, W, S) == (512, 640, 5):
-        with open(cj) as f:
-            cinfo = json.load(f)
-        if cinfo.get("batch") == B and cinfo.get("kernel_source_sha") == kernel_source_hash():      # (a probe of another kernel source is not quoted)
-            pr, pc = cinfo["noise_no_confidence"], cinfo["noise_random_confidence"]
-            ceiling = {"source": os.path.relpath(cj, ROOT), "gate_0p60_us": cinfo["gate_0p60_us"],
-                       "noise_geometry": {"probe_us": pr["probe_us"], "product_us_same_session": pr["product_us"],
-                                          "probe_frac_of_hbm_peak": round(cinfo["algorithmic_bytes_per_launch"] / (pr["probe_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                          "product_over_probe": round(pr["probe_us"] / pr["product_us"], 3)},
-                       "noise_geometry_random_confidence": {"probe_us": pc["probe_us"], "product_us_same_session": pc["product_us"],
-                                                            "product_over_probe": round(pc["probe_us"] / pc["product_us"], 3)},
-                       "reading": "the kernel's own line-request stream with NO arithmetic takes longer than the 0.60 mark allows: the 0.60 gate is above "
-                                  "what the memory system delivers for this access pattern (product_over_probe = how close the product runs to it; "
-                                  "both timed as variant builds in one session, isolated back-to-back launches)"}
+    if rank == 0 and world == 1 and a.config == "cfg2" and not a.no_probe:
+        try:
+            ceiling = getcost_ceiling_probe(model, eng, imgs, proj, dv, {"getcost": alg, "src_texels": B * S * h2 * w2})
+            ceiling["product_in_step_avg_us"] = round(gc_avg_s * 1e6, 2)
+            ceiling["product_over_probe_in_step"] = round(ceiling["in_step_probe_avg_us"] / (gc_avg_s * 1e6), 3) if gc_avg_s > 0 else None
+            ceiling["product_over_probe_isolated"] = round(ceiling["isolated_probe_avg_us"] / max(ceiling["isolated_product_avg_us"], 1e-9), 3)
+            ceiling["probe_frac_of_hbm_peak_in_step"] = round(alg / (ceiling["in_step_probe_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            ceiling["reading"] = ("in_step_probe_avg_us above gate_0p60_us = the product kernel's own line-request stream with NO arithmetic already takes longer "
+                                  "than the 0.60 mark allows; product_over_probe_* = how close the product runs to that ceiling")
+        except Exception as e:      # an absent / failing probe library must never cost the headline line
+            ceiling = {"measured_by": "this process", "error": repr(e)[:300]}
 
     result = {
         "metric": "depth-maps/sec (640x512, 5 src views)", "value": round(value, 3), "unit": "depth-maps/s",
@@ -570,7 +698,7 @@ def main():
                      "traffic_source": traffic_note,
                      "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(gc_avg_s * 1e6, 2),
                      "launches_timed": len(gc_ms), "per_gru_iteration": by_iter,
-                     "ceiling_probe_us": ceiling["noise_geometry"]["probe_us"] if ceiling else None, "ceiling_probe": ceiling},
+                     "ceiling_probe_us": (ceiling or {}).get("in_step_probe_avg_us"), "ceiling_probe": ceiling},
         "roofline_warp_init": {"kernel": ("warp_init_quad_kernel<48> (stage-1 plane sweep, quad per pixel, texels from global memory: tune DMVS_TUNE_SWEEP_GLOBAL)"
                                           if eng.ops.tune["sweep"] else
                                           "warp_init_band_kernel<48> (stage-1 plane sweep, quad per pixel, source band of a 16x4 pixel tile staged in LDS)"), "bound": "hbm",
@@ -580,11 +708,17 @@ def main():
                                "algorithmic_bytes_per_launch": alg_init, "avg_launch_us": round(wi_avg_s * 1e6, 2)},
         "roofline_scene_geometry": scene,
         # where the step's time actually goes: all 2-D convolution launches (exact-fp32 MFMA implicit GEMM) together
-        "roofline_conv2d": {"kernel": "conv2d_mfma_kernel<*> (all launches of the step)", "bound": "mfma",
+        "roofline_conv2d": {"kernel": "conv2d_mfma_kernel<*> / conv1x1_px4_kernel<*> (all 2-D convolution launches of the step)", "bound": "mfma",
                             "achieved": round(cv_flops / cv_s / 1e12, 2) if cv_s > 0 else 0.0, "peak": FP32_MFMA_PEAK_TFS,
                             "unit": "TFLOP/s", "frac": round(cv_flops / cv_s / 1e12 / FP32_MFMA_PEAK_TFS, 4) if cv_s > 0 else 0.0,
                             "launches_timed": len(timers["dmvs_conv2d_f32"]),
-                            "share_of_step_time": round(cv_s / conv_step_s, 4)},
+                            "share_of_step_time": round(cv_s / conv_step_s, 4),
+                            # the same launches against BOTH roofs: algorithmic bytes / time next to flops / time, and per layer shape the roof
+                            # that binds it (the family as a whole is matrix-bound by time share; the 1x1 and <= 8-channel rows are not)
+                            "hbm_achieved_GBs": round(sum(timers.get("_conv2d_bytes", [])) / cv_s / 1e9, 1) if cv_s > 0 else None,
+                            "ms_by_binding_roof": {k: round(sum(r["ms"] for r in conv_rows if r["bound"] == k), 3) for k in ("mfma", "hbm")},
+                            "rows": [[*r["shape"][:8], r["launches"], r["ms"], r["frac_mfma"], r["frac_hbm"], r["bound"]] for r in conv_rows[:24]],
+                            "rows_columns": "B cin cout kh kw stride Hout Wout launches ms_per_step frac_of_fp32_mfma_peak frac_of_hbm_peak binding_roof (top 24 shapes by time)"},
     }
 
     if a.config != "cfg2":

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-# DMVS_LIB: another build of the same sources (tools/build_variant.py) for A/B runs; default: the in-tree product library
+# DMVS_LIB: another build of the same sources for A/B runs; default: the in-tree product library
 HIP_LIB_PATH = os.environ.get("DMVS_LIB") or os.path.join(PKG, "libdmvs_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_SILU = range(5)
@@ -52,7 +52,7 @@ class GetCostDesc(C.Structure):
         ("disp_min", _P), ("disp_max", _P), ("out_cost", _P), ("out_samples", _P), ("worklist", _P),
         ("B", _I), ("S", _I), ("C", _I), ("G", _I), ("n", _I), ("H", _I), ("W", _I), ("vw_shift", _I),
         ("cost_cstride", _I), ("cost_coffset", _I), ("samp_cstride", _I), ("samp_coffset", _I),
-        ("interval", _F), ("min_radius", _F), ("max_radius", _F), ("feat_dtype", _I),
+        ("interval", _F), ("min_radius", _F), ("max_radius", _F), ("feat_dtype", _I), ("tune", _I),
     ]
 
 
@@ -78,6 +78,7 @@ SIGNATURES = {
     "dmvs_sigmoid_max_d_f32": [_P, _P, _I, _I, _I, _P],
     "dmvs_depth_regress_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "dmvs_convex_upsample_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "dmvs_mask_upsample4_f32": [_P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dmvs_groupnorm_silu_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "dmvs_groupnorm_apply_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "dmvs_delta_update_f32": [_P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -94,11 +95,12 @@ SIGNATURES = {
     "dmvs_sumsq_f32": [_P, C.c_int64, _P, _P],
     "dmvs_adamw_step_f32": [_P, _P, _P, _P, C.c_int64, _F, _F, _F, _F, _F, _I, _F, _P, _F, _P],
 }
-ABI_VERSION = 2
+ABI_VERSION = 3
 # dmvs.h: DMVS_TUNE_* (dmvs_conv2d_desc.tune, dmvs_featurenet_stem_f32), DMVS_TUNE3D_* (dmvs_conv3d_desc.tune), DMVS_TUNE_SWEEP_GLOBAL
 TUNE_NO_WALK, TUNE_PIECES4, TUNE_NO_LEAN, TUNE_1X1_TILED, TUNE_NO_TALL, TUNE_TALL = 0x4, 0x8, 0x100, 0x200, 0x400, 0x800
 TUNE3D_PIECES4, TUNE3D_S2_DIRECT, TUNE3D_NO_PAIR = 0x1, 0x2, 0x4
 TUNE_SWEEP_GLOBAL = 0x1
+TUNE_BWD_INTERLEAVED, BWD_GATHER_INTERLEAVED = 0x1, 2
 
 
 def tune_tile_wx(n: int) -> int:
@@ -107,6 +109,10 @@ def tune_tile_wx(n: int) -> int:
 
 def tune_tile_mt(n: int) -> int:
     return (n & 7) << 4
+
+
+def tune_stagger(n: int) -> int:
+    return (n & 15) << 12
 
 
 class DmvsError(RuntimeError):

@@ -1,4 +1,5 @@
-"""Build libdmvs_hip.so (gfx950 code object + C ABI) in-tree with hipcc.
+"""Build libdmvs_hip.so (gfx950 code object + C ABI) -- and libdmvs_probe.so, the bench-only measurement probes of
+include/dmvs_probe.h -- in-tree with hipcc.
 
     python -m diffmvs_amd.build [--force] [--save-temps]
 
@@ -15,15 +16,23 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libdmvs_hip.so")
-SOURCES = ["conv2d_k33.hip", "conv2d_k55.hip", "conv2d_k77.hip", "conv2d_k15.hip", "conv2d.hip", "stem.hip", "conv3d.hip", "warp_quad.hip", "warp_bwd.hip", "warp_bwd_win.hip", "warp_init_bwd_win.hip", "misc.hip", "optim.hip", "norm.hip", "fusion.hip"]
+PROBE_LIB = os.path.join(PKG, "libdmvs_probe.so")      # measurement probes (bench.py's untimed roofline legs); never loaded by the path
+PROBE_SOURCES = ["probe/getcost_probe.hip", "probe/random_line_gather.hip"]
+SOURCES = ["conv2d_k33.hip", "conv2d_k55.hip", "conv2d_k77.hip", "conv2d_k15.hip", "conv2d.hip", "stem.hip", "conv3d.hip", "warp_quad.hip", "warp_bwd.hip", "warp_bwd_win.hip", "warp_init_bwd_win.hip", "misc.hip", "mask_upsample.hip", "optim.hip", "norm.hip", "fusion.hip"]
+
+
+def _deps():
+    out = [os.path.join(ROOT, "include", "dmvs.h"), os.path.join(ROOT, "include", "dmvs_probe.h")]
+    for base, _, files in os.walk(CSRC):
+        out += [os.path.join(base, f) for f in files]
+    return out
 
 
 def _stale() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(PROBE_LIB):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "dmvs.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    t = min(os.path.getmtime(LIB), os.path.getmtime(PROBE_LIB))
+    return any(os.path.getmtime(d) > t for d in _deps())
 
 
 def build_hip(force: bool = False, save_temps: bool = False, verbose: bool = True) -> str:
@@ -40,8 +49,13 @@ def build_hip(force: bool = False, save_temps: bool = False, verbose: bool = Tru
         flags += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
 
     # one hipcc per translation unit, in parallel (the tiled conv2d kernel is split over four translation units for this: as one file it was 6 of the 7 minutes), then one link
+    # an object is reused when it is newer than its source and than every header (no finer dependency tracking: a header change rebuilds all)
+    hdr_t = max(os.path.getmtime(d) for d in _deps() if d.endswith(".h"))
+
     def compile_one(src):
-        obj = os.path.join(objdir, src + ".o")
+        obj = os.path.join(objdir, src.replace("/", "_") + ".o")
+        if not force and not save_temps and os.path.exists(obj) and os.path.getmtime(obj) > max(hdr_t, os.path.getmtime(os.path.join(CSRC, src))):
+            return obj
         cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print("[diffmvs_amd.build]", " ".join(cmd), flush=True)
@@ -50,11 +64,12 @@ def build_hip(force: bool = False, save_temps: bool = False, verbose: bool = Tru
 
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as pool:
-        objs = list(pool.map(compile_one, SOURCES))
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
-    if verbose:
-        print("[diffmvs_amd.build]", " ".join(link), flush=True)
-    subprocess.run(link, check=True, cwd=ROOT)
+        objs = list(pool.map(compile_one, SOURCES + PROBE_SOURCES))
+    for lib, lobjs in ((LIB, objs[:len(SOURCES)]), (PROBE_LIB, objs[len(SOURCES):])):
+        link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + lobjs + ["-o", lib]
+        if verbose:
+            print("[diffmvs_amd.build]", " ".join(link), flush=True)
+        subprocess.run(link, check=True, cwd=ROOT)
     return LIB
 
 

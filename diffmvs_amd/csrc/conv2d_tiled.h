@@ -140,6 +140,16 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF + 32];
     DMVS_LDS_POISON(lds);
 
+#ifndef DMVS_HOST_EMULATION
+    // Start-up stagger (DMVS_TUNE_STAGGER, dmvs.h): workgroups are dealt round-robin to the 8 XCDs and, inside an XCD, one per CU before any CU
+    // gets a second one -- workgroup w is the (w / 8 / 32)-th of its CU.  The first few of every CU start k * n sleep units apart, so that one is
+    // in its load / store phase while the others are in their MFMA phase; identical work keeps them apart for the rest of the launch.
+    if (const unsigned sn = ((unsigned)d.tune >> 12) & 15u) {
+        const unsigned slot = ((blockIdx.x + gridDim.x * blockIdx.y) >> 3) >> 5;
+        if (slot < 8u)
+            for (unsigned i = 0; i < slot * sn; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA bases in SGPRs
     int m = lane & 15, kq = lane >> 4;       // (tid, m, kq not const: the tile-walking form redefines them per tile, see the tile loop)
@@ -430,16 +440,12 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
             // All KH rows of taps of a 3x3 / 1x1 / 5x1 layer in one loop trip (36-72 MFMAs between two branches instead of 12-24): a loop
             // of 4 MFMAs per trip runs the matrix pipe at 0.81 of the rate of 16 per trip (tools/calib/issue_probe.hip).  Measured per
             // layer (profiles/r3_conv_ky_unroll_ab.txt): -1...-9 % on the >= 32-channel layers, 16 -> 16 unchanged; the 5x5 / 7x7 layers
-            // already have 10-40 per trip.  -DDMVS_CONV_KY_ROLLED restores one row per trip (A/B builds).  Same order of operations.
+            // already have 10-40 per trip.  Same order of operations.
             // Round 4 (profiles/r4_conv_tall_s2_ky_ab.jsonl, both removed again): all five rows of the one-n-tile 5x5 layers in one trip (50
             // MFMAs instead of 10) -1.4 % on 8 -> 16 stride 2, nothing elsewhere; the stride-2 B operand read as 8-byte pairs (ds_read2_b64:
             // a lane's taps kx, kx + 1 -- the 4-byte reads of lanes 2 floats apart meet two by two in the banks) +-1 %: LDS read
             // bandwidth is not what separates the stride-2 layers from their stride-1 peers.
-#ifdef DMVS_CONV_KY_ROLLED
-            constexpr int kKyUnroll = 1;
-#else
             constexpr int kKyUnroll = (KH * KW <= 9) ? KH : 1;
-#endif
 #pragma unroll kKyUnroll
             for (int ky = 0; ky < KH; ++ky) {
 #pragma unroll

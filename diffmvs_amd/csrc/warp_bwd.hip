@@ -10,6 +10,12 @@
 // scatter is pre-accumulated in registers while consecutive hypotheses keep the same 2x2 footprint and
 // flushed with one hardware fp32 atomic per (tap, channel) when it moves; atomics make the feature
 // gradient order-dependent in the last bits (documented non-determinism).
+//
+// Channel -> lane mapping (template CS = channel stride between a lane's consecutive channels).  Rounds 1-5: lane `sub` of a pixel owns
+// the CPL CONSECUTIVE channels sub*CPL .. +CPL-1 (CS = 1): 16-byte loads, but each of the CPL atomic instructions of a flush then touches
+// 4 bytes out of every 16 of the texel -- LPP lanes spread over the whole 4C-byte texel, CPL times over.  Round 6 (CS = LPP, "interleaved"):
+// lane `sub` owns channels sub, sub + LPP, ...: one atomic instruction covers LPP CONTIGUOUS floats of the texel (64 bytes at 16 lanes per
+// pixel), i.e. the L2's atomic units see C*4/64 full 64-byte requests per (pixel, tap) instead of CPL * C*4/64 quarter-filled ones.
 #include "dmvs_common.h"
 
 namespace {
@@ -49,8 +55,9 @@ __device__ __forceinline__ SampB project_b(const RayB& r, float depth, int Hs, i
     return s;
 }
 
-// running scatter accumulator for one (pixel-lane, view): flushes to grad_src when the footprint moves
-template <int CPL>
+// running scatter accumulator for one (pixel-lane, view): flushes to grad_src when the footprint moves.  Channel j of the lane lives at
+// float offset j * CS from the lane's base.
+template <int CPL, int CS>
 struct Scatter {
     float g[4][CPL];
     int cx, cy;
@@ -71,7 +78,7 @@ struct Scatter {
             float* p = gview + ((long)y * Ws + x) * C;
 #pragma unroll
             for (int j = 0; j < CPL; ++j)
-                if (g[t][j] != 0.0f) atomicAdd(p + j, g[t][j]);
+                if (g[t][j] != 0.0f) atomicAdd(p + j * CS, g[t][j]);
         }
         dirty = false;
 #pragma unroll
@@ -81,10 +88,10 @@ struct Scatter {
     }
 };
 
-// one hypothesis of one view: accumulate grad_ref (registers) and the scatter accumulator
-template <int CPL>
-__device__ __forceinline__ void bwd_sample(const float* view, float* gview, const SampB& s, float gc, const float (&refv)[CPL],
-                                           float (&gref)[CPL], Scatter<CPL>& sc, int Hs, int Ws, int C) {
+// one hypothesis of one view: accumulate grad_ref (registers) and the scatter accumulator.  gc[j] = the cost gradient of channel j's group
+template <int CPL, int CS>
+__device__ __forceinline__ void bwd_sample(const float* view, float* gview, const SampB& s, const float (&gc)[CPL], const float (&refv)[CPL],
+                                           float (&gref)[CPL], Scatter<CPL, CS>& sc, int Hs, int Ws, int C) {
     if (s.x0 != sc.cx || s.y0 != sc.cy) {
         sc.flush(gview, Hs, Ws, C);
         sc.cx = s.x0;
@@ -98,24 +105,33 @@ __device__ __forceinline__ void bwd_sample(const float* view, float* gview, cons
     const float* t3 = view + ((long)yb * Ws + xb) * C;
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
-        const float smp = t0[j] * s.w[0] + t1[j] * s.w[1] + t2[j] * s.w[2] + t3[j] * s.w[3];
-        gref[j] = fmaf(gc, smp, gref[j]);
-        const float gr = gc * refv[j];
+        const float smp = t0[j * CS] * s.w[0] + t1[j * CS] * s.w[1] + t2[j * CS] * s.w[2] + t3[j * CS] * s.w[3];
+        gref[j] = fmaf(gc[j], smp, gref[j]);
+        const float gr = gc[j] * refv[j];
 #pragma unroll
         for (int t = 0; t < 4; ++t) sc.g[t][j] = fmaf(gr, s.w[t], sc.g[t][j]);
     }
     sc.dirty = true;
 }
 
+// lane `sub` of a pixel's LPP lanes: float offset of its channel 0 inside a texel, stride between its channels, and channel j's index
+template <int C, int CPL, bool IL>
+struct LaneCh {
+    static constexpr int LPP = C / CPL, CS = IL ? LPP : 1;
+    static __device__ __forceinline__ int base(int sub) { return IL ? sub : sub * CPL; }
+    static __device__ __forceinline__ int ch(int sub, int j) { return base(sub) + j * CS; }
+};
+
 // ------------------------------------------------------------------------------------------
 // backward of dmvs_warp_corr_init_f32.   gcor [B,S,G,D,H,W] -> gref [B,H,W,C] (written), gsrc [S,B,Hs,Ws,C] (+=)
-template <int C, int CPL>
+template <int C, int CPL, bool IL>
 __global__ void __launch_bounds__(DMVS_BLOCK)
 warp_corr_init_bwd_kernel(const float* __restrict__ ref, const float* __restrict__ src, const float* __restrict__ rt,
                           const float* __restrict__ disp_min, const float* __restrict__ disp_max,
                           const float* __restrict__ gcor, float* __restrict__ gref, float* __restrict__ gsrc, int B, int S,
                           int D, int H, int W, int Hs, int Ws) {
-    constexpr int G = 4, LPP = C / CPL, LPG = LPP / G, PPB = DMVS_BLOCK / LPP;
+    using L = LaneCh<C, CPL, IL>;
+    constexpr int G = 4, LPP = C / CPL, PPB = DMVS_BLOCK / LPP, CS = L::CS;
     const int sub = threadIdx.x % LPP, slot = threadIdx.x / LPP;
     const long npix = (long)B * H * W;
     const long pix = (long)blockIdx.x * PPB + slot;
@@ -124,40 +140,45 @@ warp_corr_init_bwd_kernel(const float* __restrict__ ref, const float* __restrict
     const long hw = (long)H * W, yx = (long)y * W + x;
     const float inv_cg = 1.0f / (float)(C / G);
     float refv[CPL], gr[CPL];
+    int gj[CPL];                       // correlation group of the lane's channel j (the same for every j unless interleaved)
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
-        refv[j] = ref[pix * C + sub * CPL + j] * inv_cg;
+        refv[j] = ref[pix * C + L::ch(sub, j)] * inv_cg;
         gr[j] = 0.0f;
+        gj[j] = L::ch(sub, j) / (C / G);
     }
     const float dmin = disp_min[b], dmax = disp_max[b], dm1 = (float)(D - 1);
-    const int g = sub / LPG;
     for (int s = 0; s < S; ++s) {
         RayB ray;
         ray.init(rt + ((long)b * S + s) * 12, (float)x, (float)y);
-        const long voff = ((long)s * B + b) * (long)Hs * Ws * C + sub * CPL;
+        const long voff = ((long)s * B + b) * (long)Hs * Ws * C + L::base(sub);
         const float* view = src + voff;
         float* gview = gsrc + voff;
-        const float* gp = gcor + ((((long)b * S + s) * G + g) * D) * hw + yx;
-        Scatter<CPL> sc;
+        const float* gp = gcor + (((long)b * S + s) * G * D) * hw + yx;
+        Scatter<CPL, CS> sc;
         sc.reset();
         for (int d = 0; d < D; ++d) {
             const SampB sp = project_b(ray, dmvs_disp_to_depth((float)d / dm1, dmin, dmax), Hs, Ws);
-            bwd_sample<CPL>(view, gview, sp, gp[(long)d * hw], refv, gr, sc, Hs, Ws, C);
+            float gc[CPL];
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) gc[j] = (IL || j == 0) ? gp[((long)gj[j] * D + d) * hw] : gc[0];
+            bwd_sample<CPL, CS>(view, gview, sp, gc, refv, gr, sc, Hs, Ws, C);
         }
         sc.flush(gview, Hs, Ws, C);
     }
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) gref[pix * C + sub * CPL + j] = gr[j] * inv_cg;
+    for (int j = 0; j < CPL; ++j) gref[pix * C + L::ch(sub, j)] = gr[j] * inv_cg;
 }
 
 // ------------------------------------------------------------------------------------------
 // backward of dmvs_getcost_f32 w.r.t. the features.  gcost [B,G*n,H,W] (contiguous) -> gref (written), gsrc (+=)
 // TILED: only the 16x16 tiles the window kernel (warp_bwd_win.hip) left in d.worklist; plain launch inside a hybrid call
 // (d.worklist set): only when the pre-pass said "everything here".
-template <int C, int CPL, int N, bool TILED>
+template <int C, int CPL, int N, bool TILED, bool IL>
 __global__ void __launch_bounds__(DMVS_BLOCK) getcost_bwd_kernel(const dmvs_getcost_desc d, const float* __restrict__ gcost,
                                                                  float* __restrict__ gref, float* __restrict__ gsrc) {
-    constexpr int G = 4, LPP = C / CPL, LPG = LPP / G, PPB = DMVS_BLOCK / LPP;
+    using L = LaneCh<C, CPL, IL>;
+    constexpr int G = 4, LPP = C / CPL, PPB = DMVS_BLOCK / LPP, CS = L::CS;
     const int sub = threadIdx.x % LPP, slot = threadIdx.x / LPP;
     const int H = d.H, W = d.W;
     const long hw = (long)H * W;
@@ -209,33 +230,41 @@ __global__ void __launch_bounds__(DMVS_BLOCK) getcost_bwd_kernel(const dmvs_getc
     float refv[CPL], gr[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
-        refv[j] = d.ref[pix * C + sub * CPL + j] * inv_cg;
+        refv[j] = d.ref[pix * C + L::ch(sub, j)] * inv_cg;
         gr[j] = 0.0f;
     }
     const int Hv = H >> d.vw_shift, Wv = W >> d.vw_shift;
     const long vwi = (long)(y >> d.vw_shift) * Wv + (x >> d.vw_shift);
     float wsum = 1e-8f;
     for (int s = 0; s < d.S; ++s) wsum += d.view_w[((long)b * d.S + s) * Hv * Wv + vwi];
-    const int g = sub / LPG;
-    float gk[N];
+    // cost gradient of the lane's channels: one group for all of them (consecutive channels), or one per channel (interleaved)
+    constexpr int NG = IL ? CPL : 1;
+    float gk[NG][N];
 #pragma unroll
-    for (int k = 0; k < N; ++k) gk[k] = gcost[((long)b * G * N + g * N + k) * hw + yx] / wsum;
+    for (int jj = 0; jj < NG; ++jj) {
+        const int g = L::ch(sub, jj) / (C / G);
+#pragma unroll
+        for (int k = 0; k < N; ++k) gk[jj][k] = gcost[((long)b * G * N + g * N + k) * hw + yx] / wsum;
+    }
     for (int s = 0; s < d.S; ++s) {
         const float w = d.view_w[((long)b * d.S + s) * Hv * Wv + vwi];
         RayB ray;
         ray.init(d.rt + ((long)b * d.S + s) * 12, (float)x, (float)y);
-        const long voff = ((long)s * d.B + b) * hw * C + sub * CPL;
-        Scatter<CPL> sc;
+        const long voff = ((long)s * d.B + b) * hw * C + L::base(sub);
+        Scatter<CPL, CS> sc;
         sc.reset();
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             const SampB sp = project_b(ray, depth[k], H, W);
-            bwd_sample<CPL>(d.src + voff, gsrc + voff, sp, gk[k] * w, refv, gr, sc, H, W, C);
+            float gc[CPL];
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) gc[j] = gk[IL ? j : 0][k] * w;
+            bwd_sample<CPL, CS>(d.src + voff, gsrc + voff, sp, gc, refv, gr, sc, H, W, C);
         }
         sc.flush(gsrc + voff, H, W, C);
     }
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) gref[pix * C + sub * CPL + j] = gr[j] * inv_cg;
+    for (int j = 0; j < CPL; ++j) gref[pix * C + L::ch(sub, j)] = gr[j] * inv_cg;
 }
 
 }  // namespace
@@ -254,37 +283,43 @@ extern "C" int dmvs_warp_corr_init_bwd_f32(const float* ref, const float* src, c
         return dmvs_warp_init_bwd_win_dispatch(ref, src, rt, disp_min, disp_max, gcor, gref, gsrc, B, S, C, D, H, W, Hs, Ws, st);
     const long npix = (long)B * H * W;
     dim3 block(DMVS_BLOCK);
-    if (C == 48) {
-        hipLaunchKernelGGL((warp_corr_init_bwd_kernel<48, 3>), dim3(dmvs_ceil_div(npix, DMVS_BLOCK / 16)), block, 0, st, ref, src,
-                           rt, disp_min, disp_max, gcor, gref, gsrc, B, S, D, H, W, Hs, Ws);
+#define DMVS_WIB_BWD(CC, CPLL, ILL)                                                                                                       \
+    hipLaunchKernelGGL((warp_corr_init_bwd_kernel<CC, CPLL, ILL>), dim3(dmvs_ceil_div(npix, DMVS_BLOCK / (CC / CPLL))), block, 0, st, ref, src, \
+                       rt, disp_min, disp_max, gcor, gref, gsrc, B, S, D, H, W, Hs, Ws)
+    if (gather == DMVS_BWD_GATHER_INTERLEAVED) {      // 16 lanes per pixel, lane = channel mod 16: 64-byte atomic requests
+        if (C == 48) DMVS_WIB_BWD(48, 3, true);
+        else if (C == 32) DMVS_WIB_BWD(32, 2, true);
+        else if (C == 16) DMVS_WIB_BWD(16, 1, true);
+        else return DMVS_EINVAL;
+    } else if (C == 48) {
+        DMVS_WIB_BWD(48, 3, false);
     } else if (C == 32) {
-        hipLaunchKernelGGL((warp_corr_init_bwd_kernel<32, 4>), dim3(dmvs_ceil_div(npix, DMVS_BLOCK / 8)), block, 0, st, ref, src,
-                           rt, disp_min, disp_max, gcor, gref, gsrc, B, S, D, H, W, Hs, Ws);
+        DMVS_WIB_BWD(32, 4, false);
     } else if (C == 16) {
-        hipLaunchKernelGGL((warp_corr_init_bwd_kernel<16, 4>), dim3(dmvs_ceil_div(npix, DMVS_BLOCK / 4)), block, 0, st, ref, src,
-                           rt, disp_min, disp_max, gcor, gref, gsrc, B, S, D, H, W, Hs, Ws);
+        DMVS_WIB_BWD(16, 4, false);
     } else {
         return DMVS_EINVAL;
     }
+#undef DMVS_WIB_BWD
     return dmvs_launch_status();
 }
 
-template <int C, int CPL>
+template <int C, int CPL, bool IL>
 static int launch_getcost_bwd(const dmvs_getcost_desc& d, const float* gcost, float* gref, float* gsrc, hipStream_t st) {
     dim3 grid(dmvs_ceil_div((long)d.B * d.H * d.W, DMVS_BLOCK / (C / CPL))), block(DMVS_BLOCK);
-    if (d.n == 4) hipLaunchKernelGGL((getcost_bwd_kernel<C, CPL, 4, false>), grid, block, 0, st, d, gcost, gref, gsrc);
-    else if (d.n == 6) hipLaunchKernelGGL((getcost_bwd_kernel<C, CPL, 6, false>), grid, block, 0, st, d, gcost, gref, gsrc);
+    if (d.n == 4) hipLaunchKernelGGL((getcost_bwd_kernel<C, CPL, 4, false, IL>), grid, block, 0, st, d, gcost, gref, gsrc);
+    else if (d.n == 6) hipLaunchKernelGGL((getcost_bwd_kernel<C, CPL, 6, false, IL>), grid, block, 0, st, d, gcost, gref, gsrc);
     else return DMVS_EINVAL;
     return dmvs_launch_status();
 }
 
-template <int C, int CPL>
+template <int C, int CPL, bool IL>
 static int launch_getcost_bwd_tiles(const dmvs_getcost_desc& d, const float* gcost, float* gref, float* gsrc, hipStream_t st) {
     constexpr int PPB = DMVS_BLOCK / (C / CPL), T = DMVS_GETCOST_TILE, BPT = T * T / PPB;
     const long tiles = (long)d.B * ((d.H + T - 1) / T) * ((d.W + T - 1) / T);
     dim3 grid((unsigned)(tiles * BPT)), block(DMVS_BLOCK);
-    if (d.n == 4) hipLaunchKernelGGL((getcost_bwd_kernel<C, CPL, 4, true>), grid, block, 0, st, d, gcost, gref, gsrc);
-    else if (d.n == 6) hipLaunchKernelGGL((getcost_bwd_kernel<C, CPL, 6, true>), grid, block, 0, st, d, gcost, gref, gsrc);
+    if (d.n == 4) hipLaunchKernelGGL((getcost_bwd_kernel<C, CPL, 4, true, IL>), grid, block, 0, st, d, gcost, gref, gsrc);
+    else if (d.n == 6) hipLaunchKernelGGL((getcost_bwd_kernel<C, CPL, 6, true, IL>), grid, block, 0, st, d, gcost, gref, gsrc);
     else return DMVS_EINVAL;
     return dmvs_launch_status();
 }
@@ -296,16 +331,24 @@ extern "C" int dmvs_getcost_bwd_f32(const dmvs_getcost_desc* dp, const float* gc
     dmvs_getcost_desc d = *dp;
     if (d.G != 4 || !d.ref || !d.src || !d.rt || !d.inv_depth || !d.view_w || (d.n != 4 && d.n != 6)) return DMVS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    const bool il = (d.tune & DMVS_TUNE_BWD_INTERLEAVED) != 0;
     if (d.worklist && (d.C == 32 || d.C == 16) && d.S <= DMVS_GETCOST_MAX_WINDOW_VIEWS) {
         // LDS-window tiles first, then one launch for the rest: the listed tiles, or (pre-pass: mostly misfits) every pixel
         if (int rc = dmvs_getcost_bwd_win_dispatch(d, gcost, gref, gsrc, st)) return rc;
-        return d.C == 32 ? launch_getcost_bwd_tiles<32, 4>(d, gcost, gref, gsrc, st)
-                         : launch_getcost_bwd_tiles<16, 4>(d, gcost, gref, gsrc, st);
+        if (il) return d.C == 32 ? launch_getcost_bwd_tiles<32, 2, true>(d, gcost, gref, gsrc, st) : launch_getcost_bwd_tiles<16, 1, true>(d, gcost, gref, gsrc, st);
+        return d.C == 32 ? launch_getcost_bwd_tiles<32, 4, false>(d, gcost, gref, gsrc, st)
+                         : launch_getcost_bwd_tiles<16, 4, false>(d, gcost, gref, gsrc, st);
     }
     d.worklist = nullptr;
-    if (d.C == 48) return launch_getcost_bwd<48, 3>(d, gcost, gref, gsrc, st);
-    if (d.C == 32) return launch_getcost_bwd<32, 4>(d, gcost, gref, gsrc, st);
-    if (d.C == 16) return launch_getcost_bwd<16, 4>(d, gcost, gref, gsrc, st);
+    if (il) {
+        if (d.C == 48) return launch_getcost_bwd<48, 3, true>(d, gcost, gref, gsrc, st);
+        if (d.C == 32) return launch_getcost_bwd<32, 2, true>(d, gcost, gref, gsrc, st);
+        if (d.C == 16) return launch_getcost_bwd<16, 1, true>(d, gcost, gref, gsrc, st);
+        return DMVS_EINVAL;
+    }
+    if (d.C == 48) return launch_getcost_bwd<48, 3, false>(d, gcost, gref, gsrc, st);
+    if (d.C == 32) return launch_getcost_bwd<32, 4, false>(d, gcost, gref, gsrc, st);
+    if (d.C == 16) return launch_getcost_bwd<16, 4, false>(d, gcost, gref, gsrc, st);
     return DMVS_EINVAL;
 }
 

@@ -145,6 +145,12 @@ def run_mask(o: Ops, pk, context, post_scale=0.25):
     return o.conv2d(pk[1], o.conv2d(pk[0], context, act=K.ACT_RELU), post_scale=post_scale)
 
 
+def mask_head_fuses(pk, up_ratio) -> bool:
+    """the head's 1x1 layer runs inside the convex-upsampling kernel (Ops.mask_upsample4: DiffMVS, ratio 4, 64 -> 144 channels); DMVS_MASK_FUSE=0
+    keeps the two launches (A/B runs and the bit-identity test)"""
+    return up_ratio == 4 and pk[1].cin == 64 and pk[1].cout == 144 and pk[1].scale is None and os.environ.get("DMVS_MASK_FUSE", "1") != "0"
+
+
 def pack_gru(sd, p):
     """SepConvGRU (models/module.py:152-179)."""
     g = {}
@@ -273,6 +279,7 @@ class _UpdateBlock:
         c2 = lambda name, **kw: pack_conv2d(sd[f"{p}.{name}.weight"], sd.get(f"{p}.{name}.bias"), **kw)  # noqa: E731
         self.enc = pack_encoder(sd, p + ".encoder")
         self.mask = pack_mask(sd, p + ".mask")
+        self.fused_up = mask_head_fuses(self.mask, up_ratio)      # the mask never leaves registers: see Engine.forward
         u = p + ".unet"
         wi, bi = sd[f"{p}.unet.init_conv.weight"], sd.get(f"{p}.unet.init_conv.bias")
         self.init_ctx = pack_conv2d(wi[:, :self.cd], bi, pad=3)        # input channels = cat(relu(context), encoder output)
@@ -358,9 +365,14 @@ class SceneFeatureStore:
         self.feats = {k: (parts[0][k] if len(parts) == 1 else torch.cat([p[k] for p in parts], 0)) for k in parts[0]}
         self.n_views = images.shape[0]
 
-    def gather(self, view_ids: torch.Tensor) -> Dict[str, torch.Tensor]:
-        """view_ids [B,V] (column 0 = the reference view) -> {stage: [V*B,h,w,C]}, row v*B + b = features of view_ids[b, v]"""
+    def gather(self, view_ids: torch.Tensor, out: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        """view_ids [B,V] (column 0 = the reference view) -> {stage: [V*B,h,w,C]}, row v*B + b = features of view_ids[b, v].
+        out: buffers to gather INTO (the static inputs of a captured graph: one copy instead of gather + copy)"""
         idx = view_ids.to(next(iter(self.feats.values())).device).long().t().reshape(-1)
+        if out is not None:
+            for k, f in self.feats.items():
+                torch.index_select(f, 0, idx, out=out[k])
+            return out
         return {k: f.index_select(0, idx) for k, f in self.feats.items()}
 
 
@@ -506,7 +518,8 @@ class Engine:
         B, _, H, W = inv_depth.shape
         cd, n = ub.cd, ub.n
         noise = noise_fn((B, 1, H, W), o.device).float().contiguous()
-        mask = run_mask(o, ub.mask, context)
+        # (fused_up: only the head's 3x3 layer runs here; its 1x1 layer is evaluated inside the upsampling kernel at the end of the stage)
+        mask = o.conv2d(ub.mask[0], context, act=K.ACT_RELU) if ub.fused_up else run_mask(o, ub.mask, context)
         ctx_part = o.conv2d(ub.init_ctx, context)             # the context half of the Unet's 7x7 init_conv, once per stage
         E = o.empty(B, cd, H, W)                              # encoder output (cd - 1 channels) + current inverse depth
         img, img_scale = noise, float(ub.scale)
@@ -574,11 +587,18 @@ class Engine:
                 if a.stage_iters[s] == 0:
                     continue
                 f = feats.get(f"stage{s + 1}")
-                want = (V * B, H >> (3 - s), W >> (3 - s))
-                if f is None or f.dim() != 4 or tuple(f.shape[:3]) != want or f.dtype != self.feat_dtype or f.device != o.device or V < 2:
-                    raise K._lib.DmvsError(f"feats['stage{s + 1}']: expected a {self.feat_dtype} tensor [V*B={want[0]},{want[1]},{want[2]},C] on {o.device} "
+                Cs = (48, 32, 16)[s]                      # FeatureNet's output widths (module.py:357-420)
+                want = (V * B, H >> (3 - s), W >> (3 - s), Cs)
+                if f is None or f.dim() != 4 or tuple(f.shape) != want or f.dtype != self.feat_dtype or f.device != o.device or V < 2:
+                    raise K._lib.DmvsError(f"feats['stage{s + 1}']: expected a {self.feat_dtype} tensor [V*B={want[0]},{want[1]},{want[2]},{Cs}] on {o.device} "
                                            f"(SceneFeatureStore.gather of view ids [B,V], V >= 2), got "
                                            f"{None if f is None else (tuple(f.shape), f.dtype, str(f.device))}")
+                # the warp kernels index the composed projections with S = V - 1 taken from the FEATURE rows: a camera tensor with fewer
+                # views would be read out of bounds
+                pm = proj_matrices.get(f"stage{s + 1}")
+                if pm is None or pm.dim() != 5 or tuple(pm.shape[:2]) != (B, V):
+                    raise K._lib.DmvsError(f"proj_matrices['stage{s + 1}']: expected [B={B},V={V},2,4,4] to match the gathered feature rows, got "
+                                           f"{None if pm is None else tuple(pm.shape)}")
         self.arena.reset(B)
         dv = depth_values.to(o.device).float()
         depth_max_, depth_min_ = 1.0 / dv[:, 0], 1.0 / dv[:, -1]
@@ -630,6 +650,9 @@ class Engine:
                     for inv_i in inv_seq:
                         depths.append(o.depth_convert(inv_i, disp_min, disp_max, K._lib.EW_DISP_TO_DEPTH).view(B, h, w))
                     confs_seq.extend(conf_seq)
-                _, depth_up = o.convex_upsample(inv_seq[-1], mask, disp_min, disp_max, self.up_ratio, want_inv=False)
+                if ub.fused_up:
+                    _, depth_up = o.mask_upsample4(ub.mask[1], mask, inv_seq[-1], disp_min, disp_max, post_scale=0.25)
+                else:
+                    _, depth_up = o.convex_upsample(inv_seq[-1], mask, disp_min, disp_max, self.up_ratio, want_inv=False)
                 depths.append(depth_up)
         return {"depth": depths, "conf": confs_seq, "photometric_confidence": confs_full}

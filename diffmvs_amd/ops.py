@@ -141,6 +141,10 @@ def bump_weights_generation() -> None:
     _weights_generation[0] += 1
 
 
+CONV_STAGGER_DEFAULT = 0         # start-up stagger units of the tiled conv2d kernels (include/dmvs.h DMVS_TUNE_STAGGER; round-6 A/B)
+BWD_INTERLEAVED_DEFAULT = 0      # (set by the round-6 A/B: profiles/r6_bwd_interleave_ab.json)
+
+
 def _env_tune():
     """A/B knobs of the kernels' `tune` arguments (include/dmvs.h), read ONCE per binding in the Python layer -- the C library
     itself reads no environment variable -- and Ops.for_device keeps ONE binding per (library, device) for the life of the process: changing
@@ -150,6 +154,7 @@ def _env_tune():
       DMVS_CONV3D_V16=0, DMVS_CONV3D_S2=direct, DMVS_CONV3D_PAIR=0   (dmvs_conv3d_desc.tune)      DMVS_STEM_V16=0      DMVS_PLANE_SWEEP=quad"""
     e = os.environ.get
     t2 = _lib.tune_tile_wx(int(e("DMVS_CONV_WX", "0"))) | _lib.tune_tile_mt(int(e("DMVS_CONV_MT", "0")))
+    t2 |= _lib.tune_stagger(int(e("DMVS_CONV_STAGGER", "%d" % CONV_STAGGER_DEFAULT)))
     t2 |= _lib.TUNE_NO_WALK if e("DMVS_CONV_WALK") == "0" else 0
     t2 |= _lib.TUNE_PIECES4 if e("DMVS_CONV_V16") == "0" else 0
     t2 |= _lib.TUNE_NO_LEAN if e("DMVS_CONV_LEAN") == "0" else 0
@@ -160,7 +165,9 @@ def _env_tune():
     return {"conv2d": t2, "conv3d": t3, "stem": _lib.TUNE_PIECES4 if e("DMVS_STEM_V16") == "0" else 0,
             "sweep": _lib.TUNE_SWEEP_GLOBAL if e("DMVS_PLANE_SWEEP") == "quad" else 0,
             # training: GetCost backward through the per-pixel gather kernel only (no tile pre-pass / LDS-window worklist): DMVS_GETCOST_BWD=gather
-            "bwd_gather": e("DMVS_GETCOST_BWD") == "gather"}
+            "bwd_gather": e("DMVS_GETCOST_BWD") == "gather",
+            # training: channel -> lane mapping of the per-pixel scatter kernels (include/dmvs.h DMVS_TUNE_BWD_INTERLEAVED): DMVS_BWD_INTERLEAVED=0|1
+            "bwd_il": e("DMVS_BWD_INTERLEAVED", "%d" % BWD_INTERLEAVED_DEFAULT) == "1"}
 
 
 class Ops:
@@ -178,6 +185,9 @@ class Ops:
         # that a kernel that leaves part of its output unwritten -- or reads scratch it never wrote -- shows up as NaN instead of whatever the
         # allocator handed back.  None (the product default): plain torch.empty
         self.debug_fill = None
+        # measurement hook (bench.py's untimed probe legs): called as hook(descriptor, tensors) right BEFORE every GetCost launch, on the
+        # launch stream.  None in the product.
+        self.getcost_hook = None
 
     def with_conv_arith(self, arith: int) -> "Ops":
         """a binding of the same library whose conv2d() computes in `arith` (ARITH_F32 | ARITH_BF16) by default"""
@@ -309,6 +319,9 @@ class Ops:
         if self.timers is not None and "dmvs_conv2d_f32" in self.timers:      # bench: MFMA roofline over every conv launch
             self.timers.setdefault("_conv2d_flops", []).append(2.0 * B * Hout * Wout * pc.cout * pc.cin * kh * kw)
             self.timers.setdefault("_conv2d_shape", []).append((B, pc.cin, pc.cout, kh, kw, pc.stride, Hout, Wout, in_mode, int(mul0 is not None)))
+            # algorithmic bytes: every operand tensor read once, the output written once (SURVEY 8d's convention)
+            nb = sum(t.numel() * t.element_size() for t in (x0, x1, mul0, residual, gru_z, gru_h, out_mul) if t is not None)
+            self.timers.setdefault("_conv2d_bytes", []).append(nb + B * Hout * Wout * pc.cout * out.element_size())
         return out
 
     def featurenet_stem(self, pc0: PackedConv, pc1: PackedConv, x, tune=None):
@@ -450,6 +463,9 @@ class Ops:
                              worklist=None, B=B, S=S, C=Cc, G=G, n=n, H=H, W=W, vw_shift=vw_shift, cost_cstride=cost_cstride,
                              cost_coffset=cost_coffset, samp_cstride=samp_cstride, samp_coffset=samp_coffset,
                              interval=interval, min_radius=min_radius, max_radius=max_radius, feat_dtype=fdt)
+        if self.getcost_hook is not None:
+            self.getcost_hook(d, {"ref": ref, "src": src, "rt": rt, "inv_depth": inv_depth, "confidence": confidence, "view_w": view_w,
+                                  "disp_min": disp_min, "disp_max": disp_max, "out_cost": out_cost, "out_samples": out_samples})
         self._call("dmvs_getcost_quad_f32", C.byref(d), self.stream())
         if self.timers is not None and "dmvs_getcost_quad_f32" in self.timers:      # bench: algorithmic bytes of this launch
             es = ref.element_size()
@@ -478,8 +494,9 @@ class Ops:
         gref = self.empty_like(ref)
         if gsrc is None:
             gsrc = torch.zeros_like(src)
+        mode = (_lib.BWD_GATHER_INTERLEAVED if self.tune.get("bwd_il") else 1) if gather else 0
         self._call("dmvs_warp_corr_init_bwd_f32", _ptr(ref), _ptr(src), _ptr(rt), _ptr(disp_min), _ptr(disp_max), _ptr(gcor),
-                   _ptr(gref), _ptr(gsrc), B, S, Cc, G, D, H, W, Hs, Ws, int(gather), self.stream())
+                   _ptr(gref), _ptr(gsrc), B, S, Cc, G, D, H, W, Hs, Ws, mode, self.stream())
         return gref, gsrc
 
     def getcost_bwd(self, ref, src, rt, inv_depth, confidence, view_w, disp_min, disp_max, n, interval, min_radius,
@@ -497,7 +514,8 @@ class Ops:
                              confidence=_ptr(confidence), view_w=_ptr(view_w), disp_min=_ptr(disp_min),
                              disp_max=_ptr(disp_max), out_cost=None, out_samples=None, worklist=_ptr(wl), B=B, S=S, C=Cc, G=G, n=n,
                              H=H, W=W, vw_shift=vw_shift, cost_cstride=G * n, cost_coffset=0, samp_cstride=n, samp_coffset=0,
-                             interval=interval, min_radius=min_radius, max_radius=max_radius)
+                             interval=interval, min_radius=min_radius, max_radius=max_radius,
+                             tune=(_lib.TUNE_BWD_INTERLEAVED if self.tune.get("bwd_il") else 0))
         self._call("dmvs_getcost_bwd_f32", C.byref(d), _ptr(gcost), _ptr(gref), _ptr(gsrc), self.stream())
         if self.timers is not None and "dmvs_getcost_bwd_f32" in self.timers:
             # bench cfg4, algorithmic bytes: read ref + src + grad_cost, write grad_ref, read-modify-write grad_src (the scatter target)
@@ -546,6 +564,20 @@ class Ops:
         out_depth = self.empty(B, H * ratio, W * ratio)
         self._call("dmvs_convex_upsample_f32", _ptr(inv), _ptr(mask), _ptr(disp_min), _ptr(disp_max), _ptr(out_inv),
                       _ptr(out_depth), B, H, W, ratio, self.stream())
+        return out_inv, out_depth
+
+    def mask_upsample4(self, pc: PackedConv, x, inv, disp_min, disp_max, post_scale=0.25, want_inv=False):
+        """post_scale * conv1x1(pc, x) -> softmax over the 9 taps -> convex x4 upsampling of inv -> metric depth, in one launch (the
+        144-channel mask is never materialised): x [B,64,H,W], inv [B,1,H,W] or [B,H,W] -> (inv_up | None, depth_up [B,4H,4W]).
+        Bit-identical to convex_upsample(inv, conv2d(pc, x, post_scale=post_scale), ..., 4)."""
+        self._chk(x, inv, disp_min, disp_max)
+        B, cin, H, W = x.shape
+        if pc.k != (1, 1) or pc.cin != cin or pc.cout != 144 or pc.scale is not None:
+            raise _lib.DmvsError("mask_upsample4: expects the 64 -> 144 1x1 layer of the DiffMVS mask head")
+        out_inv = self.empty(B, H * 4, W * 4) if want_inv else None
+        out_depth = self.empty(B, H * 4, W * 4)
+        self._call("dmvs_mask_upsample4_f32", _ptr(x), _ptr(pc.weight), _ptr(pc.shift), post_scale, _ptr(inv), _ptr(disp_min), _ptr(disp_max),
+                   _ptr(out_inv), _ptr(out_depth), B, cin, pc.cout_pad, H, W, self.stream())
         return out_inv, out_depth
 
     def groupnorm_silu(self, x, gamma, beta, groups, scale_shift=None, residual=None, out=None, eps=1e-5):

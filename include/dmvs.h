@@ -32,7 +32,7 @@ extern "C" {
  * product, SepConvGRU's r * h) and `in0_cstride` (in0 as a channel slice) -- honoured by dmvs_conv2d_f32 only: the weight-gradient entry
  * points return DMVS_EINVAL when any of in0_cstride / gate_cstride / out_mul is set.  A caller built against version 1 passes shorter descriptors:
  * check dmvs_abi_version() == DMVS_ABI_VERSION before the first call. */
-#define DMVS_ABI_VERSION 2
+#define DMVS_ABI_VERSION 3
 #define DMVS_EINVAL (-22)
 
 /* activation codes for the fused epilogues */
@@ -83,6 +83,10 @@ int dmvs_abi_version(void);
 #define DMVS_TUNE_TILE_MT(n) (((n) & 7) << 4)     /* A/B: 1 | 2 | 4 = tile height in units of 4 rows (4: plain 3x3 / 1xk families only; timed on the stride-2 / 5x5 / 7x7 ones in round 5: +-2 %, removed) */
 #define DMVS_TUNE_1X1_TILED 0x200                 /* 1x1 layers on the LDS-tiled kernel instead of the 16-byte direct form                    */
 #define DMVS_TUNE_NO_LEAN 0x100                   /* plain layers on the generic kernel (every fused path resolved at run time)     */
+#define DMVS_TUNE_STAGGER(n) (((n) & 15) << 12)  /* start-up stagger of the first resident workgroups of a launch: the k-th workgroup a CU receives sleeps k * n * ~3.4 us
+                                                     before its first instruction (0 = off).  All workgroups of a launch do identical work, so they run in lockstep --
+                                                     everyone loads, everyone computes, everyone stores -- and the launch pays its matrix time PLUS its memory time
+                                                     (the `sum` column of bench.py --conv-table); staggered once, they stay staggered.  Same results bit for bit. */
 #define DMVS_TUNE_TALL(n) (((n) & 3) << 10)      /* 16 x 32-pixel tiles for the plain 3x3 layers: 0 = where measured better, 1 = never, 2 = wherever they apply (16 x 64 tiles: timed in round 5, 6-8 % slower, removed) */
 
 typedef struct dmvs_conv2d_desc {
@@ -258,6 +262,7 @@ typedef struct dmvs_getcost_desc {
     int32_t cost_cstride, cost_coffset, samp_cstride, samp_coffset;
     float interval, min_radius, max_radius;
     int32_t feat_dtype;     /* DMVS_DTYPE_*: element type / channel order of ref / src (the backward reads plain fp32 NHWC) */
+    int32_t tune;           /* ABI 3.  dmvs_getcost_bwd_f32: DMVS_TUNE_BWD_* (0 = default); the forward ignores it */
 } dmvs_getcost_desc;
 
 /* ---------------------------------------------------------------------------------------
@@ -295,7 +300,14 @@ int dmvs_warp_volume_f32(const float* src, const float* rt, const float* depth, 
  *   gref [B,H,W,C] is WRITTEN; gsrc [S][B,Hs,Ws,C] is ACCUMULATED with fp32 atomics (caller zeroes it,
  *   or passes the running gradient of the source features).
  */
-/* gather != 0: per-pixel atomics kernel only (A/B measurements); 0: LDS-window kernel for C = 48 (the model's stage 1) */
+/* Channel -> lane mapping of the per-pixel scatter kernels.  Default: a lane owns CONSECUTIVE channels (16-byte loads; each atomic
+ * instruction of a flush touches 4 bytes out of every 16 of the texel).  DMVS_TUNE_BWD_INTERLEAVED (dmvs_getcost_desc.tune) /
+ * gather = DMVS_BWD_GATHER_INTERLEAVED: 16 lanes per pixel, lane = channel mod 16 -- an atomic instruction covers 64 contiguous bytes of the
+ * texel, C*4/64 full requests per (pixel, tap) at the L2's atomic units instead of 4x as many quarter-filled ones.  Same sums in the same
+ * per-lane order; the two mappings differ only in how atomics from different pixels interleave (last-bit differences, as between any two runs). */
+#define DMVS_TUNE_BWD_INTERLEAVED 0x1
+#define DMVS_BWD_GATHER_INTERLEAVED 2
+/* gather != 0: per-pixel atomics kernel only (1: consecutive channels per lane, 2: interleaved); 0: LDS-window kernel for C = 48 (the model's stage 1) */
 int dmvs_warp_corr_init_bwd_f32(const float* ref, const float* src, const float* rt,
                                 const float* disp_min, const float* disp_max, const float* gcor,
                                 float* gref, float* gsrc, int32_t B, int32_t S, int32_t C, int32_t G,
@@ -331,6 +343,17 @@ int dmvs_depth_regress_f32(const float* logits, const float* disp_min, const flo
 int dmvs_convex_upsample_f32(const float* inv, const float* mask, const float* disp_min,
                              const float* disp_max, float* out_inv, float* out_depth,
                              int32_t B, int32_t H, int32_t W, int32_t ratio, void* stream);
+
+/* The mask head's last layer + upsample_depth in one launch (DiffMVS, ratio 4): logits = post_scale * (W x + bias) -- the 1x1 convolution
+ * 64 -> 144 of models/update.py:335-339 with `mask = .25 * self.mask(context)` (:473) -- then upsample_depth (models/module.py:237-248)
+ * and disp_to_depth (:220-227) exactly as dmvs_convex_upsample_f32; the 144-channel mask is never written to memory.  Results are those
+ * of dmvs_conv2d_f32 followed by dmvs_convex_upsample_f32 bit for bit.
+ *   x [B,64,H,W] (the ReLU output of the head's 3x3 layer), weight [64][1][144] (kernel layout), bias [144] or NULL, inv [B,H,W]
+ *   -> out_inv [B,4H,4W] (may be NULL), out_depth [B,4H,4W] (may be NULL; not both).  cin must be 64 and cout_pad 144 (DMVS_EINVAL otherwise:
+ *   other ratios / widths take the two entry points). */
+int dmvs_mask_upsample4_f32(const float* x, const float* weight, const float* bias, float post_scale, const float* inv,
+                            const float* disp_min, const float* disp_max, float* out_inv, float* out_depth,
+                            int32_t B, int32_t cin, int32_t cout_pad, int32_t H, int32_t W, void* stream);
 
 /* GroupNorm statistics + fused apply of Block.forward (models/update.py:124-133):
  *   y = silu( gn(x) * (scale+1) + shift ) [+ residual]

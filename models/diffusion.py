@@ -116,6 +116,8 @@ class CasDiffMVS(nn.Module):
             # warp / cost-volume nodes are libdmvs_hip.so kernels in both directions (diffmvs_amd/train.py)
             if depth_gt_ms is None:
                 raise ValueError("CasDiffMVS in train mode needs depth_gt_ms (reference diffusion.py:169)")
+            if feats is not None:      # a scene's feature store is an eval-mode cache: the train branch differentiates through FeatureNet
+                raise ValueError("CasDiffMVS.forward(feats=...) is the eval-mode scene cache; the train branch runs FeatureNet itself")
             from diffmvs_amd.train import forward_train
             ops = Ops.for_device(next(self.parameters()).device)
             return forward_train(self, imgs, proj_matrices, depth_values, depth_gt_ms, ops)

@@ -51,20 +51,48 @@ def test_descriptor_structs_match_header_field_order():
 
 def test_abi_version_pins_the_descriptor_sizes():
     """a change of a descriptor's size or of an entry point's argument list must come with a DMVS_ABI_VERSION bump (ADVICE round 3:
-    `arith` was appended under version 1): the sizes and arities of version 2 are pinned here, header and binding alike"""
+    `arith` was appended under version 1): the sizes and arities of version 3 are pinned here, header and binding alike (version 3 = version 2 +
+    dmvs_mask_upsample4_f32 and dmvs_getcost_desc.tune)"""
     src = open(os.path.join(ROOT, "include", "dmvs.h")).read()
-    assert int(re.search(r"#define DMVS_ABI_VERSION (\d+)", src).group(1)) == _lib.ABI_VERSION == 2
-    assert (ctypes.sizeof(_lib.Conv2dDesc), ctypes.sizeof(_lib.Conv3dDesc), ctypes.sizeof(_lib.GetCostDesc)) == (208, 104, 152)
+    assert int(re.search(r"#define DMVS_ABI_VERSION (\d+)", src).group(1)) == _lib.ABI_VERSION == 3
+    assert (ctypes.sizeof(_lib.Conv2dDesc), ctypes.sizeof(_lib.Conv3dDesc), ctypes.sizeof(_lib.GetCostDesc)) == (208, 104, 160)
     assert len(_lib.SIGNATURES["dmvs_featurenet_stem_f32"]) == 13 and len(_lib.SIGNATURES["dmvs_warp_corr_init_quad_f32"]) == 18
-    assert "dmvs_conv3x3_pair16_f32" not in _lib.SIGNATURES
+    assert "dmvs_conv3x3_pair16_f32" not in _lib.SIGNATURES and len(_lib.SIGNATURES["dmvs_mask_upsample4_f32"]) == 15
 
 
 def test_library_reads_no_environment_variable():
     """include/dmvs.h: no global state, no environment variables -- knobs are `tune` arguments, read from the environment (if at
     all) by the Python layer"""
     csrc = os.path.join(ROOT, "diffmvs_amd", "csrc")
-    for f in os.listdir(csrc):
-        assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+    for base, _, files in os.walk(csrc):          # (csrc/probe: the bench-only probe library obeys the same rule)
+        for f in files:
+            assert "getenv" not in open(os.path.join(base, f)).read(), f
+
+
+def test_probe_library_exports_its_header():
+    """include/dmvs_probe.h <-> diffmvs_amd/libdmvs_probe.so: the bench-only measurement kernels (GetCost ceiling probe, random line gather).
+    Built by the same build step; never loaded by the depth-estimation path (nothing under diffmvs_amd/ or models/ names it)."""
+    from diffmvs_amd.build import PROBE_LIB, build_hip
+    build_hip()
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "dmvs_probe.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\bint\s+(dmvs_probe_\w+)\s*\(", src)))
+    assert names == ["dmvs_probe_abi_version", "dmvs_probe_getcost_loads_f32", "dmvs_probe_random_line_gather"]
+    dll = ctypes.CDLL(PROBE_LIB)
+    for n in names:
+        assert hasattr(dll, n), n
+    assert dll.dmvs_probe_abi_version() == 1
+    # argument validation happens before any launch: NULL descriptor / table -> DMVS_EINVAL
+    dll.dmvs_probe_getcost_loads_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    assert dll.dmvs_probe_getcost_loads_f32(None, None) == -22
+    dll.dmvs_probe_random_line_gather.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                   ctypes.c_uint32, ctypes.c_void_p]
+    assert dll.dmvs_probe_random_line_gather(None, 1024, 16, 8, 0, 0, 1, None) == -22
+    assert dll.dmvs_probe_random_line_gather(ctypes.c_void_p(4096), 1024, 1024, 8, 0, 0, 1, None) == -22      # "once": more requests than lines
+    for pkg in ("diffmvs_amd", "models"):
+        for base, _, files in os.walk(os.path.join(ROOT, pkg)):
+            for f in files:
+                if f.endswith(".py") and f != "build.py":
+                    assert "libdmvs_probe" not in open(os.path.join(base, f)).read(), f
 
 
 def test_missing_library_fails_loudly(tmp_path):

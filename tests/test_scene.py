@@ -66,8 +66,25 @@ def test_scene_features_are_validated(ops):
         with pytest.raises(_lib.DmvsError, match="feats"):
             with torch.no_grad():
                 model(imgs[:1], proj, dv, feats=feats)
+    # a camera tensor with fewer views than the gathered rows (the kernels would index the composed projections out of bounds), a wrong channel count
+    short = {k: v[:, :2].contiguous() for k, v in proj.items()}
+    with pytest.raises(_lib.DmvsError, match="proj_matrices"):
+        with torch.no_grad():
+            model(imgs[:1], short, dv, feats=good)
+    with pytest.raises(_lib.DmvsError, match="feats"):
+        with torch.no_grad():
+            model(imgs[:1], proj, dv, feats={k: v[..., :16].contiguous() for k, v in good.items()})
     with torch.no_grad():
-        model(imgs[:1], proj, dv, feats=good)
+        out = model(imgs[:1], proj, dv, feats=good)
+        # gather(out=...): into caller-owned buffers (a captured graph's static inputs), same rows
+        bufs = {k: torch.empty_like(v) for k, v in good.items()}
+        assert store.gather(ids, out=bufs) is bufs and all(torch.equal(bufs[k], good[k]) for k in good)
+        out2 = model(imgs[:1], proj, dv, feats=bufs)
+    assert torch.equal(out["depth"][0], out2["depth"][0])
+    model.train()
+    with pytest.raises(ValueError, match="eval-mode"):
+        model(imgs, proj, dv, {"stage1": None}, feats=good)
+    model.eval()
 
 
 @pytest.mark.gpu

@@ -5,8 +5,12 @@ LDS-DMA -> ds_read dependency here).
 
     python tools/isa_dma_audit.py            # disassembles build/obj/*.o (python -m diffmvs_amd.build first); exit code 1 on a finding
 
-Heuristic, conservative: a "loop" is the address range of a backward branch; reports loops that contain a DMA and a barrier but no vmcnt(0).
-Also reports kernels with a DMA but no vmcnt(0) at all.
+Heuristic, conservative: a "loop" is the address range of a backward branch.  A loop that contains a DMA and a barrier passes when at least
+one of its barriers PUBLISHES the DMA: walking backwards from that barrier through the loop body in program (address) order, wrapping at the
+loop top, a `s_waitcnt vmcnt(0)` comes before any LDS-DMA instruction.  (Round 5 accepted any vmcnt(0) inside the range -- also one that
+sits after the barrier or serves an unrelated register dependency, the very accident dmvs_common.h describes; barriers that deliberately
+leave a prefetch in flight, DMVS_LDS_BARRIER, are fine as long as the loop has one publishing barrier.)  Also reports kernels with a DMA but
+no vmcnt(0) at all.  $HIPCC's directory / $DMVS_LLVM_BIN override the tool locations.
 """
 import os
 import re
@@ -15,7 +19,11 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LLVM = "/opt/rocm/lib/llvm/bin"
+LLVM = os.environ.get("DMVS_LLVM_BIN") or "/opt/rocm/lib/llvm/bin"
+
+
+def tools_present():
+    return all(os.path.exists(os.path.join(LLVM, t)) for t in ("clang-offload-bundler", "llvm-objdump"))
 
 
 def disassemble(obj, tmp):
@@ -60,8 +68,20 @@ def audit(text, src):
             if tgt > a or tgt not in addr_idx:
                 continue
             lo, hi = addr_idx[tgt], i
-            has_wait = any(lo <= w <= hi for w in waits)
-            loops.append((lo, hi, has_wait, any(lo <= d <= hi for d in dma) and any(lo <= b <= hi for b in bars)))
+            in_dma, in_bar, in_wait = [d for d in dma if lo <= d <= hi], [b for b in bars if lo <= b <= hi], [w for w in waits if lo <= w <= hi]
+            published = False
+            for b in in_bar:      # nearest preceding DMA-or-wait of this barrier, cyclically inside [lo, hi]
+                n = hi - lo + 1
+                for step in range(1, n + 1):
+                    j = lo + (b - lo - step) % n
+                    if j in in_wait:
+                        published = True
+                        break
+                    if j in in_dma:
+                        break
+                if published:
+                    break
+            loops.append((lo, hi, published, bool(in_dma) and bool(in_bar)))
         for lo, hi, has_wait, relevant in loops:
             if not relevant or has_wait:
                 continue
@@ -69,7 +89,7 @@ def audit(text, src):
             # enclosing backward range of the kernel waits either)
             if any(l2 <= lo <= h2 and w2 for l2, h2, w2, _ in loops):      # (their out-of-line tails may lie beyond the loop's own back edge)
                 continue
-            findings.append((src, kernel, "loop 0x%x..0x%x issues LDS-DMA and s_barrier without a vmcnt(0) inside" % (insns[lo][0], insns[hi][0])))
+            findings.append((src, kernel, "loop 0x%x..0x%x issues LDS-DMA and s_barrier, but no barrier in it is preceded by a vmcnt(0) that follows the DMA" % (insns[lo][0], insns[hi][0])))
 
     for line in text.splitlines():
         m = LABEL.match(line)
