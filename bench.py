@@ -276,25 +276,51 @@ def timed_steps(step, steps, warmup, barrier):
 
 
 def stub_main(a):
-    """The N-rank plumbing of this file (env contract, process group, barrier-bracketed timing, max over ranks, one JSON
-    line from rank 0) with a stand-in for the model: used by the CPU test over gloo, never a measurement."""
+    """The N-rank plumbing of EVERY line this file can print (env contract, process group, barrier-bracketed timing, max over ranks, one
+    JSON line from rank 0) with a stand-in for the model: used by the CPU tests over gloo, never a measurement.  Per --config the stub goes
+    through what that line's real main does between processes: cfg2 / cfg3 reference views per rank and no collective; cfg5 / --scene-mode
+    scenes dealt to the ranks by shard_scenes; cfg4 ONE all-reduce (SUM) of a flat fp32 bucket of CasDiffMVS' gradient size per step, timed."""
     from diffmvs_amd import shard
     rank, world, local = shard.env_rank_world()
     if world != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     td = shard.init_distributed(a.backend) if world > 1 else None
     x = torch.randn(64, 64)
+    kind = "scene" if a.scene_mode else a.config
+    extra, units_per_step = {}, a.batch
+    bucket, ar_s = None, []
+    if kind == "cfg4":
+        bucket = torch.full((925435,), float(rank + 1))          # CasDiffMVS: 925 435 trainable parameters (SURVEY section 8e)
+        extra = {"allreduce_bytes": bucket.numel() * 4}
+    elif kind in ("cfg5", "scene"):
+        scenes = ["scene%02d" % i for i in range(2 * world)]
+        mine = shard.shard_scenes(scenes, rank, world)
+        units_per_step = len(mine) * a.batch
+        extra = {"scene_sharding": {"scenes_total": len(scenes), "scenes_of_rank0": mine if rank == 0 else None,
+                                    "sharding": "shard_scenes: scene i -> rank i % world, no collective"}}
 
     def step():
         time.sleep(0.002 * (rank + 1))          # rank-dependent duration: the slowest rank must set the time
-        return x @ x
+        y = x @ x
+        if bucket is not None and td is not None:
+            t0 = time.perf_counter()
+            td.all_reduce(bucket, op=td.ReduceOp.SUM)        # the training path's one collective
+            ar_s.append(time.perf_counter() - t0)
+            bucket.mul_(1.0 / world)
+        return y
 
     elapsed = timed_steps(step, a.steps, a.warmup, (lambda: td.barrier()) if td else (lambda: None))
     whole = shard.barrier_and_max(elapsed)
+    total_units = shard.total_items(units_per_step) if kind in ("cfg5", "scene") else units_per_step * world
+    if bucket is not None:
+        extra["allreduce_ms_per_step"] = round(1e3 * sum(ar_s[-a.steps:]) / max(1, len(ar_s[-a.steps:])), 4) if ar_s else None
+        # every rank holds the same averaged bucket after each step (the mean of 1..world stays fixed under repeated averaging)
+        extra["bucket_value"] = float(bucket[0])
     if rank == 0:
-        print(json.dumps({"metric": "stub", "value": round(a.batch * a.steps * world / whole, 3), "n_gpus": world,
+        print(json.dumps({"metric": "stub", "stub_of": kind, "value": round(total_units * a.steps / whole, 3), "n_gpus": world,
                           "world_size_seen": td.get_world_size() if td else 1, "steps": a.steps, "warmup": a.warmup,
-                          "ms_per_step": round(whole / a.steps * 1e3, 4), "rank0_ms_per_step": round(elapsed / a.steps * 1e3, 4)}),
+                          "ms_per_step": round(whole / a.steps * 1e3, 4), "rank0_ms_per_step": round(elapsed / a.steps * 1e3, 4),
+                          "multi_gpu": "unmeasured on hardware (this is the CPU stand-in of the N-rank plumbing)", **extra}),
               flush=True)
     if td:
         td.destroy_process_group()

@@ -100,6 +100,7 @@ ABI_VERSION = 3
 TUNE_NO_WALK, TUNE_PIECES4, TUNE_NO_LEAN, TUNE_1X1_TILED, TUNE_NO_TALL, TUNE_TALL = 0x4, 0x8, 0x100, 0x200, 0x400, 0x800
 TUNE3D_PIECES4, TUNE3D_S2_DIRECT, TUNE3D_NO_PAIR = 0x1, 0x2, 0x4
 TUNE_SWEEP_GLOBAL = 0x1
+TUNE_WGRAD_ACCUMULATE = 0x1000
 TUNE_BWD_INTERLEAVED, BWD_GATHER_INTERLEAVED = 0x1, 2
 
 
@@ -109,10 +110,6 @@ def tune_tile_wx(n: int) -> int:
 
 def tune_tile_mt(n: int) -> int:
     return (n & 7) << 4
-
-
-def tune_stagger(n: int) -> int:
-    return (n & 15) << 12
 
 
 class DmvsError(RuntimeError):

@@ -38,6 +38,8 @@ def _stale() -> bool:
 def build_hip(force: bool = False, save_temps: bool = False, verbose: bool = True) -> str:
     if not force and not _stale():
         return LIB
+    import time
+    t_start = time.time()          # the libraries are stamped with the START of the build: a source edited while it ran makes them stale
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
              "-I", os.path.join(ROOT, "include"), "-I", CSRC,
@@ -59,7 +61,9 @@ def build_hip(force: bool = False, save_temps: bool = False, verbose: bool = Tru
         cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print("[diffmvs_amd.build]", " ".join(cmd), flush=True)
+        t0 = time.time()
         subprocess.run(cmd, check=True, cwd=objdir if save_temps else ROOT)
+        os.utime(obj, (t0, t0))
         return obj
 
     from concurrent.futures import ThreadPoolExecutor
@@ -70,6 +74,7 @@ def build_hip(force: bool = False, save_temps: bool = False, verbose: bool = Tru
         if verbose:
             print("[diffmvs_amd.build]", " ".join(link), flush=True)
         subprocess.run(link, check=True, cwd=ROOT)
+        os.utime(lib, (t_start, t_start))
     return LIB
 
 

@@ -241,16 +241,27 @@ static int conv1x1_px4(const dmvs_conv2d_desc& d, hipStream_t st) {
 // Workgroup = (8 input channels) x (16 output channels), sweeping 16x16 pixel tiles in a grid-stride loop;
 // wave w reduces rows 4w..4w+3 of each tile into its own accumulators, which are added to gw with hardware
 // fp32 atomics once at the end.  Same LDS-DMA staged halo tile as the forward.
-template <int KH, int KW, int S>
+//
+// V16 (round 6): both tiles staged in 16-BYTE LDS-DMA pieces.  An LDS-DMA instruction costs the texture path ~55-60 cycles whatever its
+// width (HISTORY 4.0 / 4.1), and the 4-byte form needs 27 of them per lane and tile (11 for the 8 x 18 x 18 halo, 16 for the 16 x 256 dY
+// tile) against 80 MFMAs per wave: the kernel was DMA-issue-bound at 0.15 of the matrix peak.  Here a halo row is the 16-byte aligned
+// cover of its 18 floats (SLACK extra floats on the left, pitch TWL = 24, as in conv2d_mfma_kernel's V16) and a dY row of 16 pixels is 4
+// pieces (row pitch 260 floats): 4 + 5 instructions per lane and tile.  A piece lies wholly inside or outside the image (rows of 16-byte
+// multiples: the dispatcher checks that, the alignment of the bases, a PLAIN un-gated input and "same" padding).  Same products, same order.
+template <int KH, int KW, int S, bool V16>
 __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_wgrad_kernel(const dmvs_conv2d_desc d, const float* __restrict__ gout,
                                                                   float* __restrict__ ws, int want_bias, int tiles_x, int tiles_y) {
     constexpr int T = KH * KW, CK = 8;
     constexpr int TW = 15 * S + KW, TH = 15 * S + KH;
-    constexpr int PLANE = pad16mod32(TH * TW);
-    constexpr int GROW = 257;                         // dY tile row pitch: 256 pixels + 1 (bank spread)
+    constexpr int SLACK = V16 ? (4 - ((KW - 1) / 2) % 4) % 4 : 0;      // halo column 0 inside an LDS row
+    constexpr int TWL = V16 ? (SLACK + TW + 3) / 4 * 4 : TW;           // LDS row pitch of the halo tile
+    constexpr int PLANE = pad16mod32(TH * TWL);
+    constexpr int GROW = V16 ? 260 : 257;             // dY tile row pitch: 256 pixels + 1 float (bank spread) / + one padding piece
     constexpr int NTN = (CK * T + 1 + 15) / 16;       // MFMA n-tiles over the (ci, tap) pairs of the chunk + the bias column
-    constexpr int IN_IT = (CK * PLANE + DMVS_BLOCK - 1) / DMVS_BLOCK, G_IT = (16 * GROW + DMVS_BLOCK - 1) / DMVS_BLOCK;
-    __shared__ float lds[CK * PLANE + 16 * GROW];
+    // staged units per thread: 4-byte elements, or (V16) 16-byte pieces -- piece e of the halo buffer = LDS floats 4e .. 4e+3
+    constexpr int IN_IT = ((V16 ? CK * PLANE / 4 : CK * PLANE) + DMVS_BLOCK - 1) / DMVS_BLOCK;
+    constexpr int G_IT = ((V16 ? 16 * GROW / 4 : 16 * GROW) + DMVS_BLOCK - 1) / DMVS_BLOCK;
+    __shared__ __attribute__((aligned(16))) float lds[CK * PLANE + 16 * GROW];
     DMVS_LDS_POISON(lds);
     float* s_in = lds;
     float* s_g = lds + CK * PLANE;
@@ -273,7 +284,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_wgrad_kernel(const dmvs_con
     for (int nt = 0; nt < NTN; ++nt) {
         const int jj = nt * 16 + m;
         const int ci = jj / T, t = jj - ci * T;
-        boff[nt] = jj < CK * T ? ci * PLANE + (t / KW) * TW + (t % KW) : 0;
+        boff[nt] = jj < CK * T ? ci * PLANE + (t / KW) * TWL + SLACK + (t % KW) : 0;
     }
     f32x4 acc[NTN];
 #pragma unroll
@@ -286,18 +297,27 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_wgrad_kernel(const dmvs_con
 #pragma unroll
     for (int i = 0; i < IN_IT; ++i) {
         const int e = i * DMVS_BLOCK + tid;
-        const int ci = e / PLANE, rem = e - ci * PLANE;
-        const int r = rem / TW, c = rem - r * TW;
-        const bool ok = e < CK * PLANE && rem < TH * TW && c0 + ci < cin;
-        in_cig[i] = c0 + ci;
-        in_rc[i] = ok ? (r | (c << 16)) : -1;
+        if constexpr (V16) {      // piece e -> (channel, halo row, first column of the piece relative to the halo's column 0: a multiple of 4 - SLACK)
+            const int ci = e / (PLANE / 4), rem = e - ci * (PLANE / 4);
+            const int r = rem / (TWL / 4), c = 4 * (rem - r * (TWL / 4)) - SLACK;
+            const bool ok = e < CK * PLANE / 4 && rem < TH * TWL / 4 && c0 + ci < cin;
+            in_cig[i] = c0 + ci;
+            in_rc[i] = ok ? (r | ((c + 8) << 16)) : -1;       // (+8: the slack columns are negative)
+        } else {
+            const int ci = e / PLANE, rem = e - ci * PLANE;
+            const int r = rem / TW, c = rem - r * TW;
+            const bool ok = e < CK * PLANE && rem < TH * TW && c0 + ci < cin;
+            in_cig[i] = c0 + ci;
+            in_rc[i] = ok ? (r | ((c + 8) << 16)) : -1;
+        }
     }
     int g_off[G_IT], g_pp[G_IT];
 #pragma unroll
     for (int i = 0; i < G_IT; ++i) {
         const int e = i * DMVS_BLOCK + tid;
-        const int co = e / GROW, p = e - co * GROW;
-        const bool ok = e < 16 * GROW && p < 256 && cobase + co < d.cout;
+        const int co = V16 ? e / (GROW / 4) : e / GROW;
+        const int p = V16 ? 4 * (e - co * (GROW / 4)) : e - co * GROW;      // first pixel of the piece / the pixel
+        const bool ok = e < (V16 ? 16 * GROW / 4 : 16 * GROW) && p < 256 && cobase + co < d.cout;
         g_off[i] = (cobase + co) * (int)oplane + (p >> 4) * d.Wout + (p & 15);       // relative to the tile's first pixel
         g_pp[i] = ok ? p : -1;
     }
@@ -317,29 +337,31 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_wgrad_kernel(const dmvs_con
         __syncthreads();                              // previous tile fully consumed
 #pragma unroll
         for (int i = 0; i < IN_IT; ++i) {
-            if (i * DMVS_BLOCK + tid < CK * PLANE) {
-                const int cig = in_cig[i], iy = gy0 + (in_rc[i] & 0xffff), ix = gx0 + (in_rc[i] >> 16);
+            if (i * DMVS_BLOCK + tid < (V16 ? CK * PLANE / 4 : CK * PLANE)) {
+                const int cig = in_cig[i], iy = gy0 + (in_rc[i] & 0xffff), ix = gx0 + (in_rc[i] >> 16) - 8;
                 const bool ok = in_rc[i] >= 0 && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win &&
                                 !(mode == DMVS_IN_ZEROINSERT2 && ((iy | ix) & 1));
                 int off;
-                if (mode == DMVS_IN_PLAIN) off = cig * plane0 + iy * pW + ix;
+                if (V16 || mode == DMVS_IN_PLAIN) off = cig * plane0 + iy * pW + ix;
                 else if (halfres) off = cig * plane0 + (iy >> 1) * pW + (ix >> 1);
                 else off = (cig >> 2) * plane0 + (iy * 2 + ((cig >> 1) & 1)) * pW + ix * 2 + (cig & 1);
                 const float* src = !ok ? dmvs_zero16 : (cig < d.c0 ? in0b + off : in1b + ((cig - d.c0) * plane1 + iy * d.Win + ix));
-                __builtin_amdgcn_global_load_lds(src, DMVS_LDS(s_in + i * DMVS_BLOCK + wave * 64), 4, 0, 0);
+                if constexpr (V16) __builtin_amdgcn_global_load_lds(src, DMVS_LDS(s_in + (i * DMVS_BLOCK + wave * 64) * 4), 16, 0, 0);
+                else __builtin_amdgcn_global_load_lds(src, DMVS_LDS(s_in + i * DMVS_BLOCK + wave * 64), 4, 0, 0);
             }
         }
 #pragma unroll
         for (int i = 0; i < G_IT; ++i) {
-            if (i * DMVS_BLOCK + tid < 16 * GROW) {
+            if (i * DMVS_BLOCK + tid < (V16 ? 16 * GROW / 4 : 16 * GROW)) {
                 const int p = g_pp[i];
                 const bool ok = p >= 0 && oy0 + (p >> 4) < d.Hout && ox0 + (p & 15) < d.Wout;
                 const float* src = ok ? gb + g_off[i] : dmvs_zero16;
-                __builtin_amdgcn_global_load_lds(src, DMVS_LDS(s_g + i * DMVS_BLOCK + wave * 64), 4, 0, 0);
+                if constexpr (V16) __builtin_amdgcn_global_load_lds(src, DMVS_LDS(s_g + (i * DMVS_BLOCK + wave * 64) * 4), 16, 0, 0);
+                else __builtin_amdgcn_global_load_lds(src, DMVS_LDS(s_g + i * DMVS_BLOCK + wave * 64), 4, 0, 0);
             }
         }
         DMVS_DMA_BARRIER();
-        if (mul0b) {                                   // r*h gating (GRU candidate conv): X = in0 * mul0 on the in0 channels
+        if (!V16 && mul0b) {                           // r*h gating (GRU candidate conv): X = in0 * mul0 on the in0 channels (4-byte form only)
             for (int i = 0; i < IN_IT; ++i) {
                 const int e = i * DMVS_BLOCK + tid;
                 if (e < CK * PLANE) {
@@ -358,7 +380,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_wgrad_kernel(const dmvs_con
 #pragma unroll
             for (int xg = 0; xg < 4; ++xg) {
                 const float av = s_g[m * GROW + row * 16 + xg * 4 + kq];
-                const float* ip = s_in + (row * S) * TW + (xg * 4 + kq) * S;
+                const float* ip = s_in + (row * S) * TWL + (xg * 4 + kq) * S;
 #pragma unroll
                 for (int nt = 0; nt < NTN; ++nt) {
                     float bv = ip[boff[nt]];
@@ -396,7 +418,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_wgrad_kernel(const dmvs_con
 template <int T>
 __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ gw,
                                                                          float* __restrict__ gb, int gx, int gy, int cin,
-                                                                         int cout) {
+                                                                         int cout, int accumulate) {
     constexpr int CK = 8, NTN = (CK * T + 1 + 15) / 16, PER = NTN * 256, SL = 16;
     __shared__ float red[SL][17];
     DMVS_LDS_POISON(red);
@@ -422,8 +444,12 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv2d_wgrad_reduce_kernel(const f
         const int jj = e >> 4, co = bz * 16 + (e & 15);
         const int ci = jj / T, tap = jj - ci * T;
         if (co < cout) {
-            if (jj < CK * T && by * CK + ci < cin) gw[((size_t)co * cin + by * CK + ci) * T + tap] = t;
-            else if (jj == CK * T && by == 0 && gb) gb[co] = t;
+            if (jj < CK * T && by * CK + ci < cin) {
+                float* q = gw + ((size_t)co * cin + by * CK + ci) * T + tap;
+                *q = accumulate ? *q + t : t;               // (DMVS_TUNE_WGRAD_ACCUMULATE: into the caller's running gradient)
+            } else if (jj == CK * T && by == 0 && gb) {
+                gb[co] = accumulate ? gb[co] + t : t;
+            }
         }
     }
 }
@@ -451,10 +477,17 @@ template <int KH, int KW, int S>
 int launch_wgrad(const dmvs_conv2d_desc& d, const float* gout, float* gw, float* gb, float* ws, hipStream_t st) {
     const int tiles_x = (d.Wout + 15) / 16, tiles_y = (d.Hout + 15) / 16;
     const WgradGrid g = wgrad_grid(d);
-    hipLaunchKernelGGL((conv2d_wgrad_kernel<KH, KW, S>), dim3(g.gx, g.gy, g.gz), dim3(DMVS_BLOCK), 0, st, d, gout, ws,
+    // 16-byte staging pieces: plain un-gated inputs with "same" padding, rows of 16-byte multiples on 16-byte aligned tensors
+    const bool v16 = !(d.tune & DMVS_TUNE_PIECES4) && d.in_mode == DMVS_IN_PLAIN && !d.mul0 && (d.Win & 3) == 0 && (d.Wout & 3) == 0 &&
+                     d.pad_w == (KW - 1) / 2 && (((uintptr_t)d.in0 | (uintptr_t)d.in1 | (uintptr_t)gout) & 15) == 0;
+    if (v16)
+        hipLaunchKernelGGL((conv2d_wgrad_kernel<KH, KW, S, true>), dim3(g.gx, g.gy, g.gz), dim3(DMVS_BLOCK), 0, st, d, gout, ws,
+                           gb ? 1 : 0, tiles_x, tiles_y);
+    else
+    hipLaunchKernelGGL((conv2d_wgrad_kernel<KH, KW, S, false>), dim3(g.gx, g.gy, g.gz), dim3(DMVS_BLOCK), 0, st, d, gout, ws,
                        gb ? 1 : 0, tiles_x, tiles_y);
     hipLaunchKernelGGL((conv2d_wgrad_reduce_kernel<KH * KW>), dim3(g.ntn * 16, g.gy, g.gz), dim3(DMVS_BLOCK), 0, st, ws, gw, gb,
-                       g.gx, g.gy, d.c0 + d.c1, d.cout);
+                       g.gx, g.gy, d.c0 + d.c1, d.cout, (d.tune & DMVS_TUNE_WGRAD_ACCUMULATE) ? 1 : 0);
     return dmvs_launch_status();
 }
 

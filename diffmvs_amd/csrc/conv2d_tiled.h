@@ -140,16 +140,6 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF + 32];
     DMVS_LDS_POISON(lds);
 
-#ifndef DMVS_HOST_EMULATION
-    // Start-up stagger (DMVS_TUNE_STAGGER, dmvs.h): workgroups are dealt round-robin to the 8 XCDs and, inside an XCD, one per CU before any CU
-    // gets a second one -- workgroup w is the (w / 8 / 32)-th of its CU.  The first few of every CU start k * n sleep units apart, so that one is
-    // in its load / store phase while the others are in their MFMA phase; identical work keeps them apart for the rest of the launch.
-    if (const unsigned sn = ((unsigned)d.tune >> 12) & 15u) {
-        const unsigned slot = ((blockIdx.x + gridDim.x * blockIdx.y) >> 3) >> 5;
-        if (slot < 8u)
-            for (unsigned i = 0; i < slot * sn; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA bases in SGPRs
     int m = lane & 15, kq = lane >> 4;       // (tid, m, kq not const: the tile-walking form redefines them per tile, see the tile loop)

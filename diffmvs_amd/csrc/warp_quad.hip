@@ -107,12 +107,16 @@ __device__ __forceinline__ int wave_max_i(int v) {
     return v;
 }
 
+// (Round 6, measured and removed: 8 waves per workgroup sharing one staged band, the plane chunks split over two wave sets -- 4 instead of 3
+// waves per SIMD behind the same LDS bytes, bit-identical -- 1257-1265 against 1070-1079 us per B=96 launch in the model's step
+// (profiles/r6_plane_sweep_split_ab.json): the second wave set doubles the per-group box / staging / barrier work and halves nothing but
+// the chunk loop.)
 template <int C, int TPT, int FT, int BAND_BYTES>
 __global__ void __launch_bounds__(DMVS_BLOCK)
 warp_init_band_kernel(const void* __restrict__ ref_f, const void* __restrict__ src, const float* __restrict__ rt,
                       const float* __restrict__ disp_min, const float* __restrict__ disp_max, float* __restrict__ out, int B, int S,
                       int D, int H, int W, int Hs, int Ws, int tiles_x) {
-    constexpr int NB = 8, HPL = 2, TB = Feat<C, FT>::TEXEL_BYTES, NWAVE = DMVS_BLOCK / 64;
+    constexpr int NB = 8, HPL = 2, TB = Feat<C, FT>::TEXEL_BYTES, NTHREADS = DMVS_BLOCK, NWAVE = NTHREADS / 64;
     constexpr int TAB = 256;
     __shared__ __attribute__((aligned(16))) char band[BAND_BYTES];
     __shared__ float depth_tab[TAB];
@@ -194,7 +198,7 @@ warp_init_band_kernel(const void* __restrict__ ref_f, const void* __restrict__ s
             const int ppr = ncols * (TB / 16), npieces = nrows * ppr;       // 16-byte pieces per band row / in the band
             const float inv_ppr = 1.0f / (float)ppr;
             const unsigned corner = (unsigned)(__mul24(by0, Ws) + bx0) * (unsigned)TB;
-            for (int i0 = wave * 64; i0 < npieces; i0 += DMVS_BLOCK) {
+            for (int i0 = wave * 64; i0 < npieces; i0 += NTHREADS) {
                 const int i = i0 + lane;
                 if (i < npieces) {
                     int r = (int)((float)i * inv_ppr);

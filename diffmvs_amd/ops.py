@@ -141,8 +141,7 @@ def bump_weights_generation() -> None:
     _weights_generation[0] += 1
 
 
-CONV_STAGGER_DEFAULT = 0         # start-up stagger units of the tiled conv2d kernels (include/dmvs.h DMVS_TUNE_STAGGER; round-6 A/B)
-BWD_INTERLEAVED_DEFAULT = 0      # (set by the round-6 A/B: profiles/r6_bwd_interleave_ab.json)
+BWD_INTERLEAVED_DEFAULT = 1      # round-6 A/B (profiles/r6_bwd_interleave_ab.json): getcost_bwd 33.3 -> 9.9 ms per cfg4 step, 31.3 -> 40.3 samples/s
 
 
 def _env_tune():
@@ -154,7 +153,6 @@ def _env_tune():
       DMVS_CONV3D_V16=0, DMVS_CONV3D_S2=direct, DMVS_CONV3D_PAIR=0   (dmvs_conv3d_desc.tune)      DMVS_STEM_V16=0      DMVS_PLANE_SWEEP=quad"""
     e = os.environ.get
     t2 = _lib.tune_tile_wx(int(e("DMVS_CONV_WX", "0"))) | _lib.tune_tile_mt(int(e("DMVS_CONV_MT", "0")))
-    t2 |= _lib.tune_stagger(int(e("DMVS_CONV_STAGGER", "%d" % CONV_STAGGER_DEFAULT)))
     t2 |= _lib.TUNE_NO_WALK if e("DMVS_CONV_WALK") == "0" else 0
     t2 |= _lib.TUNE_PIECES4 if e("DMVS_CONV_V16") == "0" else 0
     t2 |= _lib.TUNE_NO_LEAN if e("DMVS_CONV_LEAN") == "0" else 0
@@ -350,10 +348,12 @@ class Ops:
         self._call("dmvs_featurenet_stem_f32", _ptr(x), _ptr(pc0.weight), _ptr(pc0.scale), _ptr(pc0.shift), _ptr(pc1.weight),
                    _ptr(pc1.scale), _ptr(pc1.shift), _ptr(y), N, H, W, self.tune["stem"] if tune is None else tune, self.stream())
 
-    def conv2d_wgrad(self, pc: PackedConv, x0, grad_out, x1=None, *, mul0=None, in_mode=IN_PLAIN, want_bias=False):
+    def conv2d_wgrad(self, pc: PackedConv, x0, grad_out, x1=None, *, mul0=None, in_mode=IN_PLAIN, want_bias=False, tune=None,
+                     into_gw=None, into_gb=None):
         """Weight gradient of conv2d(pc, x0, x1, mul0=..., in_mode=...) in torch layout [cout, cin, kh, kw]
-        (and the bias gradient [cout] when want_bias) -> gw | (gw, gb)."""
-        self._chk(x0, x1, mul0, grad_out)
+        (and the bias gradient [cout] when want_bias) -> gw | (gw, gb).  into_gw (/ into_gb): ADD the gradient to these running
+        gradients (contiguous fp32 tensors of the right shapes, e.g. views of the trainer's flat bucket) instead of returning new tensors."""
+        self._chk(x0, x1, mul0, grad_out, into_gw, into_gb)
         B = x0.shape[0]
         if in_mode == IN_PLAIN:
             c0, Hin, Win = x0.shape[1], x0.shape[2], x0.shape[3]
@@ -364,14 +364,18 @@ class Ops:
         c1 = 0 if x1 is None else x1.shape[1]
         kh, kw = pc.k
         Hout, Wout = grad_out.shape[2], grad_out.shape[3]
-        gw = self.empty(pc.cout, pc.cin, kh, kw)
-        gb = self.empty(pc.cout) if want_bias else None
+        acc = into_gw is not None
+        if acc and (tuple(into_gw.shape) != (pc.cout, pc.cin, kh, kw) or (want_bias and (into_gb is None or tuple(into_gb.shape) != (pc.cout,)))):
+            raise _lib.DmvsError("conv2d_wgrad: into_gw / into_gb do not have the gradient's shape")
+        gw = into_gw if acc else self.empty(pc.cout, pc.cin, kh, kw)
+        gb = (into_gb if acc else self.empty(pc.cout)) if want_bias else None
         d = _lib.Conv2dDesc(
             in0=_ptr(x0), in1=_ptr(x1), mul0=_ptr(mul0), weight=None, scale=None, shift=None, residual=None, gru_z=None,
             gru_h=None, out=None, gn_stats=None, gn_groups=0, B=B, c0=c0, c1=c1, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout,
             cout=pc.cout, cout_pad=pc.cout_pad, kh=kh, kw=kw, stride=pc.stride, pad_h=pc.pad[0], pad_w=pc.pad[1],
             in_mode=in_mode, act=ACT_NONE, res_mode=IN_PLAIN, res_after_act=0, out_layout=LAYOUT_NCHW,
-            out_cstride=pc.cout, out_coffset=0, post_scale=1.0, gate_cstride=0, arith=ARITH_F32)
+            out_cstride=pc.cout, out_coffset=0, post_scale=1.0, gate_cstride=0, arith=ARITH_F32,
+            tune=((self.tune["conv2d"] & _lib.TUNE_PIECES4) if tune is None else tune) | (_lib.TUNE_WGRAD_ACCUMULATE if acc else 0))
         nbytes = C.c_int64(0)
         self._call("dmvs_conv2d_wgrad_workspace_f32", C.byref(d), C.byref(nbytes))
         ws = self.empty(nbytes.value // 4)

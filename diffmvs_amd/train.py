@@ -275,6 +275,8 @@ def forward_train(model, imgs, proj_matrices, depth_values, depth_gt_ms, ops: Op
     """-> {"depth": [...all iterates...], "conf": [...], "photometric_confidence": [...]} with autograd history"""
     a = model.args
     n = _Net(model, ops)
+    # a Trainer that owns the parameters' .grad views asks the convolution nodes to add weight gradients straight into them
+    n.cache["grad_into_bucket"] = bool(getattr(model, "grad_into_flat_bucket", False))
     o = ops
     dev = o.device
     t_source = getattr(model, "t_source", None) or (lambda B, T, device: torch.randint(0, T, (B,), device=device).long())

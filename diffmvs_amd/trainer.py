@@ -97,6 +97,9 @@ class Trainer:
         dev = next(model.parameters()).device
         self.ops = ops if ops is not None else Ops.for_device(dev)
         self.flat = FlatParams(model)
+        # every step goes zero_grad() -> backward: the convolution nodes may add their weight gradients straight into the bucket's views
+        # (diffmvs_amd.autograd._Conv2dFn) instead of handing autograd one tensor + one add kernel per use
+        model.grad_into_flat_bucket = True
         self.exp_avg = torch.zeros_like(self.flat.data)
         self.exp_avg_sq = torch.zeros_like(self.flat.data)
         self.sumsq = torch.zeros(1, dtype=torch.float64, device=dev)

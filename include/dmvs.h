@@ -83,10 +83,6 @@ int dmvs_abi_version(void);
 #define DMVS_TUNE_TILE_MT(n) (((n) & 7) << 4)     /* A/B: 1 | 2 | 4 = tile height in units of 4 rows (4: plain 3x3 / 1xk families only; timed on the stride-2 / 5x5 / 7x7 ones in round 5: +-2 %, removed) */
 #define DMVS_TUNE_1X1_TILED 0x200                 /* 1x1 layers on the LDS-tiled kernel instead of the 16-byte direct form                    */
 #define DMVS_TUNE_NO_LEAN 0x100                   /* plain layers on the generic kernel (every fused path resolved at run time)     */
-#define DMVS_TUNE_STAGGER(n) (((n) & 15) << 12)  /* start-up stagger of the first resident workgroups of a launch: the k-th workgroup a CU receives sleeps k * n * ~3.4 us
-                                                     before its first instruction (0 = off).  All workgroups of a launch do identical work, so they run in lockstep --
-                                                     everyone loads, everyone computes, everyone stores -- and the launch pays its matrix time PLUS its memory time
-                                                     (the `sum` column of bench.py --conv-table); staggered once, they stay staggered.  Same results bit for bit. */
 #define DMVS_TUNE_TALL(n) (((n) & 3) << 10)      /* 16 x 32-pixel tiles for the plain 3x3 layers: 0 = where measured better, 1 = never, 2 = wherever they apply (16 x 64 tiles: timed in round 5, 6-8 % slower, removed) */
 
 typedef struct dmvs_conv2d_desc {
@@ -160,7 +156,11 @@ int dmvs_featurenet_stem_f32(const float* x, const float* w0, const float* scale
  * summation order is fixed: workgroups store per-slot partial sums into `workspace` (caller-owned scratch of at
  * least dmvs_conv2d_wgrad_workspace_f32() bytes) and a second kernel folds the slots -- run-to-run reproducible
  * gradients.  The input gradient needs no entry point of its own: it is dmvs_conv2d_f32 on grad_out with the
- * spatially flipped, cin<->cout transposed weights (DMVS_IN_ZEROINSERT2 for stride 2). */
+ * spatially flipped, cin<->cout transposed weights (DMVS_IN_ZEROINSERT2 for stride 2).
+ * d->tune: DMVS_TUNE_PIECES4 = 4-byte staging pieces (A/B; bit-identical); DMVS_TUNE_WGRAD_ACCUMULATE = the fold kernel ADDS its sums to gw /
+ * gb instead of storing them (the caller's running gradient of a weight that several layers of a step share: one read-modify-write
+ * per element instead of a store here + an add kernel elsewhere; the order of the additions is the order of the calls on the stream). */
+#define DMVS_TUNE_WGRAD_ACCUMULATE 0x1000
 int dmvs_conv2d_wgrad_workspace_f32(const dmvs_conv2d_desc* d, int64_t* bytes);
 int dmvs_conv2d_wgrad_f32(const dmvs_conv2d_desc* d, const float* grad_out, float* gw, float* gb, float* workspace,
                           int64_t workspace_bytes, void* stream);

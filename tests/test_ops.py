@@ -1595,3 +1595,37 @@ def test_mask_upsample4(ops, B, H, W):
     pc36 = K.pack_conv2d(rnd(36, 64, 1, 1, seed=5), rnd(36, seed=6))
     with pytest.raises(K._lib.DmvsError):
         ops.mask_upsample4(pc36, xd, invd, lod, hid)
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,H,W,two", [(8, 16, 3, 1, 1, 12, 20, False), (13, 20, 3, 1, 1, 33, 40, True), (6, 10, 5, 2, 2, 24, 32, False),
+                                                            (16, 8, 7, 1, 3, 17, 24, False), (12, 20, 1, 1, 0, 9, 16, False), (9, 7, (1, 5), 1, (0, 2), 10, 12, False)])
+def test_conv2d_wgrad_16_byte_staging_pieces(ops, cin, cout, k, stride, pad, H, W, two):
+    """the weight-gradient kernel with both tiles staged in 16-byte LDS-DMA pieces (round 6: 9 instead of 27 DMA instructions per lane and
+    tile) against autograd, and bit for bit against the 4-byte form (DMVS_TUNE_PIECES4): channel counts that are not multiples of the
+    8-channel workgroup slice, a concatenated second input, ragged tiles in y, stride 2, several tiles per workgroup"""
+    B = 2
+    ks = (k, k) if isinstance(k, int) else k
+    pd = (pad, pad) if isinstance(pad, int) else pad
+    c1 = 5 if two else 0
+    x0 = rnd(B, cin - c1, H, W, seed=1)
+    x1 = rnd(B, c1, H, W, seed=2) if two else None
+    x = (x0 if x1 is None else torch.cat([x0, x1], 1)).requires_grad_(False)
+    w = (rnd(cout, cin, *ks, seed=3) * 0.2).requires_grad_(True)
+    bias = rnd(cout, seed=4).requires_grad_(True)
+    y = F.conv2d(x, w, bias, stride, pd)
+    gy = rnd(*y.shape, seed=5)
+    y.backward(gy)
+    pc = K.pack_conv2d(w.detach(), bias.detach(), stride=stride, pad=pd)
+    args = (pc, dev(ops, x0), dev(ops, gy), None if x1 is None else dev(ops, x1))
+    gw, gb = ops.conv2d_wgrad(*args, want_bias=True)
+    close(gw, w.grad, 2e-4)
+    close(gb, bias.grad, 2e-4)
+    gw4, gb4 = ops.conv2d_wgrad(*args, want_bias=True, tune=K._lib.TUNE_PIECES4)
+    assert torch.equal(gw, gw4) and torch.equal(gb, gb4)
+    # DMVS_TUNE_WGRAD_ACCUMULATE: the fold kernel adds into the caller's running gradient (the trainer's flat-bucket views)
+    run_w, run_b = dev(ops, torch.full_like(w.detach(), 0.5), torch.full_like(bias.detach(), -1.0))
+    for _ in range(2):
+        ops.conv2d_wgrad(*args, want_bias=True, into_gw=run_w, into_gb=run_b)
+    close(run_w, 0.5 + 2 * w.grad, 4e-4)
+    close(run_b, -1.0 + 2 * bias.grad, 4e-4)
+    assert torch.equal(run_w.cpu(), (0.5 + gw.cpu()) + gw.cpu())

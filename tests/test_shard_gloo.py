@@ -82,3 +82,27 @@ def test_bench_spawns_ranks(tmp_path):
     cp2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub-model", "--backend", "gloo"],
                          env=env2, capture_output=True, text=True, timeout=120)
     assert cp2.returncode != 0 and "WORLD_SIZE=1" in cp2.stderr
+
+
+def test_bench_spawns_ranks_for_every_line(tmp_path):
+    """every line bench.py can print with --gpus N -- the training step (cfg4: one all-reduce of the flat gradient bucket per step), the
+    scene-sharded configurations (cfg5, --scene-mode) and cfg3 -- spawned over 2 gloo ranks with the stand-in model, reduced and printed once.
+    None of them has run on more than one MI355X (1-GPU leases): the lines say so."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    for extra, kind in ((["--config", "cfg4"], "cfg4"), (["--config", "cfg5"], "cfg5"), (["--config", "cfg3"], "cfg3"), (["--scene-mode"], "scene")):
+        cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo",
+                             "--stub-model", "--batch", "2"] + extra, env=env, capture_output=True, text=True, timeout=180)
+        assert cp.returncode == 0, (kind, cp.stderr[-2000:])
+        lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, (kind, cp.stdout)
+        r = json.loads(lines[0])
+        assert r["stub_of"] == kind and r["n_gpus"] == 2 and r["world_size_seen"] == 2 and "unmeasured on hardware" in r["multi_gpu"]
+        assert r["ms_per_step"] >= 3.9                                   # the slower rank sets the time
+        if kind == "cfg4":
+            assert r["allreduce_bytes"] == 925435 * 4 and r["allreduce_ms_per_step"] > 0
+            assert abs(r["bucket_value"] - 1.5) < 1e-6                  # SUM over ranks (1 + 2) / world: both ranks hold the average
+        if kind in ("cfg5", "scene"):
+            sh = r["scene_sharding"]
+            assert sh["scenes_total"] == 4 and sh["scenes_of_rank0"] == ["scene00", "scene02"]
+            assert abs(r["value"] - 4 * 2 * 3 / (r["ms_per_step"] * 3e-3)) < 1e-2 * r["value"]      # all ranks' scenes x batch x steps / whole time
