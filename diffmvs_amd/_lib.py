@@ -101,6 +101,10 @@ TUNE_NO_WALK, TUNE_PIECES4, TUNE_NO_LEAN, TUNE_1X1_TILED, TUNE_NO_TALL, TUNE_TAL
 TUNE3D_PIECES4, TUNE3D_S2_DIRECT, TUNE3D_NO_PAIR = 0x1, 0x2, 0x4
 TUNE_SWEEP_GLOBAL = 0x1
 TUNE_WGRAD_ACCUMULATE = 0x1000
+
+
+def tune_xcd_group(n: int) -> int:      # DMVS_TUNE_XCD_GROUP(n)
+    return (int(n) & 7) << 14
 TUNE_BWD_INTERLEAVED, BWD_GATHER_INTERLEAVED = 0x1, 2
 
 

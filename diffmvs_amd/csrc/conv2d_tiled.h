@@ -146,6 +146,14 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     const int wx = wave % WX, wy = wave / WX;      // this wave's 16-pixel column block and row block inside the tile
     int tile = blockIdx.x;   // round-robin over XCDs: an XCD-contiguous remap measured 6-8 % SLOWER here (HBM channel spread)
     const int ntiles = tiles_x * tiles_y * d.B;
+    if constexpr (!WALK) {
+        // DMVS_TUNE_XCD_GROUP (round 6): groups of x-adjacent tiles per XCD (dmvs_xcd_grouped_block) -- wave-uniform, a bijection of the tiles
+        const int xg = (d.tune >> 14) & 7;
+        if (xg >= 2) {
+            const int g = xg <= 4 ? (1 << (xg - 1)) : (xg == 5 ? tiles_x : (xg == 6 ? 2 * tiles_x : tiles_x * tiles_y));
+            tile = (int)dmvs_xcd_grouped_block((unsigned)tile, (unsigned)ntiles, (unsigned)g);
+        }
+    }
     // s_* / gy0 / gx0: the tile whose input is being STAGED; b / ox0 / oy0 (set at the top of the tile loop): the tile being
     // computed and stored.  They differ only while WALK prefetches the next tile under the last chunk of the current one.
     int s_b, s_ox0, s_oy0, gy0, gx0;

@@ -147,3 +147,15 @@ __device__ __forceinline__ unsigned dmvs_xcd_contiguous_block(unsigned bid, unsi
     const unsigned q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u, idx = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
+
+// The in-between mapping (round 6): XCD x takes GROUPS of g consecutive logical blocks -- blocks b, b + 8, b + 16, ... of one XCD are the
+// g members of one group, then of the group 8 further on -- so that x-adjacent tiles, whose rows are halves of the same 128-byte lines
+// (a 16-pixel fp32 tile row is 64 bytes) and whose halo columns overlap, meet in ONE L2, while the eight XCDs still sweep the same
+// region of the tensor at the same time (the HBM channel spread of the plain round-robin order, which the contiguous-eighths
+// mapping above gives up).  Bijective: the last nblk % (8 g) blocks keep their own index.
+__device__ __forceinline__ unsigned dmvs_xcd_grouped_block(unsigned bid, unsigned nblk, unsigned g) {
+    const unsigned span = 8u * g, full = nblk / span * span;
+    if (bid >= full) return bid;
+    const unsigned xcd = bid & 7u, idx = bid >> 3;
+    return ((idx / g) * 8u + xcd) * g + idx % g;
+}

@@ -149,7 +149,7 @@ def _env_tune():
     itself reads no environment variable -- and Ops.for_device keeps ONE binding per (library, device) for the life of the process: changing
     a variable after the first forward has no effect (A/B tools pass tune= per call, mutate ops.tune, or construct a fresh Ops).
     All default to 0 = the library's measured-best path:
-      DMVS_CONV_WX=1|2, DMVS_CONV_MT=1|2|4, DMVS_CONV_WALK=0, DMVS_CONV_LEAN=0, DMVS_CONV_V16=0, DMVS_CONV1X1_PX4=0, DMVS_CONV_TALL=0|1   (dmvs_conv2d_desc.tune)
+      DMVS_CONV_WX=1|2, DMVS_CONV_MT=1|2|4, DMVS_CONV_WALK=0, DMVS_CONV_LEAN=0, DMVS_CONV_V16=0, DMVS_CONV1X1_PX4=0, DMVS_CONV_TALL=0|1, DMVS_CONV_XCD=1..7   (dmvs_conv2d_desc.tune)
       DMVS_CONV3D_V16=0, DMVS_CONV3D_S2=direct, DMVS_CONV3D_PAIR=0   (dmvs_conv3d_desc.tune)      DMVS_STEM_V16=0      DMVS_PLANE_SWEEP=quad"""
     e = os.environ.get
     t2 = _lib.tune_tile_wx(int(e("DMVS_CONV_WX", "0"))) | _lib.tune_tile_mt(int(e("DMVS_CONV_MT", "0")))
@@ -158,6 +158,7 @@ def _env_tune():
     t2 |= _lib.TUNE_NO_LEAN if e("DMVS_CONV_LEAN") == "0" else 0
     t2 |= _lib.TUNE_1X1_TILED if e("DMVS_CONV1X1_PX4") == "0" else 0
     t2 |= {"0": _lib.TUNE_NO_TALL, "1": _lib.TUNE_TALL}.get(e("DMVS_CONV_TALL"), 0)
+    t2 |= _lib.tune_xcd_group(int(e("DMVS_CONV_XCD", "0")))      # round 6: which tiles share an XCD's L2 (include/dmvs.h DMVS_TUNE_XCD_GROUP)
     t3 = (_lib.TUNE3D_PIECES4 if e("DMVS_CONV3D_V16") == "0" else 0) | (_lib.TUNE3D_S2_DIRECT if e("DMVS_CONV3D_S2") == "direct" else 0)
     t3 |= _lib.TUNE3D_NO_PAIR if e("DMVS_CONV3D_PAIR") == "0" else 0
     return {"conv2d": t2, "conv3d": t3, "stem": _lib.TUNE_PIECES4 if e("DMVS_STEM_V16") == "0" else 0,

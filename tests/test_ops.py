@@ -817,6 +817,21 @@ def test_conv2d_tall_tiles(ops, cin, c1, cout, HW, extra):
         assert float((a - b).abs().max()) <= 1e-3 * max(1.0, float(a.abs().max()))
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,HW,B", [(16, 16, 3, 1, (64, 80), 5), (16, 32, 3, 1, (40, 52), 3), (8, 16, 5, 2, (50, 72), 4), (32, 16, 7, 1, (37, 36), 9),
+                                                     (16, 16, 3, 1, (33, 36), 17)])
+def test_conv2d_xcd_grouped_tiles(ops, cin, cout, k, stride, HW, B):
+    """DMVS_TUNE_XCD_GROUP(n): which tiles meet in one XCD's L2 is a bijection of the tile indices -- every group size, with tile counts
+    that are and are not multiples of 8 x the group, gives the round-robin order's bits"""
+    x = rnd(B, cin, *HW, seed=1)
+    w, bias = rnd(cout, cin, k, k, seed=2) * 0.2, rnd(cout, seed=3)
+    ref = F.relu(F.conv2d(x, w, bias, stride, k // 2))
+    pc = K.pack_conv2d(*dev(ops, w, bias), stride=stride, pad=k // 2)
+    outs = [ops.conv2d(pc, dev(ops, x), act=K.ACT_RELU, tune=K._lib.tune_xcd_group(n)).cpu() for n in range(1, 8)]
+    close(outs[0], ref, 2e-5)
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)
+
+
 @pytest.mark.parametrize("cin,cout,k,stride,HW", [(8, 16, 5, 2, (50, 72)), (16, 32, 5, 2, (44, 40)), (32, 16, 7, 1, (37, 36)), (8, 16, 3, 2, (40, 52)),
                                                    (32, 64, 5, 2, (36, 40)), (16, 16, 3, 1, (33, 36))])
 def test_conv2d_forced_tile_heights(ops, cin, cout, k, stride, HW):
