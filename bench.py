@@ -81,10 +81,12 @@ class ProbeLib:
         from diffmvs_amd import _lib
         self.dll = C.CDLL(self.PATH)
         self.dll.dmvs_probe_abi_version.restype = C.c_int
-        if self.dll.dmvs_probe_abi_version() != 1:
+        if self.dll.dmvs_probe_abi_version() != 2:
             raise RuntimeError("libdmvs_probe.so: unexpected ABI version")
         self.dll.dmvs_probe_getcost_loads_f32.argtypes = [C.POINTER(_lib.GetCostDesc), C.c_void_p]
         self.dll.dmvs_probe_getcost_loads_f32.restype = C.c_int
+        self.dll.dmvs_probe_getcost_pair_loads_f32.argtypes = [C.POINTER(_lib.GetCostDesc), C.c_void_p]
+        self.dll.dmvs_probe_getcost_pair_loads_f32.restype = C.c_int
         self.dll.dmvs_probe_random_line_gather.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p]
         self.dll.dmvs_probe_random_line_gather.restype = C.c_int
         self._C = C
@@ -93,6 +95,11 @@ class ProbeLib:
         rc = self.dll.dmvs_probe_getcost_loads_f32(self._C.byref(desc), stream)
         if rc:
             raise RuntimeError(f"dmvs_probe_getcost_loads_f32 -> {rc}")
+
+    def getcost_pair_loads(self, desc, stream):
+        rc = self.dll.dmvs_probe_getcost_pair_loads_f32(self._C.byref(desc), stream)
+        if rc:
+            raise RuntimeError(f"dmvs_probe_getcost_pair_loads_f32 -> {rc}")
 
     def random_line_gather(self, table, n_lines, n_quads, lines_per_quad, mode, window, seed, stream):
         rc = self.dll.dmvs_probe_random_line_gather(self._C.c_void_p(table.data_ptr()), n_lines, n_quads, lines_per_quad, mode, window, seed, stream)
@@ -503,7 +510,7 @@ def main():
                          "configs[4]: CasDiffMVS 1920x1056, 11 source views, numdepth_initial 96, fp16 feature storage, scenes sharded "
                          "over the ranks (second lines, not the headline)")
     ap.add_argument("--precision", default=None, choices=["fp32", "bf16", "fp16"], help="feature storage precision (default: the config's)")
-    ap.add_argument("--conv-arith", default=None, choices=["fp32", "bf16"],
+    ap.add_argument("--conv-arith", default=None, choices=["fp32", "bf16", "split"],
                     help="matrix arithmetic of the 2-D convolutions (default: fp32 for cfg2 -- the headline is an fp32 number -- and "
                          "bf16 for cfg3, whose BASELINE.json entry is a bf16 configuration)")
     ap.add_argument("--scene-mode", action="store_true",

@@ -17,7 +17,7 @@ ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_SILU = range(5)
 IN_PLAIN, IN_UPSAMPLE2, IN_UNSHUFFLE2, IN_ZEROINSERT2 = range(4)
 LAYOUT_NCHW, LAYOUT_NHWC, LAYOUT_NHWC_BF16, LAYOUT_NHWC_F16 = 0, 1, 2, 3
 DTYPE_F32, DTYPE_BF16, DTYPE_F16, DTYPE_F32_PLAIN = 0, 1, 2, 3
-ARITH_F32, ARITH_BF16 = 0, 1
+ARITH_F32, ARITH_BF16, ARITH_SPLIT = 0, 1, 2
 EW_DEPTH_TO_DISP, EW_DISP_TO_DEPTH = 0, 1
 
 _P = C.c_void_p
@@ -105,6 +105,10 @@ TUNE_WGRAD_ACCUMULATE = 0x1000
 
 def tune_xcd_group(n: int) -> int:      # DMVS_TUNE_XCD_GROUP(n)
     return (int(n) & 7) << 14
+
+
+def tune3d_xcd_group(n: int) -> int:      # DMVS_TUNE3D_XCD_GROUP(n)
+    return (int(n) & 7) << 4
 TUNE_BWD_INTERLEAVED, BWD_GATHER_INTERLEAVED = 0x1, 2
 
 

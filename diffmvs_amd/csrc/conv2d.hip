@@ -508,7 +508,7 @@ extern "C" int dmvs_conv2d_f32(const dmvs_conv2d_desc* dp, void* stream) {
     if (d.in0_cstride < 0 || (d.in0_cstride && (d.in_mode != DMVS_IN_PLAIN || d.in0_cstride < d.c0))) return DMVS_EINVAL;
     if (d.out_mul && (d.out_mul_c0 < 0 || d.out_mul_c0 >= d.cout || d.gn_stats)) return DMVS_EINVAL;
     if (d.gn_stats && (d.gn_groups != 4 || d.cout % 4)) return DMVS_EINVAL;
-    if (d.arith != DMVS_ARITH_F32 && d.arith != DMVS_ARITH_BF16) return DMVS_EINVAL;
+    if (d.arith != DMVS_ARITH_F32 && d.arith != DMVS_ARITH_BF16 && d.arith != DMVS_ARITH_SPLIT) return DMVS_EINVAL;
     const int eh = (d.Hin + 2 * d.pad_h - d.kh) / d.stride + 1, ew = (d.Win + 2 * d.pad_w - d.kw) / d.stride + 1;
     if (eh != d.Hout || ew != d.Wout) return DMVS_EINVAL;
     // 32-bit element offsets inside one batch item

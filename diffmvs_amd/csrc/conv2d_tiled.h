@@ -41,6 +41,28 @@ __device__ __forceinline__ f32x4 dmvs_mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
 }
 #endif
 
+// DMVS_ARITH_SPLIT: an fp32 value as the sum of three bf16 values, hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid), each rounded to
+// nearest even: the two remainders are exact in fp32, |mid| <= 2^-9 |x|, |lo| <= 2^-18 |x|, and x - (hi + mid + lo) is below 2^-27 |x|.  (Splitting
+// by truncation is exact but gives all three parts the sign of x: the dropped partial products then all have the product's sign and add up to
+// a bias of ~1e-7 x sum |a b| -- measured 2.4x the fma chain's error on a 7x7 layer.  Rounded parts have independent signs.)  For 8 values at
+// once, packed as the three k-slot operands of v_mfma_f32_16x16x32_bf16: 1.5 conversions + 2 unpacks + 2 subtractions per value.  (inf -> NaN.)
+__device__ __forceinline__ void dmvs_bf16x8_to_f32(const bf16x8& p, float (&f)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = __uint_as_float((uint32_t)(uint16_t)p[j] << 16);
+}
+__device__ __forceinline__ void dmvs_split3_bf16x8(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+    float f[8], r1[8], r2[8];
+    h = dmvs_pack_bf16x8(v);
+    dmvs_bf16x8_to_f32(h, f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r1[j] = v[j] - f[j];
+    m = dmvs_pack_bf16x8(r1);
+    dmvs_bf16x8_to_f32(m, f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r2[j] = r1[j] - f[j];
+    l = dmvs_pack_bf16x8(r2);
+}
+
 namespace {
 
 
@@ -72,7 +94,10 @@ struct ConvCfg {
     // input channels per LDS chunk: 8 when the double-buffered chunk stays within 40 KB, else 4 (the bf16 form: always 8,
     // its matrix instruction spans 8 channels); decided on the 4-byte form's plane so that both staging forms chunk alike
     // (4-channel chunks for the one-n-tile 3x3 layers -- half the LDS, 8 instead of 5 workgroups per CU -- measured 4-6 % slower)
-    static constexpr int CK = AR == DMVS_ARITH_BF16 ? 8 : ((2 * 8 * (pad16mod32(TH * TW) + WPAD) * 4 > 40960) ? 4 : 8);
+    static constexpr int CK = AR != DMVS_ARITH_F32 ? 8 : ((2 * 8 * (pad16mod32(TH * TW) + WPAD) * 4 > 40960) ? 4 : 8);
+    // (DMVS_ARITH_SPLIT) the chunk's halo tile as three bf16 planes [plane][TH * TW positions][8 channels]: 16 bytes per position and plane
+    static constexpr int QPOS = TH * TW;
+    static constexpr int QFLOATS = AR == DMVS_ARITH_SPLIT ? 3 * QPOS * 4 : 0;
     static constexpr int BUF = CK * (PLANE + WPAD);            // floats per pipeline stage
     static constexpr int IN_IT = (CK * PLANE + DMVS_BLOCK - 1) / DMVS_BLOCK;           // 4-byte DMA pieces per thread
     static constexpr int W_IT = (CK * WPAD / 4 + DMVS_BLOCK - 1) / DMVS_BLOCK;         // 16-byte DMA pieces per thread
@@ -137,7 +162,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     constexpr int CK = Cfg::CK, BUF = Cfg::BUF, IN_IT = Cfg::IN_IT, W_IT = Cfg::W_IT;
     // one LDS object on purpose (tile buffers + the 32-float GroupNorm scratch): with separate objects hipcc orders reads of
     // one against LDS-DMA into another with vmcnt(0) waits (conv3d.hip, conv3d_mfma_stream_kernel)
-    __shared__ __attribute__((aligned(16))) float lds[2 * BUF + 32];
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF + 32 + Cfg::QFLOATS];
     DMVS_LDS_POISON(lds);
 
     int tid = threadIdx.x;
@@ -146,18 +171,20 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     const int wx = wave % WX, wy = wave / WX;      // this wave's 16-pixel column block and row block inside the tile
     int tile = blockIdx.x;   // round-robin over XCDs: an XCD-contiguous remap measured 6-8 % SLOWER here (HBM channel spread)
     const int ntiles = tiles_x * tiles_y * d.B;
-    if constexpr (!WALK) {
-        // DMVS_TUNE_XCD_GROUP (round 6): groups of x-adjacent tiles per XCD (dmvs_xcd_grouped_block) -- wave-uniform, a bijection of the tiles
-        const int xg = (d.tune >> 14) & 7;
-        if (xg >= 2) {
-            const int g = xg <= 4 ? (1 << (xg - 1)) : (xg == 5 ? tiles_x : (xg == 6 ? 2 * tiles_x : tiles_x * tiles_y));
-            tile = (int)dmvs_xcd_grouped_block((unsigned)tile, (unsigned)ntiles, (unsigned)g);
-        }
-    }
+    // Which tiles meet in one XCD's L2 (round 6; dmvs_common.h dmvs_xcd_grouped_block): a 16-pixel fp32 tile row is 64 bytes -- half a cache line
+    // -- and x-adjacent tiles share halo columns, so under the plain round-robin dispatch every line of the input is fetched, and every line
+    // of the output written, by two XCDs.  Groups of 4 (one-n-tile 3x3 layers: 8) x-adjacent tiles per XCD, measured over plain round
+    // robin / 2 / 4 / 8 / a tile row / two rows / an image (profiles/r6_conv_xcd_group_ab.json): the 16 -> 16 layers -3 ... -10 %, the
+    // convolutions of a B = 96 step 52.9 -> 52.2 ms; whole rows or images per XCD give half of that.  `tile` stays the dispatch index
+    // (the walking form strides it); the remap happens at decode.  A bijection of the tile indices: bit-identical results.
+    const int xg = (d.tune >> 14) & 7;
+    const unsigned xgroup = xg == 0 ? ((NT == 1 && KH * KW == 9) ? 8u : 4u)
+                                    : (xg <= 4 ? 1u << (xg - 1) : (unsigned)(xg == 5 ? tiles_x : (xg == 6 ? 2 * tiles_x : tiles_x * tiles_y)));
     // s_* / gy0 / gx0: the tile whose input is being STAGED; b / ox0 / oy0 (set at the top of the tile loop): the tile being
     // computed and stored.  They differ only while WALK prefetches the next tile under the last chunk of the current one.
     int s_b, s_ox0, s_oy0, gy0, gx0;
     auto decode_tile = [&](int t) {
+        t = (int)dmvs_xcd_grouped_block((unsigned)t, (unsigned)ntiles, xgroup);
         const int tx = t % tiles_x;
         t /= tiles_x;
         const int ty = t % tiles_y;
@@ -361,10 +388,14 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     }
     const int b = s_b, ox0 = s_ox0, oy0 = s_oy0;
     f32x4 acc[MT][NT];
+    [[maybe_unused]] f32x4 acc_small[AR == DMVS_ARITH_SPLIT ? MT : 1][AR == DMVS_ARITH_SPLIT ? NT : 1];      // (split arithmetic) the small partial products
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int j = 0; j < NT; ++j) {
+            acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if constexpr (AR == DMVS_ARITH_SPLIT) acc_small[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
     for (int c0 = 0; c0 < cin; c0 += CK, cur ^= 1) {
         float* s_in = lds + cur * BUF;
         float* s_w = s_in + CK * PLANE;
@@ -395,7 +426,80 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
             if (border) zero_padding(other);
             stage(0, other);
         }
-        if constexpr (AR == DMVS_ARITH_BF16) {
+        if constexpr (AR == DMVS_ARITH_SPLIT) {
+            // Split-bf16 arithmetic with fp32 accuracy (round 6).  The fp32 MFMA runs at the vector ALU's rate and -- measured with
+            // tools/calib/overlap_probe.hip -- a CU executing it makes NO progress on vector-memory instructions (fp32 MFMAs and HBM streaming
+            // in one CU take the SUM of their times; bf16 MFMAs and VALU work overlap with memory), which is why every fp32 layer's time is
+            // its matrix time plus its memory time.  Here every fp32 operand is split into three bf16 values (hi + mid + lo = x to 2^-27) and the
+            // product a * b is formed as the six partial products down to 2^-18 (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi; the three
+            // dropped ones are below 2^-26 of the product) on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: 6 x 16 cycles per K = 32
+            // instead of 8 x 32, and the staging DMA proceeds underneath.  K = 32 = the chunk's 8 channels x 4 taps, as in the bf16 form.
+            //   pass 1: the staged fp32 halo tile -> three bf16 planes in LDS, ONCE per element (not once per tap that reads it);
+            //   pass 2: per tap group, weights split on the fly (amortised over the wave's MT rows), the pixel operand is three 16-byte reads.
+            static_assert(CK == 8, "the split form maps the 8 channels of an LDS chunk onto the 8 k-slots of a lane");
+            typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+            u32x4s* const q_hi = reinterpret_cast<u32x4s*>(lds + 2 * BUF + 32);
+            u32x4s* const q_mid = q_hi + Cfg::QPOS;
+            u32x4s* const q_lo = q_mid + Cfg::QPOS;
+            for (int e = tid; e < Cfg::QPOS; e += DMVS_BLOCK) {
+                const int r = e / TW, c = e - r * TW;
+                const float* sp = s_in + r * TWL + SLACK + c;
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = sp[j * PLANE];
+                bf16x8 h8, m8, l8;
+                dmvs_split3_bf16x8(v, h8, m8, l8);
+                q_hi[e] = __builtin_bit_cast(u32x4s, h8);
+                q_mid[e] = __builtin_bit_cast(u32x4s, m8);
+                q_lo[e] = __builtin_bit_cast(u32x4s, l8);
+            }
+            DMVS_LDS_BARRIER();        // the planes are complete (ds_writes only: the next chunk's DMA stays in flight)
+            constexpr int NG = (T + 3) / 4;          // tap groups: K = 32 = 4 taps x 8 channels
+#pragma unroll 1
+            for (int g = 0; g < NG; ++g) {
+                const int t = 4 * g + kq;
+                const bool tv = t < T;
+                const int tc = tv ? t : T - 1;
+                const int ky = tc / KW, kx = tc - ky * KW;
+                const float* wp = s_w + tc * NW + m;
+                bf16x8 ah[NT], am[NT], al[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    float a[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a[j] = tv ? wp[j * WPAD + nt * 16] : 0.0f;      // tap beyond the kernel: zero weights
+                    dmvs_split3_bf16x8(a, ah[nt], am[nt], al[nt]);
+                }
+                const int qbase = ((wy * MT * S) + ky) * TW + (wx * 16 + m) * S + kx;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int qp = qbase + (mt * S) * TW;
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, q_hi[qp]), bm = __builtin_bit_cast(bf16x8, q_mid[qp]), bl = __builtin_bit_cast(bf16x8, q_lo[qp]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        // the five small partial products (<= 2^-8 of hi*hi) in their own accumulator: their roundings are relative to a sum
+                        // 2^-8 the size, so the result carries the rounding error of ONE accumulation chain, like the fma chain it replaces
+                        f32x4 c = acc_small[mt][nt];
+                        if constexpr (TR) {
+                            c = dmvs_mfma_bf16(bl, ah[nt], c);
+                            c = dmvs_mfma_bf16(bh, al[nt], c);
+                            c = dmvs_mfma_bf16(bm, am[nt], c);
+                            c = dmvs_mfma_bf16(bm, ah[nt], c);
+                            c = dmvs_mfma_bf16(bh, am[nt], c);
+                            acc[mt][nt] = dmvs_mfma_bf16(bh, ah[nt], acc[mt][nt]);
+                        } else {
+                            c = dmvs_mfma_bf16(ah[nt], bl, c);
+                            c = dmvs_mfma_bf16(al[nt], bh, c);
+                            c = dmvs_mfma_bf16(am[nt], bm, c);
+                            c = dmvs_mfma_bf16(ah[nt], bm, c);
+                            c = dmvs_mfma_bf16(am[nt], bh, c);
+                            acc[mt][nt] = dmvs_mfma_bf16(ah[nt], bh, acc[mt][nt]);
+                        }
+                        acc_small[mt][nt] = c;
+                    }
+                }
+            }
+        } else if constexpr (AR == DMVS_ARITH_BF16) {
             static_assert(CK == 8, "the bf16 form maps the 8 channels of an LDS chunk onto the 8 k-slots of a lane");
             constexpr int NG = (T + 3) / 4;          // tap groups: K = 32 = 4 taps x 8 channels
 #pragma unroll 1
@@ -465,6 +569,12 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
         }
     }
 
+    if constexpr (AR == DMVS_ARITH_SPLIT) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] += acc_small[i][j];
+    }
     // ---- epilogue: this lane holds couts nbase + nt*16 + 4*kq + r of pixels (oy0 + MT*wave + mt, ox0 + m)
     const int ox = ox0 + wx * 16 + m;
     const int oplane = d.Hout * d.Wout;
@@ -751,6 +861,16 @@ static bool conv_bf16_honoured(const dmvs_conv2d_desc& d) {
     return d.arith == DMVS_ARITH_BF16 && d.out_layout == DMVS_LAYOUT_NCHW && d.stride == 1 && d.kh * d.kw > 1 && d.c0 + d.c1 >= 24;
 }
 
+// Which layers compute in split-bf16 (fp32-accurate) arithmetic when the caller asks for DMVS_ARITH_SPLIT: multi-tap layers with a planar fp32
+// output whose input can be staged in 16-byte pieces (every layer of the reference configurations); 1x1 layers (one tap per K = 32 group would
+// waste three quarters of the matrix work), channel-last outputs and the training-only zero-insert form keep the exact-fp32 kernels.
+template <int KW>
+static bool conv_v16_ok(const dmvs_conv2d_desc& d);
+template <int KW>
+static bool conv_split_honoured(const dmvs_conv2d_desc& d) {
+    return d.arith == DMVS_ARITH_SPLIT && d.out_layout == DMVS_LAYOUT_NCHW && d.kh * d.kw > 1 && d.in_mode != DMVS_IN_ZEROINSERT2 && conv_v16_ok<KW>(d);
+}
+
 // Waves side by side in a workgroup's tile (template WX) for a 3x3 / 5x5 layer with planar output.  Measured at B = 96
 // (profiles/r3_conv_wx_ab.txt; WX = 1 / 2 / 4, ms per step): two n-tiles on planes of >= 128 x 160 pixels gain with 32-wide tiles
 // -- 32 -> 32 3x3 4.79 / 4.46 / 5.32 and 4.21 / 3.96 / 4.73, 16 -> 32 5x5 stride 2 3.14 / 2.95 / 4.25, 24 -> 32 1.18 / 1.08 /
@@ -818,6 +938,25 @@ int launch_conv2d_mt(const dmvs_conv2d_desc& d, hipStream_t st, int nt, int ngro
     dim3 grid((unsigned)(tiles_x * tiles_y * d.B), (unsigned)ngroups), block(DMVS_BLOCK);
     const bool v16 = !ZI && conv_v16_ok<KW>(d);
     if (d.out_layout == DMVS_LAYOUT_NCHW) {      // transposed accumulators: 16-byte NCHW stores
+        if constexpr (!ZI && KH * KW > 1) {      // split-bf16 arithmetic (fp32-accurate): 16-byte staging pieces, lean or generic epilogue
+            if (conv_split_honoured<KW>(d)) {
+                const bool lean = conv_lean_ok(d);
+#define DMVS_SP(NTV) do { \
+                    using SCfg = ConvCfg<KH, KW, S, NTV, MT, DMVS_ARITH_SPLIT, 1, true>; \
+                    if constexpr ((2 * SCfg::BUF + 32 + SCfg::QFLOATS) * 4 <= 150 * 1024) { \
+                        if (lean) hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, NTV, MT, false, DMVS_DTYPE_F32, true, false, DMVS_ARITH_SPLIT, 1, true, true>), grid, block, 0, st, d, tiles_x, tiles_y); \
+                        else hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, NTV, MT, false, DMVS_DTYPE_F32, true, false, DMVS_ARITH_SPLIT, 1, true, false>), grid, block, 0, st, d, tiles_x, tiles_y); \
+                        return dmvs_launch_status(); \
+                    } } while (0)
+                switch (nt) {      // (a shape whose buffers exceed the LDS falls through to the fp32 kernel)
+                    case 1: DMVS_SP(1); break;
+                    case 2: DMVS_SP(2); break;
+                    case 3: DMVS_SP(3); break;
+                    default: DMVS_SP(4); break;
+                }
+#undef DMVS_SP
+            }
+        }
         if constexpr (!ZI && MT == 2 && KH * KW > 1 && S == 1) {      // bf16 matrix arithmetic: one tile shape (16 x 8), NCHW fp32 outputs
             if (conv_bf16_honoured(d)) {
 #define DMVS_BF(NTV) do { \
@@ -949,6 +1088,17 @@ int launch_conv2d(const dmvs_conv2d_desc& d, hipStream_t st) {
     // output channels per workgroup: up to 4 MFMA n-tiles share one staged input tile
     const int nt = ntiles <= 4 ? ntiles : (ntiles % 3 == 0 ? 3 : 4);
     const int ngroups = (ntiles + nt - 1) / nt;
+    if constexpr (KH * KW > 1) {
+        if (conv_split_honoured<KW>(d)) {      // split-bf16 arithmetic: 16 x 16 tiles for the light families (the weight split is per wave and tap group), 16 x 8 otherwise
+            constexpr bool heavy_ = (S == 2) || (KH * KW >= 25);
+            const int force_mt_ = (d.tune >> 4) & 7;
+            if constexpr (!heavy_) {
+                const long wg16_ = (long)((d.Wout + 15) / 16) * ((d.Hout + 15) / 16) * d.B * ngroups;
+                if (force_mt_ == 4 || (force_mt_ == 0 && nt <= 2 && wg16_ >= 1024)) return launch_conv2d_mt<KH, KW, S, 4, false>(d, st, nt, ngroups);
+            }
+            return launch_conv2d_mt<KH, KW, S, 2, false>(d, st, nt, ngroups);
+        }
+    }
     if constexpr (KH == 3 && KW == 3 && S == 1) {
         if (conv_tall_ok<KH, KW, S>(d, nt)) {
             const int tiles_x = (d.Wout + 15) / 16, tiles_y = (d.Hout + 31) / 32;

@@ -21,6 +21,16 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// Which tiles meet in one XCD's L2 (round 6, dmvs_common.h dmvs_xcd_grouped_block): a tile row is 16 voxels = 64 bytes, half a cache line, and
+// x-adjacent tiles share halo columns.  DMVS_TUNE3D_XCD_GROUP: 0 = groups of 4 x-adjacent tiles, 1 = plain round robin, 2 | 3 | 4 = groups of
+// 2 | 4 | 8.  A bijection of the tile indices: bit-identical results.
+__device__ __forceinline__ int conv3d_xcd_tile(int tile, int ntiles, int tune) {
+    const int xg = (tune >> 4) & 7;
+    if (xg == 1) return tile;
+    const unsigned g = xg == 0 ? 4u : (xg <= 4 ? 1u << (xg - 1) : 4u);
+    return (int)dmvs_xcd_grouped_block((unsigned)tile, (unsigned)ntiles, g);
+}
+
 constexpr int pad16mod32_3d(int n) {
     int m = n;
     while (m % 32 != 16) ++m;
@@ -281,6 +291,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_kernel(const dm
         for (int ci = 0; ci < CK; ++ci) halo.stage(origin + (long)ci * vol, ci < d.cin, lo, him1, buf + ci * PLANE, wave);
     };
     auto decode = [&](int tile, int& b, int& td, int& ty, int& tx) {
+        tile = conv3d_xcd_tile(tile, ntiles, d.tune);
         tx = tile % tiles_x; tile /= tiles_x;
         ty = tile % tiles_y; tile /= tiles_y;
         td = tile % tiles_d;
@@ -415,6 +426,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_pair_kernel(con
         for (int ci = 0; ci < CK; ++ci) halo.stage(origin + (long)ci * vol, ci < d.cin, lo, him1, buf + ci * PLANE, wave);
     };
     auto decode = [&](int tile, int& b, int& td, int& ty, int& tx) {
+        tile = conv3d_xcd_tile(tile, ntiles, d.tune);
         tx = tile % tiles_x; tile /= tiles_x;
         ty = tile % tiles_y; tile /= tiles_y;
         td = tile % tiles_d;
@@ -538,6 +550,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_stream_pair8_kernel(co
         for (int ci = 0; ci < CK; ++ci) halo.stage(origin + (long)ci * vol, 4 * c + ci < d.cin, lo, him1, buf + ci * PLANE, wave);
     };
     auto decode = [&](int tile, int& b, int& td, int& ty, int& tx) {
+        tile = conv3d_xcd_tile(tile, ntiles, d.tune);
         tx = tile % tiles_x; tile /= tiles_x;
         ty = tile % tiles_y; tile /= tiles_y;
         td = tile % tiles_d;
@@ -637,7 +650,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_mfma_kernel(const dmvs_conv
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, kq = lane >> 4;
-    int tile = blockIdx.x;
+    int tile = conv3d_xcd_tile((int)blockIdx.x, (int)gridDim.x, d.tune);
     const int tx = tile % tiles_x; tile /= tiles_x;
     const int ty = tile % tiles_y; tile /= tiles_y;
     const int td = tile % tiles_d;
@@ -727,7 +740,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) conv3d_c1_kernel(const dmvs_conv3d
     __shared__ __attribute__((aligned(16))) float lds[2 * PLANE];
     DMVS_LDS_POISON(lds);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int tile = blockIdx.x;
+    int tile = conv3d_xcd_tile((int)blockIdx.x, (int)gridDim.x, d.tune);
     const int tx = tile % tiles_x; tile /= tiles_x;
     const int ty = tile % tiles_y; tile /= tiles_y;
     const int td = tile % tiles_d;
@@ -1079,7 +1092,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK) deconv3d_mfma_kernel(const dmvs_co
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, kq = lane >> 4;
-    int tile = blockIdx.x;
+    int tile = conv3d_xcd_tile((int)blockIdx.x, (int)gridDim.x, d.tune);
     const int tx = tile % tiles_x; tile /= tiles_x;
     const int ty = tile % tiles_y; tile /= tiles_y;
     const int td = tile % tiles_d;

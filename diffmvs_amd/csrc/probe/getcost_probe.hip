@@ -12,6 +12,7 @@
 namespace {
 
 struct QuadLoadsOnly {
+    static constexpr bool kPairUnits = false;
     template <int C, int FT, int NH, int TPT>
     static __device__ __forceinline__ void texels(const Feat<C, FT> (&t)[TPT], const bool (&)[TPT], const float (&)[TPT], const float (&)[TPT],
                                                   const float (&)[(NH + 3) / 4], const float (&)[(NH + 3) / 4], const float (&)[C / 4], float,
@@ -26,6 +27,15 @@ struct QuadLoadsOnly {
 template <int C, int N, int TPT, int FT>
 __global__ void __launch_bounds__(GC_BLOCK) getcost_loads_probe_kernel(const dmvs_getcost_desc d) {
     getcost_quad_body<QuadLoadsOnly, C, N, TPT, FT>(d);
+}
+
+// the same stream with the texel PAIR (x, x + 1) as the load unit (16-bit features with 16 channels: warp_quad_core.h, quad_accumulate)
+struct QuadPairLoadsOnly : QuadLoadsOnly {
+    static constexpr bool kPairUnits = true;
+};
+template <int N, int TPT, int FT>
+__global__ void __launch_bounds__(GC_BLOCK) getcost_pair_loads_probe_kernel(const dmvs_getcost_desc d) {
+    getcost_quad_body<QuadPairLoadsOnly, 16, N, TPT, FT>(d);
 }
 
 template <int FT>
@@ -52,4 +62,16 @@ extern "C" int dmvs_probe_getcost_loads_f32(const dmvs_getcost_desc* dp, void* s
     if (d.feat_dtype == DMVS_DTYPE_F16) return launch_probe<DMVS_DTYPE_F16>(d, grid, block, st);
     if (d.feat_dtype == DMVS_DTYPE_F32) return launch_probe<DMVS_DTYPE_F32>(d, grid, block, st);
     return DMVS_EINVAL;
+}
+
+extern "C" int dmvs_probe_getcost_pair_loads_f32(const dmvs_getcost_desc* dp, void* stream) {
+    if (!dp || !getcost_desc_ok(*dp)) return DMVS_EINVAL;
+    const dmvs_getcost_desc& d = *dp;
+    if (d.C != 16 || d.n != 4 || (d.W & 1)) return DMVS_EINVAL;
+    const dim3 grid = getcost_grid(d), block(GC_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+    if (d.feat_dtype == DMVS_DTYPE_BF16) hipLaunchKernelGGL((getcost_pair_loads_probe_kernel<4, QUAD_TPT, DMVS_DTYPE_BF16>), grid, block, 0, st, d);
+    else if (d.feat_dtype == DMVS_DTYPE_F16) hipLaunchKernelGGL((getcost_pair_loads_probe_kernel<4, QUAD_TPT, DMVS_DTYPE_F16>), grid, block, 0, st, d);
+    else return DMVS_EINVAL;
+    return dmvs_launch_status();
 }

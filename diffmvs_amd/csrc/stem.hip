@@ -44,7 +44,7 @@ template <bool V16>
 __global__ void __launch_bounds__(DMVS_BLOCK)
 featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0, const float* __restrict__ scale0,
                        const float* __restrict__ shift0, const float* __restrict__ w1, const float* __restrict__ scale1,
-                       const float* __restrict__ shift1, float* __restrict__ y, int N, int H, int W, int tiles_x, int tiles_y) {
+                       const float* __restrict__ shift1, float* __restrict__ y, int N, int H, int W, int tiles_x, int tiles_y, int xgroup) {
     // ONE LDS object: with the input buffers, the intermediate and the weights as separate __shared__ arrays hipcc
     // tags the accesses with alias scopes and then waits vmcnt(0) before the first ds_read of an input buffer while
     // the LDS-DMA into the OTHER buffer (same object) is in flight -- the prefetch this kernel is built around would
@@ -99,7 +99,7 @@ featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0
         }
     }
     auto stage = [&](int tile, float* buf) {
-        int tq = tile;
+        int tq = (int)dmvs_xcd_grouped_block((unsigned)tile, (unsigned)ntiles, (unsigned)xgroup);      // which tiles meet in one XCD's L2: conv2d_tiled.h
         const int tx = tq % tiles_x; tq /= tiles_x;
         const int ty = tq % tiles_y;
         const int n = tq / tiles_y;
@@ -177,7 +177,7 @@ featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0
     int pn = -1, pox0 = 0, poy0 = 0;
     if (tile < ntiles) stage(tile, lds);
     for (; tile < ntiles; tile += gridDim.x, cur ^= 1) {
-        int tq = tile;
+        int tq = (int)dmvs_xcd_grouped_block((unsigned)tile, (unsigned)ntiles, (unsigned)xgroup);
         const int tx = tq % tiles_x; tq /= tiles_x;
         const int ty = tq % tiles_y;
         const int n = tq / tiles_y;
@@ -253,14 +253,17 @@ extern "C" int dmvs_featurenet_stem_f32(const float* x, const float* w0, const f
     const bool v16 = !(tune & DMVS_TUNE_PIECES4) && (W & 3) == 0 && ((uintptr_t)x & 15) == 0;
     const int resident = v16 ? resident16 : resident4;
     const unsigned grid = (unsigned)(ntiles < resident ? ntiles : resident);
+    // DMVS_TUNE_XCD_GROUP: 0 = groups of 4 x-adjacent tiles per XCD (a 16-pixel tile row is half a cache line), 1 = plain round robin, 2 | 3 | 4 = 2 | 4 | 8
+    const int xg = (tune >> 14) & 7;
+    const int xgroup = xg == 0 ? 4 : (xg <= 4 ? 1 << (xg - 1) : 4);
     // input halo in 16-byte LDS-DMA pieces wherever rows are 16-byte multiples on a 16-byte aligned tensor (6 instead of 19 wave-level
     // DMA instructions per tile, 84 instead of 96 VGPRs): 1094 -> 938 us per 96 images on the MI355X, bit-identical
     // (profiles/r4_optins_ab.jsonl); DMVS_TUNE_PIECES4 forces the 4-byte form
     if (v16)
         hipLaunchKernelGGL(featurenet_stem_kernel<true>, dim3(grid), dim3(DMVS_BLOCK), 0, (hipStream_t)stream, x, w0, scale0, shift0, w1,
-                           scale1, shift1, y, N, H, W, tiles_x, tiles_y);
+                           scale1, shift1, y, N, H, W, tiles_x, tiles_y, xgroup);
     else
         hipLaunchKernelGGL(featurenet_stem_kernel<false>, dim3(grid), dim3(DMVS_BLOCK), 0, (hipStream_t)stream, x, w0, scale0, shift0, w1,
-                           scale1, shift1, y, N, H, W, tiles_x, tiles_y);
+                           scale1, shift1, y, N, H, W, tiles_x, tiles_y, xgroup);
     return dmvs_launch_status();
 }

@@ -266,6 +266,7 @@ __device__ __forceinline__ void scatter_pair(float (&acc)[NH], const float (&w0)
 // The arithmetic of a texel-loop trip (the Body of quad_accumulate): group dot of each texel with the lane's reference channels,
 // the bilinear hat weights of the lane's own hypotheses, the DPP scatter into every hypothesis of the pixel.
 struct QuadProduct {
+    static constexpr bool kPairUnits = false;      // load unit of the texel loop: one texel (see quad_accumulate)
     template <int C, int FT, int NH, int TPT>
     static __device__ __forceinline__ void texels(const Feat<C, FT> (&t)[TPT], const bool (&has)[TPT], const float (&fc)[TPT], const float (&fr)[TPT],
                                                   const float (&ur)[(NH + 3) / 4], const float (&vr)[(NH + 3) / 4], const float (&ref)[C / 4],
@@ -367,21 +368,51 @@ __device__ __forceinline__ void quad_accumulate(P base, unsigned view_off, int p
             // TPT texels per trip (their loads in flight together); a pixel that runs out repeats its last texel with weight 0
             int bit[TPT];
             bool has[TPT];
+            [[maybe_unused]] bool has_r[TPT];
 #pragma unroll
             for (int i = 0; i < TPT; ++i) {
                 has[i] = m != 0u;
                 bit[i] = (i == 0 || has[i]) ? __ffs((int)m) - 1 : bit[i > 0 ? i - 1 : 0];
-                m &= m - 1u;
+                if constexpr (Body::kPairUnits) {      // the unit also covers the texel's right-hand neighbour in the row: both bits leave the mask
+                    const unsigned b1 = has[i] ? 1u << bit[i] : 0u, nb = (bit[i] & 7) != 7 ? b1 << 1 : 0u;
+                    has_r[i] = (m & nb) != 0u;
+                    m &= ~(b1 | nb);
+                } else {
+                    m &= m - 1u;
+                }
             }
             Feat<C, FT> t[TPT];
             float fc[TPT], fr[TPT];
 #pragma unroll
             for (int i = 0; i < TPT; ++i) {
                 const int c = bit[i] & 7, r = (bit[i] >> 3) + rbase;
-                // r * pitch + c < 2^24: one full-rate 24-bit multiply-add each (left alone, hipcc picks the 64-bit v_mad_u64_u32)
-                t[i].load(base + mad_u24(mad_u24((unsigned)r, (unsigned)pitch, (unsigned)c), (unsigned)TB, texel_off));
                 fc[i] = (float)c;
                 fr[i] = (float)r;
+                if constexpr (!Body::kPairUnits) {
+                    // r * pitch + c < 2^24: one full-rate 24-bit multiply-add each (left alone, hipcc picks the 64-bit v_mad_u64_u32)
+                    t[i].load(base + mad_u24(mad_u24((unsigned)r, (unsigned)pitch, (unsigned)c), (unsigned)TB, texel_off));
+                }
+            }
+            if constexpr (Body::kPairUnits) {
+                // PAIR UNITS (csrc/probe only so far: what would a 16-bit C = 16 feature layout buy whose load unit is the texel pair (x, x + 1) --
+                // 64 contiguous bytes, the request of one fp32 C = 32 unit -- instead of the 32-byte texel?).  The quad reads the pair with ONE
+                // 16-byte load per lane (lane q: bytes 16q .. 16q + 15 of the pair; view_off already holds the lane's 8q of the single-texel form).
+                static_assert(Feat<C, FT>::NW == 2, "pair units: 16-bit features with 16 channels");
+                Feat<C, FT> tr[TPT];
+#pragma unroll
+                for (int i = 0; i < TPT; ++i) {
+                    const int c = bit[i] & 7, r = (bit[i] >> 3) + rbase;
+                    const u32x4 v = ldv<u32x4>(base + (mad_u24(mad_u24((unsigned)r, (unsigned)pitch, (unsigned)c), (unsigned)TB, texel_off) + (unsigned)q * (TB / 4)));
+                    t[i].w[0] = v[0]; t[i].w[1] = v[1];
+                    tr[i].w[0] = v[2]; tr[i].w[1] = v[3];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                float fcr[TPT];
+#pragma unroll
+                for (int i = 0; i < TPT; ++i) fcr[i] = fc[i] + 1.0f;
+                Body::template texels<C, FT, NH, TPT>(t, has, fc, fr, ur, vr, ref, wscale, acc);
+                Body::template texels<C, FT, NH, TPT>(tr, has_r, fcr, fr, ur, vr, ref, wscale, acc);
+                continue;
             }
             // every load of the trip is issued before anything waits on one: without this fence the scheduler, chasing one
             // more wave of occupancy, re-uses one texel's registers and serialises load -> wait -> FMAs per texel

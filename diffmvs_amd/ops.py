@@ -15,11 +15,11 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU, ACT_TANH, ARITH_BF16, ARITH_F32, DTYPE_BF16, DTYPE_F16, DTYPE_F32, IN_PLAIN,  # noqa: F401
+from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU, ACT_TANH, ARITH_BF16, ARITH_F32, ARITH_SPLIT, DTYPE_BF16, DTYPE_F16, DTYPE_F32, IN_PLAIN,  # noqa: F401
                    IN_UNSHUFFLE2, IN_UPSAMPLE2, IN_ZEROINSERT2, LAYOUT_NCHW, LAYOUT_NHWC, LAYOUT_NHWC_BF16, LAYOUT_NHWC_F16)
 
 # matrix arithmetic of the multi-tap 2-D convolutions: "fp32" (exact, the reference's) | "bf16" (bf16 products, fp32 accumulation)
-CONV_ARITH = {"fp32": ARITH_F32, "bf16": ARITH_BF16}
+CONV_ARITH = {"fp32": ARITH_F32, "bf16": ARITH_BF16, "split": ARITH_SPLIT}
 # reduced-precision FEATURE storage (BASELINE.json's bf16 / fp16 configurations): torch dtype <-> C-ABI codes
 FEATURE_DTYPES = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
 _DTYPE_CODE = {torch.float32: DTYPE_F32, torch.bfloat16: DTYPE_BF16, torch.float16: DTYPE_F16}
@@ -150,7 +150,7 @@ def _env_tune():
     a variable after the first forward has no effect (A/B tools pass tune= per call, mutate ops.tune, or construct a fresh Ops).
     All default to 0 = the library's measured-best path:
       DMVS_CONV_WX=1|2, DMVS_CONV_MT=1|2|4, DMVS_CONV_WALK=0, DMVS_CONV_LEAN=0, DMVS_CONV_V16=0, DMVS_CONV1X1_PX4=0, DMVS_CONV_TALL=0|1, DMVS_CONV_XCD=1..7   (dmvs_conv2d_desc.tune)
-      DMVS_CONV3D_V16=0, DMVS_CONV3D_S2=direct, DMVS_CONV3D_PAIR=0   (dmvs_conv3d_desc.tune)      DMVS_STEM_V16=0      DMVS_PLANE_SWEEP=quad"""
+      DMVS_CONV3D_V16=0, DMVS_CONV3D_S2=direct, DMVS_CONV3D_PAIR=0, DMVS_CONV3D_XCD=1..4   (dmvs_conv3d_desc.tune)      DMVS_STEM_V16=0, DMVS_STEM_XCD=1..4      DMVS_PLANE_SWEEP=quad"""
     e = os.environ.get
     t2 = _lib.tune_tile_wx(int(e("DMVS_CONV_WX", "0"))) | _lib.tune_tile_mt(int(e("DMVS_CONV_MT", "0")))
     t2 |= _lib.TUNE_NO_WALK if e("DMVS_CONV_WALK") == "0" else 0
@@ -161,7 +161,8 @@ def _env_tune():
     t2 |= _lib.tune_xcd_group(int(e("DMVS_CONV_XCD", "0")))      # round 6: which tiles share an XCD's L2 (include/dmvs.h DMVS_TUNE_XCD_GROUP)
     t3 = (_lib.TUNE3D_PIECES4 if e("DMVS_CONV3D_V16") == "0" else 0) | (_lib.TUNE3D_S2_DIRECT if e("DMVS_CONV3D_S2") == "direct" else 0)
     t3 |= _lib.TUNE3D_NO_PAIR if e("DMVS_CONV3D_PAIR") == "0" else 0
-    return {"conv2d": t2, "conv3d": t3, "stem": _lib.TUNE_PIECES4 if e("DMVS_STEM_V16") == "0" else 0,
+    t3 |= _lib.tune3d_xcd_group(int(e("DMVS_CONV3D_XCD", "0")))
+    return {"conv2d": t2, "conv3d": t3, "stem": (_lib.TUNE_PIECES4 if e("DMVS_STEM_V16") == "0" else 0) | _lib.tune_xcd_group(int(e("DMVS_STEM_XCD", "0"))),
             "sweep": _lib.TUNE_SWEEP_GLOBAL if e("DMVS_PLANE_SWEEP") == "quad" else 0,
             # training: GetCost backward through the per-pixel gather kernel only (no tile pre-pass / LDS-window worklist): DMVS_GETCOST_BWD=gather
             "bwd_gather": e("DMVS_GETCOST_BWD") == "gather",

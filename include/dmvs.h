@@ -74,6 +74,7 @@ int dmvs_abi_version(void);
  */
 #define DMVS_ARITH_F32 0
 #define DMVS_ARITH_BF16 1
+#define DMVS_ARITH_SPLIT 2
 
 /* dmvs_conv2d_desc.tune: 0 = the library's own choice (measured best on the MI355X); the bits force a code path for A/B runs.
  * Results do not depend on them (bit-identical kernels). */
@@ -126,7 +127,11 @@ typedef struct dmvs_conv2d_desc {
                                cores, fp32 accumulation (v_mfma_f32_16x16x32_bf16) -- the reduced-precision configurations of
                                BASELINE.json (configs[2], [4]); tensors in memory stay fp32.  Honoured by stride-1 layers with
                                more than one tap, >= 24 input channels and an NCHW output (where it is faster); every other
-                               layer computes in fp32 in either mode.                                                     */
+                               layer computes in fp32 in either mode.
+                               DMVS_ARITH_SPLIT (2): fp32 accuracy on the bf16 matrix cores -- every fp32 operand is split into three
+                               bf16 values (hi + mid + lo = x to 2^-27) and a product is the sum of its six partial products down
+                               to 2^-18 of it (the dropped ones are below 2^-26), fp32 accumulation.  Honoured by multi-tap layers with an NCHW
+                               output on 16-byte aligned rows; the others compute in exact fp32.                           */
     int32_t tune;           /* DMVS_TUNE_* bits, 0 = automatic                                                              */
     int32_t out_mul_c0;     /* first output channel out_mul applies to                                                       */
     int32_t in0_cstride;    /* 0: in0 is a dense [B,c0,..] tensor.  > 0 (DMVS_IN_PLAIN only): in0 is a channel slice (the pointer includes
@@ -194,6 +199,7 @@ typedef struct dmvs_conv3d_desc {
 #define DMVS_TUNE3D_S2_DIRECT 0x2     /* stride-2 layers on the direct (VALU) kernels of round 1 instead of the matrix cores      */
 #define DMVS_TUNE3D_NO_PAIR 0x4       /* A/B: the <= 8 -> <= 8 channel stride-1 layers on the generic / streamed kernels instead of the paired ones (two output depth
                                          slices per MFMA; bit-identical results; round 5: PixelViewWeight conv0 -5 %, CostRegNet conv1 1517 -> 983 us per 96 volumes) */
+#define DMVS_TUNE3D_XCD_GROUP(n) (((n) & 7) << 4) /* tiled 3-D kernels: which tiles share an XCD's L2.  0 = groups of 4 x-adjacent tiles (the default), 1 = plain round robin, 2 | 3 | 4 = groups of 2 | 4 | 8 (bit-identical results) */
 
 /* Size limit of the stride-1 layers (DMVS_EINVAL beyond): cin * Din*Hin*Win < 2^31 and cout * Dout*Hout*Wout < 2^31
  * (one batch item is addressed with 32-bit element offsets). */

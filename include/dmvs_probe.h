@@ -14,7 +14,7 @@
 extern "C" {
 #endif
 
-#define DMVS_PROBE_ABI_VERSION 1
+#define DMVS_PROBE_ABI_VERSION 2
 int dmvs_probe_abi_version(void);
 
 /* The memory-system ceiling of GetCost's address stream.  Same descriptor, same launch grid and the SAME kernel body as
@@ -22,6 +22,11 @@ int dmvs_probe_abi_version(void);
  * body that only waits for the loaded registers: no group dot, no hat weights, no scatter.  out_samples receives the hypotheses, out_cost
  * zeros.  Its launch time is what the L1 / L2 / HBM path alone needs for the product's line requests (reference path: models/module.py:583-667). */
 int dmvs_probe_getcost_loads_f32(const dmvs_getcost_desc* d, void* stream);
+
+/* The same stream with the texel PAIR (x, x + 1) as the load unit -- one 16-byte load per lane fetches the 64 contiguous bytes of two 16-bit
+ * C = 16 texels (ABI 2; round 6: would a pair-packed 16-bit feature layout pay?  16-bit features, C = 16, n = 4, even W only; the last texel
+ * of an image row pairs with the first of the next, whose bytes are read and ignored). */
+int dmvs_probe_getcost_pair_loads_f32(const dmvs_getcost_desc* d, void* stream);
 
 /* Random 128-byte-line gather: every quad of lanes requests `lines_per_quad` lines of `table` (n_lines x 128 bytes), each as two 64-byte
  * quad-coalesced pieces (one 16-byte load per lane and piece -- the request shape of a C = 32 fp32 texel in GetCost), two lines in flight per

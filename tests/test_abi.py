@@ -76,14 +76,16 @@ def test_probe_library_exports_its_header():
     build_hip()
     src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "dmvs_probe.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\bint\s+(dmvs_probe_\w+)\s*\(", src)))
-    assert names == ["dmvs_probe_abi_version", "dmvs_probe_getcost_loads_f32", "dmvs_probe_random_line_gather"]
+    assert names == ["dmvs_probe_abi_version", "dmvs_probe_getcost_loads_f32", "dmvs_probe_getcost_pair_loads_f32", "dmvs_probe_random_line_gather"]
     dll = ctypes.CDLL(PROBE_LIB)
     for n in names:
         assert hasattr(dll, n), n
-    assert dll.dmvs_probe_abi_version() == 1
+    assert dll.dmvs_probe_abi_version() == 2
     # argument validation happens before any launch: NULL descriptor / table -> DMVS_EINVAL
     dll.dmvs_probe_getcost_loads_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     assert dll.dmvs_probe_getcost_loads_f32(None, None) == -22
+    dll.dmvs_probe_getcost_pair_loads_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    assert dll.dmvs_probe_getcost_pair_loads_f32(None, None) == -22
     dll.dmvs_probe_random_line_gather.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                    ctypes.c_uint32, ctypes.c_void_p]
     assert dll.dmvs_probe_random_line_gather(None, 1024, 16, 8, 0, 0, 1, None) == -22

@@ -770,6 +770,65 @@ def test_conv2d_bf16_matrix_arithmetic(ops, cin, cout, k, stride, HW, extras):
         assert torch.allclose(st[..., 0] / yg.shape[-1], yg.mean(-1), atol=1e-4)
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,HW,extras", [
+    (16, 16, (3, 3), 1, (24, 36), "plain"), (28, 31, (3, 3), 1, (16, 32), "res_relu"), (8, 16, (5, 5), 2, (36, 52), "bn"),
+    (32, 64, (5, 5), 2, (20, 24), "bn"), (32, 16, (7, 7), 1, (18, 20), "plain"), (64, 64, (1, 5), 1, (9, 40), "gru"),
+    (64, 32, (5, 1), 1, (12, 16), "plain"), (32, 32, (3, 3), 2, (22, 32), "plain"), (24, 48, (3, 3), 1, (8, 8), "concat_gn"),
+    (37, 20, (3, 3), 1, (40, 72), "plain"), (3, 8, (3, 3), 1, (33, 40), "bn"), (16, 16, (3, 3), 1, (70, 36), "mt4")])
+def test_conv2d_split_bf16_arithmetic(ops, cin, cout, k, stride, HW, extras):
+    """arith = ARITH_SPLIT: every fp32 operand split exactly into three bf16 values, six partial products per product on the bf16 matrix
+    cores, fp32 accumulation -- fp32 ACCURACY, not fp32 bits.  Against torch's convolution in fp64: the split kernel's error is of the size
+    of the exact-fp32 kernel's own rounding error (both a few 1e-7 of the output scale; bf16 arithmetic would be 4e-3), for every kernel
+    shape, channel counts that are not multiples of the 8-channel chunks, both tile heights, and the fused staging / epilogue paths (concat,
+    GRU gating + blend, residual, BN, GroupNorm statistics)."""
+    B = 2
+    kh, kw = k
+    pad = (kh // 2, kw // 2)
+    x = rnd(B, cin, *HW, seed=1)
+    w = rnd(cout, cin, kh, kw, seed=2) * (2.0 / (cin * kh * kw) ** 0.5)
+    kw_call, ref_in, x0, x1 = {}, x, x, None
+    bn = None
+    if extras == "bn":
+        bn = {"weight": rnd(cout, seed=4, lo=0.5, hi=1.5), "bias": rnd(cout, seed=5), "running_mean": rnd(cout, seed=6),
+              "running_var": rnd(cout, seed=7, lo=0.5, hi=1.5)}
+    if extras == "concat_gn":
+        x0, x1 = x[:, :10].contiguous(), x[:, 10:].contiguous()
+    if extras == "gru":      # candidate conv of SepConvGRU: input cat(r * h, x), output blended with z and h
+        r = rnd(B, 32, *HW, seed=11, lo=0.0, hi=1.0)
+        h = x[:, :32].contiguous()
+        x0, x1 = h, x[:, 32:].contiguous()
+        ref_in = torch.cat([r * h, x[:, 32:]], 1)
+        z, hh = rnd(B, cout, *HW, seed=12, lo=0.0, hi=1.0), rnd(B, cout, *HW, seed=13)
+    ref = F.conv2d(ref_in.double(), w.double(), None, stride, pad)
+    if bn is not None:
+        ref = F.relu(F.batch_norm(ref, bn["running_mean"].double(), bn["running_var"].double(), bn["weight"].double(), bn["bias"].double(), False, 0.0, 1e-5))
+        kw_call["act"] = K.ACT_RELU
+    if extras == "res_relu":
+        res = rnd(*ref.shape, seed=9)
+        ref = F.relu(ref + res.double())
+        kw_call.update(residual=dev(ops, res), act=K.ACT_RELU)
+    if extras == "gru":
+        ref = (1 - z.double()) * hh.double() + z.double() * torch.tanh(ref)
+        kw_call.update(mul0=dev(ops, r), gru_z=dev(ops, z), gru_h=dev(ops, hh), act=K.ACT_TANH)
+    stats = None
+    if extras == "concat_gn":
+        stats = torch.zeros(B * 8, dtype=torch.float64, device=ops.device)
+        kw_call.update(gn_stats=stats)
+    if extras == "mt4":
+        kw_call.update(tune=K._lib.tune_tile_mt(4))
+    pc = K.pack_conv2d(dev(ops, w), bn=None if bn is None else {k_: v.to(ops.device) for k_, v in bn.items()}, stride=stride, pad=pad)
+    out = ops.conv2d(pc, dev(ops, x0), None if x1 is None else dev(ops, x1), arith=K.ARITH_SPLIT, **kw_call).cpu().double()
+    out32 = ops.conv2d(pc, dev(ops, x0), None if x1 is None else dev(ops, x1), **{k_: v for k_, v in kw_call.items() if k_ != "gn_stats"}).cpu().double()
+    scale = float(ref.abs().max())
+    e_split, e_f32 = float((out - ref).abs().max()) / scale, float((out32 - ref).abs().max()) / scale
+    assert e_f32 < 2e-6 and e_split < 2e-6, (e_split, e_f32)
+    assert e_split < 4.0 * e_f32 + 2e-7, (e_split, e_f32)          # same class of error as the fma chain's own rounding
+    if stats is not None:
+        st = (stats.cpu().view(torch.int64).double() / 65536.0).view(B, 4, 2)
+        yg = ref.view(B, 4, -1)
+        assert torch.allclose(st[..., 0] / yg.shape[-1], yg.mean(-1), atol=1e-4)
+
+
 @pytest.mark.parametrize("cin,cout,k,stride,HW,with_res", [(16, 16, 3, 1, (40, 52), False), (32, 32, 3, 1, (37, 36), True), (8, 16, 5, 2, (50, 72), False),
                                                           (16, 32, 3, 2, (44, 40), False), (12, 20, 3, 1, (17, 20), True), (16, 16, 3, 1, (128, 176), False)])
 def test_conv2d_tile_walking_workgroups(ops, cin, cout, k, stride, HW, with_res):
@@ -1142,6 +1201,30 @@ def test_featurenet_stem_16_byte_pieces(ops, N, H, W):
     ref = F.relu(F.conv2d(F.relu(F.conv2d(x, w0, rnd(8, seed=4), 1, 1)), w1, rnd(8, seed=5), 1, 1))
     close(b, ref, 2e-5)
     assert torch.equal(a.cpu(), b.cpu())
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 37, 52), (3, 64, 96)])
+def test_featurenet_stem_xcd_grouped_tiles(ops, N, H, W):
+    """DMVS_TUNE_XCD_GROUP on the stem's tile walk: every group size gives the round-robin order's bits"""
+    x = dev(ops, rnd(N, 3, H, W, seed=1))
+    w0, w1 = rnd(8, 3, 3, 3, seed=2) * 0.4, rnd(8, 8, 3, 3, seed=3) * 0.3
+    pc0, pc1 = K.pack_conv2d(*dev(ops, w0, rnd(8, seed=4)), pad=1), K.pack_conv2d(*dev(ops, w1, rnd(8, seed=5)), pad=1)
+    outs = [ops.featurenet_stem(pc0, pc1, x, tune=K._lib.tune_xcd_group(n)).cpu() for n in (1, 0, 2, 4)]
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)
+
+
+@pytest.mark.parametrize("cin,cout,stride,transposed,B,D,H,W", [(4, 8, 1, False, 2, 23, 62, 100), (3, 16, 1, False, 2, 23, 62, 100), (8, 8, 1, False, 3, 9, 14, 36),
+                                                                 (8, 16, 2, False, 2, 10, 20, 36), (16, 8, 2, True, 2, 5, 10, 18)])
+def test_conv3d_xcd_grouped_tiles(ops, cin, cout, stride, transposed, B, D, H, W):
+    """DMVS_TUNE3D_XCD_GROUP: which tiles meet in one XCD's L2 is a bijection of the tile indices -- streamed, paired, generic, stride-2 and
+    transposed kernels give the round-robin order's bits with every group size"""
+    x = dev(ops, rnd(B, cin, D, H, W, seed=1))
+    w = rnd(cin, cout, 3, 3, 3, seed=2) * 0.2 if transposed else rnd(cout, cin, 3, 3, 3, seed=2) * 0.2
+    pc = K.pack_conv3d(*dev(ops, w, rnd(cout, seed=3)), stride=stride, transposed=transposed)
+    outs = [ops.conv3d(pc, x, act=K.ACT_RELU, tune=K._lib.tune3d_xcd_group(n)).cpu() for n in (1, 0, 2, 4)]
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)
 
 
 @pytest.mark.parametrize("cin,cout,with_res", [(4, 8, False), (3, 8, True)])

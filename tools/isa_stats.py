@@ -57,7 +57,7 @@ def main():
     old = json.load(open(sys.argv[sys.argv.index("--diff") + 1])) if "--diff" in sys.argv else None
     for name in sorted(stats):
         if pat in name:
-            line = "%-62s " % name[:62] + " ".join("%s=%s" % kv for kv in stats[name].items())
+            line = "%-62s " % name[:int(os.environ.get("ISA_NAME_WIDTH", "62"))] + " ".join("%s=%s" % kv for kv in stats[name].items())
             if old and name in old:
                 ch = {k: (old[name][k], v) for k, v in stats[name].items() if old[name].get(k) != v}
                 line += "   CHANGED " + str(ch) if ch else "   (same)"
