@@ -33,7 +33,7 @@ class Conv2dDesc(C.Structure):
         ("cout", _I), ("cout_pad", _I), ("kh", _I), ("kw", _I), ("stride", _I), ("pad_h", _I), ("pad_w", _I),
         ("in_mode", _I), ("act", _I), ("res_mode", _I), ("res_after_act", _I),
         ("out_layout", _I), ("out_cstride", _I), ("out_coffset", _I), ("gn_groups", _I), ("post_scale", _F),
-        ("gate_cstride", _I), ("arith", _I), ("tune", _I), ("out_mul_c0", _I), ("in0_cstride", _I),
+        ("gate_cstride", _I), ("arith", _I), ("tune", _I), ("out_mul_c0", _I), ("in0_cstride", _I), ("weight_split", _P),
     ]
 
 
@@ -95,7 +95,7 @@ SIGNATURES = {
     "dmvs_sumsq_f32": [_P, C.c_int64, _P, _P],
     "dmvs_adamw_step_f32": [_P, _P, _P, _P, C.c_int64, _F, _F, _F, _F, _F, _I, _F, _P, _F, _P],
 }
-ABI_VERSION = 3
+ABI_VERSION = 4
 # dmvs.h: DMVS_TUNE_* (dmvs_conv2d_desc.tune, dmvs_featurenet_stem_f32), DMVS_TUNE3D_* (dmvs_conv3d_desc.tune), DMVS_TUNE_SWEEP_GLOBAL
 TUNE_NO_WALK, TUNE_PIECES4, TUNE_NO_LEAN, TUNE_1X1_TILED, TUNE_NO_TALL, TUNE_TALL = 0x4, 0x8, 0x100, 0x200, 0x400, 0x800
 TUNE3D_PIECES4, TUNE3D_S2_DIRECT, TUNE3D_NO_PAIR = 0x1, 0x2, 0x4

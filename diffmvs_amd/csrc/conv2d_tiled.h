@@ -97,8 +97,12 @@ struct ConvCfg {
     static constexpr int CK = AR != DMVS_ARITH_F32 ? 8 : ((2 * 8 * (pad16mod32(TH * TW) + WPAD) * 4 > 40960) ? 4 : 8);
     // (DMVS_ARITH_SPLIT) the chunk's halo tile as three bf16 planes [plane][TH * TW positions][8 channels]: 16 bytes per position and plane
     static constexpr int QPOS = TH * TW;
-    static constexpr int QFLOATS = AR == DMVS_ARITH_SPLIT ? 3 * QPOS * 4 : 0;
-    static constexpr int BUF = CK * (PLANE + WPAD);            // floats per pipeline stage
+    static constexpr int NG = (T + 3) / 4;                     // tap groups of the bf16 forms: K = 32 = 8 channels x 4 taps
+    static constexpr bool SPLIT = AR == DMVS_ARITH_SPLIT;
+    // floats per pipeline stage (the split form keeps no weight slab in LDS: its pre-split weights go from global memory to registers)
+    static constexpr int BUF = CK * (PLANE + (SPLIT ? 0 : WPAD));
+    static constexpr int NBUF = SPLIT ? 1 : 2;                 // the split form converts a staged chunk at once and then re-uses the one buffer
+    static constexpr int LDS_FLOATS = NBUF * BUF + 32 + (SPLIT ? 3 * TH * TW * 4 : 0);
     static constexpr int IN_IT = (CK * PLANE + DMVS_BLOCK - 1) / DMVS_BLOCK;           // 4-byte DMA pieces per thread
     static constexpr int W_IT = (CK * WPAD / 4 + DMVS_BLOCK - 1) / DMVS_BLOCK;         // 16-byte DMA pieces per thread
 };
@@ -108,7 +112,10 @@ struct ConvCfg {
 // on the 3x3 NT=1 MT=4 kernel when it was a run-time branch of the same code).
 // minimum waves per SIMD the register allocator must leave room for: the 32->32 (NT=2, MT=4) and 64->64 (NT=4, MT=2)
 // shapes otherwise settle at 160 / 212 VGPRs = 3 / 2 waves, too few to cover the per-chunk barrier + DMA latency
-constexpr int conv_min_waves(int nt, int mt) { return (nt == 2 && mt == 4) ? 4 : ((nt == 4 && mt == 2) ? 3 : 1); }
+constexpr int conv_min_waves(int nt, int mt, int ar = DMVS_ARITH_F32) {
+    if (ar == DMVS_ARITH_SPLIT) return nt <= 2 ? 3 : 2;      // two accumulator sets + the tap group's weights (and the next group's) in registers
+    return (nt == 2 && mt == 4) ? 4 : ((nt == 4 && mt == 2) ? 3 : 1);
+}
 
 // OT = element type of a channel-last output (DMVS_DTYPE_*): 16-bit feature storage is its own instantiation so that the
 // fp32 kernels keep their register allocation.
@@ -154,7 +161,7 @@ constexpr int conv_min_waves(int nt, int mt) { return (nt == 2 && mt == 4) ? 4 :
 // plain layers (FeatureNet / ContextNet trunks, encoder, heads: ~65 % of the conv2d time) need none of it.
 template <int KH, int KW, int S, int NT, int MT, bool ZI, int OT = DMVS_DTYPE_F32, bool TR = false, bool WALK = false, int AR = DMVS_ARITH_F32,
           int WX = 1, bool V16 = false, bool LEAN = false>
-__global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfma_kernel(const dmvs_conv2d_desc d, int tiles_x, int tiles_y) {
+__global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT, AR)) conv2d_mfma_kernel(const dmvs_conv2d_desc d, int tiles_x, int tiles_y) {
     using Cfg = ConvCfg<KH, KW, S, NT, MT, AR, WX, V16>;
     static_assert(!(V16 && ZI), "16-byte staging pieces: PLAIN inputs only");
     constexpr int T = Cfg::T, TW = Cfg::TW, TH = Cfg::TH, PLANE = Cfg::PLANE, NW = Cfg::NW, WPAD = Cfg::WPAD;
@@ -162,7 +169,9 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
     constexpr int CK = Cfg::CK, BUF = Cfg::BUF, IN_IT = Cfg::IN_IT, W_IT = Cfg::W_IT;
     // one LDS object on purpose (tile buffers + the 32-float GroupNorm scratch): with separate objects hipcc orders reads of
     // one against LDS-DMA into another with vmcnt(0) waits (conv3d.hip, conv3d_mfma_stream_kernel)
-    __shared__ __attribute__((aligned(16))) float lds[2 * BUF + 32 + Cfg::QFLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
+    constexpr bool kSplit = AR == DMVS_ARITH_SPLIT;
+    constexpr int NBUF = Cfg::NBUF;
     DMVS_LDS_POISON(lds);
 
     int tid = threadIdx.x;
@@ -300,14 +309,14 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
 #pragma unroll
                 for (int ci = 0; ci < CK; ++ci) {
                     if (p_sp[it] < 0 || ci >= cin) *reinterpret_cast<f32x4*>(&lds[ci * PLANE + 4 * rem]) = z4;
-                    if (p_sp[it] < 0 || CK + ci >= cin) *reinterpret_cast<f32x4*>(&lds[BUF + ci * PLANE + 4 * rem]) = z4;
+                    if (NBUF == 2 && (p_sp[it] < 0 || CK + ci >= cin)) *reinterpret_cast<f32x4*>(&lds[BUF + ci * PLANE + 4 * rem]) = z4;
                 }
             }
         } else if (rem < PLANE) {
 #pragma unroll
             for (int ci = 0; ci < CK; ++ci) {
                 if (p_sp[it] < 0 || ci >= cin) lds[ci * PLANE + rem] = 0.0f;
-                if (p_sp[it] < 0 || CK + ci >= cin) lds[BUF + ci * PLANE + rem] = 0.0f;
+                if (NBUF == 2 && (p_sp[it] < 0 || CK + ci >= cin)) lds[BUF + ci * PLANE + rem] = 0.0f;
             }
         }
     }
@@ -341,6 +350,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
             }
             cb += plane0;
         }
+        if constexpr (kSplit) return;                               // (no weight slab in LDS)
         float* wbuf = buf + CK * PLANE;
 #pragma unroll
         for (int i = 0; i < W_IT; ++i) {
@@ -373,7 +383,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
             }
         }
     };
-    float* const gn_scratch = lds + 2 * BUF;      // (not the tile buffers: a walking workgroup's next tile is streaming into them)
+    float* const gn_scratch = lds + NBUF * BUF;      // (not the tile buffers: a walking workgroup's next tile is streaming into them)
 
     stage(0, lds);
     int cur = 0;
@@ -396,8 +406,26 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
             acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             if constexpr (AR == DMVS_ARITH_SPLIT) acc_small[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
+    // (split arithmetic) this lane's pre-split weights of one tap group: 16 bytes = the 8 channels of the chunk for (plane, tap 4g + kq, cout)
+    typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+    [[maybe_unused]] u32x4s a_cur[kSplit ? 3 : 1][kSplit ? NT : 1], a_next[kSplit ? 3 : 1][kSplit ? NT : 1];
+    [[maybe_unused]] const u32x4s* const wsp = reinterpret_cast<const u32x4s*>(d.weight_split);
+    [[maybe_unused]] int a_co[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) a_co[nt] = min(nbase + nt * 16 + m, d.cout_pad - 1) + kq * d.cout_pad;      // (a channel tile beyond cout_pad: discarded by the epilogue)
+    [[maybe_unused]] auto load_a = [&](u32x4s (&a)[kSplit ? 3 : 1][kSplit ? NT : 1], int chunk, int g) __attribute__((always_inline)) {
+        if constexpr (kSplit) {
+            const u32x4s* base = wsp + (size_t)((chunk * Cfg::NG + g) * 3) * 4 * d.cout_pad;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) a[pl][nt] = base[pl * 4 * d.cout_pad + a_co[nt]];
+        }
+    };
+    constexpr bool kPrefetchA = kSplit && NT <= 2;      // the next tap group's weights in a second register set (48 registers at two n-tiles)
+    if constexpr (kSplit) load_a(a_cur, 0, 0);
     for (int c0 = 0; c0 < cin; c0 += CK, cur ^= 1) {
-        float* s_in = lds + cur * BUF;
+        float* s_in = lds + (kSplit ? 0 : cur) * BUF;
         float* s_w = s_in + CK * PLANE;
         // drains this wave's LDS-DMA (explicit vmcnt(0), dmvs_common.h) and orders it against everyone's ds_reads:
         // after it, chunk c0 is complete in `cur` and the other buffer is free for the next chunk
@@ -413,6 +441,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
             }
             __syncthreads();
         }
+        if constexpr (!kSplit) {
         float* other = lds + (cur ^ 1) * BUF;
         if (c0 + CK < cin) {
             if (WALK && border) zero_padding(other);
@@ -426,6 +455,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
             if (border) zero_padding(other);
             stage(0, other);
         }
+        }
         if constexpr (AR == DMVS_ARITH_SPLIT) {
             // Split-bf16 arithmetic with fp32 accuracy (round 6).  The fp32 MFMA runs at the vector ALU's rate and -- measured with
             // tools/calib/overlap_probe.hip -- a CU executing it makes NO progress on vector-memory instructions (fp32 MFMAs and HBM streaming
@@ -434,11 +464,12 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
             // product a * b is formed as the six partial products down to 2^-18 (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi; the three
             // dropped ones are below 2^-26 of the product) on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: 6 x 16 cycles per K = 32
             // instead of 8 x 32, and the staging DMA proceeds underneath.  K = 32 = the chunk's 8 channels x 4 taps, as in the bf16 form.
-            //   pass 1: the staged fp32 halo tile -> three bf16 planes in LDS, ONCE per element (not once per tap that reads it);
-            //   pass 2: per tap group, weights split on the fly (amortised over the wave's MT rows), the pixel operand is three 16-byte reads.
+            //   pass 1: the staged fp32 halo tile -> three bf16 planes in LDS [plane][position][8 channels], ONCE per element (not once per
+            //           tap that reads it); the one fp32 buffer is then free, and the next chunk streams into it under this chunk's MFMAs;
+            //   pass 2: per tap group the lane's weights arrive PRE-SPLIT from global memory (d.weight_split, packed once per layer: 3 x NT
+            //           16-byte loads, the next group's in flight), the pixel operand is three 16-byte LDS reads: no VALU work in the loop.
             static_assert(CK == 8, "the split form maps the 8 channels of an LDS chunk onto the 8 k-slots of a lane");
-            typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
-            u32x4s* const q_hi = reinterpret_cast<u32x4s*>(lds + 2 * BUF + 32);
+            u32x4s* const q_hi = reinterpret_cast<u32x4s*>(lds + NBUF * BUF + 32);
             u32x4s* const q_mid = q_hi + Cfg::QPOS;
             u32x4s* const q_lo = q_mid + Cfg::QPOS;
             for (int e = tid; e < Cfg::QPOS; e += DMVS_BLOCK) {
@@ -453,51 +484,67 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT)) conv2d_mfm
                 q_mid[e] = __builtin_bit_cast(u32x4s, m8);
                 q_lo[e] = __builtin_bit_cast(u32x4s, l8);
             }
-            DMVS_LDS_BARRIER();        // the planes are complete (ds_writes only: the next chunk's DMA stays in flight)
-            constexpr int NG = (T + 3) / 4;          // tap groups: K = 32 = 4 taps x 8 channels
+            DMVS_LDS_BARRIER();        // the planes are complete and the fp32 buffer is free (ds accesses only: nothing is in flight)
+            if (c0 + CK < cin) stage(c0 + CK, lds);      // lands while the matrix cores chew on chunk c0
+            const int chunk = c0 / CK;
 #pragma unroll 1
-            for (int g = 0; g < NG; ++g) {
+            for (int g = 0; g < Cfg::NG; ++g) {
+                if constexpr (kPrefetchA) {
+                    if (g + 1 < Cfg::NG) load_a(a_next, chunk, g + 1);
+                    else if (c0 + CK < cin) load_a(a_next, chunk + 1, 0);
+                } else if (g > 0) {
+                    load_a(a_cur, chunk, g);
+                }
                 const int t = 4 * g + kq;
-                const bool tv = t < T;
-                const int tc = tv ? t : T - 1;
+                const int tc = t < T ? t : T - 1;      // (a tap slot beyond the kernel meets zero weights)
                 const int ky = tc / KW, kx = tc - ky * KW;
-                const float* wp = s_w + tc * NW + m;
+                const int qbase = ((wy * MT * S) + ky) * TW + (wx * 16 + m) * S + kx;
+                // RB rows at a time, the partial product outermost: the RB * NT MFMAs of one product are independent, so an accumulator is
+                // re-used RB * NT instructions later (back to back on one accumulator the matrix pipe waits out its own latency: the first
+                // form of this loop ran two interleaved chains and reached 40 % of the bf16 pipe's rate)
+                constexpr int RB = MT < 2 ? 1 : ((NT >= 2 || MT < 4) ? 2 : 4);
                 bf16x8 ah[NT], am[NT], al[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    float a[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) a[j] = tv ? wp[j * WPAD + nt * 16] : 0.0f;      // tap beyond the kernel: zero weights
-                    dmvs_split3_bf16x8(a, ah[nt], am[nt], al[nt]);
+                    ah[nt] = __builtin_bit_cast(bf16x8, a_cur[0][nt]);
+                    am[nt] = __builtin_bit_cast(bf16x8, a_cur[1][nt]);
+                    al[nt] = __builtin_bit_cast(bf16x8, a_cur[2][nt]);
                 }
-                const int qbase = ((wy * MT * S) + ky) * TW + (wx * 16 + m) * S + kx;
+                auto mf = [&](const bf16x8& bq, const bf16x8& aq, f32x4 c) __attribute__((always_inline)) -> f32x4 {
+                    return TR ? dmvs_mfma_bf16(bq, aq, c) : dmvs_mfma_bf16(aq, bq, c);
+                };
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const int qp = qbase + (mt * S) * TW;
-                    const bf16x8 bh = __builtin_bit_cast(bf16x8, q_hi[qp]), bm = __builtin_bit_cast(bf16x8, q_mid[qp]), bl = __builtin_bit_cast(bf16x8, q_lo[qp]);
+                for (int mt0 = 0; mt0 < MT; mt0 += RB) {
+                    bf16x8 bh[RB], bm[RB], bl[RB];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        // the five small partial products (<= 2^-8 of hi*hi) in their own accumulator: their roundings are relative to a sum
-                        // 2^-8 the size, so the result carries the rounding error of ONE accumulation chain, like the fma chain it replaces
-                        f32x4 c = acc_small[mt][nt];
-                        if constexpr (TR) {
-                            c = dmvs_mfma_bf16(bl, ah[nt], c);
-                            c = dmvs_mfma_bf16(bh, al[nt], c);
-                            c = dmvs_mfma_bf16(bm, am[nt], c);
-                            c = dmvs_mfma_bf16(bm, ah[nt], c);
-                            c = dmvs_mfma_bf16(bh, am[nt], c);
-                            acc[mt][nt] = dmvs_mfma_bf16(bh, ah[nt], acc[mt][nt]);
-                        } else {
-                            c = dmvs_mfma_bf16(ah[nt], bl, c);
-                            c = dmvs_mfma_bf16(al[nt], bh, c);
-                            c = dmvs_mfma_bf16(am[nt], bm, c);
-                            c = dmvs_mfma_bf16(ah[nt], bm, c);
-                            c = dmvs_mfma_bf16(am[nt], bh, c);
-                            acc[mt][nt] = dmvs_mfma_bf16(ah[nt], bh, acc[mt][nt]);
-                        }
-                        acc_small[mt][nt] = c;
+                    for (int r = 0; r < RB; ++r) {
+                        const int qp = qbase + ((mt0 + r) * S) * TW;
+                        bh[r] = __builtin_bit_cast(bf16x8, q_hi[qp]);
+                        bm[r] = __builtin_bit_cast(bf16x8, q_mid[qp]);
+                        bl[r] = __builtin_bit_cast(bf16x8, q_lo[qp]);
                     }
+                    // the five small partial products (<= 2^-8 of hi*hi) in their own accumulator: their roundings are relative to a sum
+                    // 2^-8 the size, so the result carries the rounding error of ONE accumulation chain, like the fma chain it replaces
+#define DMVS_SPLIT_PRODUCT(BQ, AQ, ACC) \
+                    _Pragma("unroll") for (int r = 0; r < RB; ++r) \
+                        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) ACC[mt0 + r][nt] = mf(BQ[r], AQ[nt], ACC[mt0 + r][nt]);
+                    DMVS_SPLIT_PRODUCT(bl, ah, acc_small)
+                    DMVS_SPLIT_PRODUCT(bh, al, acc_small)
+                    DMVS_SPLIT_PRODUCT(bm, am, acc_small)
+                    DMVS_SPLIT_PRODUCT(bm, ah, acc_small)
+                    DMVS_SPLIT_PRODUCT(bh, am, acc_small)
+                    DMVS_SPLIT_PRODUCT(bh, ah, acc)
+#undef DMVS_SPLIT_PRODUCT
                 }
+                if constexpr (kPrefetchA) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) a_cur[pl][nt] = a_next[pl][nt];
+                }
+            }
+            if constexpr (!kPrefetchA) {
+                if (c0 + CK < cin) load_a(a_cur, chunk + 1, 0);
             }
         } else if constexpr (AR == DMVS_ARITH_BF16) {
             static_assert(CK == 8, "the bf16 form maps the 8 channels of an LDS chunk onto the 8 k-slots of a lane");
@@ -868,7 +915,8 @@ template <int KW>
 static bool conv_v16_ok(const dmvs_conv2d_desc& d);
 template <int KW>
 static bool conv_split_honoured(const dmvs_conv2d_desc& d) {
-    return d.arith == DMVS_ARITH_SPLIT && d.out_layout == DMVS_LAYOUT_NCHW && d.kh * d.kw > 1 && d.in_mode != DMVS_IN_ZEROINSERT2 && conv_v16_ok<KW>(d);
+    return d.arith == DMVS_ARITH_SPLIT && d.weight_split && !((uintptr_t)d.weight_split & 15) && d.out_layout == DMVS_LAYOUT_NCHW && d.kh * d.kw > 1 &&
+           d.in_mode != DMVS_IN_ZEROINSERT2 && conv_v16_ok<KW>(d);
 }
 
 // Waves side by side in a workgroup's tile (template WX) for a 3x3 / 5x5 layer with planar output.  Measured at B = 96
@@ -943,7 +991,7 @@ int launch_conv2d_mt(const dmvs_conv2d_desc& d, hipStream_t st, int nt, int ngro
                 const bool lean = conv_lean_ok(d);
 #define DMVS_SP(NTV) do { \
                     using SCfg = ConvCfg<KH, KW, S, NTV, MT, DMVS_ARITH_SPLIT, 1, true>; \
-                    if constexpr ((2 * SCfg::BUF + 32 + SCfg::QFLOATS) * 4 <= 150 * 1024) { \
+                    if constexpr (SCfg::LDS_FLOATS * 4 <= 150 * 1024) { \
                         if (lean) hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, NTV, MT, false, DMVS_DTYPE_F32, true, false, DMVS_ARITH_SPLIT, 1, true, true>), grid, block, 0, st, d, tiles_x, tiles_y); \
                         else hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, NTV, MT, false, DMVS_DTYPE_F32, true, false, DMVS_ARITH_SPLIT, 1, true, false>), grid, block, 0, st, d, tiles_x, tiles_y); \
                         return dmvs_launch_status(); \

@@ -43,6 +43,26 @@ class PackedConv:
     stride: int = 1
     pad: tuple = (0, 0)
     transposed: bool = False
+    wsplit: Optional[torch.Tensor] = None      # (conv2d, ARITH_SPLIT) the weights as bf16 triples in the matrix cores' operand order: split_weights()
+
+
+def split_weights(pc: "PackedConv") -> torch.Tensor:
+    """dmvs_conv2d_desc.weight_split (include/dmvs.h): [ceil(cin/8)][ceil(T/4)][3 planes hi, mid, lo][4][cout_pad][8] bf16, element
+    (c, g, p, q, co, j) = part p of the weight of input channel 8c + j, tap 4g + q, output channel co; hi = bf16(w), mid = bf16(w - hi),
+    lo = bf16(w - hi - mid), round to nearest even; zero beyond cin / the taps.  Built once per packed layer, cached on it."""
+    if pc.wsplit is None:
+        kh, kw = pc.k
+        T, cp = kh * kw, pc.cout_pad
+        NG, NC = (T + 3) // 4, (pc.cin + 7) // 8
+        w = torch.zeros(NC * 8, NG * 4, cp, dtype=torch.float32, device=pc.weight.device)
+        w[:pc.cin, :T] = pc.weight.reshape(pc.cin, T, cp)
+        hi = w.to(torch.bfloat16)
+        r1 = w - hi.float()
+        mid = r1.to(torch.bfloat16)
+        lo = (r1 - mid.float()).to(torch.bfloat16)
+        planes = torch.stack([hi, mid, lo]).view(3, NC, 8, NG, 4, cp)          # [p, c, j, g, q, co]
+        pc.wsplit = planes.permute(1, 3, 0, 4, 5, 2).contiguous()              # [c, g, p, q, co, j]
+    return pc.wsplit
 
 
 def _pad_cout(cout: int) -> int:
@@ -306,14 +326,17 @@ class Ops:
         if out is None:
             shape = (B, out_cstride, Hout, Wout) if out_layout == LAYOUT_NCHW else (B, Hout, Wout, out_cstride)
             out = self.empty(*shape, dtype=out_dtype)
+        arith = self.conv_arith if arith is None else arith
+        wsplit = split_weights(pc) if (arith == ARITH_SPLIT and kh * kw > 1 and out_layout == LAYOUT_NCHW) else None
         d = _lib.Conv2dDesc(
+            weight_split=_ptr(wsplit),
             in0=_ptr(x0), in1=_ptr(x1), mul0=_ptr(mul0), weight=_ptr(pc.weight), scale=_ptr(pc.scale),
             shift=_ptr(pc.shift), residual=_ptr(residual), gru_z=_ptr(gru_z), gru_h=_ptr(gru_h), out=_ptr(out),
             gn_stats=_ptr(gn_stats), gn_groups=(gn_groups if gn_stats is not None else 0), B=B, c0=c0, c1=c1, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, cout=pc.cout, cout_pad=pc.cout_pad,
             kh=kh, kw=kw, stride=pc.stride, pad_h=pc.pad[0], pad_w=pc.pad[1], in_mode=in_mode, act=act,
             res_mode=res_mode, res_after_act=int(res_after_act), out_layout=out_layout, out_cstride=out_cstride,
             out_coffset=out_coffset, post_scale=post_scale, gate_cstride=gate_cstride,
-            arith=(self.conv_arith if arith is None else arith), tune=(self.tune["conv2d"] if tune is None else tune),
+            arith=arith, tune=(self.tune["conv2d"] if tune is None else tune),
             out_mul=_ptr(out_mul), out_mul_c0=out_mul_c0, in0_cstride=in0_cstride)
         self._call("dmvs_conv2d_f32", C.byref(d), self.stream())
         if self.timers is not None and "dmvs_conv2d_f32" in self.timers:      # bench: MFMA roofline over every conv launch

@@ -32,7 +32,7 @@ extern "C" {
  * product, SepConvGRU's r * h) and `in0_cstride` (in0 as a channel slice) -- honoured by dmvs_conv2d_f32 only: the weight-gradient entry
  * points return DMVS_EINVAL when any of in0_cstride / gate_cstride / out_mul is set.  A caller built against version 1 passes shorter descriptors:
  * check dmvs_abi_version() == DMVS_ABI_VERSION before the first call. */
-#define DMVS_ABI_VERSION 3
+#define DMVS_ABI_VERSION 4
 #define DMVS_EINVAL (-22)
 
 /* activation codes for the fused epilogues */
@@ -136,6 +136,11 @@ typedef struct dmvs_conv2d_desc {
     int32_t out_mul_c0;     /* first output channel out_mul applies to                                                       */
     int32_t in0_cstride;    /* 0: in0 is a dense [B,c0,..] tensor.  > 0 (DMVS_IN_PLAIN only): in0 is a channel slice (the pointer includes
                                the channel offset) of a tensor with this many channels per batch item                         */
+    const void* weight_split; /* ABI 4.  DMVS_ARITH_SPLIT only (else NULL): the layer's weights pre-split into bf16 triples in the matrix
+                               cores' operand order, 16-byte aligned: [ceil(cin / 8)][ceil(kh*kw / 4)][3 planes: hi, mid, lo][4][cout_pad][8]
+                               bf16 -- element (c, g, p, q, co, j) = part p of the weight of input channel 8c + j, tap 4g + q, output
+                               channel co (zero beyond cin / kh*kw / cout); hi = bf16(w), mid = bf16(w - hi), lo = bf16(w - hi - mid),
+                               round to nearest even.  A NULL pointer with DMVS_ARITH_SPLIT computes in exact fp32.               */
 } dmvs_conv2d_desc;
 
 /* Size limits (DMVS_EINVAL beyond them; the kernels address one batch item with 32-bit element offsets):

@@ -42,7 +42,7 @@ def test_descriptor_structs_match_header_field_order():
             if not decl:
                 continue
             typ, names = decl.rsplit(" ", 1)[0], decl
-            names = re.sub(r"^(const\s+)?(float|double|int32_t)\s*\*?", "", decl)
+            names = re.sub(r"^(const\s+)?(float|double|int32_t|void)\s*\*?", "", decl)
             for n in names.split(","):
                 fields.append(n.replace("*", "").strip())
         got = [f[0].rstrip("_") for f in cls._fields_]
@@ -54,8 +54,8 @@ def test_abi_version_pins_the_descriptor_sizes():
     `arith` was appended under version 1): the sizes and arities of version 3 are pinned here, header and binding alike (version 3 = version 2 +
     dmvs_mask_upsample4_f32 and dmvs_getcost_desc.tune)"""
     src = open(os.path.join(ROOT, "include", "dmvs.h")).read()
-    assert int(re.search(r"#define DMVS_ABI_VERSION (\d+)", src).group(1)) == _lib.ABI_VERSION == 3
-    assert (ctypes.sizeof(_lib.Conv2dDesc), ctypes.sizeof(_lib.Conv3dDesc), ctypes.sizeof(_lib.GetCostDesc)) == (208, 104, 160)
+    assert int(re.search(r"#define DMVS_ABI_VERSION (\d+)", src).group(1)) == _lib.ABI_VERSION == 4
+    assert (ctypes.sizeof(_lib.Conv2dDesc), ctypes.sizeof(_lib.Conv3dDesc), ctypes.sizeof(_lib.GetCostDesc)) == (216, 104, 160)
     assert len(_lib.SIGNATURES["dmvs_featurenet_stem_f32"]) == 13 and len(_lib.SIGNATURES["dmvs_warp_corr_init_quad_f32"]) == 18
     assert "dmvs_conv3x3_pair16_f32" not in _lib.SIGNATURES and len(_lib.SIGNATURES["dmvs_mask_upsample4_f32"]) == 15
 

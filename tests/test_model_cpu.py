@@ -173,3 +173,24 @@ def test_bf16_matrix_arithmetic_emulated(golden, variant):
     print(variant, "bf16 arithmetic vs the bf16 oracle:", ["%.2e" % x for x in errs], "vs the fp32 reference:", ["%.2e" % x for x in loose])
     assert max(errs) < 2e-3, errs
     assert 1e-5 < max(loose) < 2e-2, loose
+
+
+@pytest.mark.parametrize("variant", ["casdiffmvs", "diffmvs"])
+def test_split_bf16_arithmetic_emulated(golden, variant):
+    """conv_arith = "split": the multi-tap 2-D convolutions form every product from bf16 triples of their fp32 operands (six partial
+    products on the bf16 matrix cores, fp32 accumulation).  fp32 accuracy: against the REFERENCE's recorded fp32 outputs the depth maps
+    stay where the exact-fp32 path's are (1e-5 relative L1; the plain bf16 arithmetic is 1e-3) -- no rounded-operand oracle is involved."""
+    from models import CasDiffMVS
+    e = golden(f"e2e_{variant}_b2.npz")
+    meta = e.meta()
+    args = synth.make_args(variant, numdepth_initial=meta["nd_init"], conv_arith="split")
+    model = CasDiffMVS(args, test=True).eval()
+    sd = synth.synth_state_dict(model.state_dict(), meta["weight_seed"])
+    model.load_state_dict(sd, strict=True)
+    imgs, proj, dv = synth.synth_inputs(meta["H"], meta["W"], meta["n_src"], B=meta["B"], seed=meta["scene_seed"])
+    eng = model.engine(emu_ops())
+    assert eng.conv_arith == "split" and eng.precision == "fp32"
+    out = eng.forward(imgs, proj, dv, noise_fn=synth.NoiseSource(meta["noise_seed"]))
+    errs = [rel_l1(a, b) for a, b in zip(out["depth"], e.seq("out.depth"))]
+    print(variant, "split arithmetic vs the fp32 reference:", ["%.2e" % x for x in errs])
+    assert max(errs) < 1e-5, errs

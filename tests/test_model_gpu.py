@@ -168,6 +168,22 @@ def test_cfg3_full_size_bf16_matrix_arithmetic():
         assert torch.isfinite(d).all() and float(d.min()) >= 424.9 and float(d.max()) <= 935.1
 
 
+def test_cfg2_full_size_split_bf16_arithmetic():
+    """BASELINE.json configs[1] at its stated size with conv_arith = "split" (fp32 operands as bf16 triples, six partial products per product
+    on the bf16 matrix cores, fp32 accumulation) against the fp32 CPU oracle: the north star's 1e-3 relative L1 with three orders of
+    magnitude to spare, like the exact-fp32 kernels; bit-reproducible run to run."""
+    model, sd, args = make_model("diffmvs", 48, conv_arith="split")
+    imgs, proj, dv = synth.synth_inputs(512, 640, 5, B=1, seed=9)
+    out = run(model, imgs, proj, dv, 2)
+    assert model.engine().conv_arith == "split"
+    want = _oracle(sd, args, imgs, proj, dv, 2)
+    errs = [rel_l1(a.cpu(), b) for a, b in zip(out["depth"], want["depth"])]
+    print("cfg2 split arithmetic, depth rel-L1 vs the fp32 oracle:", ["%.2e" % x for x in errs])
+    assert max(errs) < 1e-5, errs
+    assert conf_close(out["photometric_confidence"][0], want["photometric_confidence"][0])
+    assert_reproducible(model, imgs, proj, dv, 2, out)
+
+
 def test_full_size_properties():
     """BASELINE.json configs[1] (640x512, 5 src, nd_init 48), batch 2: size-independent properties on top of
     test_full_size_against_oracle: batch items are independent (B=2 equals two B=1 runs bit-for-bit
