@@ -113,7 +113,7 @@ struct ConvCfg {
 // minimum waves per SIMD the register allocator must leave room for: the 32->32 (NT=2, MT=4) and 64->64 (NT=4, MT=2)
 // shapes otherwise settle at 160 / 212 VGPRs = 3 / 2 waves, too few to cover the per-chunk barrier + DMA latency
 constexpr int conv_min_waves(int nt, int mt, int ar = DMVS_ARITH_F32) {
-    if (ar == DMVS_ARITH_SPLIT) return nt <= 2 ? 3 : 2;      // two accumulator sets + the tap group's weights (and the next group's) in registers
+    if (ar == DMVS_ARITH_SPLIT) return nt <= 2 ? 4 : 2;      // accumulators + the tap group's weights (and the next group's) in registers
     return (nt == 2 && mt == 4) ? 4 : ((nt == 4 && mt == 2) ? 3 : 1);
 }
 
@@ -398,13 +398,18 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT, AR)) conv2d
     }
     const int b = s_b, ox0 = s_ox0, oy0 = s_oy0;
     f32x4 acc[MT][NT];
-    [[maybe_unused]] f32x4 acc_small[AR == DMVS_ARITH_SPLIT ? MT : 1][AR == DMVS_ARITH_SPLIT ? NT : 1];      // (split arithmetic) the small partial products
+    // (split arithmetic) a separate accumulator for the five small partial products would keep their roundings relative to a sum 2^-8 the size; the
+    // matrix instruction rounds once per K = 32 (not once per product as an fma chain does), so six roundings per 32 products in ONE accumulator are
+    // already fewer than the chain's 32 -- measured on the MI355X against fp64 the single accumulator is as close as the fp32 kernel
+    // (tests/test_ops.py::test_conv2d_split_bf16_arithmetic) -- and the 32 registers are the difference between 3 and 4 waves per SIMD
+    constexpr bool kSmallAcc = false;
+    [[maybe_unused]] f32x4 acc_small[(kSplit && kSmallAcc) ? MT : 1][(kSplit && kSmallAcc) ? NT : 1];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            if constexpr (AR == DMVS_ARITH_SPLIT) acc_small[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if constexpr (kSplit && kSmallAcc) acc_small[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
     // (split arithmetic) this lane's pre-split weights of one tap group: 16 bytes = the 8 channels of the chunk for (plane, tap 4g + kq, cout)
     typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
@@ -487,28 +492,20 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT, AR)) conv2d
             DMVS_LDS_BARRIER();        // the planes are complete and the fp32 buffer is free (ds accesses only: nothing is in flight)
             if (c0 + CK < cin) stage(c0 + CK, lds);      // lands while the matrix cores chew on chunk c0
             const int chunk = c0 / CK;
-#pragma unroll 1
-            for (int g = 0; g < Cfg::NG; ++g) {
-                if constexpr (kPrefetchA) {
-                    if (g + 1 < Cfg::NG) load_a(a_next, chunk, g + 1);
-                    else if (c0 + CK < cin) load_a(a_next, chunk + 1, 0);
-                } else if (g > 0) {
-                    load_a(a_cur, chunk, g);
-                }
+            auto tap_group = [&](int g, const u32x4s (&au)[kSplit ? 3 : 1][kSplit ? NT : 1]) __attribute__((always_inline)) {
                 const int t = 4 * g + kq;
                 const int tc = t < T ? t : T - 1;      // (a tap slot beyond the kernel meets zero weights)
                 const int ky = tc / KW, kx = tc - ky * KW;
                 const int qbase = ((wy * MT * S) + ky) * TW + (wx * 16 + m) * S + kx;
                 // RB rows at a time, the partial product outermost: the RB * NT MFMAs of one product are independent, so an accumulator is
-                // re-used RB * NT instructions later (back to back on one accumulator the matrix pipe waits out its own latency: the first
-                // form of this loop ran two interleaved chains and reached 40 % of the bf16 pipe's rate)
+                // re-used RB * NT instructions later
                 constexpr int RB = MT < 2 ? 1 : ((NT >= 2 || MT < 4) ? 2 : 4);
                 bf16x8 ah[NT], am[NT], al[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    ah[nt] = __builtin_bit_cast(bf16x8, a_cur[0][nt]);
-                    am[nt] = __builtin_bit_cast(bf16x8, a_cur[1][nt]);
-                    al[nt] = __builtin_bit_cast(bf16x8, a_cur[2][nt]);
+                    ah[nt] = __builtin_bit_cast(bf16x8, au[0][nt]);
+                    am[nt] = __builtin_bit_cast(bf16x8, au[1][nt]);
+                    al[nt] = __builtin_bit_cast(bf16x8, au[2][nt]);
                 }
                 auto mf = [&](const bf16x8& bq, const bf16x8& aq, f32x4 c) __attribute__((always_inline)) -> f32x4 {
                     return TR ? dmvs_mfma_bf16(bq, aq, c) : dmvs_mfma_bf16(aq, bq, c);
@@ -523,28 +520,59 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT, AR)) conv2d
                         bm[r] = __builtin_bit_cast(bf16x8, q_mid[qp]);
                         bl[r] = __builtin_bit_cast(bf16x8, q_lo[qp]);
                     }
-                    // the five small partial products (<= 2^-8 of hi*hi) in their own accumulator: their roundings are relative to a sum
-                    // 2^-8 the size, so the result carries the rounding error of ONE accumulation chain, like the fma chain it replaces
 #define DMVS_SPLIT_PRODUCT(BQ, AQ, ACC) \
                     _Pragma("unroll") for (int r = 0; r < RB; ++r) \
                         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) ACC[mt0 + r][nt] = mf(BQ[r], AQ[nt], ACC[mt0 + r][nt]);
-                    DMVS_SPLIT_PRODUCT(bl, ah, acc_small)
-                    DMVS_SPLIT_PRODUCT(bh, al, acc_small)
-                    DMVS_SPLIT_PRODUCT(bm, am, acc_small)
-                    DMVS_SPLIT_PRODUCT(bm, ah, acc_small)
-                    DMVS_SPLIT_PRODUCT(bh, am, acc_small)
+                    if constexpr (kSmallAcc) {
+                        DMVS_SPLIT_PRODUCT(bl, ah, acc_small)
+                        DMVS_SPLIT_PRODUCT(bh, al, acc_small)
+                        DMVS_SPLIT_PRODUCT(bm, am, acc_small)
+                        DMVS_SPLIT_PRODUCT(bm, ah, acc_small)
+                        DMVS_SPLIT_PRODUCT(bh, am, acc_small)
+                    } else {      // smallest partial products first
+                        DMVS_SPLIT_PRODUCT(bl, ah, acc)
+                        DMVS_SPLIT_PRODUCT(bh, al, acc)
+                        DMVS_SPLIT_PRODUCT(bm, am, acc)
+                        DMVS_SPLIT_PRODUCT(bm, ah, acc)
+                        DMVS_SPLIT_PRODUCT(bh, am, acc)
+                    }
                     DMVS_SPLIT_PRODUCT(bh, ah, acc)
 #undef DMVS_SPLIT_PRODUCT
                 }
-                if constexpr (kPrefetchA) {
+            };
+            const bool more = c0 + CK < cin;
+            if constexpr (kPrefetchA) {
+                // two register sets, used alternately WITHOUT copies (a rotating copy at the end of the loop body made hipcc wait for the
+                // prefetch at the top of the next trip: the L2 latency of the weights was exposed once per tap group -- 17 k cycles per
+                // chunk on the 32 -> 32 layer where the matrix work is 2.3 k); invariant: a_cur holds (chunk, 0) when a chunk starts
+                auto groups = [&]() __attribute__((always_inline)) {
+                    int g = 0;
+                    for (; g + 1 < Cfg::NG; g += 2) {
+                        load_a(a_next, chunk, g + 1);
+                        tap_group(g, a_cur);
+                        if (g + 2 < Cfg::NG) load_a(a_cur, chunk, g + 2);
+                        else if (more) load_a(a_cur, chunk + 1, 0);
+                        tap_group(g + 1, a_next);
+                    }
+                    if (g < Cfg::NG) {      // odd number of groups: the last one's weights are in a_cur
+                        if (more) load_a(a_next, chunk + 1, 0);
+                        tap_group(g, a_cur);
+                        if (more) {
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
+                            for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) a_cur[pl][nt] = a_next[pl][nt];
+                                for (int nt = 0; nt < NT; ++nt) a_cur[pl][nt] = a_next[pl][nt];
+                        }
+                    }
+                };
+                groups();
+            } else {
+#pragma unroll 1
+                for (int g = 0; g < Cfg::NG; ++g) {
+                    if (g > 0) load_a(a_cur, chunk, g);
+                    tap_group(g, a_cur);
                 }
-            }
-            if constexpr (!kPrefetchA) {
-                if (c0 + CK < cin) load_a(a_cur, chunk + 1, 0);
+                if (more) load_a(a_cur, chunk + 1, 0);
             }
         } else if constexpr (AR == DMVS_ARITH_BF16) {
             static_assert(CK == 8, "the bf16 form maps the 8 channels of an LDS chunk onto the 8 k-slots of a lane");
@@ -616,7 +644,7 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT, AR)) conv2d
         }
     }
 
-    if constexpr (AR == DMVS_ARITH_SPLIT) {
+    if constexpr (kSplit && kSmallAcc) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -737,7 +765,9 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT, AR)) conv2d
                         y *= *reinterpret_cast<const f32x4*>(mb);
                     } else {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) y[r] *= mb[ok[r] ? r : 0];
+                        for (int r = 0; r < 4; ++r)
+                            if (ok[r]) y[r] *= mb[r];      // (mb already holds the pixel offset: a lane whose pixels lie beyond the row must not touch it --
+                                                            //  mb[0] of the last row's last lanes is past the end of the tensor; found by the host emulation under ASan, round 6)
                     }
                 }
                 if (fast) {
@@ -913,10 +943,21 @@ static bool conv_bf16_honoured(const dmvs_conv2d_desc& d) {
 // waste three quarters of the matrix work), channel-last outputs and the training-only zero-insert form keep the exact-fp32 kernels.
 template <int KW>
 static bool conv_v16_ok(const dmvs_conv2d_desc& d);
+// Measured per layer at B = 96 (profiles/r6_conv_split_ab.txt, ms per step, exact fp32 -> split): 7x7 32 -> 16 4.11 -> 2.43, 3x3 64 -> 64 at
+// 576 x 64 x 80 3.31 -> 2.50, 32 -> 32 at 576 x 128 x 160 3.50 -> 2.84 and at 96 x 128 x 160 (x 13) 4.02 -> 3.33, 64 -> 31 2.24 -> 1.71, 5x5 stride 2
+// 32 -> 64 2.51 -> 1.98, 24 -> 32 0.95 -> 0.81, 1x5 / 5x1 64 -> 64 0.91 -> 0.76; the one-n-tile 16 -> 16 / 32 -> 16 layers gain 4-6 %.  It loses where
+// a tile's conversion pass and the two barriers per chunk outweigh the halved matrix time: few input channels (3 -> 8 0.49 -> 0.74, 6 -> 32 even)
+// and the stride-2 layers below 32 input channels, whose tile holds four times the positions per output (8 -> 16 5x5 3.52 -> 4.65, 16 -> 32 5x5
+// 2.79 -> 3.10, 3x3 stride 2 all).  Honoured: stride 1 with >= 16 input channels; stride 2 with >= 25 taps and >= 32 input channels.
+// DMVS_TUNE_SPLIT_ALL: wherever the form applies (A/B runs, tests).
 template <int KW>
 static bool conv_split_honoured(const dmvs_conv2d_desc& d) {
-    return d.arith == DMVS_ARITH_SPLIT && d.weight_split && !((uintptr_t)d.weight_split & 15) && d.out_layout == DMVS_LAYOUT_NCHW && d.kh * d.kw > 1 &&
-           d.in_mode != DMVS_IN_ZEROINSERT2 && conv_v16_ok<KW>(d);
+    if (d.arith != DMVS_ARITH_SPLIT || !d.weight_split || ((uintptr_t)d.weight_split & 15) || d.kh * d.kw <= 1 || d.in_mode == DMVS_IN_ZEROINSERT2 ||
+        (d.out_layout != DMVS_LAYOUT_NCHW && d.out_layout != DMVS_LAYOUT_NHWC) || !conv_v16_ok<KW>(d))
+        return false;
+    if (d.tune & DMVS_TUNE_SPLIT_ALL) return true;
+    const int cin = d.c0 + d.c1;
+    return d.stride == 1 ? cin >= 16 : (cin >= 32 && d.kh * d.kw >= 25);
 }
 
 // Waves side by side in a workgroup's tile (template WX) for a 3x3 / 5x5 layer with planar output.  Measured at B = 96
@@ -996,11 +1037,11 @@ int launch_conv2d_mt(const dmvs_conv2d_desc& d, hipStream_t st, int nt, int ngro
                         else hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, NTV, MT, false, DMVS_DTYPE_F32, true, false, DMVS_ARITH_SPLIT, 1, true, false>), grid, block, 0, st, d, tiles_x, tiles_y); \
                         return dmvs_launch_status(); \
                     } } while (0)
-                switch (nt) {      // (a shape whose buffers exceed the LDS falls through to the fp32 kernel)
+                switch (nt) {      // (a shape whose buffers exceed the LDS falls through to the fp32 kernel; launch_conv2d hands the stride-1 layers at most two n-tiles)
                     case 1: DMVS_SP(1); break;
                     case 2: DMVS_SP(2); break;
-                    case 3: DMVS_SP(3); break;
-                    default: DMVS_SP(4); break;
+                    case 3: if constexpr (S == 2) DMVS_SP(3); break;
+                    default: if constexpr (S == 2) DMVS_SP(4); break;
                 }
 #undef DMVS_SP
             }
@@ -1081,6 +1122,22 @@ int launch_conv2d_mt(const dmvs_conv2d_desc& d, hipStream_t st, int nt, int ngro
         }
         return dmvs_launch_status();
     }
+    if constexpr (!ZI && KH * KW > 1) {      // fp32 channel-last outputs in split-bf16 arithmetic (the D[cout][pixel] form: 16-byte channel runs per pixel)
+        if (d.out_layout == DMVS_LAYOUT_NHWC && conv_split_honoured<KW>(d)) {
+#define DMVS_SPC(NTV) do { \
+                using SCfg = ConvCfg<KH, KW, S, NTV, MT, DMVS_ARITH_SPLIT, 1, true>; \
+                if constexpr (SCfg::LDS_FLOATS * 4 <= 150 * 1024) { \
+                    hipLaunchKernelGGL((conv2d_mfma_kernel<KH, KW, S, NTV, MT, false, DMVS_DTYPE_F32, false, false, DMVS_ARITH_SPLIT, 1, true, false>), grid, block, 0, st, d, tiles_x, tiles_y); \
+                    return dmvs_launch_status(); \
+                } } while (0)
+            switch (nt) {
+                case 1: DMVS_SPC(1); break;
+                case 2: DMVS_SPC(2); break;
+                default: break;
+            }
+#undef DMVS_SPC
+        }
+    }
     if constexpr (!ZI) {      // fp32 channel-last outputs (FeatureNet's out1 / out2 / out3)
         if (v16) {
             switch (nt) {
@@ -1131,7 +1188,10 @@ static bool conv_tall_ok(const dmvs_conv2d_desc& d, int nt) {
 }
 
 template <int KH, int KW, int S>
-int launch_conv2d(const dmvs_conv2d_desc& d, hipStream_t st) {
+int launch_conv2d(const dmvs_conv2d_desc& d_in, hipStream_t st) {
+    // a layer the split form is not honoured for is an exact-fp32 layer in every respect (lean / tall / walking kernels included)
+    dmvs_conv2d_desc d = d_in;
+    if (d.arith == DMVS_ARITH_SPLIT && !conv_split_honoured<KW>(d)) d.arith = DMVS_ARITH_F32;
     const int ntiles = (d.cout_pad + 15) / 16;
     // output channels per workgroup: up to 4 MFMA n-tiles share one staged input tile
     const int nt = ntiles <= 4 ? ntiles : (ntiles % 3 == 0 ? 3 : 4);
@@ -1140,11 +1200,15 @@ int launch_conv2d(const dmvs_conv2d_desc& d, hipStream_t st) {
         if (conv_split_honoured<KW>(d)) {      // split-bf16 arithmetic: 16 x 16 tiles for the light families (the weight split is per wave and tap group), 16 x 8 otherwise
             constexpr bool heavy_ = (S == 2) || (KH * KW >= 25);
             const int force_mt_ = (d.tune >> 4) & 7;
+            // at most two n-tiles per workgroup: the tap group's weights and the next group's (2 x 3 planes x NT x 4 registers) live in registers
+            // (stride 2: a tile's conversion pass covers four times the positions per output, so splitting the output channels over more
+            // workgroups costs more than the exposed weight latency -- 32 -> 64 5x5 stride 2: 1.94 ms with four n-tiles, 2.78 with two)
+            const int nts = S == 2 ? nt : (nt < 2 ? nt : 2), ngs = (ntiles + nts - 1) / nts;
             if constexpr (!heavy_) {
-                const long wg16_ = (long)((d.Wout + 15) / 16) * ((d.Hout + 15) / 16) * d.B * ngroups;
-                if (force_mt_ == 4 || (force_mt_ == 0 && nt <= 2 && wg16_ >= 1024)) return launch_conv2d_mt<KH, KW, S, 4, false>(d, st, nt, ngroups);
+                const long wg16_ = (long)((d.Wout + 15) / 16) * ((d.Hout + 15) / 16) * d.B * ngs;
+                if (force_mt_ == 4 || (force_mt_ == 0 && wg16_ >= 1024)) return launch_conv2d_mt<KH, KW, S, 4, false>(d, st, nts, ngs);
             }
-            return launch_conv2d_mt<KH, KW, S, 2, false>(d, st, nt, ngroups);
+            return launch_conv2d_mt<KH, KW, S, 2, false>(d, st, nts, ngs);
         }
     }
     if constexpr (KH == 3 && KW == 3 && S == 1) {

@@ -444,12 +444,17 @@ class Engine:
         if prec not in K.FEATURE_DTYPES:
             raise K._lib.DmvsError(f"precision '{prec}': expected one of {sorted(K.FEATURE_DTYPES)}")
         self.precision, self.feat_dtype = prec, K.FEATURE_DTYPES[prec]
-        # matrix arithmetic of the 2-D convolutions: args.conv_arith / DMVS_CONV_ARITH in {"fp32", "bf16"}.  "bf16" rounds the
-        # inputs and weights of every multi-tap convolution with a planar output to bf16 as they enter the matrix cores (fp32
-        # accumulation; tensors in memory, the FeatureNet stem, the 1x1 layers, the channel-last feature outputs, the 3-D
-        # convolutions, the warps and every epilogue stay fp32) -- the arithmetic of BASELINE.json's bf16 configuration.  The
-        # reference's eps switch for non-fp32 activations (update.py:87,102) does not apply: activations are fp32 here.
-        arith = getattr(args, "conv_arith", None) or os.environ.get("DMVS_CONV_ARITH") or "fp32"   # an explicit args value wins
+        # matrix arithmetic of the 2-D convolutions: args.conv_arith / DMVS_CONV_ARITH in {"split", "fp32", "bf16"}.
+        #   "split" (the default, round 6): fp32 ACCURACY on the bf16 matrix cores -- every fp32 operand of a multi-tap convolution is split into
+        #       three bf16 values and a product is the sum of its six partial products down to 2^-18 (fp32 accumulation); against fp64 it is as
+        #       close as the exact-fp32 kernels (tests/test_ops.py::test_conv2d_split_bf16_arithmetic, measured on the MI355X).  Honoured where it
+        #       is faster (csrc/conv2d_tiled.h: conv_split_honoured); the other layers, the FeatureNet stem, the 1x1 layers, the 3-D convolutions,
+        #       the warps and every epilogue compute in exact fp32.
+        #   "fp32": exact fp32 products everywhere (v_mfma_f32_16x16x4_f32: bitwise a k-ordered fma chain).
+        #   "bf16": inputs and weights of every multi-tap convolution with a planar output ROUNDED to bf16 as they enter the matrix cores (fp32
+        #       accumulation) -- the arithmetic of BASELINE.json's bf16 configuration, a reduced-precision mode.
+        # The reference's eps switch for non-fp32 activations (update.py:87,102) does not apply: activations are fp32 here.
+        arith = getattr(args, "conv_arith", None) or os.environ.get("DMVS_CONV_ARITH") or "split"   # an explicit args value wins
         if arith not in K.CONV_ARITH:
             raise K._lib.DmvsError(f"conv_arith '{arith}': expected one of {sorted(K.CONV_ARITH)}")
         self.conv_arith = arith

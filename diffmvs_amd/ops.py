@@ -178,6 +178,7 @@ def _env_tune():
     t2 |= _lib.TUNE_NO_LEAN if e("DMVS_CONV_LEAN") == "0" else 0
     t2 |= _lib.TUNE_1X1_TILED if e("DMVS_CONV1X1_PX4") == "0" else 0
     t2 |= {"0": _lib.TUNE_NO_TALL, "1": _lib.TUNE_TALL}.get(e("DMVS_CONV_TALL"), 0)
+    t2 |= _lib.TUNE_SPLIT_ALL if e("DMVS_CONV_SPLIT_ALL") == "1" else 0
     t2 |= _lib.tune_xcd_group(int(e("DMVS_CONV_XCD", "0")))      # round 6: which tiles share an XCD's L2 (include/dmvs.h DMVS_TUNE_XCD_GROUP)
     t3 = (_lib.TUNE3D_PIECES4 if e("DMVS_CONV3D_V16") == "0" else 0) | (_lib.TUNE3D_S2_DIRECT if e("DMVS_CONV3D_S2") == "direct" else 0)
     t3 |= _lib.TUNE3D_NO_PAIR if e("DMVS_CONV3D_PAIR") == "0" else 0
@@ -327,7 +328,7 @@ class Ops:
             shape = (B, out_cstride, Hout, Wout) if out_layout == LAYOUT_NCHW else (B, Hout, Wout, out_cstride)
             out = self.empty(*shape, dtype=out_dtype)
         arith = self.conv_arith if arith is None else arith
-        wsplit = split_weights(pc) if (arith == ARITH_SPLIT and kh * kw > 1 and out_layout == LAYOUT_NCHW) else None
+        wsplit = split_weights(pc) if (arith == ARITH_SPLIT and kh * kw > 1 and out_layout in (LAYOUT_NCHW, LAYOUT_NHWC)) else None
         d = _lib.Conv2dDesc(
             weight_split=_ptr(wsplit),
             in0=_ptr(x0), in1=_ptr(x1), mul0=_ptr(mul0), weight=_ptr(pc.weight), scale=_ptr(pc.scale),

