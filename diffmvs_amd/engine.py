@@ -585,6 +585,12 @@ class Engine:
             noise_fn = lambda shape, device: torch.randn(shape, device=device)  # noqa: E731
         B = imgs[0].shape[0]
         V = len(imgs)
+        Hi, Wi = int(imgs[0].shape[-2]), int(imgs[0].shape[-1])
+        if Hi % 32 or Wi % 32 or Hi < 32 or Wi < 32:
+            # FeatureNet halves the image three times and CostRegNet_small the stage-1 volume twice: the reference's own skip connections
+            # (module.py:444-445, `conv3 + conv6(x)`) only line up -- and this engine's kernels only stay inside their tensors -- on multiples of
+            # 32 (its datasets crop to that, datasets/mvs.py); found by running the host emulation under ASan on a 72 x 104 input, round 6
+            raise K._lib.DmvsError(f"image size {Hi}x{Wi}: height and width must be multiples of 32")
         if feats is not None:      # rows gathered from a scene's store: validate before any launch reads them
             H, W = imgs[0].shape[-2:]
             V = next(iter(feats.values())).shape[0] // max(B, 1)

@@ -194,3 +194,16 @@ def test_split_bf16_arithmetic_emulated(golden, variant):
     errs = [rel_l1(a, b) for a, b in zip(out["depth"], e.seq("out.depth"))]
     print(variant, "split arithmetic vs the fp32 reference:", ["%.2e" % x for x in errs])
     assert max(errs) < 1e-5, errs
+
+
+def test_image_sizes_that_are_not_multiples_of_32_are_rejected():
+    """the reference's own skip connections only line up on multiples of 32 (module.py:444-445); the engine says so before any launch instead of
+    reading past its tensors (the transposed 3-D convolution's residual on a 72 x 104 input: found under ASan on the host emulation)"""
+    from diffmvs_amd import _lib
+    from models import CasDiffMVS
+    args = synth.make_args("diffmvs", numdepth_initial=8)
+    model = CasDiffMVS(args, test=True).eval()
+    model.load_state_dict(synth.synth_state_dict(model.state_dict(), 3), strict=True)
+    imgs, proj, dv = synth.synth_inputs(72, 104, 2, B=1, seed=1)
+    with pytest.raises(_lib.DmvsError, match="multiples of 32"):
+        model.engine(emu_ops()).forward(imgs, proj, dv, noise_fn=synth.NoiseSource(1))
