@@ -102,6 +102,7 @@ TUNE3D_PIECES4, TUNE3D_S2_DIRECT, TUNE3D_NO_PAIR = 0x1, 0x2, 0x4
 TUNE_SWEEP_GLOBAL = 0x1
 TUNE_WGRAD_ACCUMULATE = 0x1000
 TUNE_SPLIT_ALL = 0x20000
+TUNE_STEM_EXACT = 0x40000
 
 
 def tune_xcd_group(n: int) -> int:      # DMVS_TUNE_XCD_GROUP(n)

@@ -14,10 +14,18 @@
 //     rows 0-7 carry W[ky = j] (output row y) and rows 8-15 W[ky = j-1] (output row y+1) for input row y+j, j = 0..3 -- both
 //     outputs read the same input operand: 24 instead of 36 MFMAs per row pair.  The pixels are the A operand and the paired
 //     weights B, so a lane ends up with 4 consecutive pixels of one (row, channel): BN + ReLU + one 16-byte NCHW store.
-// Exact-fp32 MFMA; conv0.0's 27 products are summed in (ci, tap) order here and in (tap, ci) order by the generic
-// kernel, so the two agree to the last bits, not bitwise.
+// conv0.0: exact-fp32 MFMA; its 27 products are summed in (ci, tap) order here and in (tap, ci) order by the generic kernel, so the two agree
+// to the last bits, not bitwise.
+// conv0.1 (two thirds of the matrix work), template SPLIT (round 6, the default): split-bf16 arithmetic with fp32 accuracy (conv2d_tiled.h,
+// DESIGN.md 4.5) -- conv0.0's epilogue writes the intermediate as three bf16 planes [plane][18 x 18][8 channels] (it holds the values in
+// registers anyway: the split is 5.5 VALU per value, once), conv0.1's K = 8 channels x 12 (input row, kx) slots = 96 is exactly three
+// v_mfma_f32_16x16x32_bf16 steps, six partial products each: 18 instructions of 16 cycles per row pair instead of 24 of 32, the lane's paired
+// weights pre-split in 36 registers for the life of the persistent workgroup, and the next tile's input DMA proceeds under them (an fp32 MFMA
+// stops the CU's vector memory: tools/calib/overlap_probe.hip).  conv0.0 stays fp32: its operand is gathered per k-slot from the 3-channel halo,
+// so a split would cost more VALU work than the matrix time it saves.  DMVS_TUNE_STEM_EXACT: the exact-fp32 conv0.1.
 
 #include "dmvs_common.h"
+#include "dmvs_bf16.h"
 #include "dmvs_lds_poison.h"
 
 namespace {
@@ -40,7 +48,7 @@ constexpr int W1S = 208;                           // conv0.1 paired weight slab
 
 __device__ __attribute__((aligned(16))) const float stem_zero16[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
-template <bool V16>
+template <bool V16, bool SPLIT>
 __global__ void __launch_bounds__(DMVS_BLOCK)
 featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0, const float* __restrict__ scale0,
                        const float* __restrict__ shift0, const float* __restrict__ w1, const float* __restrict__ scale1,
@@ -51,11 +59,12 @@ featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0
     // be waited out immediately.
     constexpr int IWP = V16 ? IWL16 : IW, X0 = V16 ? SLACK16 : 0;      // LDS row pitch of the input halo, halo column 0 inside a row
     constexpr int IPL = IW * IWP, INF = 3 * IPL;                       // one channel plane / one input buffer in LDS
-    __shared__ __attribute__((aligned(16))) float lds[2 * INF + 8 * MPLANE + K0 * 16 + 8 * W1S];
+    constexpr int MIDF = SPLIT ? 3 * MP * 4 : 8 * MPLANE;               // intermediate: three bf16 planes [324 positions][8 channels] / eight fp32 planes
+    __shared__ __attribute__((aligned(16))) float lds[2 * INF + MIDF + K0 * 16 + (SPLIT ? 0 : 8 * W1S)];
     DMVS_LDS_POISON(lds);
     float* const s_mid = lds + 2 * INF;
-    float* const s_w0 = s_mid + 8 * MPLANE;
-    float* const s_w1 = s_w0 + K0 * 16;
+    float* const s_w0 = s_mid + MIDF;
+    [[maybe_unused]] float* const s_w1 = s_w0 + K0 * 16;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, kq = lane >> 4;
@@ -69,11 +78,29 @@ featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0
         const int ky = row < 8 ? j : j - 1;
         s_w0[e] = (ky >= 0 && ky <= 2) ? w0[(ci * 9 + ky * 3 + kx) * 8 + (row & 7)] : 0.0f;
     }
+    if constexpr (!SPLIT) {
     for (int e = tid; e < 8 * W1S; e += DMVS_BLOCK) {
         const int ci = e / W1S, r = e - ci * W1S, jt = r >> 4, row = r & 15;
         const int j = jt / 3, kx = jt - j * 3;
         const int ky = row < 8 ? j : j - 1;              // rows 0-7: output row y, rows 8-15: output row y + 1
         s_w1[e] = (jt < 12 && ky >= 0 && ky <= 2) ? w1[(ci * 9 + ky * 3 + kx) * 8 + (row & 7)] : 0.0f;
+    }
+    }
+    // (SPLIT) this lane's paired conv0.1 weights as bf16 triples, for the life of the workgroup: matrix column m = (output row of the pair m >> 3,
+    // cout m & 7), k-slots = the 8 input channels of slot s = 4g + kq of the 12 (input row j, kx) slots: rows 0-7 take tap row ky = j, rows 8-15 ky = j - 1
+    [[maybe_unused]] bf16x8 w1h[3], w1m[3], w1l[3];
+    if constexpr (SPLIT) {
+        const int mrow = threadIdx.x & 15;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const int sl = 4 * g + ((threadIdx.x & 63) >> 4);
+            const int j = sl / 3, kx = sl - j * 3;
+            const int ky = mrow < 8 ? j : j - 1;
+            float wv[8];
+#pragma unroll
+            for (int ci = 0; ci < 8; ++ci) wv[ci] = (ky >= 0 && ky <= 2) ? w1[(ci * 9 + ky * 3 + kx) * 8 + (mrow & 7)] : 0.0f;
+            dmvs_split3_bf16x8(wv, w1h[g], w1m[g], w1l[g]);
+        }
     }
 
     // Input halo staging (3 x 20 x 20, zero padded): 4-byte LDS-DMA, 64 consecutive words per wave.  Which (channel,
@@ -202,9 +229,28 @@ featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0
             const int gy = oy0 - 1 + py, gx = ox0 - 1 + px;
             const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
             if (gidx * 16 + m < NSLOT) {
+                if constexpr (SPLIT) {
+                    // the lane's 4 channels 4 * (kq & 1) + r of position (py, px) as bf16 triples: 8 bytes per plane
+                    float v[8];
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    s_mid[(4 * (kq & 1) + r) * MPLANE + py * MW + px] = inside ? fmaxf(fmaf(acc[r], sc0[r], sh0[r]), 0.0f) : 0.0f;
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = inside ? fmaxf(fmaf(acc[r], sc0[r], sh0[r]), 0.0f) : 0.0f;
+                        v[4 + r] = 0.0f;
+                    }
+                    bf16x8 h8, m8, l8;
+                    dmvs_split3_bf16x8(v, h8, m8, l8);
+                    typedef uint32_t u32x2s __attribute__((ext_vector_type(2)));
+                    typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+                    u32x2s* const q = reinterpret_cast<u32x2s*>(s_mid) + (py * MW + px) * 2 + (kq & 1);
+                    const u32x4s hh = __builtin_bit_cast(u32x4s, h8), mm = __builtin_bit_cast(u32x4s, m8), ll = __builtin_bit_cast(u32x4s, l8);
+                    q[0] = u32x2s{hh[0], hh[1]};
+                    q[MP * 2] = u32x2s{mm[0], mm[1]};
+                    q[2 * MP * 2] = u32x2s{ll[0], ll[1]};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        s_mid[(4 * (kq & 1) + r) * MPLANE + py * MW + px] = inside ? fmaxf(fmaf(acc[r], sc0[r], sh0[r]), 0.0f) : 0.0f;
+                }
             }
         }
         DMVS_LDS_BARRIER();     // s_mid complete (ds_writes only); the next tile's input DMA stays in flight
@@ -213,6 +259,39 @@ featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0
         f32x4 acc[2];
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) acc[pr] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (SPLIT) {
+            typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+            const u32x4s* const q_hi = reinterpret_cast<const u32x4s*>(s_mid);
+            const u32x4s* const q_mid = q_hi + MP;
+            const u32x4s* const q_lo = q_mid + MP;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const int sl = 4 * g + kq;
+                const int j = sl / 3, kx = sl - j * 3;
+                const int qb = (wave * 4 + j) * MW + m + kx;
+                bf16x8 ph[2], pm[2], pl[2];
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const int qp = qb + 2 * pr * MW;
+                    ph[pr] = __builtin_bit_cast(bf16x8, q_hi[qp]);
+                    pm[pr] = __builtin_bit_cast(bf16x8, q_mid[qp]);
+                    pl[pr] = __builtin_bit_cast(bf16x8, q_lo[qp]);
+                }
+                // the partial product outermost (the two row pairs are independent accumulators), smallest products first
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) acc[pr] = dmvs_mfma_bf16(pl[pr], w1h[g], acc[pr]);
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) acc[pr] = dmvs_mfma_bf16(ph[pr], w1l[g], acc[pr]);
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) acc[pr] = dmvs_mfma_bf16(pm[pr], w1m[g], acc[pr]);
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) acc[pr] = dmvs_mfma_bf16(pm[pr], w1h[g], acc[pr]);
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) acc[pr] = dmvs_mfma_bf16(ph[pr], w1m[g], acc[pr]);
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) acc[pr] = dmvs_mfma_bf16(ph[pr], w1h[g], acc[pr]);
+            }
+        } else {
 #pragma unroll
         for (int c4 = 0; c4 < 2; ++c4) {
             const int ci = c4 * 4 + kq;
@@ -227,6 +306,7 @@ featurenet_stem_kernel(const float* __restrict__ x, const float* __restrict__ w0
                     for (int pr = 0; pr < 2; ++pr)
                         acc[pr] = __builtin_amdgcn_mfma_f32_16x16x4f32(mp[(2 * pr + j) * MW + kx], av, acc[pr], 0, 0, 0);      // D[pixel][(row, cout)]
                 }
+        }
         }
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) pend[pr] = acc[pr];
@@ -248,22 +328,23 @@ extern "C" int dmvs_featurenet_stem_f32(const float* x, const float* w0, const f
     // persistent workgroups: exactly as many as are resident at once (the occupancy query: 5 per CU with the 16-byte form's 31 KB of
     // LDS, 7 with the 4-byte form's 22 KB).  Until round 4 this was a fixed 6 per CU -- with 31 KB the sixth workgroup of every CU started
     // when the other five had walked all their tiles, and then walked its own share alone on an otherwise idle CU.
-    static const int resident16 = dmvs_resident_workgroups(reinterpret_cast<const void*>(featurenet_stem_kernel<true>));
-    static const int resident4 = dmvs_resident_workgroups(reinterpret_cast<const void*>(featurenet_stem_kernel<false>));
     const bool v16 = !(tune & DMVS_TUNE_PIECES4) && (W & 3) == 0 && ((uintptr_t)x & 15) == 0;
-    const int resident = v16 ? resident16 : resident4;
-    const unsigned grid = (unsigned)(ntiles < resident ? ntiles : resident);
+    const bool split = !(tune & DMVS_TUNE_STEM_EXACT);
     // DMVS_TUNE_XCD_GROUP: 0 = groups of 4 x-adjacent tiles per XCD (a 16-pixel tile row is half a cache line), 1 = plain round robin, 2 | 3 | 4 = 2 | 4 | 8
     const int xg = (tune >> 14) & 7;
     const int xgroup = xg == 0 ? 4 : (xg <= 4 ? 1 << (xg - 1) : 4);
     // input halo in 16-byte LDS-DMA pieces wherever rows are 16-byte multiples on a 16-byte aligned tensor (6 instead of 19 wave-level
-    // DMA instructions per tile, 84 instead of 96 VGPRs): 1094 -> 938 us per 96 images on the MI355X, bit-identical
-    // (profiles/r4_optins_ab.jsonl); DMVS_TUNE_PIECES4 forces the 4-byte form
-    if (v16)
-        hipLaunchKernelGGL(featurenet_stem_kernel<true>, dim3(grid), dim3(DMVS_BLOCK), 0, (hipStream_t)stream, x, w0, scale0, shift0, w1,
-                           scale1, shift1, y, N, H, W, tiles_x, tiles_y, xgroup);
-    else
-        hipLaunchKernelGGL(featurenet_stem_kernel<false>, dim3(grid), dim3(DMVS_BLOCK), 0, (hipStream_t)stream, x, w0, scale0, shift0, w1,
-                           scale1, shift1, y, N, H, W, tiles_x, tiles_y, xgroup);
+    // DMA instructions per tile): 1094 -> 938 us per 96 images on the MI355X, bit-identical (profiles/r4_optins_ab.jsonl); DMVS_TUNE_PIECES4
+    // forces the 4-byte form
+#define DMVS_STEM_LAUNCH(V16V, SPLITV) do { \
+        static const int resident = dmvs_resident_workgroups(reinterpret_cast<const void*>(featurenet_stem_kernel<V16V, SPLITV>)); \
+        const unsigned grid = (unsigned)(ntiles < resident ? ntiles : resident); \
+        hipLaunchKernelGGL((featurenet_stem_kernel<V16V, SPLITV>), dim3(grid), dim3(DMVS_BLOCK), 0, (hipStream_t)stream, x, w0, scale0, shift0, w1, \
+                           scale1, shift1, y, N, H, W, tiles_x, tiles_y, xgroup); } while (0)
+    if (v16 && split) DMVS_STEM_LAUNCH(true, true);
+    else if (v16) DMVS_STEM_LAUNCH(true, false);
+    else if (split) DMVS_STEM_LAUNCH(false, true);
+    else DMVS_STEM_LAUNCH(false, false);
+#undef DMVS_STEM_LAUNCH
     return dmvs_launch_status();
 }

@@ -170,7 +170,7 @@ def _env_tune():
     a variable after the first forward has no effect (A/B tools pass tune= per call, mutate ops.tune, or construct a fresh Ops).
     All default to 0 = the library's measured-best path:
       DMVS_CONV_WX=1|2, DMVS_CONV_MT=1|2|4, DMVS_CONV_WALK=0, DMVS_CONV_LEAN=0, DMVS_CONV_V16=0, DMVS_CONV1X1_PX4=0, DMVS_CONV_TALL=0|1, DMVS_CONV_XCD=1..7   (dmvs_conv2d_desc.tune)
-      DMVS_CONV3D_V16=0, DMVS_CONV3D_S2=direct, DMVS_CONV3D_PAIR=0, DMVS_CONV3D_XCD=1..4   (dmvs_conv3d_desc.tune)      DMVS_STEM_V16=0, DMVS_STEM_XCD=1..4      DMVS_PLANE_SWEEP=quad"""
+      DMVS_CONV3D_V16=0, DMVS_CONV3D_S2=direct, DMVS_CONV3D_PAIR=0, DMVS_CONV3D_XCD=1..4   (dmvs_conv3d_desc.tune)      DMVS_STEM_V16=0, DMVS_STEM_XCD=1..4, DMVS_STEM_EXACT=1      DMVS_PLANE_SWEEP=quad"""
     e = os.environ.get
     t2 = _lib.tune_tile_wx(int(e("DMVS_CONV_WX", "0"))) | _lib.tune_tile_mt(int(e("DMVS_CONV_MT", "0")))
     t2 |= _lib.TUNE_NO_WALK if e("DMVS_CONV_WALK") == "0" else 0
@@ -183,7 +183,7 @@ def _env_tune():
     t3 = (_lib.TUNE3D_PIECES4 if e("DMVS_CONV3D_V16") == "0" else 0) | (_lib.TUNE3D_S2_DIRECT if e("DMVS_CONV3D_S2") == "direct" else 0)
     t3 |= _lib.TUNE3D_NO_PAIR if e("DMVS_CONV3D_PAIR") == "0" else 0
     t3 |= _lib.tune3d_xcd_group(int(e("DMVS_CONV3D_XCD", "0")))
-    return {"conv2d": t2, "conv3d": t3, "stem": (_lib.TUNE_PIECES4 if e("DMVS_STEM_V16") == "0" else 0) | _lib.tune_xcd_group(int(e("DMVS_STEM_XCD", "0"))),
+    return {"conv2d": t2, "conv3d": t3, "stem": (_lib.TUNE_PIECES4 if e("DMVS_STEM_V16") == "0" else 0) | _lib.tune_xcd_group(int(e("DMVS_STEM_XCD", "0"))) | (_lib.TUNE_STEM_EXACT if e("DMVS_STEM_EXACT") == "1" else 0),
             "sweep": _lib.TUNE_SWEEP_GLOBAL if e("DMVS_PLANE_SWEEP") == "quad" else 0,
             # training: GetCost backward through the per-pixel gather kernel only (no tile pre-pass / LDS-window worklist): DMVS_GETCOST_BWD=gather
             "bwd_gather": e("DMVS_GETCOST_BWD") == "gather",
@@ -371,8 +371,11 @@ class Ops:
                 pc1.k == (3, 3) and pc0.stride == 1 and pc1.stride == 1 and pc0.pad == (1, 1) and pc1.pad == (1, 1) and
                 pc0.cout_pad == 8 and pc1.cout_pad == 8):
             raise _lib.DmvsError("featurenet_stem: expects the 3->8->8 3x3 stem of FeatureNet")
+        tune = self.tune["stem"] if tune is None else tune
+        if self.conv_arith != ARITH_SPLIT:      # conv0.1 in split-bf16 arithmetic (the library's default) only under conv_arith = "split"
+            tune |= _lib.TUNE_STEM_EXACT
         self._call("dmvs_featurenet_stem_f32", _ptr(x), _ptr(pc0.weight), _ptr(pc0.scale), _ptr(pc0.shift), _ptr(pc1.weight),
-                   _ptr(pc1.scale), _ptr(pc1.shift), _ptr(y), N, H, W, self.tune["stem"] if tune is None else tune, self.stream())
+                   _ptr(pc1.scale), _ptr(pc1.shift), _ptr(y), N, H, W, tune, self.stream())
 
     def conv2d_wgrad(self, pc: PackedConv, x0, grad_out, x1=None, *, mul0=None, in_mode=IN_PLAIN, want_bias=False, tune=None,
                      into_gw=None, into_gb=None):

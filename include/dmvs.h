@@ -85,6 +85,7 @@ int dmvs_abi_version(void);
 #define DMVS_TUNE_1X1_TILED 0x200                 /* 1x1 layers on the LDS-tiled kernel instead of the 16-byte direct form                    */
 #define DMVS_TUNE_NO_LEAN 0x100                   /* plain layers on the generic kernel (every fused path resolved at run time)     */
 #define DMVS_TUNE_TALL(n) (((n) & 3) << 10)      /* 16 x 32-pixel tiles for the plain 3x3 layers: 0 = where measured better, 1 = never, 2 = wherever they apply (16 x 64 tiles: timed in round 5, 6-8 % slower, removed) */
+#define DMVS_TUNE_STEM_EXACT 0x40000             /* dmvs_featurenet_stem_f32: conv0.1 in exact fp32 (0 = split-bf16 arithmetic with fp32 accuracy, the default) */
 #define DMVS_TUNE_SPLIT_ALL 0x20000              /* DMVS_ARITH_SPLIT on every layer the form applies to, not only where it measured faster (A/B runs, tests) */
 #define DMVS_TUNE_XCD_GROUP(n) (((n) & 7) << 14) /* tiled kernels, one tile per workgroup: which tiles share an XCD's L2.  0 = the library's choice, 1 = plain round robin, 2 | 3 | 4 = groups of 2 | 4 | 8 x-adjacent tiles, 5 = one tile row, 6 = two tile rows, 7 = one image (bit-identical results) */
 

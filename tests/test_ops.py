@@ -1211,6 +1211,27 @@ def test_featurenet_stem_16_byte_pieces(ops, N, H, W):
     assert torch.equal(a.cpu(), b.cpu())
 
 
+@pytest.mark.parametrize("N,H,W", [(2, 37, 52), (1, 64, 96), (2, 9, 12)])
+def test_featurenet_stem_split_bf16_arithmetic(ops, N, H, W):
+    """conv0.1 of the fused stem in split-bf16 arithmetic (the default under conv_arith = "split"; conv0.0's epilogue writes the intermediate as
+    bf16 triples): against torch in fp64 its error is of the size of the exact-fp32 stem's own, both staging forms give the same bits"""
+    x = rnd(N, 3, H, W, seed=1)
+    w0, w1 = rnd(8, 3, 3, 3, seed=2) * 0.4, rnd(8, 8, 3, 3, seed=3) * 0.3
+    b0, b1 = rnd(8, seed=4), rnd(8, seed=5)
+    pc0, pc1 = K.pack_conv2d(*dev(ops, w0, b0), pad=1), K.pack_conv2d(*dev(ops, w1, b1), pad=1)
+    so = ops.with_conv_arith(K.ARITH_SPLIT)
+    a = so.featurenet_stem(pc0, pc1, dev(ops, x)).cpu()
+    b = so.featurenet_stem(pc0, pc1, dev(ops, x), tune=K._lib.TUNE_PIECES4).cpu()
+    e = ops.featurenet_stem(pc0, pc1, dev(ops, x)).cpu()
+    ref = F.relu(F.conv2d(F.relu(F.conv2d(x.double(), w0.double(), b0.double(), 1, 1)), w1.double(), b1.double(), 1, 1))
+    scale = float(ref.abs().max())
+    e_split, e_f32 = float((a.double() - ref).abs().max()) / scale, float((e.double() - ref).abs().max()) / scale
+    print("stem split vs fp64: %.2e   exact fp32 vs fp64: %.2e" % (e_split, e_f32))
+    assert e_f32 < 1e-6 and e_split < 2e-6 and e_split < 4.0 * e_f32 + 2e-7, (e_split, e_f32)
+    assert torch.equal(a, b)
+    assert not torch.equal(a, e)      # (the mode is really on)
+
+
 @pytest.mark.parametrize("N,H,W", [(2, 37, 52), (3, 64, 96)])
 def test_featurenet_stem_xcd_grouped_tiles(ops, N, H, W):
     """DMVS_TUNE_XCD_GROUP on the stem's tile walk: every group size gives the round-robin order's bits"""
