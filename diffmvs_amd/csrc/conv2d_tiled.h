@@ -906,10 +906,9 @@ static bool conv_split_honoured(const dmvs_conv2d_desc& d) {
         return false;
     if (d.tune & DMVS_TUNE_SPLIT_ALL) return true;
     const int cin = d.c0 + d.c1;
-    // a launch of fewer than 256 16 x 16 tiles (one workgroup per CU and less: the batch-1 / batch-2 forward's stage-2 layers) is a dependent
-    // chain per workgroup, where the form's second barrier and conversion pass per chunk cost more than its matrix cycles save (batch 1
-    // graphed 3.05 -> 3.15 ms per map with the form everywhere): exact fp32 there
-    if ((long)((d.Wout + 15) / 16) * ((d.Hout + 15) / 16) * d.B < 256) return false;
+    // (The rule must not look at the batch size: which arithmetic a layer runs in decides its bits, and the forward is independent of the batch
+    // composition -- what makes the scene cache exact.  A "small launches stay fp32" rule was measured -- batch 1 graphed 3.15 -> 3.00 ms per
+    // map -- and removed for that reason: tests/test_scene.py caught the scene store's FeatureNet pass differing from the per-sample one.)
     return d.stride == 1 ? cin >= 16 : (cin >= 32 && d.kh * d.kw >= 25);
 }
 
