@@ -779,7 +779,7 @@ def main():
         # tests/test_ops.py::test_conv2d_split_bf16_arithmetic, tests/test_model_gpu.py::test_cfg2_full_size_split_bf16_arithmetic)
         result["config"]["conv_arith_note"] = ("split = fp32-accurate products from bf16 triples (hi + mid + lo, six partial products down to 2^-18, fp32 "
                                                "accumulation) in the multi-tap 2-D convolutions where faster; measured against fp64 as close as the exact-fp32 "
-                                               "kernels; --conv-arith fp32 runs exact fp32 MFMAs everywhere")
+                                               "kernels (profiles/r6_split_accuracy.txt); --conv-arith fp32 runs exact fp32 MFMAs everywhere")
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.config == "cfg2":
         # the CPU leg runs in a child process with a hard time limit so that an oversubscribed or slow
         # host can never stall the GPU measurement
