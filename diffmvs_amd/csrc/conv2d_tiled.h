@@ -347,18 +347,15 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT, AR)) conv2d
     }
     const int b = s_b, ox0 = s_ox0, oy0 = s_oy0;
     f32x4 acc[MT][NT];
-    // (split arithmetic) a separate accumulator for the five small partial products would keep their roundings relative to a sum 2^-8 the size; the
-    // matrix instruction rounds once per K = 32 (not once per product as an fma chain does), so six roundings per 32 products in ONE accumulator are
-    // already fewer than the chain's 32 -- measured on the MI355X against fp64 the single accumulator is as close as the fp32 kernel
-    // (tests/test_ops.py::test_conv2d_split_bf16_arithmetic) -- and the 32 registers are the difference between 3 and 4 waves per SIMD
-    constexpr bool kSmallAcc = false;
-    [[maybe_unused]] f32x4 acc_small[(kSplit && kSmallAcc) ? MT : 1][(kSplit && kSmallAcc) ? NT : 1];
+    // (split arithmetic: ONE accumulator per output.  A separate one for the five small partial products would keep their roundings relative to a
+    // sum 2^-8 the size; but the matrix instruction rounds once per K = 32, not once per product as an fma chain does, so six roundings per 32
+    // products are already fewer than the chain's 32 -- measured on the MI355X against fp64 the single accumulator is as close as the fp32 kernel,
+    // profiles/r6_split_accuracy.txt -- and the 32 registers were the difference between 3 and 4 waves per SIMD: built, measured, removed.)
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            if constexpr (kSplit && kSmallAcc) acc_small[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
     // (split arithmetic) this lane's pre-split weights of one tap group: 16 bytes = the 8 channels of the chunk for (plane, tap 4g + kq, cout)
     typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
@@ -472,19 +469,11 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT, AR)) conv2d
 #define DMVS_SPLIT_PRODUCT(BQ, AQ, ACC) \
                     _Pragma("unroll") for (int r = 0; r < RB; ++r) \
                         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) ACC[mt0 + r][nt] = mf(BQ[r], AQ[nt], ACC[mt0 + r][nt]);
-                    if constexpr (kSmallAcc) {
-                        DMVS_SPLIT_PRODUCT(bl, ah, acc_small)
-                        DMVS_SPLIT_PRODUCT(bh, al, acc_small)
-                        DMVS_SPLIT_PRODUCT(bm, am, acc_small)
-                        DMVS_SPLIT_PRODUCT(bm, ah, acc_small)
-                        DMVS_SPLIT_PRODUCT(bh, am, acc_small)
-                    } else {      // smallest partial products first
-                        DMVS_SPLIT_PRODUCT(bl, ah, acc)
-                        DMVS_SPLIT_PRODUCT(bh, al, acc)
-                        DMVS_SPLIT_PRODUCT(bm, am, acc)
-                        DMVS_SPLIT_PRODUCT(bm, ah, acc)
-                        DMVS_SPLIT_PRODUCT(bh, am, acc)
-                    }
+                    DMVS_SPLIT_PRODUCT(bl, ah, acc)      // smallest partial products first
+                    DMVS_SPLIT_PRODUCT(bh, al, acc)
+                    DMVS_SPLIT_PRODUCT(bm, am, acc)
+                    DMVS_SPLIT_PRODUCT(bm, ah, acc)
+                    DMVS_SPLIT_PRODUCT(bh, am, acc)
                     DMVS_SPLIT_PRODUCT(bh, ah, acc)
 #undef DMVS_SPLIT_PRODUCT
                 }
@@ -593,12 +582,6 @@ __global__ void __launch_bounds__(DMVS_BLOCK, conv_min_waves(NT, MT, AR)) conv2d
         }
     }
 
-    if constexpr (kSplit && kSmallAcc) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] += acc_small[i][j];
-    }
     // ---- epilogue: this lane holds couts nbase + nt*16 + 4*kq + r of pixels (oy0 + MT*wave + mt, ox0 + m)
     const int ox = ox0 + wx * 16 + m;
     const int oplane = d.Hout * d.Wout;
