@@ -19,7 +19,7 @@ def block():
 `tools/sessions/r6_final.sh`: the whole GPU suite with `-x` green, `smoke()`, this command, the rocprofv3 kernel stats and PMC passes of the same
 command, the second lines; no `csrc/` / `include/` change after it): **{round(line['value'])} depth-maps/s** at the default 96 reference views per step
 ({line['ms_per_step']:.1f} ms per step, `conv_arith` = {line['config'].get('conv_arith')}; round 5: 1313 / 73.1 on the driver's run, round 4: 1299, round 3: 1200, round 2: 1118, round 1: 848 at B=16;
-box-to-box spread of one build ~2 %: 1472 / 1494 on two other boxes, `r6_final_b.sh`).
+box-to-box spread of one build ~2 %: 1472 / 1494 / 1501 in other sessions of the same kernels).
 `roofline.frac` {rf['frac']:.2f} ({rf['avg_launch_us']:.0f} us per launch; first GRU iteration {it[0]['frac']:.2f}, iterations 2-4 {min(x['frac'] for x in it[1:]):.3f}-{max(x['frac'] for x in it[1:]):.3f};
 `traffic` {('%.2f GB' % (tr / 1e9)) if tr else 'n/a'} per launch against {rf['algorithmic_bytes_per_launch'] / 1e9:.2f} GB algorithmic; `ceiling_probe_us` {rf['ceiling_probe_us']:.0f} in-step,
 measured by this process: product / probe {cp['product_over_probe_in_step']:.2f} in-step, {cp['product_over_probe_isolated']:.2f} isolated; the 0.60 mark is {cp['gate_0p60_us']:.0f} us;
